@@ -1,0 +1,240 @@
+"""Generate golden vectors by running the *reference itself* (read-only at /root/reference).
+
+Run only in the build container (the reference never travels to the GPU box):
+
+    python oracle/gen_golden.py
+
+Outputs small ``.npz`` fixtures (data only: inputs, weights, expected outputs) under
+``tests/golden/``. Third-party packages missing offline are replaced by import stand-ins
+that are NOT reference code:
+  * ``timm.models.layers.DropPath`` (timm==0.9.16, requirements_frozen.txt:6): stand-in with the
+    published semantics (per-row-of-dim-0 Bernoulli(keep)/keep in train mode, identity in eval);
+    it also records the masks it drew so the oracle can be fed identical masks.
+  * ``mup.MuReadout`` (mup==1.0.0): subclass of nn.Linear, never instantiated with mup=False.
+``rotation_tools.normalize_vector`` hard-codes ``.cuda()`` (rotation_tools.py:10-13); it is
+replaced at run time by the same arithmetic on the input's device.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import manipose_ref as orc  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+RECORDED_MASKS = []
+
+
+class DropPath(nn.Module):
+    def __init__(self, drop_prob=0.0, scale_by_keep=True):
+        super().__init__()
+        self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1 - self.drop_prob
+        m = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0 and self.scale_by_keep:
+            m.div_(keep)
+        RECORDED_MASKS.append(m.reshape(-1).clone())
+        return x * m
+
+
+def import_reference():
+    tl = types.ModuleType("timm.models.layers")
+    tl.DropPath = DropPath
+    sys.modules.update({"timm": types.ModuleType("timm"), "timm.models": types.ModuleType("timm.models"),
+                        "timm.models.layers": tl})
+    mup = types.ModuleType("mup")
+    mup.MuReadout = type("MuReadout", (nn.Linear,), {})
+    sys.modules["mup"] = mup
+    sys.path.insert(0, "/root/reference/hpe")
+    import mh_so3_hpe.architectures.utils.rotation_tools as rt
+
+    def _nv(v):
+        mag = torch.max(torch.sqrt(v.pow(2).sum(1)), torch.tensor([1e-8], dtype=v.dtype, device=v.device))
+        return v / mag.view(-1, 1).expand(-1, v.shape[1])
+    rt.normalize_vector = _nv
+    from mh_so3_hpe.architectures import RMCLManifoldMixSTE, ManifoldMixSTE, MixSTE
+    import mh_so3_hpe.metrics as M
+    from mh_so3_hpe.data.skeleton import Skeleton
+    from mh_so3_hpe.data.h36m_lifting import T_POSE_OPERATORS
+    from mh_so3_hpe.architectures.pose_decoder import PoseDecoder
+    sk = Skeleton(parents=list(orc.H36M_PARENTS), joints_left=list(orc.H36M_JOINTS_LEFT),
+                  joints_right=list(orc.H36M_JOINTS_RIGHT), t_pose_operators=T_POSE_OPERATORS)
+    return dict(RMCL=RMCLManifoldMixSTE, Manifold=ManifoldMixSTE, MixSTE=MixSTE, M=M, sk=sk,
+                PoseDecoder=PoseDecoder)
+
+
+def build_ref_model(ref, cfg, drop_path_rate):
+    kw = dict(skeleton=ref["sk"], num_frame=cfg["T"], num_joints=cfg["J"], num_bones=cfg["num_bones"],
+              in_chans=2, rot_rep_dim=6, embed_dim_rot=cfg["C_rot"], depth_rot=cfg["depth_rot"],
+              num_heads_rot=cfg["heads_rot"], embed_dim_seg=cfg["C_seg"], depth_seg=cfg["depth_seg"],
+              num_heads_seg=cfg["heads_seg"], drop_path_rate=drop_path_rate)
+    if cfg["n_hyp"] > 0:
+        return ref["RMCL"](n_hyp=cfg["n_hyp"], **kw)
+    return ref["Manifold"](**kw)
+
+
+def ref_losses(ref, poses, scores, y):
+    """The four default loss terms exactly as main_h36m_lifting.py:101-209 assembles them."""
+    M = ref["M"]
+    w = M.STANDARD_H36M_WEIGHTS
+    wl = M.wta_l2_loss_and_activate_head(hypothesis=poses, y=y, weights=w, squared=False)[0].mean()
+    sr = M.wta_with_scoring_loss(hypothesis=poses, scores=scores, y=y, beta=0.1, weights=w, squared=False)[1]
+    vl = 2.0 * M.mean_velocity_error(predicted=poses, target=y, squared=False, axis=2)
+    sg = 0.5 * M.smoothness_regularization(prediction=poses, weights=w, axis=2)
+    return wl, sr, vl, sg
+
+
+def np_state(st):
+    return {"w::" + k: v.detach().numpy() for k, v in st.items()}
+
+
+def gen_model_fixture(ref, name, cfg, B, seed, drop_path_rate=0.0, train=False):
+    torch.manual_seed(seed)
+    st = orc.make_state(cfg, seed=seed)
+    model = build_ref_model(ref, cfg, drop_path_rate)
+    missing = model.load_state_dict(st, strict=True)   # also proves the key/shape layout
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.train(train)
+    X, y = orc.synthetic_batch(B, cfg["T"], cfg["J"], seed=seed + 1)
+    RECORDED_MASKS.clear()
+    out = {"cfg": np.array([cfg[k] for k in ("T", "J", "num_bones", "C_rot", "depth_rot", "heads_rot",
+                                              "C_seg", "depth_seg", "heads_seg", "n_hyp")], dtype=np.int64),
+           "X": X.numpy(), "y": y.numpy(), "drop_path_rate": np.float64(drop_path_rate)}
+    if cfg["n_hyp"] > 0:
+        rot, sc_only = model.rotations_module(X)
+        RECORDED_MASKS.clear()
+        bl = model.segments_module(X)
+        RECORDED_MASKS.clear()
+        torch.manual_seed(seed + 7)
+        poses, scores = model(X)
+        masks = [m.numpy() for m in RECORDED_MASKS]
+        wl, sr, vl, sg = ref_losses(ref, poses, scores, y)
+        total = wl + sr + vl + sg
+        model.zero_grad()
+        total.backward()
+        if not train:
+            out["rot6d"] = rot.detach().numpy()
+            out["bones"] = bl.detach().numpy()
+        out.update(poses=poses.detach().numpy(), scores=scores.detach().numpy(),
+                   loss_terms=np.array([wl.item(), sr.item(), vl.item(), sg.item()], dtype=np.float64),
+                   loss_total=np.float64(total.item()))
+        e, idx = ref["M"].wta_l2_loss_and_activate_head(hypothesis=poses.detach(), y=y,
+                                                        weights=ref["M"].STANDARD_H36M_WEIGHTS)
+        out["wta_idx"] = idx.numpy()
+        out["wta_val"] = e.numpy()
+        # eval-time aggregation + the parity metric (rmcl_manifold_mix_ste.py:141-185, mean_joint_errors.py:31-36)
+        with torch.no_grad():
+            agg = model.aggregate(poses, scores, mode="weighted_ave")
+            best = model.aggregate(poses, scores, mode="best_score")
+            oe, op = model.aggregate(poses, mode="oracle", ground_truth=y)
+            out.update(agg_weighted=agg.numpy(), agg_best=best.numpy(), agg_oracle=op.numpy(),
+                       agg_oracle_err=oe.numpy(),
+                       mpjpe_weighted=np.float64(ref["M"].mpjpe_error(agg, y, mode="average").item()))
+    else:
+        pred = model(X)
+        masks = [m.numpy() for m in RECORDED_MASKS]
+        M = ref["M"]
+        w = M.STANDARD_H36M_WEIGHTS
+        wl = M.weighted_mpjpe_loss(pred, y, weights=w)
+        vl = 2.0 * M.mean_velocity_error(predicted=pred, target=y, squared=False, axis=1)
+        sg = 0.5 * M.smoothness_regularization(prediction=pred, weights=w, axis=1)
+        total = wl + vl + sg
+        model.zero_grad()
+        total.backward()
+        out.update(poses=pred.detach().numpy(),
+                   loss_terms=np.array([wl.item(), vl.item(), sg.item()], dtype=np.float64),
+                   loss_total=np.float64(total.item()))
+    for i, m in enumerate(masks):
+        out[f"mask::{i:03d}"] = m
+    out["n_masks"] = np.int64(len(masks))
+    out.update(np_state(st))
+    for k, p in model.named_parameters():
+        out["g::" + k] = p.grad.detach().numpy()
+    # one Adam step (main_h36m_lifting.py:234-238) on the same grads
+    opt = torch.optim.Adam(model.parameters(), lr=4e-5, weight_decay=1e-6)
+    opt.step()
+    for k in ("rotations_module.STEblocks.0.attn.qkv.weight", "segments_module.head.1.weight",
+              "rotations_module.Spatial_norm.bias"):
+        out["adam1::" + k] = dict(model.named_parameters())[k].detach().numpy()
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1e3:.0f} kB, loss={total.item():.6f}, masks={len(masks)}")
+
+
+def gen_decoder_fixture(ref):
+    torch.manual_seed(5)
+    dec = ref["PoseDecoder"](skeleton=ref["sk"], rot_rep_dim=6)
+    B, L = 3, 7
+    rot = torch.randn(B * L, 17, 6)
+    rot[0, 3] = 0.0                       # degenerate: both vectors zero -> 1e-8 clamp path
+    rot[1, 5, 3:] = rot[1, 5, :3] * 2.0   # degenerate: colinear -> zero cross product
+    rot[2, 0, :] = torch.tensor([1., 0, 0, 0, 1, 0])
+    bl = torch.randn(B, 16, 1) * 0.3
+    rot.requires_grad_(True)
+    bl.requires_grad_(True)
+    poses = dec(rotations_repr=rot, bones_lengths_repr=bl, root_positions=torch.zeros(B * L, 3))
+    gp = torch.randn_like(poses)
+    (poses * gp).sum().backward()
+    # known answer from SURVEY section 4: identity rotations -> T-pose
+    ident = torch.tensor([1., 0, 0, 0, 1, 0]).repeat(1, 17, 1)
+    lens = torch.tensor([.2, .5, .5, .2, .5, .5, .2, .2, .2, .2, .2, .4, .4, .2, .4, .4]).view(1, 16, 1)
+    tp = dec(rotations_repr=ident, bones_lengths_repr=lens, root_positions=torch.zeros(1, 3))
+    np.savez_compressed(os.path.join(OUT, "decoder.npz"), rot6d=rot.detach().numpy(), bones=bl.detach().numpy(),
+                        poses=poses.detach().numpy(), gpos=gp.numpy(), g_rot6d=rot.grad.numpy(),
+                        g_bones=bl.grad.numpy(), tpose_lens=lens.numpy(), tpose=tp.detach().numpy())
+    print("decoder: ok")
+
+
+def gen_loss_fixture(ref):
+    torch.manual_seed(9)
+    B, H, L, J = 2, 5, 9, 17
+    poses = (0.3 * torch.randn(B, H, L, J, 3)).requires_grad_(True)
+    logits = torch.randn(B, H, L, 1)
+    scores = logits.softmax(dim=1).requires_grad_(True)
+    y = 0.3 * torch.randn(B, L, J, 3)
+    wl, sr, vl, sg = ref_losses(ref, poses, scores, y)
+    total = wl + sr + vl + sg
+    total.backward()
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), poses=poses.detach().numpy(), scores=scores.detach().numpy(),
+                        y=y.numpy(), loss_terms=np.array([wl.item(), sr.item(), vl.item(), sg.item()]),
+                        g_poses=poses.grad.numpy(), g_scores=scores.grad.numpy())
+    print("loss: ok")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = import_reference()
+    tiny = dict(T=9, J=17, num_bones=16, C_rot=32, depth_rot=2, heads_rot=4, C_seg=16, depth_seg=1, heads_seg=4, n_hyp=3)
+    small = dict(T=27, J=17, num_bones=16, C_rot=64, depth_rot=2, heads_rot=8, C_seg=32, depth_seg=2, heads_seg=8, n_hyp=5)
+    k1 = dict(T=27, J=17, num_bones=16, C_rot=64, depth_rot=2, heads_rot=8, C_seg=32, depth_seg=1, heads_seg=8, n_hyp=0)
+    gen_model_fixture(ref, "rmcl_tiny", tiny, B=2, seed=11)
+    gen_model_fixture(ref, "rmcl_small", small, B=2, seed=12)
+    gen_model_fixture(ref, "manifold_k1", k1, B=2, seed=13)
+    gen_model_fixture(ref, "rmcl_tiny_droppath", tiny, B=3, seed=14, drop_path_rate=0.5, train=True)
+    gen_decoder_fixture(ref)
+    gen_loss_fixture(ref)
+    # parameter-count known answers
+    counts = {}
+    for nm, T, K in (("rmcl_T243_K5", 243, 5), ("rmcl_T81_K5", 81, 5), ("manifold_T27", 27, 0)):
+        cfg = dict(orc.FULL_CFG, T=T, n_hyp=K)
+        m = build_ref_model(ref, cfg, 0.1)
+        counts[nm] = sum(p.numel() for p in m.parameters())
+        if nm == "rmcl_T243_K5":
+            keys = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in m.state_dict().items())
+            with open(os.path.join(OUT, "state_dict_keys_T243_K5.txt"), "w") as f:
+                f.write("\n".join(keys) + "\n")
+    np.savez(os.path.join(OUT, "param_counts.npz"), **{k: np.int64(v) for k, v in counts.items()})
+    print(counts)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,488 @@
+"""CPU oracle for the ManiPose lifting hot path (TEST INFRASTRUCTURE ONLY).
+
+This file is a plain torch-CPU fp32 restatement of the reference algorithm
+(cedricrommel/manipose @ 2025-01-17). It is the *checker* for the HIP path:
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it. The product package ``manipose_amd`` never imports it and
+has no CPU fallback.
+
+Parity pin: the functions below are checked against golden vectors generated
+by importing the reference itself in the build container
+(``oracle/gen_golden.py`` -> ``tests/golden/*.npz``, see
+``tests/test_oracle_golden.py``). The reference holds no tests/fixtures of its
+own for this path, so those generated vectors plus the
+closed-form known answers of SURVEY.md section 4 are the pin.
+
+Every function takes a flat ``state`` dict using the reference's state-dict
+key names so that fixtures, oracle and product share
+one weight format. All citations are ``path:line`` under ``/root/reference``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+# ---------------------------------------------------------------------------
+# Skeleton tables (hpe/mh_so3_hpe/data/skeleton.py:87-120; 17-joint tree literal
+# hpe/mh_so3_hpe/data/dataset_3dhp.py:132-138; T-pose operators
+# hpe/mh_so3_hpe/data/h36m_lifting.py:40-57)
+# ---------------------------------------------------------------------------
+H36M_PARENTS = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 8, 11, 12, 8, 14, 15]
+H36M_JOINTS_LEFT = [4, 5, 6, 11, 12, 13]
+H36M_JOINTS_RIGHT = [1, 2, 3, 14, 15, 16]
+# unit translation taking a joint's parent to the joint in T-pose, index = joint
+T_POSE_OPERATORS = {
+    1: (1.0, 0.0, 0.0), 2: (0.0, -1.0, 0.0), 3: (0.0, -1.0, 0.0),
+    4: (-1.0, 0.0, 0.0), 5: (0.0, -1.0, 0.0), 6: (0.0, -1.0, 0.0),
+    7: (0.0, 1.0, 0.0), 8: (0.0, 1.0, 0.0), 9: (0.0, 1.0, 0.0),
+    10: (0.0, 1.0, 0.0), 11: (-1.0, 0.0, 0.0), 12: (-1.0, 0.0, 0.0),
+    13: (-1.0, 0.0, 0.0), 14: (1.0, 0.0, 0.0), 15: (1.0, 0.0, 0.0),
+    16: (1.0, 0.0, 0.0),
+}
+# hpe/mh_so3_hpe/metrics/losses.py:6-8
+STANDARD_H36M_WEIGHTS = [1, 1, 2.5, 2.5, 1, 2.5, 2.5, 1, 1, 1, 1.5, 1.5, 4, 4, 1.5, 4, 4]
+
+
+def has_children(parents):
+    """skeleton.py:88-91."""
+    out = [False] * len(parents)
+    for p in parents:
+        if p != -1:
+            out[p] = True
+    return out
+
+
+# ---------------------------------------------------------------------------
+# Transformer backbone (hpe/mh_so3_hpe/architectures/mix_ste.py)
+# ---------------------------------------------------------------------------
+def attention(x: Tensor, st: Dict[str, Tensor], pre: str, num_heads: int,
+              scale: Optional[float] = None) -> Tensor:
+    """Attention.forward, mix_ste.py:255-282 (comb=False branch)."""
+    B, N, C = x.shape
+    d = C // num_heads
+    scale = scale if scale is not None else d ** -0.5          # mix_ste.py:243-244
+    qkv = F.linear(x, st[pre + "qkv.weight"], st[pre + "qkv.bias"])
+    qkv = qkv.reshape(B, N, 3, num_heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = (q @ k.transpose(-2, -1)) * scale
+    attn = attn.softmax(dim=-1)
+    x = (attn @ v).transpose(1, 2).reshape(B, N, C)
+    return F.linear(x, st[pre + "proj.weight"], st[pre + "proj.bias"])
+
+
+def mlp(x: Tensor, st: Dict[str, Tensor], pre: str) -> Tensor:
+    """Mlp.forward, mix_ste.py:216-222 (GELU = exact erf form, drop p=0)."""
+    x = F.linear(x, st[pre + "fc1.weight"], st[pre + "fc1.bias"])
+    x = F.gelu(x)
+    return F.linear(x, st[pre + "fc2.weight"], st[pre + "fc2.bias"])
+
+
+def block(x: Tensor, st: Dict[str, Tensor], pre: str, num_heads: int,
+          mask_attn: Optional[Tensor] = None, mask_mlp: Optional[Tensor] = None) -> Tensor:
+    """Block.forward, mix_ste.py:352-368 with residual_scale = 1 (mup=False).
+
+    ``mask_*`` are the DropPath multipliers of timm.models.layers.DropPath
+    (third party, timm==0.9.16, not vendored in the reference; parity unpinned
+    for train-mode randomness): shape (x.shape[0],), values 0 or 1/keep_prob.
+    ``None`` = identity (eval mode or drop_prob == 0).
+    """
+    C = x.shape[-1]
+    a = attention(F.layer_norm(x, (C,), st[pre + "norm1.weight"], st[pre + "norm1.bias"], 1e-6),
+                  st, pre + "attn.", num_heads)
+    if mask_attn is not None:
+        a = a * mask_attn.view(-1, 1, 1)
+    x = x + a
+    m = mlp(F.layer_norm(x, (C,), st[pre + "norm2.weight"], st[pre + "norm2.bias"], 1e-6),
+            st, pre + "mlp.")
+    if mask_mlp is not None:
+        m = m * mask_mlp.view(-1, 1, 1)
+    return x + m
+
+
+def mixste_backbone(x: Tensor, st: Dict[str, Tensor], pre: str, depth: int,
+                    num_heads: int, masks: Optional[Dict[str, Tensor]] = None,
+                    embed: bool = True) -> Tensor:
+    """MixSTE.STE_forward / TTE_foward / ST_foward, mix_ste.py:128-173.
+
+    x: (B, L, J, Cin) -> (B, L, J, C). ``masks`` maps
+    ``f"{pre}STEblocks.{i}.attn"`` / ``.mlp`` (and TTEblocks) to DropPath
+    multipliers. ``embed=False`` is BonesMixSTE's Identity patch embedding
+    (manifold_mix_ste.py:133).
+    """
+    masks = masks or {}
+    B, L, J, _ = x.shape
+
+    def snorm(z):
+        C = z.shape[-1]
+        return F.layer_norm(z, (C,), st[pre + "Spatial_norm.weight"], st[pre + "Spatial_norm.bias"], 1e-6)
+
+    def tnorm(z):
+        C = z.shape[-1]
+        return F.layer_norm(z, (C,), st[pre + "Temporal_norm.weight"], st[pre + "Temporal_norm.bias"], 1e-6)
+
+    def blk(z, name):
+        return block(z, st, pre + name + ".", num_heads,
+                     masks.get(pre + name + ".attn"), masks.get(pre + name + ".mlp"))
+
+    # STE_forward :128-145
+    x = x.reshape(B * L, J, -1)
+    if embed:
+        x = F.linear(x, st[pre + "Spatial_patch_to_embedding.weight"],
+                     st[pre + "Spatial_patch_to_embedding.bias"])
+    x = x + st[pre + "Spatial_pos_embed"]
+    x = blk(x, "STEblocks.0")
+    x = snorm(x)
+    C = x.shape[-1]
+    x = x.reshape(B, L, J, C).permute(0, 2, 1, 3).reshape(B * J, L, C)
+    # TTE_foward :147-155
+    x = x + st[pre + "Temporal_pos_embed"]
+    x = blk(x, "TTEblocks.0")
+    x = tnorm(x)
+    x = x.reshape(B, J, L, C).permute(0, 2, 1, 3)                    # (B L J C)
+    # ST_foward :157-173
+    for i in range(1, depth):
+        x = x.reshape(B * L, J, C)
+        x = blk(x, f"STEblocks.{i}")
+        x = snorm(x)
+        x = x.reshape(B, L, J, C).permute(0, 2, 1, 3).reshape(B * J, L, C)
+        x = blk(x, f"TTEblocks.{i}")
+        x = tnorm(x)
+        x = x.reshape(B, J, L, C).permute(0, 2, 1, 3)
+    return x.contiguous()
+
+
+def mixste_forward(x: Tensor, st, pre: str, depth: int, num_heads: int, masks=None) -> Tensor:
+    """MixSTE.forward, mix_ste.py:175-191: backbone + head Sequential(LN eps 1e-5, Linear)."""
+    h = mixste_backbone(x, st, pre, depth, num_heads, masks)
+    C = h.shape[-1]
+    h = F.layer_norm(h, (C,), st[pre + "head.0.weight"], st[pre + "head.0.bias"], 1e-5)
+    return F.linear(h, st[pre + "head.1.weight"], st[pre + "head.1.bias"])
+
+
+def rmcl_rot_forward(x: Tensor, st, pre: str, depth: int, num_heads: int, n_hyp: int,
+                     masks=None) -> Tuple[Tensor, Tensor]:
+    """RMCLRotMixSTE.forward (rmcl_manifold_mix_ste.py:239-264) with MCLHead.forward (:291-298)."""
+    h = mixste_backbone(x, st, pre, depth, num_heads, masks)
+    C = h.shape[-1]
+    preds, logits = [], []
+    for k in range(n_hyp):
+        hp = f"{pre}head.{k}."
+        z = F.layer_norm(h, (C,), st[hp + "norm.weight"], st[hp + "norm.bias"], 1e-5)
+        z = F.linear(z, st[hp + "prediction_head.weight"], st[hp + "prediction_head.bias"])
+        preds.append(z[..., :-1])                                                  # (B, L, J, 6)
+        logits.append(F.linear(z[..., -1], st[hp + "score_head.weight"], st[hp + "score_head.bias"]))
+    hyp = torch.stack(preds, dim=1)                                                # (B, H, L, J, 6)
+    logit = torch.stack(logits, dim=1)                                             # (B, H, L, 1)
+    return hyp, logit.softmax(dim=1)
+
+
+def bones_forward(x: Tensor, st, pre: str, depth: int, num_heads: int, num_bones: int,
+                  masks=None) -> Tensor:
+    """BonesMixSTE.forward, manifold_mix_ste.py:139-154. x (B,L,J,2) -> (B,S,1)."""
+    B, L, _, _ = x.shape
+    z = F.linear(x.reshape(B * L, -1), st[pre + "joints_to_segments_proj.weight"],
+                 st[pre + "joints_to_segments_proj.bias"])
+    z = z.reshape(B, L, num_bones, -1)
+    h = mixste_backbone(z, st, pre, depth, num_heads, masks, embed=False)
+    C = h.shape[-1]
+    h = F.layer_norm(h, (C,), st[pre + "head.0.weight"], st[pre + "head.0.bias"], 1e-5)
+    h = F.linear(h, st[pre + "head.1.weight"], st[pre + "head.1.bias"])            # (B, L, S, 1)
+    return h.mean(dim=1)
+
+
+# ---------------------------------------------------------------------------
+# Decoder (pose_decoder.py, utils/rotation_tools.py, utils/forward_kinematics.py)
+# ---------------------------------------------------------------------------
+def normalize_vector(v: Tensor) -> Tensor:
+    """rotation_tools.py:6-17 (same arithmetic; the reference's hard-coded .cuda() dropped)."""
+    mag = torch.sqrt(v.pow(2).sum(1))
+    mag = torch.max(mag, torch.tensor([1e-8], dtype=v.dtype, device=v.device))
+    return v / mag.view(-1, 1)
+
+
+def cross_product(u: Tensor, v: Tensor) -> Tensor:
+    """rotation_tools.py:21-32."""
+    i = u[:, 1] * v[:, 2] - u[:, 2] * v[:, 1]
+    j = u[:, 2] * v[:, 0] - u[:, 0] * v[:, 2]
+    k = u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0]
+    return torch.stack((i, j, k), dim=1)
+
+
+def rotation_from_ortho6d(p: Tensor) -> Tensor:
+    """compute_rotation_matrix_from_ortho6d, rotation_tools.py:35-57. (N,6)->(N,3,3), x|y|z as columns."""
+    x = normalize_vector(p[:, 0:3])
+    z = normalize_vector(cross_product(x, p[:, 3:6]))
+    y = cross_product(z, x)
+    return torch.stack((x, y, z), dim=2)
+
+
+def build_t_pose(bones_length: Tensor, parents=H36M_PARENTS) -> Tensor:
+    """PoseDecoder.build_t_pose_from_bone_lengths, pose_decoder.py:98-120. (N,S,1)->(N,J,3)."""
+    N = bones_length.shape[0]
+    J = len(parents)
+    cols = [torch.zeros(N, 3, dtype=bones_length.dtype)]
+    for b in range(J - 1):
+        op = torch.tensor(T_POSE_OPERATORS[b + 1], dtype=bones_length.dtype)
+        cols.append(cols[parents[b + 1]] + op * bones_length[:, b])
+    return torch.stack(cols, dim=1)
+
+
+def forward_kinematics(t_pose: Tensor, rotations: Tensor, root: Tensor, parents=H36M_PARENTS) -> Tensor:
+    """forward_kinematics.py:6-48. t_pose (N,J,3), rotations (N,J,3,3), root (N,3) -> (N,J,3)."""
+    pos, rot = [], []
+    for j in range(len(parents)):
+        p = parents[j]
+        if p == -1:
+            pos.append(root)
+            rot.append(rotations[:, 0])
+        else:
+            off = (t_pose[:, j] - t_pose[:, p]).view(-1, 3, 1)
+            rw = rot[p].matmul(rotations[:, j])
+            pos.append(rw.matmul(off).view(-1, 3) + pos[p])
+            rot.append(rw)       # leaf rotations are simply unused (:41-46)
+    return torch.stack(pos, dim=1)
+
+
+def pose_decoder(rot6d: Tensor, bones_lengths: Tensor, parents=H36M_PARENTS) -> Tensor:
+    """PoseDecoder.forward, pose_decoder.py:32-55. rot6d (N,J,6); bones_lengths (B,S,1), N % B == 0."""
+    N, J, _ = rot6d.shape
+    B = bones_lengths.shape[0]
+    assert N % B == 0
+    L = N // B
+    bl = torch.stack([bones_lengths] * L, dim=1).reshape(N, -1, 1)                 # :85-96
+    R = rotation_from_ortho6d(rot6d.reshape(-1, 6)).reshape(N, J, 3, 3)           # :57-83
+    return forward_kinematics(build_t_pose(bl, parents), R, torch.zeros(N, 3, dtype=rot6d.dtype), parents)
+
+
+# ---------------------------------------------------------------------------
+# Whole models
+# ---------------------------------------------------------------------------
+def rmcl_manifold_forward(x: Tensor, st, cfg: dict, masks=None) -> Tuple[Tensor, Tensor]:
+    """RMCLManifoldMixSTE.forward, rmcl_manifold_mix_ste.py:83-106.
+
+    cfg keys: depth_rot, heads_rot, depth_seg, heads_seg, n_hyp, num_bones.
+    Returns poses (B,H,L,J,3), scores (B,H,L,1).
+    """
+    B, L, J, _ = x.shape
+    H = cfg["n_hyp"]
+    rot, scores = rmcl_rot_forward(x, st, "rotations_module.", cfg["depth_rot"], cfg["heads_rot"], H, masks)
+    bl = bones_forward(x, st, "segments_module.", cfg["depth_seg"], cfg["heads_seg"], cfg["num_bones"], masks)
+    poses = pose_decoder(rot.reshape(B * H * L, J, -1), bl)
+    return poses.reshape(B, H, L, J, 3), scores
+
+
+def manifold_forward(x: Tensor, st, cfg: dict, masks=None) -> Tensor:
+    """ManifoldMixSTE.forward, manifold_mix_ste.py:75-88 (single hypothesis). -> (B,L,J,3)."""
+    B, L, J, _ = x.shape
+    rot = mixste_forward(x, st, "rotations_module.", cfg["depth_rot"], cfg["heads_rot"], masks)
+    bl = bones_forward(x, st, "segments_module.", cfg["depth_seg"], cfg["heads_seg"], cfg["num_bones"], masks)
+    return pose_decoder(rot.reshape(B * L, J, -1), bl).reshape(B, L, J, 3)
+
+
+# ---------------------------------------------------------------------------
+# Losses (hpe/mh_so3_hpe/metrics/losses.py, regularizations.py:160-174,
+# loss assembly hpe/main_h36m_lifting.py:101-209)
+# ---------------------------------------------------------------------------
+def weighted_mpjpe_per_hyp(hyp: Tensor, y: Tensor, weights: Optional[Tensor]) -> Tensor:
+    """_l2_loss_per_hyp (losses.py:104-123) -> weighted_mpjpe_loss(dims=[3]) (:14-43). -> (B,H,L)."""
+    w = torch.ones(y.shape[-2]) if weights is None else weights
+    return (w[None, None, :] * torch.norm(hyp - y[:, None], p=2, dim=-1)).mean(dim=3)
+
+
+def wta_l2_loss_and_activate_head(hyp, y, weights=None):
+    """losses.py:126-138 (squared=False)."""
+    return torch.min(weighted_mpjpe_per_hyp(hyp, y, weights), dim=1)
+
+
+def wta_with_scoring_loss(hyp, scores, y, beta, weights=None):
+    """losses.py:141-170. Returns (wta.mean() + beta*bce, beta*bce)."""
+    wta, idx = wta_l2_loss_and_activate_head(hyp, y, weights)
+    B, H, L = hyp.shape[:3]
+    gt = F.one_hot(idx, H).permute(0, 2, 1).to(scores.dtype)                       # (B, H, L)
+    bce = F.binary_cross_entropy(scores.view(B, H, L), gt)
+    return wta.mean() + beta * bce, beta * bce
+
+
+def mean_velocity_error(pred, target, axis):
+    """losses.py:75-101 (squared=False)."""
+    if pred.dim() > target.dim():
+        target = target.unsqueeze(1).expand_as(pred)
+    dv = torch.diff(pred, dim=axis) - torch.diff(target, dim=axis)
+    return torch.norm(dv, dim=-1).mean()
+
+
+def smoothness_regularization(pred, weights, axis):
+    """regularizations.py:160-174."""
+    v = torch.diff(pred, dim=axis)
+    w = torch.ones(v.shape[-2]) if weights is None else weights
+    return (w[None, None, :, None] * v ** 2).mean()
+
+
+def weighted_mpjpe_loss(pred, target, weights=None):
+    """losses.py:14-43 with dims=None (single-hypothesis wloss)."""
+    w = torch.ones(target.shape[-2]) if weights is None else weights
+    return (w[None, None, :] * torch.norm(pred - target, p=2, dim=-1)).mean()
+
+
+DEFAULT_TRAIN_CFG = dict(w_loss=True, vel_loss=2.0, smooth_reg=0.5, rmcl_score_reg=0.1)  # conf/config.yaml:32-38
+
+
+def rmcl_training_loss(poses, scores, y, train_cfg=DEFAULT_TRAIN_CFG):
+    """make_loss + compute_and_acc_loss for the rmcl model, main_h36m_lifting.py:101-209.
+
+    Returns (total, dict of the four terms). time axis = 2.
+    """
+    w = torch.tensor(STANDARD_H36M_WEIGHTS, dtype=poses.dtype) if train_cfg["w_loss"] else None
+    terms = {}
+    terms["wloss"] = wta_l2_loss_and_activate_head(poses, y, w)[0].mean()
+    terms["score_reg"] = wta_with_scoring_loss(poses, scores, y, train_cfg["rmcl_score_reg"], w)[1]
+    if train_cfg["vel_loss"] > 0:
+        terms["vloss"] = train_cfg["vel_loss"] * mean_velocity_error(poses, y, axis=2)
+    if train_cfg["smooth_reg"] > 0:
+        terms["sreg"] = train_cfg["smooth_reg"] * smoothness_regularization(poses, w, axis=2)
+    total = sum(terms.values())
+    return total, terms
+
+
+def manifold_training_loss(pred, y, train_cfg=DEFAULT_TRAIN_CFG):
+    """make_loss for single-hypothesis models (time axis 1), main_h36m_lifting.py:113-127,152-169."""
+    w = torch.tensor(STANDARD_H36M_WEIGHTS, dtype=pred.dtype) if train_cfg["w_loss"] else None
+    terms = {"wloss": weighted_mpjpe_loss(pred, y, w)}
+    if train_cfg["vel_loss"] > 0:
+        terms["vloss"] = train_cfg["vel_loss"] * mean_velocity_error(pred, y, axis=1)
+    if train_cfg["smooth_reg"] > 0:
+        terms["sreg"] = train_cfg["smooth_reg"] * smoothness_regularization(pred, w, axis=1)
+    return sum(terms.values()), terms
+
+
+# ---------------------------------------------------------------------------
+# Eval aggregation + parity metric (rmcl_manifold_mix_ste.py:108-185,
+# metrics/mean_joint_errors.py:8-36)
+# ---------------------------------------------------------------------------
+def mpjpe_error(pred: Tensor, gt: Tensor, mode: str = "average") -> Tensor:
+    """mean_joint_errors.py:31-36."""
+    d = torch.norm(gt.reshape(-1, 3) - pred.reshape(-1, 3), 2, 1)
+    return d.mean() if mode == "average" else d.sum()
+
+
+def poses_from_hyp_idx(hyp: Tensor, idx: Tensor) -> Tensor:
+    """rmcl_manifold_mix_ste.py:121-139. hyp (B,H,L,J,3), idx (B,L) -> (B,L,J,3)."""
+    B, H, L, J, _ = hyp.shape
+    g = idx[:, None, :, None, None].expand(B, 1, L, J, 3)
+    return hyp.gather(1, g)[:, 0]
+
+
+def aggregate(hyp, scores=None, mode="weighted_ave", ground_truth=None):
+    """RMCLManifoldMixSTE.aggregate, rmcl_manifold_mix_ste.py:141-185."""
+    if mode == "best_score":
+        return poses_from_hyp_idx(hyp, torch.argmax(scores, dim=1)[..., 0])
+    if mode == "weighted_ave":
+        return torch.sum(hyp * scores.unsqueeze(-1), dim=1)
+    if mode == "oracle":
+        e, idx = wta_l2_loss_and_activate_head(hyp, ground_truth, None)
+        return e, poses_from_hyp_idx(hyp, idx)
+    raise ValueError(f"Only best_score and weighted_ave modes are implemented.Got {mode}.")
+
+
+# ---------------------------------------------------------------------------
+# Optimizer (torch.optim.Adam with L2 weight decay, main_h36m_lifting.py:234-238)
+# ---------------------------------------------------------------------------
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr=4e-5, beta1=0.9,
+              beta2=0.999, eps=1e-8, weight_decay=1e-6):
+    """One torch.optim.Adam (non-AMSGrad, L2 decay) update, restated; returns (p, m, v)."""
+    g = g + weight_decay * p
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    return p - (lr / bc1) * (m / denom), m, v
+
+
+# ---------------------------------------------------------------------------
+# Parameter construction (shapes/keys of SURVEY.md section 8b) and synthetic data
+# 
+# ---------------------------------------------------------------------------
+def _linear_init(out_f, in_f, gen):
+    """nn.Linear default init (kaiming_uniform(a=sqrt(5)) -> U(-1/sqrt(in), 1/sqrt(in)) for both)."""
+    bound = 1.0 / math.sqrt(in_f)
+    w = (torch.rand(out_f, in_f, generator=gen) * 2 - 1) * bound
+    b = (torch.rand(out_f, generator=gen) * 2 - 1) * bound
+    return w, b
+
+
+def _mixste_state(st, pre, gen, T, J, C, depth, in_chans, embed=True, pos_std=0.02):
+    if embed:
+        st[pre + "Spatial_patch_to_embedding.weight"], st[pre + "Spatial_patch_to_embedding.bias"] = \
+            _linear_init(C, in_chans, gen)
+    st[pre + "Spatial_pos_embed"] = pos_std * torch.randn(1, J, C, generator=gen)
+    st[pre + "Temporal_pos_embed"] = pos_std * torch.randn(1, T, C, generator=gen)
+    for kind in ("STEblocks", "TTEblocks"):
+        for i in range(depth):
+            bp = f"{pre}{kind}.{i}."
+            for n in ("norm1", "norm2"):
+                st[bp + n + ".weight"] = 1 + 0.1 * torch.randn(C, generator=gen)
+                st[bp + n + ".bias"] = 0.1 * torch.randn(C, generator=gen)
+            st[bp + "attn.qkv.weight"], st[bp + "attn.qkv.bias"] = _linear_init(3 * C, C, gen)
+            st[bp + "attn.proj.weight"], st[bp + "attn.proj.bias"] = _linear_init(C, C, gen)
+            st[bp + "mlp.fc1.weight"], st[bp + "mlp.fc1.bias"] = _linear_init(2 * C, C, gen)
+            st[bp + "mlp.fc2.weight"], st[bp + "mlp.fc2.bias"] = _linear_init(C, 2 * C, gen)
+    for n in ("Spatial_norm", "Temporal_norm"):
+        st[pre + n + ".weight"] = 1 + 0.1 * torch.randn(C, generator=gen)
+        st[pre + n + ".bias"] = 0.1 * torch.randn(C, generator=gen)
+
+
+def make_state(cfg: dict, seed: int = 0) -> Dict[str, Tensor]:
+    """Random weights with the reference's key layout; LN affine and pos-embeds are perturbed
+    away from their (1, 0, 0) defaults so that every parameter is exercised by parity tests.
+
+    cfg: T, J, num_bones, C_rot, depth_rot, heads_rot, C_seg, depth_seg, heads_seg, n_hyp
+    (n_hyp == 0 -> ManifoldMixSTE layout with a plain MixSTE head of out_dim 6).
+    """
+    gen = torch.Generator().manual_seed(seed)
+    st: Dict[str, Tensor] = {}
+    T, J, S = cfg["T"], cfg["J"], cfg["num_bones"]
+    C, Cs = cfg["C_rot"], cfg["C_seg"]
+    rp, sp = "rotations_module.", "segments_module."
+    _mixste_state(st, rp, gen, T, J, C, cfg["depth_rot"], 2)
+    if cfg["n_hyp"] > 0:
+        for k in range(cfg["n_hyp"]):
+            hp = f"{rp}head.{k}."
+            st[hp + "norm.weight"] = 1 + 0.1 * torch.randn(C, generator=gen)
+            st[hp + "norm.bias"] = 0.1 * torch.randn(C, generator=gen)
+            st[hp + "prediction_head.weight"], st[hp + "prediction_head.bias"] = _linear_init(7, C, gen)
+            st[hp + "score_head.weight"], st[hp + "score_head.bias"] = _linear_init(1, J, gen)
+    else:
+        st[rp + "head.0.weight"] = 1 + 0.1 * torch.randn(C, generator=gen)
+        st[rp + "head.0.bias"] = 0.1 * torch.randn(C, generator=gen)
+        st[rp + "head.1.weight"], st[rp + "head.1.bias"] = _linear_init(6, C, gen)
+    _mixste_state(st, sp, gen, T, S, Cs, cfg["depth_seg"], 2, embed=False)
+    st[sp + "head.0.weight"] = 1 + 0.1 * torch.randn(Cs, generator=gen)
+    st[sp + "head.0.bias"] = 0.1 * torch.randn(Cs, generator=gen)
+    st[sp + "head.1.weight"], st[sp + "head.1.bias"] = _linear_init(1, Cs, gen)
+    st[sp + "joints_to_segments_proj.weight"], st[sp + "joints_to_segments_proj.bias"] = \
+        _linear_init(S * Cs, J * 2, gen)
+    return st
+
+
+def oracle_cfg(cfg: dict) -> dict:
+    return dict(depth_rot=cfg["depth_rot"], heads_rot=cfg["heads_rot"], depth_seg=cfg["depth_seg"],
+                heads_seg=cfg["heads_seg"], n_hyp=cfg["n_hyp"], num_bones=cfg["num_bones"])
+
+
+def synthetic_batch(B: int, T: int, J: int = 17, seed: int = 42):
+    """X = clamp(0.3 randn, -1, 1) screen coords; y = 0.3 randn metres, root 0."""
+    gen = torch.Generator().manual_seed(seed)
+    X = (0.3 * torch.randn(B, T, J, 2, generator=gen)).clamp(-1, 1)
+    y = 0.3 * torch.randn(B, T, J, 3, generator=gen)
+    y[:, :, 0] = 0
+    return X, y
+
+
+FULL_CFG = dict(T=243, J=17, num_bones=16, C_rot=512, depth_rot=8, heads_rot=8,
+                C_seg=128, depth_seg=2, heads_seg=8, n_hyp=5)

@@ -1,0 +1,148 @@
+"""Pin the CPU oracle (oracle/manipose_ref.py) against golden vectors produced by the reference itself
+(oracle/gen_golden.py) and against the closed-form known answers of SURVEY.md section 4."""
+import numpy as np
+import pytest
+import torch
+
+import manipose_ref as orc
+from helpers import fixture_masks, fixture_state, load_fixture
+
+TOL = dict(rtol=1e-5, atol=2e-6)
+
+
+def _run_rmcl(fx, masks=None):
+    st = {k: v.requires_grad_(True) for k, v in fixture_state(fx).items()}
+    X, y = torch.from_numpy(fx["X"]), torch.from_numpy(fx["y"])
+    poses, scores = orc.rmcl_manifold_forward(X, st, orc.oracle_cfg(fx["cfg"]), masks)
+    total, terms = orc.rmcl_training_loss(poses, scores, y)
+    total.backward()
+    return st, poses, scores, total, terms
+
+
+@pytest.mark.parametrize("name", ["rmcl_tiny", "rmcl_small"])
+def test_rmcl_forward_loss_grads(name):
+    fx = load_fixture(name)
+    st, poses, scores, total, terms = _run_rmcl(fx)
+    np.testing.assert_allclose(poses.detach().numpy(), fx["poses"], **TOL)
+    np.testing.assert_allclose(scores.detach().numpy(), fx["scores"], **TOL)
+    got = np.array([terms[k].item() for k in ("wloss", "score_reg", "vloss", "sreg")])
+    np.testing.assert_allclose(got, fx["loss_terms"], rtol=1e-5)
+    np.testing.assert_allclose(total.item(), float(fx["loss_total"]), rtol=1e-5)
+    for k, v in st.items():
+        np.testing.assert_allclose(v.grad.numpy(), fx["g::" + k], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_rmcl_intermediates_and_aggregation():
+    fx = load_fixture("rmcl_small")
+    st = fixture_state(fx)
+    cfg = fx["cfg"]
+    X, y = torch.from_numpy(fx["X"]), torch.from_numpy(fx["y"])
+    rot, _ = orc.rmcl_rot_forward(X, st, "rotations_module.", cfg["depth_rot"], cfg["heads_rot"], cfg["n_hyp"])
+    bl = orc.bones_forward(X, st, "segments_module.", cfg["depth_seg"], cfg["heads_seg"], cfg["num_bones"])
+    np.testing.assert_allclose(rot.numpy(), fx["rot6d"], **TOL)
+    np.testing.assert_allclose(bl.numpy(), fx["bones"], **TOL)
+    poses, scores = torch.from_numpy(fx["poses"]), torch.from_numpy(fx["scores"])
+    val, idx = orc.wta_l2_loss_and_activate_head(poses, y, torch.tensor(orc.STANDARD_H36M_WEIGHTS))
+    np.testing.assert_array_equal(idx.numpy(), fx["wta_idx"])
+    np.testing.assert_allclose(val.numpy(), fx["wta_val"], **TOL)
+    np.testing.assert_allclose(orc.aggregate(poses, scores, "weighted_ave").numpy(), fx["agg_weighted"], **TOL)
+    np.testing.assert_allclose(orc.aggregate(poses, scores, "best_score").numpy(), fx["agg_best"], **TOL)
+    e, p = orc.aggregate(poses, mode="oracle", ground_truth=y)
+    np.testing.assert_allclose(p.numpy(), fx["agg_oracle"], **TOL)
+    np.testing.assert_allclose(e.numpy(), fx["agg_oracle_err"], **TOL)
+    np.testing.assert_allclose(orc.mpjpe_error(orc.aggregate(poses, scores), y).item(),
+                               float(fx["mpjpe_weighted"]), rtol=1e-6)
+    with pytest.raises(ValueError):
+        orc.aggregate(poses, scores, mode="median")
+
+
+def test_manifold_single_hypothesis():
+    fx = load_fixture("manifold_k1")
+    st = {k: v.requires_grad_(True) for k, v in fixture_state(fx).items()}
+    X, y = torch.from_numpy(fx["X"]), torch.from_numpy(fx["y"])
+    pred = orc.manifold_forward(X, st, orc.oracle_cfg(fx["cfg"]))
+    total, terms = orc.manifold_training_loss(pred, y)
+    total.backward()
+    np.testing.assert_allclose(pred.detach().numpy(), fx["poses"], **TOL)
+    got = np.array([terms[k].item() for k in ("wloss", "vloss", "sreg")])
+    np.testing.assert_allclose(got, fx["loss_terms"], rtol=1e-5)
+    for k, v in st.items():
+        np.testing.assert_allclose(v.grad.numpy(), fx["g::" + k], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_droppath_mask_placement():
+    """Train mode with the masks the (stand-in) DropPath drew injected into the oracle: pins WHERE the
+    reference applies stochastic depth (mix_ste.py:352-358) and its per-dim-0-row granularity."""
+    fx = load_fixture("rmcl_tiny_droppath")
+    masks = fixture_masks(fx)
+    assert len(masks) == 4
+    st, poses, scores, total, _ = _run_rmcl(fx, masks)
+    np.testing.assert_allclose(poses.detach().numpy(), fx["poses"], **TOL)
+    np.testing.assert_allclose(total.item(), float(fx["loss_total"]), rtol=1e-5)
+    for k, v in st.items():
+        np.testing.assert_allclose(v.grad.numpy(), fx["g::" + k], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_decoder_with_degenerate_rotations():
+    fx = load_fixture("decoder")
+    rot = torch.from_numpy(fx["rot6d"]).requires_grad_(True)
+    bl = torch.from_numpy(fx["bones"]).requires_grad_(True)
+    poses = orc.pose_decoder(rot, bl)
+    (poses * torch.from_numpy(fx["gpos"])).sum().backward()
+    np.testing.assert_allclose(poses.detach().numpy(), fx["poses"], **TOL)
+    np.testing.assert_allclose(rot.grad.numpy(), fx["g_rot6d"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bl.grad.numpy(), fx["g_bones"], rtol=1e-4, atol=1e-5)
+    assert np.all(poses.detach().numpy()[:, 0] == 0)          # root joint exactly 0
+
+
+def test_known_answer_tpose():
+    """identity 6-D input -> T-pose with the stated joint coordinates."""
+    fx = load_fixture("decoder")
+    ident = torch.tensor([1., 0, 0, 0, 1, 0]).repeat(1, 17, 1)
+    tp = orc.pose_decoder(ident, torch.from_numpy(fx["tpose_lens"]))[0]
+    np.testing.assert_allclose(tp.numpy(), fx["tpose"][0], atol=1e-7)
+    expect = {1: (.2, 0, 0), 2: (.2, -.5, 0), 3: (.2, -1, 0), 4: (-.2, 0, 0), 10: (0, .8, 0),
+              13: (-1, .4, 0), 16: (1, .4, 0)}
+    for j, xyz in expect.items():
+        np.testing.assert_allclose(tp[j].numpy(), np.array(xyz, dtype=np.float32), atol=1e-6)
+
+
+def test_manifold_property_segment_lengths():
+    """Every decoded pose has exactly the predicted segment lengths."""
+    fx = load_fixture("rmcl_small")
+    poses = torch.from_numpy(fx["poses"])                      # (B,H,L,J,3)
+    bones = torch.from_numpy(fx["bones"]).abs()[:, :, 0]       # (B,S)
+    par = torch.tensor(orc.H36M_PARENTS[1:])
+    seg = (poses[..., 1:, :] - poses[..., par, :]).norm(dim=-1)
+    np.testing.assert_allclose(seg.numpy(), bones[:, None, None, :].expand_as(seg).numpy(), atol=2e-6)
+
+
+def test_loss_terms_and_grads():
+    fx = load_fixture("loss")
+    poses = torch.from_numpy(fx["poses"]).requires_grad_(True)
+    scores = torch.from_numpy(fx["scores"]).requires_grad_(True)
+    total, terms = orc.rmcl_training_loss(poses, scores, torch.from_numpy(fx["y"]))
+    total.backward()
+    got = np.array([terms[k].item() for k in ("wloss", "score_reg", "vloss", "sreg")])
+    np.testing.assert_allclose(got, fx["loss_terms"], rtol=1e-6)
+    np.testing.assert_allclose(poses.grad.numpy(), fx["g_poses"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(scores.grad.numpy(), fx["g_scores"], rtol=1e-5, atol=1e-8)
+
+
+def test_adam_step_restated():
+    fx = load_fixture("rmcl_tiny")
+    for k in [k[7:] for k in fx if k.startswith("adam1::")]:
+        p = torch.from_numpy(fx["w::" + k])
+        g = torch.from_numpy(fx["g::" + k])
+        p1, _, _ = orc.adam_step(p, g, torch.zeros_like(p), torch.zeros_like(p), 1)
+        np.testing.assert_allclose(p1.numpy(), fx["adam1::" + k], rtol=1e-6, atol=1e-9)
+
+
+def test_param_counts_and_key_layout(golden_dir):
+    z = np.load(golden_dir + "/param_counts.npz")
+    assert int(z["rmcl_T243_K5"]) == 34440062 and int(z["rmcl_T81_K5"]) == 34336382
+    st = orc.make_state(orc.FULL_CFG)
+    assert sum(v.numel() for v in st.values()) == 34440062 and len(st) == 290
+    want = open(golden_dir + "/state_dict_keys_T243_K5.txt").read().split()
+    got = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in st.items())
+    assert got == want
