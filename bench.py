@@ -1,0 +1,142 @@
+#!/usr/bin/env python
+"""bench.py -- train poses/sec of the ManiPose lifting hot path on MI355X (BASELINE.json metric).
+
+One "step" = forward + WTA multi-hypothesis loss + backward + gradient all-reduce + Adam on a synthetic batch of
+B windows per GPU of H36M shape (T=243, J=17, K=5, C=512, depth 8), inputs resident in HBM.
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank/GPU)
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the forward GEMM kernel; HIP events inside the
+engine on the compute stream) and `cpu_baseline` (oracle/manipose_ref.py timed on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TRAIN_GFLOP_PER_POSE = {243: 3.705, 81: 3.562, 27: 3.513}      # SURVEY.md 8d (3 x forward GEMM+attention FLOPs)
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}                  # MI355X_MICROARCH.md: dense matrix peaks
+
+
+def cpu_baseline(T, K, steps=3):
+    """Oracle (CPU restatement of the reference, fp32, torch autograd + torch.optim.Adam) on a bounded sample:
+    B=1 window of the same workload, 1 warm-up + `steps` timed training steps."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import manipose_ref as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = dict(orc.FULL_CFG, T=T, n_hyp=K)
+    st = {k: v.requires_grad_(True) for k, v in orc.make_state(cfg, seed=0).items()}
+    opt = torch.optim.Adam(list(st.values()), lr=4e-5, weight_decay=1e-6)
+    X, y = orc.synthetic_batch(1, T, seed=42)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        poses, scores = orc.rmcl_manifold_forward(X, st, orc.oracle_cfg(cfg))
+        total, _ = orc.rmcl_training_loss(poses, scores, y)
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": T / dt, "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"B=1 window T={T} K={K}, eval-mode DropPath off, 1 warm-up + {steps} timed steps (median), "
+                      f"fwd+loss+bwd+Adam, torch {torch.__version__} CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MANIPOSE_BENCH_BATCH", "16")), help="windows per GPU")
+    ap.add_argument("--frames", type=int, default=243)
+    ap.add_argument("--hyp", type=int, default=5)
+    ap.add_argument("--precision", default=os.environ.get("MANIPOSE_PRECISION", "fp32"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    from manipose_amd.training import LiftingTrainer
+    torch.manual_seed(42)
+    model = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=args.frames, n_hyp=args.hyp, drop_path_rate=0.1)
+    with torch.no_grad():                      # exercise the (zero-initialised) positional tables too
+        for n, p in model.named_parameters():
+            if n.endswith("pos_embed"):
+                p.normal_(0.0, 0.02)
+    model.precision = args.precision
+    model.max_batch_hint = args.batch
+    model = model.cuda().train()
+    trainer = LiftingTrainer(model, lr=4e-5, weight_decay=1e-6, seed=42)
+    B, T = args.batch, args.frames
+    g = torch.Generator(device="cuda").manual_seed(42 + rank)
+    X = (0.3 * torch.randn(B, T, 17, 2, device="cuda", generator=g)).clamp(-1, 1)
+    y = 0.3 * torch.randn(B, T, 17, 3, device="cuda", generator=g)
+    y[:, :, 0] = 0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        terms = trainer.train_step(X, y)
+    barrier()
+    eng = model._engine
+    if not args.no_prof:
+        eng.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        terms = trainer.train_step(X, y)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.prof_collect() if not args.no_prof else None
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    loss = float(terms.sum().item())
+    if rank == 0:
+        poses_per_s = world * B * T * args.steps / dt
+        gf = TRAIN_GFLOP_PER_POSE.get(T, 3.705)
+        out = {"metric": "train poses/sec (whole node), H36M T=243 J=17 K=5", "value": poses_per_s, "unit": "poses/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+               "config": {"workload": f"H36M lifting T={T} J=17 K={args.hyp} ManiPose full (C=512, depth 8), train step "
+                                      f"fwd+WTA loss+bwd+allreduce+Adam", "windows_per_gpu": B, "global_batch": world * B,
+                          "seq_len": T, "parallelism": f"dp{world}", "precision": args.precision, "drop_path_rate": 0.1},
+               "loss": loss, "model_tflops": poses_per_s * gf / 1e3}
+        if prof is not None:
+            k = prof["gemm_fwd"]
+            ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+            peak = PEAK_TFLOPS[args.precision]
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<AL=0,BL=0> (forward Linear GEMMs)",
+                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                               "avg_launch_ms": k["ms"] / max(1, k["launches"]), "launches": k["launches"]}
+            tot = sum(v["ms"] for v in prof.values())
+            out["kernel_classes"] = {n: {"ms_per_step": v["ms"] / args.steps, "share": v["ms"] / tot if tot else 0.0,
+                                         "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}
+                                     for n, v in prof.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(T, args.hyp)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

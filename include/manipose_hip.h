@@ -1,0 +1,160 @@
+/* manipose_hip.h -- C ABI of libmanipose_hip.so: the MI355X (gfx950) implementation of ManiPose's
+ * data-parallel 2D->3D lifting hot path.
+ *
+ * The reference (cedricrommel/manipose @ 2025-01-17) is pure Python/PyTorch and has NO native interface;
+ * its "plugin API" for this path is the nn.Module contract of hpe/mh_so3_hpe/architectures.
+ * This header is the boundary a binding for that contract attaches to (ctypes stub: INTEGRATION.md; the
+ * in-tree binding is manipose_amd/_lib.py).  Each entry point names the reference code it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  All data pointers are DEVICE pointers to
+ *     contiguous fp32 buffers unless stated otherwise; `stream` is a hipStream_t (NULL = default stream).
+ *   - every function returns 0 on success, non-zero on error (1 bad argument, 2 HIP runtime error,
+ *     3 bad state); mp_last_error() returns the message of the last failure on the calling thread.
+ *   - calls only ENQUEUE work on `stream`; nothing synchronises the host except mp_prof_collect().
+ *   - token layout everywhere: row m = (b*T + t)*J + j of a (B, T, J, C) activation.
+ *   - pose layout: (B, K, T, 17, 3); scores: (B, K, T[, 1]); targets: (B, T, 17, 3)  (reference layouts).
+ */
+#ifndef MANIPOSE_HIP_H
+#define MANIPOSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_ABI_VERSION 1
+
+int mp_abi_version(void);
+const char* mp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stand-alone operators (the HBM-bound kernels of the path; also used by the roofline harness)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* PoseDecoder.forward: architectures/pose_decoder.py:32-55 = _compute_rotation_mats (:57-83,
+ * utils/rotation_tools.py:35-57) + build_t_pose_from_bone_lengths (:98-120) + forward_kinematics
+ * (utils/forward_kinematics.py:6-48), root at the origin (rmcl_manifold_mix_ste.py:92).
+ *   rot6d  : (K, B*T*17, rot_stride) head output, channels 0..5 are the 6-D rotation (rot_stride >= 6)
+ *   lengths: (B, 16) segment lengths;  poses: (B, K, T, 17, 3) */
+int mp_fk_decode_fwd(const float* rot6d, int rot_stride, const float* lengths, float* poses, int B, int K, int T,
+                     void* stream);
+/* gradient of the above: d_rot6d has rot6d's layout (channels >= 6 untouched); d_len_pose: (B*K*T, 16)
+ * per-pose segment-length gradients (summed over a window's poses by mp_bones_mean_bwd). */
+int mp_fk_decode_bwd(const float* rot6d, int rot_stride, const float* lengths, const float* d_poses, float* d_rot6d,
+                     float* d_len_pose, int B, int K, int T, void* stream);
+
+/* Multi-hypothesis training loss with its gradient, metrics/losses.py:104-170 + :75-101 +
+ * metrics/regularizations.py:160-174 assembled like make_loss/compute_and_acc_loss
+ * (hpe/main_h36m_lifting.py:101-209).  terms (device, 4 floats) = wloss, score_reg, vloss, sreg (already
+ * weighted; total = their sum).  argmin (device int32 (B,T)) / d_poses / d_scores may be NULL.
+ * scratch: >= 4*ceil(B*T/256) floats. */
+typedef struct mp_loss_config {
+  float rmcl_score_reg; /* beta, conf/config.yaml:36 (0.1) */
+  float vel_loss;       /* conf/config.yaml:33 (2.0) */
+  float smooth_reg;     /* conf/config.yaml:34 (0.5) */
+  int w_loss;           /* conf/config.yaml:32: weight joints by STANDARD_H36M_WEIGHTS (losses.py:6-8) */
+} mp_loss_config;
+int mp_wta_loss(const float* poses, const float* scores, const float* target, const mp_loss_config* cfg, float* terms,
+                int32_t* argmin, float* d_poses, float* d_scores, int B, int K, int T, float* scratch,
+                int64_t scratch_floats, void* stream);
+/* single-hypothesis variant (ManifoldMixSTE, make_loss :113-127): terms (3 floats) = wloss, vloss, sreg */
+int mp_single_loss(const float* poses, const float* target, const mp_loss_config* cfg, float* terms, float* d_poses,
+                   int B, int T, float* scratch, int64_t scratch_floats, void* stream);
+
+/* RMCLManifoldMixSTE.aggregate (rmcl_manifold_mix_ste.py:141-185): mode 0 "weighted_ave", 1 "best_score",
+ * 2 "oracle" (needs target).  out: (B, T, 17, 3). */
+int mp_aggregate(const float* poses, const float* scores, const float* target, int mode, float* out, int B, int K, int T,
+                 void* stream);
+/* mpjpe_error(mode="sum") (metrics/mean_joint_errors.py:31-36): out_sum (device, 1 float) = sum of the
+ * per-joint L2 errors of n_joints joints.  scratch >= 4*min(ceil(n/256),1024)+4 floats. */
+int mp_mpjpe_sum(const float* pred, const float* target, int64_t n_joints, float* out_sum, float* scratch,
+                 int64_t scratch_floats, void* stream);
+
+/* torch.optim.Adam(lr, weight_decay) update (hpe/main_h36m_lifting.py:234-238), fused over a flat buffer.
+ * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). step counts from 1. */
+int mp_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
+/* Building blocks exposed for unit parity tests (same kernels the model engine launches). */
+int mp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* stats, int M, int C,
+                     void* stream);
+int mp_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx,
+                     float* dgamma, float* dbeta, int M, int C, float* scratch, int64_t scratch_floats, void* stream);
+/* y = x W^T + b (nn.Linear); epilogue 0 none, 1 GELU (z receives the pre-activation), 2 residual: y = r + y */
+int mp_linear_fwd(const float* x, const float* W, const float* b, float* y, float* z, const float* r, int M, int N, int K,
+                  int epilogue, void* stream);
+/* dx = dy W ; dW += dy^T x ; db += colsum(dy).  slab >= workspace reported by mp_linear_bwd_slab_floats */
+int64_t mp_linear_bwd_slab_floats(int N, int K);
+int mp_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, int M, int N, int K,
+                  float* slab, int64_t slab_floats, void* stream);
+/* Attention core of Attention.forward (architectures/mix_ste.py:271-279) on a fused qkv buffer (M, 3C).
+ * temporal = 0: attends over the J tokens of a frame; 1: over the T frames of a joint. */
+int mp_attention_fwd(const float* qkv, float* out, float* lse, int temporal, int B, int T, int J, int C, int H, void* stream);
+int mp_attention_bwd(const float* qkv, const float* out, const float* d_out, const float* lse, float* delta, float* d_qkv,
+                     int temporal, int B, int T, int J, int C, int H, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model engine: RMCLManifoldMixSTE / ManifoldMixSTE forward + backward as one native launch sequence
+ * (replaces RMCLManifoldMixSTE.forward, architectures/rmcl_manifold_mix_ste.py:83-106 and everything it
+ * calls: mix_ste.py:128-173,216-222,255-282,352-368; manifold_mix_ste.py:75-88,139-154; pose_decoder.py)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mp_model mp_model;
+
+typedef struct mp_model_config {
+  int arch;            /* 0 = "rmcl_manifold" (K heads + scores), 1 = "manifold" (single hypothesis) */
+  int num_frame;       /* T  (cfg.data.seq_len) */
+  int num_joints;      /* 17 */
+  int num_bones;       /* 16 */
+  int embed_dim_rot, depth_rot, num_heads_rot;
+  int embed_dim_seg, depth_seg, num_heads_seg;
+  int n_hyp;           /* K (ignored for arch 1) */
+  float drop_path_rate;/* stochastic depth: linspace(0, rate, depth) per module (mix_ste.py:70) */
+  int max_batch;       /* workspace is sized for this many windows */
+  int precision;       /* 0 = fp32 matrix cores (parity mode), 1 = bf16 matrix cores / fp32 accumulate */
+} mp_model_config;
+
+int mp_model_create(const mp_model_config* cfg, mp_model** out);
+void mp_model_destroy(mp_model* m);
+int64_t mp_model_workspace_bytes(const mp_model* m);
+
+/* Flat parameter layout: parameter i (state-dict key `name`, reference naming) occupies
+ * floats [offset, offset + numel) of the flat parameter buffer (offsets are 16-byte aligned; gaps are
+ * padding).  The gradient buffer and the Adam moment buffers use the same layout. */
+int mp_model_num_params(const mp_model* m);
+int64_t mp_model_flat_size(const mp_model* m);
+int mp_model_param_info(const mp_model* m, int index, char* name, int name_cap, int64_t* offset, int64_t* numel);
+
+/* DropPath mask layout for a batch of B windows: branch i (name like "rotations_module.STEblocks.3.attn")
+ * uses floats [offset, offset+count) of the mask buffer; values are 0 or 1/keep. */
+int mp_model_num_mask_branches(const mp_model* m);
+int mp_model_mask_info(const mp_model* m, int B, int index, char* name, int name_cap, int64_t* offset, int64_t* count,
+                       float* keep_prob);
+int64_t mp_model_mask_floats(const mp_model* m, int B);
+
+/* forward: x (B, T, 17, 2) -> poses (B, K, T, 17, 3) [, scores (B, K, T, 1) for arch 0].
+ * train != 0 applies DropPath: masks = masks_override (device, layout above) if non-NULL, else drawn from
+ * (seed, step).  Activations needed by mp_model_backward are kept inside the model until the next forward. */
+int mp_model_forward(mp_model* m, const float* flat_params, const float* x, int B, float* poses, float* scores, int train,
+                     const float* masks_override, uint64_t seed, uint64_t step, void* stream);
+/* backward of the LAST forward: d_poses (B,K,T,17,3), d_scores (B,K,T,1) or NULL; parameter gradients are
+ * ACCUMULATED into flat_grads (zero it first for a fresh gradient). */
+int mp_model_backward(mp_model* m, const float* flat_params, float* flat_grads, const float* d_poses, const float* d_scores,
+                      void* stream);
+/* intermediate outputs of the last forward (device pointers owned by the model): 0 = head output
+ * (K, B*T*17, O), 1 = segment lengths (B, 16) */
+int mp_model_peek(const mp_model* m, int which, const float** ptr, int64_t* numel);
+
+/* per-kernel-class device timing (HIP events on `stream`): classes 0 gemm_fwd, 1 gemm_dgrad, 2 gemm_wgrad,
+ * 3 attention, 4 layernorm, 5 other.  collect() synchronises the events, adds up elapsed ms / launch counts /
+ * algorithmic FLOPs per class since the last reset and resets. */
+#define MP_PROF_CLASSES 6
+int mp_prof_enable(mp_model* m, int on);
+int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MANIPOSE_HIP_H */

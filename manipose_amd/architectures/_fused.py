@@ -1,0 +1,121 @@
+"""Glue between the nn.Module parameter tree and the native engine: flat parameter storage + autograd bridge."""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional
+
+import torch
+
+from .engine import LiftEngine
+
+
+class _LiftFunction(torch.autograd.Function):
+    """(x, *params) -> poses[, scores] through mp_model_forward; backward through mp_model_backward."""
+
+    @staticmethod
+    def forward(ctx, model, x, train, masks, *params):
+        eng = model._engine
+        model._step_counter += 1
+        poses, scores = eng.forward(model._flat, x, train=train, masks=masks, seed=model._seed, step=model._step_counter)
+        ctx.model = model
+        ctx.has_scores = scores is not None
+        ctx.fwd_id = model._step_counter
+        if scores is None:
+            return poses
+        return poses, scores
+
+    @staticmethod
+    def backward(ctx, d_poses, d_scores=None):
+        model = ctx.model
+        if ctx.fwd_id != model._step_counter:
+            raise RuntimeError("manipose_amd: backward() must follow the forward it belongs to (the engine keeps the "
+                               "activations of the last forward only)")
+        eng = model._engine
+        flat_grads = torch.zeros_like(model._flat)
+        d_poses = d_poses.contiguous()
+        d_scores = d_scores.contiguous() if (ctx.has_scores and d_scores is not None) else None
+        eng.backward(model._flat, flat_grads, d_poses, d_scores)
+        model._last_flat_grad = flat_grads
+        grads = tuple(flat_grads[off:off + n].view(p.shape) for (off, n), p in zip(model._slots, model._plist))
+        return (None, None, None, None) + grads
+
+
+class FusedLiftingMixin:
+    """Mixed into ManifoldMixSTE / RMCLManifoldMixSTE: keeps every nn.Parameter a view of ONE flat device buffer laid
+    out as the engine expects (mp_model_param_info), so that the engine, the fused Adam and the gradient all-reduce
+    each see a single contiguous array while state-dict keys stay those of the reference."""
+
+    def _init_fused(self, arch: str, cfg: dict):
+        self._arch = arch
+        self._engine_cfg = cfg
+        self._engine: Optional[LiftEngine] = None
+        self._flat: Optional[torch.Tensor] = None
+        self._last_flat_grad: Optional[torch.Tensor] = None
+        self._slots: List = []
+        self._plist: List[torch.nn.Parameter] = []
+        self._step_counter = 0
+        self._seed = 42
+        self._injected_masks: Optional[Dict[str, torch.Tensor]] = None
+        self.precision = os.environ.get("MANIPOSE_PRECISION", "fp32")
+        self.max_batch_hint = 0
+
+    # -- engine / flat storage -----------------------------------------------------------------
+    def _ensure_engine(self, B: int, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("manipose_amd: this model runs on MI355X through hand-written HIP kernels only; move the "
+                               "model and its inputs to a ROCm device (model.cuda()). There is no CPU fallback.")
+        eng = self._engine
+        if eng is None or eng.max_batch < B or eng.device != device:
+            with torch.cuda.device(device):
+                self._engine = None
+                eng = LiftEngine(arch=self._arch, max_batch=max(B, self.max_batch_hint), precision=self.precision,
+                                 **self._engine_cfg)
+            self._engine = eng
+            self._flat = None
+        if self._flat is None or not self._views_intact():
+            self._flatten(eng, device)
+
+    def _views_intact(self) -> bool:
+        base = self._flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * off for (off, _), p in zip(self._slots, self._plist))
+
+    def _flatten(self, eng: LiftEngine, device: torch.device):
+        named = dict(self.named_parameters())
+        if set(named) != {n for n, _, _ in eng.layout}:
+            missing = {n for n, _, _ in eng.layout} ^ set(named)
+            raise RuntimeError(f"manipose_amd: parameter tree does not match the engine layout: {sorted(missing)[:6]}")
+        flat = torch.zeros(eng.flat_size, dtype=torch.float32, device=device)
+        self._slots, self._plist = [], []
+        for name, off, numel in eng.layout:
+            p = named[name]
+            if p.numel() != numel:
+                raise RuntimeError(f"manipose_amd: {name} has {p.numel()} elements, engine expects {numel}")
+            flat[off:off + numel].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
+            p.data = flat[off:off + numel].view(p.shape)
+            self._slots.append((off, numel))
+            self._plist.append(p)
+        self._flat = flat
+
+    def flat_parameters(self) -> torch.Tensor:
+        """The single contiguous fp32 buffer all parameters live in (engine layout); build it if needed."""
+        if self._flat is None:
+            p = next(self.parameters())
+            self._ensure_engine(max(1, self.max_batch_hint), p.device)
+        return self._flat
+
+    def set_droppath_masks(self, masks: Optional[Dict[str, torch.Tensor]]):
+        """Inject DropPath multipliers (branch name -> per-sample tensor) for the next train-mode forwards
+        (parity tests); ``None`` returns to the engine's own counter-based RNG."""
+        self._injected_masks = masks
+
+    def _run(self, x: torch.Tensor):
+        if x.dim() != 4 or x.shape[1] != self._engine_cfg["num_frame"] or x.shape[2] != self._engine_cfg["num_joints"] \
+                or x.shape[3] != 2:
+            raise AssertionError(f"expected input of shape (B, {self._engine_cfg['num_frame']}, "
+                                 f"{self._engine_cfg['num_joints']}, 2), got {tuple(x.shape)}")
+        self._ensure_engine(x.shape[0], x.device)
+        x = x.contiguous().float()
+        masks = None
+        if self.training and self._injected_masks is not None:
+            masks = self._engine.pack_masks(x.shape[0], self._injected_masks)
+        return _LiftFunction.apply(self, x, self.training, masks, *self._plist)

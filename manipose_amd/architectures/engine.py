@@ -1,0 +1,107 @@
+"""Python handle on the native model engine (``mp_model_*`` in include/manipose_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import _lib
+
+PRECISIONS = {"fp32": 0, "bf16": 1}
+
+
+class LiftEngine:
+    """Owns one ``mp_model`` (activation workspace + launch sequence) on the current ROCm device."""
+
+    def __init__(self, *, arch: str, num_frame: int, num_joints: int, num_bones: int, embed_dim_rot: int, depth_rot: int,
+                 num_heads_rot: int, embed_dim_seg: int, depth_seg: int, num_heads_seg: int, n_hyp: int,
+                 drop_path_rate: float, max_batch: int, precision: str = "fp32"):
+        self.lib = _lib.load()
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {list(PRECISIONS)}, got {precision}")
+        self.cfg = _lib.ModelConfig(arch={"rmcl_manifold": 0, "manifold": 1}[arch], num_frame=num_frame,
+                                    num_joints=num_joints, num_bones=num_bones, embed_dim_rot=embed_dim_rot,
+                                    depth_rot=depth_rot, num_heads_rot=num_heads_rot, embed_dim_seg=embed_dim_seg,
+                                    depth_seg=depth_seg, num_heads_seg=num_heads_seg, n_hyp=max(1, n_hyp),
+                                    drop_path_rate=drop_path_rate, max_batch=max_batch,
+                                    precision=PRECISIONS[precision])
+        self.arch = arch
+        self.K = max(1, n_hyp) if arch == "rmcl_manifold" else 1
+        self.max_batch = max_batch
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        h = C.c_void_p()
+        _lib.check(self.lib.mp_model_create(C.byref(self.cfg), C.byref(h)), "mp_model_create")
+        self.handle = h
+        self.flat_size = int(self.lib.mp_model_flat_size(h))
+        self.layout: List[Tuple[str, int, int]] = []
+        buf = C.create_string_buffer(256)
+        off, num = C.c_int64(), C.c_int64()
+        for i in range(self.lib.mp_model_num_params(h)):
+            _lib.check(self.lib.mp_model_param_info(h, i, buf, 256, C.byref(off), C.byref(num)), "mp_model_param_info")
+            self.layout.append((buf.value.decode(), int(off.value), int(num.value)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.mp_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self.lib.mp_model_workspace_bytes(self.handle))
+
+    def mask_layout(self, B: int) -> List[Tuple[str, int, int, float]]:
+        buf = C.create_string_buffer(256)
+        off, cnt, keep = C.c_int64(), C.c_int64(), C.c_float()
+        out = []
+        for i in range(self.lib.mp_model_num_mask_branches(self.handle)):
+            _lib.check(self.lib.mp_model_mask_info(self.handle, B, i, buf, 256, C.byref(off), C.byref(cnt), C.byref(keep)),
+                       "mp_model_mask_info")
+            out.append((buf.value.decode(), int(off.value), int(cnt.value), float(keep.value)))
+        return out
+
+    def pack_masks(self, B: int, masks: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Mask dict (branch name -> (count,) multipliers) -> flat device buffer in engine layout (missing = 1)."""
+        n = int(self.lib.mp_model_mask_floats(self.handle, B))
+        flat = torch.ones(max(n, 1), dtype=torch.float32, device=self.device)
+        for name, off, cnt, _ in self.mask_layout(B):
+            if name in masks:
+                flat[off:off + cnt] = masks[name].reshape(-1).to(self.device, torch.float32)
+        return flat
+
+    def forward(self, flat_params: torch.Tensor, x: torch.Tensor, train: bool = False,
+                masks: Optional[torch.Tensor] = None, seed: int = 0, step: int = 0):
+        B, T = x.shape[0], x.shape[1]
+        poses = torch.empty(B, self.K, T, 17, 3, dtype=torch.float32, device=x.device)
+        scores = torch.empty(B, self.K, T, 1, dtype=torch.float32, device=x.device) if self.arch == "rmcl_manifold" else None
+        _lib.check(self.lib.mp_model_forward(self.handle, _lib.ptr(flat_params), _lib.ptr(x), B, _lib.ptr(poses),
+                                             _lib.ptr(scores), int(train), _lib.ptr(masks), seed, step, _lib.stream_ptr()),
+                   "mp_model_forward")
+        return poses, scores
+
+    def backward(self, flat_params: torch.Tensor, flat_grads: torch.Tensor, d_poses: torch.Tensor,
+                 d_scores: Optional[torch.Tensor]) -> None:
+        _lib.check(self.lib.mp_model_backward(self.handle, _lib.ptr(flat_params), _lib.ptr(flat_grads), _lib.ptr(d_poses),
+                                              _lib.ptr(d_scores), _lib.stream_ptr()), "mp_model_backward")
+
+    def peek(self, which: int) -> torch.Tensor:
+        """Copy of an intermediate of the last forward: 0 head output (K, B*T*17, O), 1 segment lengths (B, 16)."""
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.mp_model_peek(self.handle, which, C.byref(p), C.byref(n)), "mp_model_peek")
+        out = torch.empty(int(n.value), dtype=torch.float32, device=self.device)
+        rc = torch.cuda.cudart().cudaMemcpy(out.data_ptr(), p.value, int(n.value) * 4, 3)   # 3 = device to device
+        if int(rc) != 0:
+            raise RuntimeError(f"hipMemcpy failed with code {rc}")
+        return out
+
+    def prof_enable(self, on: bool = True) -> None:
+        _lib.check(self.lib.mp_prof_enable(self.handle, int(on)), "mp_prof_enable")
+
+    def prof_collect(self) -> Dict[str, Dict[str, float]]:
+        n = len(_lib.PROF_CLASSES)
+        ms, cnt, fl = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)()
+        _lib.check(self.lib.mp_prof_collect(self.handle, ms, cnt, fl), "mp_prof_collect")
+        return {name: {"ms": ms[i], "launches": int(cnt[i]), "flops": fl[i]} for i, name in enumerate(_lib.PROF_CLASSES)}

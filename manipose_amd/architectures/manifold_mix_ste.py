@@ -1,0 +1,60 @@
+"""ManifoldMixSTE (single hypothesis) and BonesMixSTE with the reference's constructor / forward contract
+(hpe/mh_so3_hpe/architectures/manifold_mix_ste.py:10-88, :91-154); the forward runs in the native HIP engine."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ._fused import FusedLiftingMixin
+from .mix_ste import MixSTE
+from .pose_decoder import PoseDecoder
+
+
+class BonesMixSTE(MixSTE):
+    """Segment-length network container (reference :91-137): a MixSTE over num_bones tokens whose patch embedding is
+    replaced by one Linear(J*in_chans -> S*C) and whose output is averaged over time (done by the engine)."""
+
+    def __init__(self, num_frame=243, num_joints=17, num_bones=16, in_chans=2, out_dim=1, embed_dim=128, depth=2,
+                 num_heads=8, mlp_ratio=2, qkv_bias=True, qk_scale=None, drop_rate=0, attn_drop_rate=0, drop_path_rate=0.2,
+                 norm_layer=None, mup=False):
+        super().__init__(num_frame=num_frame, num_joints=num_bones, in_chans=in_chans, out_dim=out_dim,
+                         embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=float(mlp_ratio),
+                         qkv_bias=qkv_bias, qk_scale=qk_scale, drop_rate=float(drop_rate),
+                         attn_drop_rate=float(attn_drop_rate), drop_path_rate=drop_path_rate, norm_layer=norm_layer, mup=mup)
+        self.num_joints = num_joints
+        self.num_bones = num_bones
+        self.embed_dim = embed_dim
+        self.Spatial_patch_to_embedding = nn.Identity()
+        self.joints_to_segments_proj = nn.Linear(in_features=num_joints * in_chans, out_features=num_bones * embed_dim)
+
+
+class ManifoldMixSTE(FusedLiftingMixin, nn.Module):
+    def __init__(self, skeleton, num_frame: int = 243, num_joints: int = 17, num_bones: int = 16, in_chans: int = 2,
+                 rot_rep_dim: int = 6, embed_dim_rot: int = 512, depth_rot: int = 8, num_heads_rot: int = 8,
+                 embed_dim_seg: int = 128, depth_seg: int = 2, num_heads_seg: int = 8, mlp_ratio: float = 2.0,
+                 qkv_bias: bool = True, qk_scale: float = None, drop_rate: float = 0.0, attn_drop_rate: float = 0.0,
+                 drop_path_rate: float = 0.2, norm_layer: nn.Module = None, mup: bool = False):
+        nn.Module.__init__(self)
+        if in_chans != 2:
+            raise NotImplementedError("manipose_amd: the input embedding kernels take 2-D keypoints (in_chans=2)")
+        self.num_joints = num_joints
+        self.rotations_module = MixSTE(num_frame=num_frame, num_joints=num_joints, in_chans=in_chans, out_dim=rot_rep_dim,
+                                       embed_dim=embed_dim_rot, depth=depth_rot, num_heads=num_heads_rot,
+                                       mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop_rate=drop_rate,
+                                       attn_drop_rate=attn_drop_rate, drop_path_rate=drop_path_rate, norm_layer=norm_layer,
+                                       mup=mup)
+        self.segments_module = BonesMixSTE(num_frame=num_frame, num_joints=num_joints, num_bones=num_bones,
+                                           in_chans=in_chans, out_dim=1, embed_dim=embed_dim_seg, depth=depth_seg,
+                                           num_heads=num_heads_seg, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                           qk_scale=qk_scale, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate,
+                                           drop_path_rate=drop_path_rate, norm_layer=norm_layer, mup=mup)
+        self.decoder = PoseDecoder(skeleton=skeleton, rot_rep_dim=rot_rep_dim)
+        self._init_fused("manifold", dict(num_frame=num_frame, num_joints=num_joints, num_bones=num_bones,
+                                          embed_dim_rot=embed_dim_rot, depth_rot=depth_rot, num_heads_rot=num_heads_rot,
+                                          embed_dim_seg=embed_dim_seg, depth_seg=depth_seg, num_heads_seg=num_heads_seg,
+                                          n_hyp=1, drop_path_rate=drop_path_rate))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x (B, L, J, 2) -> poses (B, L, J, 3); root joint exactly 0 (reference :75-88)."""
+        poses = self._run(x)                       # (B, 1, L, J, 3)
+        return poses[:, 0]

@@ -1,0 +1,114 @@
+// extern "C" shims of the stand-alone operators declared in include/manipose_hip.h
+#include "common.h"
+#include "kernels.h"
+#include "../../include/manipose_hip.h"
+
+namespace mp {
+const char* last_error();
+long wgrad_f32_slab_floats(int Mtok, int Nout, int Kin);
+}
+using namespace mp;
+
+static LossCfg to_cfg(const mp_loss_config* c) {
+  LossCfg l;
+  l.beta = c->rmcl_score_reg; l.vel_w = c->vel_loss; l.smooth_w = c->smooth_reg; l.use_joint_weights = c->w_loss;
+  return l;
+}
+
+extern "C" {
+
+int mp_abi_version(void) { return MP_ABI_VERSION; }
+const char* mp_last_error(void) { return mp::last_error(); }
+
+int mp_fk_decode_fwd(const float* rot6d, int rot_stride, const float* lengths, float* poses, int B, int K, int T, void* stream) {
+  MP_CHECK(rot6d && lengths && poses, MP_ERR_ARG, "mp_fk_decode_fwd: null pointer");
+  return fk_decode_fwd(rot6d, rot_stride, lengths, poses, B, K, T, (hipStream_t)stream);
+}
+int mp_fk_decode_bwd(const float* rot6d, int rot_stride, const float* lengths, const float* d_poses, float* d_rot6d,
+                     float* d_len_pose, int B, int K, int T, void* stream) {
+  MP_CHECK(rot6d && lengths && d_poses && d_rot6d && d_len_pose, MP_ERR_ARG, "mp_fk_decode_bwd: null pointer");
+  return fk_decode_bwd(rot6d, rot_stride, lengths, d_poses, d_rot6d, d_len_pose, B, K, T, (hipStream_t)stream);
+}
+
+int mp_wta_loss(const float* poses, const float* scores, const float* target, const mp_loss_config* cfg, float* terms,
+                int32_t* argmin, float* d_poses, float* d_scores, int B, int K, int T, float* scratch, int64_t scratch_floats,
+                void* stream) {
+  MP_CHECK(poses && scores && target && cfg && terms && scratch, MP_ERR_ARG, "mp_wta_loss: null pointer");
+  return wta_loss(poses, scores, target, to_cfg(cfg), terms, argmin, d_poses, d_scores, B, K, T, scratch, scratch_floats,
+                  (hipStream_t)stream);
+}
+int mp_single_loss(const float* poses, const float* target, const mp_loss_config* cfg, float* terms, float* d_poses, int B, int T,
+                   float* scratch, int64_t scratch_floats, void* stream) {
+  MP_CHECK(poses && target && cfg && terms && scratch, MP_ERR_ARG, "mp_single_loss: null pointer");
+  return single_loss(poses, target, to_cfg(cfg), terms, d_poses, B, T, scratch, scratch_floats, (hipStream_t)stream);
+}
+int mp_aggregate(const float* poses, const float* scores, const float* target, int mode, float* out, int B, int K, int T,
+                 void* stream) {
+  MP_CHECK(poses && out, MP_ERR_ARG, "mp_aggregate: null pointer");
+  return aggregate_poses(poses, scores, target, mode, out, B, K, T, (hipStream_t)stream);
+}
+int mp_mpjpe_sum(const float* pred, const float* target, int64_t n_joints, float* out_sum, float* scratch, int64_t scratch_floats,
+                 void* stream) {
+  MP_CHECK(pred && target && out_sum && scratch && n_joints > 0, MP_ERR_ARG, "mp_mpjpe_sum: bad argument");
+  return mpjpe_sum(pred, target, n_joints, out_sum, scratch, scratch_floats, (hipStream_t)stream);
+}
+int mp_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+  MP_CHECK(params && grads && exp_avg && exp_avg_sq && n > 0, MP_ERR_ARG, "mp_adam_step: bad argument");
+  return adam_step(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                   (hipStream_t)stream);
+}
+
+int mp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* stats, int M, int C,
+                     void* stream) {
+  MP_CHECK(x && gamma && beta && y && stats, MP_ERR_ARG, "mp_layernorm_fwd: null pointer");
+  LnFwdArgs a = {};
+  a.x = x; a.M = M; a.C = C; a.g2 = gamma; a.b2 = beta; a.eps2 = eps; a.y2 = y; a.stats2 = stats;
+  return ln_fwd(a, 0, (hipStream_t)stream);
+}
+int mp_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx,
+                     float* dgamma, float* dbeta, int M, int C, float* scratch, int64_t scratch_floats, void* stream) {
+  MP_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta && scratch, MP_ERR_ARG, "mp_layernorm_bwd: null pointer");
+  return ln_bwd(dy, x, stats, gamma, dskip, dx, dgamma, dbeta, M, C, scratch, scratch_floats, (hipStream_t)stream);
+}
+
+int mp_linear_fwd(const float* x, const float* W, const float* b, float* y, float* z, const float* r, int M, int N, int K,
+                  int epilogue, void* stream) {
+  MP_CHECK(x && W && y, MP_ERR_ARG, "mp_linear_fwd: null pointer");
+  MP_CHECK(epilogue >= 0 && epilogue <= 2, MP_ERR_ARG, "mp_linear_fwd: epilogue %d", epilogue);
+  MP_CHECK(epilogue != 1 || z, MP_ERR_ARG, "mp_linear_fwd: GELU epilogue needs z");
+  MP_CHECK(epilogue != 2 || r, MP_ERR_ARG, "mp_linear_fwd: residual epilogue needs r");
+  GemmF32Args g = {};
+  g.A = x; g.lda = K; g.B = W; g.ldb = K; g.C = y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b; g.Z = z; g.R = r;
+  return gemm_f32(0, 0, epilogue == 0 ? EPI_BIAS : (epilogue == 1 ? EPI_BIAS_GELU : EPI_BIAS_RESID), g, (hipStream_t)stream);
+}
+int64_t mp_linear_bwd_slab_floats(int N, int K) {
+  const int tiles = cdiv(N, 128) * cdiv(K, 128);
+  const int splits = max(1, min(64, (1024 + tiles - 1) / tiles));
+  return ((int64_t)N * K + N) * (splits + 1);
+}
+int mp_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, int M, int N, int K,
+                  float* slab, int64_t slab_floats, void* stream) {
+  MP_CHECK(dy && x && W && dW && slab, MP_ERR_ARG, "mp_linear_bwd: null pointer");
+  if (dx) {
+    GemmF32Args g = {};
+    g.A = dy; g.lda = N; g.B = W; g.ldb = K; g.C = dx; g.ldc = K; g.M = M; g.N = K; g.K = N;
+    int rc = gemm_f32(0, 1, EPI_BIAS, g, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return wgrad_f32(dy, N, x, K, M, N, K, dW, db, slab, slab_floats, (hipStream_t)stream);
+}
+
+int mp_attention_fwd(const float* qkv, float* out, float* lse, int temporal, int B, int T, int J, int C, int H, void* stream) {
+  MP_CHECK(qkv && out && (!temporal || lse), MP_ERR_ARG, "mp_attention_fwd: null pointer");
+  return temporal ? attn_temporal_fwd(qkv, out, lse, B, T, J, C, H, (hipStream_t)stream)
+                  : attn_spatial_fwd(qkv, out, B, T, J, C, H, (hipStream_t)stream);
+}
+int mp_attention_bwd(const float* qkv, const float* out, const float* d_out, const float* lse, float* delta, float* d_qkv,
+                     int temporal, int B, int T, int J, int C, int H, void* stream) {
+  MP_CHECK(qkv && d_out && d_qkv && (!temporal || (out && lse && delta)), MP_ERR_ARG, "mp_attention_bwd: null pointer");
+  return temporal ? attn_temporal_bwd(qkv, out, d_out, lse, delta, d_qkv, B, T, J, C, H, (hipStream_t)stream)
+                  : attn_spatial_bwd(qkv, d_out, d_qkv, B, T, J, C, H, (hipStream_t)stream);
+}
+
+}  // extern "C"

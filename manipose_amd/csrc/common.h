@@ -1,0 +1,94 @@
+// Shared helpers for the ManiPose gfx950 kernels (internal; the public surface is include/manipose_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+
+namespace mp {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define MP_CHECK(cond, code, ...)                 \
+  do {                                            \
+    if (!(cond)) {                                \
+      mp::set_error(__VA_ARGS__);                 \
+      return (code);                              \
+    }                                             \
+  } while (0)
+#define MP_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      mp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return MP_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+#define MP_LAUNCH_CHECK() MP_HIP(hipGetLastError())
+
+enum { MP_OK = 0, MP_ERR_ARG = 1, MP_ERR_HIP = 2, MP_ERR_STATE = 3 };
+
+__host__ __device__ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- activation storage types ---------------------------------------------------------------
+typedef __hip_bfloat16 bf16;
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16 v) { return __bfloat162float(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return __float2bfloat16(v); }
+
+// 4-wide vector load/store of activations as floats (16 B for f32, 8 B for bf16)
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 ld4(const bf16* p) {
+  uint2 r = *reinterpret_cast<const uint2*>(p);
+  float4 v;
+  v.x = __uint_as_float(r.x << 16);
+  v.y = __uint_as_float(r.x & 0xffff0000u);
+  v.z = __uint_as_float(r.y << 16);
+  v.w = __uint_as_float(r.y & 0xffff0000u);
+  return v;
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  bf16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
+  return (unsigned)(*reinterpret_cast<unsigned short*>(&a)) | ((unsigned)(*reinterpret_cast<unsigned short*>(&b)) << 16);
+}
+__device__ __forceinline__ void st4(bf16* p, float4 v) {
+  uint2 r;
+  r.x = pack_bf16x2(v.x, v.y);
+  r.y = pack_bf16x2(v.z, v.w);
+  *reinterpret_cast<uint2*>(p) = r;
+}
+
+// ---- wave (64-lane) reductions ----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact (erf) GELU and its derivative, as torch.nn.GELU() (mix_ste.py:297 act_layer=nn.GELU)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// DropPath row-group index of token row m (layout (b,t,j), m = (b*T + t)*J + j):
+// mode 1 = spatial block: sample = (b,t) = m / J ; mode 2 = temporal block: sample = (b,j)
+__device__ __forceinline__ float droppath_scale(const float* mask, int mode, int m, int T, int J) {
+  if (mask == nullptr || mode == 0) return 1.0f;
+  if (mode == 1) return mask[m / J];
+  const int b = m / (T * J);
+  return mask[b * J + (m % J)];
+}
+
+}  // namespace mp

@@ -1,0 +1,498 @@
+// HBM-bound row kernels of the MixSTE backbone: LayerNorm fwd/bwd (wave per token row), the two input
+// embeddings, positional-embedding gradients, DropPath masks and the fused Adam update.
+#include <stdarg.h>
+#include "common.h"
+#include "kernels.h"
+
+namespace mp {
+
+// ---------------------------------------------------------------------------------------------
+// error string
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm forward.  mix_ste.py:353-358 (norm1/norm2, eps 1e-6), :143,154,166,170 (shared
+// Spatial_norm / Temporal_norm), :149 (x += Temporal_pos_embed fused behind the spatial post-norm).
+// One wave per token row, row held in registers (C <= 1024), two-pass mean/variance like ATen.
+// ---------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 4;  // float4 per lane -> C <= 1024
+
+__device__ __forceinline__ void row_stats(const float4 (&v)[LN_MAXV], int lane, int C, float eps, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i)
+    if (lane * 4 + 256 * i < C) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i)
+    if (lane * 4 + 256 * i < C) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int C = a.C;
+  for (int m = wave; m < a.M; m += nwaves) {
+    float4 v[LN_MAXV];
+    const float* xr = a.x + (long)m * C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < C) v[i] = ld4(xr + c);
+    }
+    if (a.g1 != nullptr) {
+      float mean, rstd;
+      row_stats(v, lane, C, a.eps1, mean, rstd);
+      const float* pr = (a.pos != nullptr) ? a.pos + (long)((m / a.J) % a.T) * C : nullptr;
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < C) {
+          const float4 g = ld4(a.g1 + c), b = ld4(a.b1 + c);
+          float4 o;
+          o.x = (v[i].x - mean) * rstd * g.x + b.x;
+          o.y = (v[i].y - mean) * rstd * g.y + b.y;
+          o.z = (v[i].z - mean) * rstd * g.z + b.z;
+          o.w = (v[i].w - mean) * rstd * g.w + b.w;
+          if (pr != nullptr) {
+            const float4 p = ld4(pr + c);
+            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+          }
+          v[i] = o;
+          st4(a.x1 + (long)m * C + c, o);
+        }
+      }
+      if (lane == 0) {
+        a.stats1[2 * (long)m] = mean;
+        a.stats1[2 * (long)m + 1] = rstd;
+      }
+    }
+    if (a.g2 != nullptr) {
+      float mean, rstd;
+      row_stats(v, lane, C, a.eps2, mean, rstd);
+      T* yr = reinterpret_cast<T*>(a.y2) + (long)m * C;
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < C) {
+          const float4 g = ld4(a.g2 + c), b = ld4(a.b2 + c);
+          float4 o;
+          o.x = (v[i].x - mean) * rstd * g.x + b.x;
+          o.y = (v[i].y - mean) * rstd * g.y + b.y;
+          o.z = (v[i].z - mean) * rstd * g.z + b.z;
+          o.w = (v[i].w - mean) * rstd * g.w + b.w;
+          st4(yr + c, o);
+        }
+      }
+      if (lane == 0) {
+        a.stats2[2 * (long)m] = mean;
+        a.stats2[2 * (long)m + 1] = rstd;
+      }
+    }
+  }
+}
+
+static int row_grid(int M) { return max(1, min(cdiv(M, 4), 256 * 8)); }
+
+int ln_fwd(const LnFwdArgs& a, int out_bf16, hipStream_t st) {
+  MP_CHECK(a.C % 4 == 0 && a.C <= 256 * LN_MAXV, MP_ERR_ARG, "ln_fwd: C=%d must be a multiple of 4 and <= 1024", a.C);
+  MP_CHECK(a.g1 != nullptr || a.g2 != nullptr, MP_ERR_ARG, "ln_fwd: no stage requested");
+  if (out_bf16)
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16>, dim3(row_grid(a.M)), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(row_grid(a.M)), dim3(256), 0, st, a);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward: dx = [dskip +] rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)),
+// dxhat = dy * gamma.  dgamma/dbeta: per-wave register sums -> per-block LDS sum -> partial rows
+// in scratch -> reduce_partials_kernel (deterministic, no atomics).
+// ---------------------------------------------------------------------------------------------
+constexpr int LNB_GRID = 512;
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                      const float* dskip, float* dx, float* __restrict__ partial, int M,
+                                                      int C) {
+  __shared__ float red[4 * 2 * 1024];  // [wave][dgamma|dbeta][C<=1024]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  float4 dg[LN_MAXV], db[LN_MAXV], gm[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = lane * 4 + 256 * i;
+    gm[i] = (c < C) ? ld4(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int m = wave; m < M; m += nwaves) {
+    const float mean = stats[2 * (long)m], rstd = stats[2 * (long)m + 1];
+    float4 xh[LN_MAXV], d[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < C) {
+        const float4 xv = ld4(x + (long)m * C + c);
+        const float4 g = ld4(dy + (long)m * C + c);
+        xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        dg[i].x += g.x * xh[i].x; dg[i].y += g.y * xh[i].y; dg[i].z += g.z * xh[i].z; dg[i].w += g.w * xh[i].w;
+        db[i].x += g.x; db[i].y += g.y; db[i].z += g.z; db[i].w += g.w;
+        d[i] = make_float4(g.x * gm[i].x, g.y * gm[i].y, g.z * gm[i].z, g.w * gm[i].w);
+        s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+        s2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < C) {
+        float4 o;
+        o.x = rstd * (d[i].x - s1 - xh[i].x * s2);
+        o.y = rstd * (d[i].y - s1 - xh[i].y * s2);
+        o.z = rstd * (d[i].z - s1 - xh[i].z * s2);
+        o.w = rstd * (d[i].w - s1 - xh[i].w * s2);
+        if (dskip != nullptr) {
+          const float4 k = ld4(dskip + (long)m * C + c);
+          o.x += k.x; o.y += k.y; o.z += k.z; o.w += k.w;
+        }
+        st4(dx + (long)m * C + c, o);
+      }
+    }
+  }
+  // block reduction of dgamma/dbeta
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < C) {
+      *reinterpret_cast<float4*>(&red[(wv * 2 + 0) * 1024 + c]) = dg[i];
+      *reinterpret_cast<float4*>(&red[(wv * 2 + 1) * 1024 + c]) = db[i];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i - which * C;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * 1024 + c];
+    partial[(long)blockIdx.x * 2 * C + i] = s;
+  }
+}
+
+// out segment j (<=4): dst[j][i] += sum_p partial[p][off_j + i]
+struct ReduceDst { float* dst[4]; int off[5]; int stride[4]; };
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int P, int n, ReduceDst d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += partial[(long)p * n + i];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (i >= d.off[j] && i < d.off[j + 1] && d.dst[j] != nullptr) d.dst[j][(long)(i - d.off[j]) * d.stride[j]] += s;
+}
+
+int ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx,
+           float* dgamma, float* dbeta, int M, int C, float* scratch, long scratch_floats, hipStream_t st) {
+  MP_CHECK(C % 4 == 0 && C <= 1024, MP_ERR_ARG, "ln_bwd: C=%d unsupported", C);
+  const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
+  MP_CHECK(scratch_floats >= (long)grid * 2 * C, MP_ERR_ARG, "ln_bwd: scratch too small");
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, st, dy, x, stats, gamma, dskip, dx, scratch, M, C);
+  MP_LAUNCH_CHECK();
+  ReduceDst d = {{dgamma, dbeta, nullptr, nullptr}, {0, C, 2 * C, 2 * C, 2 * C}, {1, 1, 1, 1}};
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, scratch, grid, 2 * C, d);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rotation backbone input embedding: Linear(2, C) + Spatial_pos_embed (mix_ste.py:134-138)
+// ---------------------------------------------------------------------------------------------
+__global__ void embed_fwd_kernel(const float* __restrict__ xin, const float* __restrict__ W, const float* __restrict__ b,
+                                 const float* __restrict__ spos, float* __restrict__ out, int M, int C, int J) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 of channels
+  const int c4 = C / 4;
+  if (i >= (long)M * c4) return;
+  const int m = (int)(i / c4), c = (int)(i % c4) * 4;
+  const float x0 = xin[2 * (long)m], x1 = xin[2 * (long)m + 1];
+  const float4 w01 = ld4(W + 2 * c), w23 = ld4(W + 2 * c + 4);   // W[c][0..1] interleaved
+  const float4 bb = ld4(b + c), p = ld4(spos + (long)(m % J) * C + c);
+  float4 o;
+  o.x = w01.x * x0 + w01.y * x1 + bb.x + p.x;
+  o.y = w01.z * x0 + w01.w * x1 + bb.y + p.y;
+  o.z = w23.x * x0 + w23.y * x1 + bb.z + p.z;
+  o.w = w23.z * x0 + w23.w * x1 + bb.w + p.w;
+  st4(out + (long)m * C + c, o);
+}
+
+int embed_fwd(const float* xin, const float* W, const float* b, const float* spos, float* out, int M, int C, int J,
+              hipStream_t st) {
+  MP_CHECK(C % 4 == 0, MP_ERR_ARG, "embed_fwd: C %% 4");
+  const long n = (long)M * (C / 4);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, xin, W, b, spos, out, M, C, J);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// dW[c][i] = sum_m g[m][c] x[m][i]; db[c] = sum_m g[m][c]; dspos[j][c] = sum_{m % J == j} g[m][c]
+// grid (cdiv(C,256), chunks): thread = channel, rows of a chunk walked frame by frame.
+constexpr int EMB_CHUNKS = 128;
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g, const float* __restrict__ xin,
+                                                         float* __restrict__ partial, int M, int C, int J) {
+  extern __shared__ float sp[];  // [J][256] spatial-pos partial sums
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int frames = M / J;
+  const int per = cdiv(frames, gridDim.y);
+  const int f0 = blockIdx.y * per, f1 = min(frames, f0 + per);
+  for (int j = 0; j < J; ++j) sp[j * 256 + threadIdx.x] = 0.f;
+  float w0 = 0.f, w1 = 0.f, bs = 0.f;
+  if (c < C) {
+    for (int f = f0; f < f1; ++f) {
+      for (int j = 0; j < J; ++j) {
+        const long m = (long)f * J + j;
+        const float v = g[m * C + c];
+        w0 += v * xin[2 * m];
+        w1 += v * xin[2 * m + 1];
+        bs += v;
+        sp[j * 256 + threadIdx.x] += v;
+      }
+    }
+    const long n = (long)(3 + J) * C;
+    float* pr = partial + (long)blockIdx.y * n;
+    pr[2 * c] = w0;
+    pr[2 * c + 1] = w1;
+    pr[2 * C + c] = bs;
+    for (int j = 0; j < J; ++j) pr[3 * C + (long)j * C + c] = sp[j * 256 + threadIdx.x];
+  }
+}
+
+int embed_bwd(const float* g, const float* xin, float* dW, float* db, float* dspos, int M, int C, int J, float* scratch,
+              long scratch_floats, hipStream_t st) {
+  const int chunks = max(1, min(EMB_CHUNKS, M / J));
+  const int n = (3 + J) * C;
+  MP_CHECK(scratch_floats >= (long)chunks * n, MP_ERR_ARG, "embed_bwd: scratch too small");
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(cdiv(C, 256), chunks), dim3(256), J * 256 * sizeof(float), st, g, xin, scratch,
+                     M, C, J);
+  MP_LAUNCH_CHECK();
+  ReduceDst d = {{dW, db, dspos, nullptr}, {0, 2 * C, 3 * C, n, n}, {1, 1, 1, 1}};
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, scratch, chunks, n, d);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bones net input: Linear(J*2 = IN, S*Cs = O) + Spatial_pos_embed flattened (manifold_mix_ste.py:133-150)
+// ---------------------------------------------------------------------------------------------
+constexpr int BE_FRAMES = 8, BE_IN = 34;
+__global__ __launch_bounds__(256) void bones_embed_fwd_kernel(const float* __restrict__ xin, const float* __restrict__ W,
+                                                               const float* __restrict__ b, const float* __restrict__ spos,
+                                                               float* __restrict__ out, int BT, int O) {
+  __shared__ float xs[BE_FRAMES * BE_IN];
+  const int f0 = blockIdx.y * BE_FRAMES;
+  for (int i = threadIdx.x; i < BE_FRAMES * BE_IN; i += 256) {
+    const int f = f0 + i / BE_IN;
+    xs[i] = (f < BT) ? xin[(long)f0 * BE_IN + i] : 0.f;
+  }
+  __syncthreads();
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= O) return;
+  float acc[BE_FRAMES];
+  const float base = b[o] + spos[o];
+#pragma unroll
+  for (int f = 0; f < BE_FRAMES; ++f) acc[f] = base;
+  for (int i = 0; i < BE_IN; ++i) {
+    const float w = W[(long)o * BE_IN + i];
+#pragma unroll
+    for (int f = 0; f < BE_FRAMES; ++f) acc[f] += w * xs[f * BE_IN + i];
+  }
+#pragma unroll
+  for (int f = 0; f < BE_FRAMES; ++f)
+    if (f0 + f < BT) out[(long)(f0 + f) * O + o] = acc[f];
+}
+
+int bones_embed_fwd(const float* xin, const float* W, const float* b, const float* spos, float* out, int BT, int IN, int O,
+                    hipStream_t st) {
+  MP_CHECK(IN == BE_IN, MP_ERR_ARG, "bones_embed_fwd: in_features %d != 34 (17 joints x 2)", IN);
+  hipLaunchKernelGGL(bones_embed_fwd_kernel, dim3(cdiv(O, 256), cdiv(BT, BE_FRAMES)), dim3(256), 0, st, xin, W, b, spos, out,
+                     BT, O);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+constexpr int BEB_CHUNKS = 32;
+__global__ __launch_bounds__(256) void bones_embed_bwd_kernel(const float* __restrict__ g, const float* __restrict__ xin,
+                                                               float* __restrict__ partial, int BT, int O) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int per = cdiv(BT, gridDim.y);
+  const int f0 = blockIdx.y * per, f1 = min(BT, f0 + per);
+  if (o >= O) return;
+  float acc[BE_IN + 1];
+#pragma unroll
+  for (int i = 0; i <= BE_IN; ++i) acc[i] = 0.f;
+  for (int f = f0; f < f1; ++f) {
+    const float v = g[(long)f * O + o];
+    const float* xr = xin + (long)f * BE_IN;   // wave-uniform address
+#pragma unroll
+    for (int i = 0; i < BE_IN; ++i) acc[i] += v * xr[i];
+    acc[BE_IN] += v;
+  }
+  float* pr = partial + (long)blockIdx.y * O * (BE_IN + 1);
+#pragma unroll
+  for (int i = 0; i < BE_IN; ++i) pr[(long)o * BE_IN + i] = acc[i];
+  pr[(long)O * BE_IN + o] = acc[BE_IN];
+}
+
+__global__ void add_vec_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+int bones_embed_bwd(const float* g, const float* xin, float* dW, float* db, float* dspos, int BT, int IN, int O,
+                    float* scratch, long scratch_floats, hipStream_t st) {
+  MP_CHECK(IN == BE_IN, MP_ERR_ARG, "bones_embed_bwd: in_features %d != 34", IN);
+  const int chunks = max(1, min(BEB_CHUNKS, BT));
+  const int n = O * (BE_IN + 1);
+  MP_CHECK(scratch_floats >= (long)(chunks + 1) * n, MP_ERR_ARG, "bones_embed_bwd: scratch too small");
+  hipLaunchKernelGGL(bones_embed_bwd_kernel, dim3(cdiv(O, 256), chunks), dim3(256), 0, st, g, xin, scratch, BT, O);
+  MP_LAUNCH_CHECK();
+  // the positional table is added exactly like the bias (index o = s*Cs + c), so dspos == db contribution
+  ReduceDst d = {{dW, db, nullptr, nullptr}, {0, O * BE_IN, n, n, n}, {1, 1, 1, 1}};
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, scratch, chunks, n, d);
+  MP_LAUNCH_CHECK();
+  ReduceDst d2 = {{nullptr, dspos, nullptr, nullptr}, {0, O * BE_IN, n, n, n}, {1, 1, 1, 1}};
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, scratch, chunks, n, d2);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dTemporal_pos_embed[t][c] += sum_{b,j} g[(b,t,j)][c]   (mix_ste.py:149)
+// ---------------------------------------------------------------------------------------------
+__global__ void tpos_grad_kernel(const float* __restrict__ g, float* __restrict__ dtpos, int B, int T, int J, int C) {
+  const int t = blockIdx.x, c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < J; ++j) s += g[((long)(b * T + t) * J + j) * C + c];
+  dtpos[(long)t * C + c] += s;
+}
+
+int tpos_grad(const float* g, float* dtpos, int B, int T, int J, int C, hipStream_t st) {
+  hipLaunchKernelGGL(tpos_grad_kernel, dim3(T, cdiv(C, 128)), dim3(128), 0, st, g, dtpos, B, T, J, C);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// out[m][:] = mask(m) * g[m][:]  (DropPath backward on a branch gradient)
+__global__ void scale_rows_kernel(const float* __restrict__ g, const float* __restrict__ mask, int mode, float* __restrict__ out,
+                                  int M, int C, int T, int J) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C / 4;
+  if (i >= (long)M * c4) return;
+  const int m = (int)(i / c4);
+  const float s = droppath_scale(mask, mode, m, T, J);
+  float4 v = ld4(g + i * 4);
+  v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+  st4(out + i * 4, v);
+}
+
+int scale_rows(const float* g, const float* mask, int mask_mode, float* out, int M, int C, int T, int J, hipStream_t st) {
+  const long n = (long)M * (C / 4);
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, g, mask, mask_mode, out, M, C, T, J);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam with L2 weight decay == torch.optim.Adam(lr, weight_decay) (main_h36m_lifting.py:234-238)
+// ---------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr_bc1, float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd,
+                            float gscale) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 pp = ld4(p + i), gg = ld4(g + i), mm = ld4(m + i), vv = ld4(v + i);
+    float* P = &pp.x; float* G = &gg.x; float* Mo = &mm.x; float* V = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = G[k] * gscale + wd * P[k];
+      Mo[k] = beta1 * Mo[k] + (1.f - beta1) * gr;
+      V[k] = beta2 * V[k] + (1.f - beta2) * gr * gr;
+      P[k] -= lr_bc1 * (Mo[k] / (sqrtf(V[k]) * inv_sqrt_bc2 + eps));
+    }
+    st4(p + i, pp); st4(m + i, mm); st4(v + i, vv);
+  } else {
+    for (; i < n; ++i) {
+      const float gr = g[i] * gscale + wd * p[i];
+      m[i] = beta1 * m[i] + (1.f - beta1) * gr;
+      v[i] = beta2 * v[i] + (1.f - beta2) * gr * gr;
+      p[i] -= lr_bc1 * (m[i] / (sqrtf(v[i]) * inv_sqrt_bc2 + eps));
+    }
+  }
+}
+
+int adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1, float beta2, float eps,
+              float weight_decay, float grad_scale, hipStream_t st) {
+  MP_CHECK(step >= 1, MP_ERR_ARG, "adam_step: step must be >= 1");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1),
+                     (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DropPath masks (timm DropPath semantics: Bernoulli(keep) / keep per sample of dim 0), counter-based
+// hash RNG so that the masks are a pure function of (seed, step, branch, sample).
+// ---------------------------------------------------------------------------------------------
+struct MaskDescs { MaskDesc d[48]; int n; };
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void droppath_masks_kernel(float* __restrict__ masks, MaskDescs ds, unsigned long long seed,
+                                      unsigned long long step) {
+  const int k = blockIdx.y;
+  if (k >= ds.n) return;
+  const MaskDesc d = ds.d[k];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.count; i += gridDim.x * blockDim.x) {
+    const unsigned long long r = splitmix64(splitmix64(seed ^ (step * 0xD1342543DE82EF95ull)) ^ ((unsigned long long)k << 40) ^ i);
+    const float u = (float)(r >> 40) * (1.0f / 16777216.0f);
+    masks[d.offset + i] = (d.keep >= 1.0f) ? 1.0f : ((u < d.keep) ? 1.0f / d.keep : 0.0f);
+  }
+}
+
+int droppath_masks(float* masks, const MaskDesc* descs, int ndesc, unsigned long long seed, unsigned long long step,
+                   hipStream_t st) {
+  MP_CHECK(ndesc <= 48, MP_ERR_ARG, "droppath_masks: too many branches (%d)", ndesc);
+  if (ndesc == 0) return MP_OK;
+  MaskDescs ds;
+  ds.n = ndesc;
+  for (int i = 0; i < ndesc; ++i) ds.d[i] = descs[i];
+  hipLaunchKernelGGL(droppath_masks_kernel, dim3(8, ndesc), dim3(256), 0, st, masks, ds, seed, step);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+}  // namespace mp

@@ -1,0 +1,630 @@
+// Model engine: owns the activation workspace and issues the whole forward / backward launch sequence of
+// RMCLManifoldMixSTE (rmcl_manifold_mix_ste.py:83-106) / ManifoldMixSTE (manifold_mix_ste.py:75-88) natively,
+// one kernel stream, no host synchronisation, no tensor transposes.  The Python nn.Module mirror
+// (manipose_amd/architectures) only hands over device pointers.
+#include <string>
+#include <vector>
+#include "common.h"
+#include "kernels.h"
+#include "../../include/manipose_hip.h"
+
+namespace mp {
+
+const char* last_error();
+long wgrad_f32_slab_floats(int Mtok, int Nout, int Kin);
+
+struct ParamDesc { std::string name; long offset, numel; };
+struct BlockP { int n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b; };
+struct BlockWS { float *x_in, *st1, *a1, *qkv, *lse, *ao, *x_mid, *st2, *a2, *z, *f, *x_out, *stp; };
+struct MaskBranch { std::string name; float keep; int spatial; };
+
+struct Module {
+  std::string prefix;
+  bool is_rot;
+  int N, C, H, depth;     // tokens per frame (17 joints / 16 bones), width, heads, depth
+  int K, O;               // heads, out features per head
+  int emb_w, emb_b, spos, tpos, sn_w, sn_b, tn_w, tn_b;
+  std::vector<BlockP> bp; // order: STE0, TTE0, STE1, TTE1, ...
+  int hg[8], hb[8], hw[8], hbias[8], sw[8], sb[8];
+  std::vector<BlockWS> ws;
+  float *x_final, *hstats, *headout, *dheadout;
+  std::vector<MaskBranch> masks;   // 2 per block: attn, mlp
+  int mask_base;                   // index of this module's first branch in the global list
+};
+
+}  // namespace mp
+
+using namespace mp;
+
+struct mp_model {
+  mp_model_config cfg;
+  std::vector<ParamDesc> params;
+  long flat_size = 0;
+  Module rot, seg;
+  // workspace
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  float *g = nullptr, *tmpC = nullptr, *tmpMask = nullptr, *tmp2C = nullptr, *tmp3C = nullptr, *delta = nullptr;
+  float *slab = nullptr, *small = nullptr, *lengths = nullptr, *dlen_pose = nullptr, *maskbuf = nullptr, *dscore_zero = nullptr;
+  long slab_floats = 0, small_floats = 0;
+  // state of the last forward
+  int B = 0;
+  bool train = false;
+  const float* x_in = nullptr;
+  // profiling
+  bool prof = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> ev_cls;
+  std::vector<double> ev_flops;
+  size_t ev_used = 0;
+};
+
+namespace mp {
+
+static int add_param(mp_model* m, const std::string& name, long numel) {
+  ParamDesc d{name, m->flat_size, numel};
+  m->params.push_back(d);
+  m->flat_size += (numel + 63) / 64 * 64;   // 256-byte aligned slots
+  return (int)m->params.size() - 1;
+}
+
+static void build_module_params(mp_model* m, Module& md) {
+  const std::string& p = md.prefix;
+  const int C = md.C;
+  if (md.is_rot) {
+    md.emb_w = add_param(m, p + "Spatial_patch_to_embedding.weight", (long)C * 2);
+    md.emb_b = add_param(m, p + "Spatial_patch_to_embedding.bias", C);
+  } else {
+    md.emb_w = add_param(m, p + "joints_to_segments_proj.weight", (long)md.N * C * m->cfg.num_joints * 2);
+    md.emb_b = add_param(m, p + "joints_to_segments_proj.bias", (long)md.N * C);
+  }
+  md.spos = add_param(m, p + "Spatial_pos_embed", (long)md.N * C);
+  md.tpos = add_param(m, p + "Temporal_pos_embed", (long)m->cfg.num_frame * C);
+  md.bp.resize(2 * md.depth);
+  for (int i = 0; i < md.depth; ++i) {
+    for (int kind = 0; kind < 2; ++kind) {
+      const std::string b = p + (kind == 0 ? "STEblocks." : "TTEblocks.") + std::to_string(i) + ".";
+      BlockP& q = md.bp[2 * i + kind];
+      q.n1w = add_param(m, b + "norm1.weight", C);
+      q.n1b = add_param(m, b + "norm1.bias", C);
+      q.qkvw = add_param(m, b + "attn.qkv.weight", 3L * C * C);
+      q.qkvb = add_param(m, b + "attn.qkv.bias", 3L * C);
+      q.pw = add_param(m, b + "attn.proj.weight", (long)C * C);
+      q.pb = add_param(m, b + "attn.proj.bias", C);
+      q.n2w = add_param(m, b + "norm2.weight", C);
+      q.n2b = add_param(m, b + "norm2.bias", C);
+      q.f1w = add_param(m, b + "mlp.fc1.weight", 2L * C * C);
+      q.f1b = add_param(m, b + "mlp.fc1.bias", 2L * C);
+      q.f2w = add_param(m, b + "mlp.fc2.weight", 2L * C * C);
+      q.f2b = add_param(m, b + "mlp.fc2.bias", C);
+      const float rate = (md.depth > 1) ? m->cfg.drop_path_rate * (float)i / (float)(md.depth - 1) : 0.f;   // linspace(0, rate, depth)
+      md.masks.push_back({b + "attn", 1.0f - rate, kind == 0});
+      md.masks.push_back({b + "mlp", 1.0f - rate, kind == 0});
+    }
+  }
+  md.sn_w = add_param(m, p + "Spatial_norm.weight", C);
+  md.sn_b = add_param(m, p + "Spatial_norm.bias", C);
+  md.tn_w = add_param(m, p + "Temporal_norm.weight", C);
+  md.tn_b = add_param(m, p + "Temporal_norm.bias", C);
+  if (md.is_rot && m->cfg.arch == 0) {
+    for (int k = 0; k < md.K; ++k) {
+      const std::string h = p + "head." + std::to_string(k) + ".";
+      md.hg[k] = add_param(m, h + "norm.weight", C);
+      md.hb[k] = add_param(m, h + "norm.bias", C);
+      md.hw[k] = add_param(m, h + "prediction_head.weight", (long)md.O * C);
+      md.hbias[k] = add_param(m, h + "prediction_head.bias", md.O);
+      md.sw[k] = add_param(m, h + "score_head.weight", md.N);
+      md.sb[k] = add_param(m, h + "score_head.bias", 1);
+    }
+  } else {
+    md.hg[0] = add_param(m, p + "head.0.weight", C);
+    md.hb[0] = add_param(m, p + "head.0.bias", C);
+    md.hw[0] = add_param(m, p + "head.1.weight", (long)md.O * C);
+    md.hbias[0] = add_param(m, p + "head.1.bias", md.O);
+  }
+}
+
+struct Bump {
+  size_t off = 0;
+  char* base = nullptr;
+  float* take(long floats) {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += ((size_t)floats * 4 + 255) / 256 * 256;
+    return p;
+  }
+};
+
+static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax) {
+  const long C = md.C;
+  md.ws.resize(2 * md.depth);
+  for (auto& w : md.ws) {
+    w.x_in = bp.take(M * C);   w.st1 = bp.take(M * 2);     w.a1 = bp.take(M * C);   w.qkv = bp.take(M * 3 * C);
+    w.lse = bp.take((long)Bmax * md.N * md.H * T);
+    w.ao = bp.take(M * C);     w.x_mid = bp.take(M * C);   w.st2 = bp.take(M * 2);  w.a2 = bp.take(M * C);
+    w.z = bp.take(M * 2 * C);  w.f = bp.take(M * 2 * C);   w.x_out = bp.take(M * C); w.stp = bp.take(M * 2);
+  }
+  md.x_final = bp.take(M * C);
+  md.hstats = bp.take(M * 2);
+  md.headout = bp.take((long)md.K * M * md.O);
+  md.dheadout = bp.take((long)md.K * M * md.O);
+}
+
+static long small_scratch_floats(const mp_model* m) {
+  long s = 512L * 2 * 1024;                                                        // ln_bwd partials
+  const Module* mods[2] = {&m->rot, &m->seg};
+  for (const Module* md : mods) s = max(s, 128L * md->K * ((long)md->O * md->C + md->O + 2 * md->C));   // heads_bwd
+  s = max(s, 128L * (3 + m->rot.N) * m->rot.C);                                   // embed_bwd
+  s = max(s, 33L * m->seg.N * m->seg.C * 35);                                     // bones_embed_bwd
+  s = max(s, 8L * m->cfg.max_batch * m->cfg.num_frame + 64);                       // scores_bwd dlogit / loss partials
+  return s + 1024;
+}
+
+static void carve_all(mp_model* m, Bump& bp) {
+  const int Bm = m->cfg.max_batch, T = m->cfg.num_frame;
+  const long Mr = (long)Bm * T * m->rot.N, Ms = (long)Bm * T * m->seg.N;
+  carve_module(m->rot, bp, Mr, T, Bm);
+  carve_module(m->seg, bp, Ms, T, Bm);
+  const long MC = max(Mr * m->rot.C, Ms * m->seg.C);
+  m->g = bp.take(MC);
+  m->tmpC = bp.take(MC);
+  m->tmpMask = bp.take(MC);
+  m->tmp2C = bp.take(2 * MC);
+  m->tmp3C = bp.take(3 * MC);
+  m->delta = bp.take(max((long)Bm * m->rot.N * m->rot.H * T, (long)Bm * m->seg.N * m->seg.H * T));
+  long slab = 0;
+  const Module* mods[2] = {&m->rot, &m->seg};
+  for (const Module* md : mods) {
+    const long M = (long)Bm * T * md->N;
+    const int C = md->C;
+    slab = max(slab, wgrad_f32_slab_floats((int)M, 3 * C, C));
+    slab = max(slab, wgrad_f32_slab_floats((int)M, C, C));
+    slab = max(slab, wgrad_f32_slab_floats((int)M, 2 * C, C));
+    slab = max(slab, wgrad_f32_slab_floats((int)M, C, 2 * C));
+  }
+  m->slab_floats = slab;
+  m->slab = bp.take(slab);
+  m->small_floats = small_scratch_floats(m);
+  m->small = bp.take(m->small_floats);
+  m->lengths = bp.take((long)Bm * m->seg.N);
+  m->dlen_pose = bp.take((long)Bm * m->rot.K * T * m->seg.N);
+  long nm = 0;
+  for (const Module* md : mods)
+    for (const auto& b : md->masks) nm += b.spatial ? (long)Bm * T : (long)Bm * md->N;
+  m->maskbuf = bp.take(nm + 64);
+  m->dscore_zero = bp.take((long)Bm * m->rot.K * T);
+}
+
+// ---- profiling helpers -------------------------------------------------------------------------
+struct ProfScope {
+  mp_model* m;
+  hipStream_t st;
+  bool on;
+  ProfScope(mp_model* mm, hipStream_t s, int cls, double flops) : m(mm), st(s), on(false) {
+    if (m->prof && m->ev_used + 2 <= m->ev.size()) {
+      on = true;
+      m->ev_cls.push_back(cls);
+      m->ev_flops.push_back(flops);
+      (void)hipEventRecord(m->ev[m->ev_used], st);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      (void)hipEventRecord(m->ev[m->ev_used + 1], st);
+      m->ev_used += 2;
+    }
+  }
+};
+#define RUN(cls, flops, call)                  \
+  do {                                         \
+    ProfScope ps__(m, st, (cls), (flops));     \
+    int rc__ = (call);                         \
+    if (rc__) return rc__;                     \
+  } while (0)
+enum { PC_GEMM_FWD = 0, PC_GEMM_DGRAD = 1, PC_GEMM_WGRAD = 2, PC_ATTN = 3, PC_LN = 4, PC_OTHER = 5 };
+
+static const float* P(const mp_model* m, const float* flat, int idx) { return flat + m->params[idx].offset; }
+static float* G(const mp_model* m, float* flat, int idx) { return flat + m->params[idx].offset; }
+
+static int linear_fwd(mp_model* m, hipStream_t st, const float* A, const float* W, const float* b, float* Cc, long M, int N, int K,
+                      int epi, float* Z, const float* R, const float* mask, int mask_mode, int T, int J) {
+  GemmF32Args g = {};
+  g.A = A; g.lda = K; g.B = W; g.ldb = K; g.C = Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
+  g.bias = b; g.Z = Z; g.R = R; g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
+  RUN(PC_GEMM_FWD, 2.0 * M * N * K, gemm_f32(0, 0, epi, g, st));
+  return MP_OK;
+}
+// dX[M,K] = dY[M,N] W[N,K]  (optionally * gelu'(Z))
+static int linear_dgrad(mp_model* m, hipStream_t st, const float* dY, const float* W, float* dX, long M, int N, int K, float* Z) {
+  GemmF32Args g = {};
+  g.A = dY; g.lda = N; g.B = W; g.ldb = K; g.C = dX; g.ldc = K; g.M = (int)M; g.N = K; g.K = N; g.Z = Z;
+  RUN(PC_GEMM_DGRAD, 2.0 * M * N * K, gemm_f32(0, 1, Z ? EPI_DGELU : EPI_BIAS, g, st));
+  return MP_OK;
+}
+static int linear_wgrad(mp_model* m, hipStream_t st, const float* dY, const float* X, float* dW, float* db, long M, int N, int K) {
+  RUN(PC_GEMM_WGRAD, 2.0 * M * N * K, wgrad_f32(dY, N, X, K, (int)M, N, K, dW, db, m->slab, m->slab_floats, st));
+  return MP_OK;
+}
+
+static const float* branch_mask(const mp_model* m, const Module& md, int l, int br, int B, bool train) {
+  if (!train) return nullptr;
+  const MaskBranch& mb = md.masks[2 * l + br];
+  if (mb.keep >= 1.0f) return nullptr;
+  // offset of this branch inside maskbuf for batch B
+  long off = 0;
+  const Module* mods[2] = {&m->rot, &m->seg};
+  for (const Module* q : mods) {
+    for (size_t i = 0; i < q->masks.size(); ++i) {
+      if (q == &md && (int)i == 2 * l + br) return m->maskbuf + off;
+      off += q->masks[i].spatial ? (long)B * m->cfg.num_frame : (long)B * q->N;
+    }
+  }
+  return nullptr;
+}
+
+static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStream_t st) {
+  const int T = m->cfg.num_frame, N = md.N, C = md.C, H = md.H, L = 2 * md.depth;
+  const long M = (long)B * T * N;
+  // norm1 of block 0 (the input embedding has already been written to ws[0].x_in)
+  {
+    LnFwdArgs a = {};
+    a.x = md.ws[0].x_in; a.M = (int)M; a.C = C;
+    a.g2 = P(m, fp, md.bp[0].n1w); a.b2 = P(m, fp, md.bp[0].n1b); a.eps2 = 1e-6f; a.y2 = md.ws[0].a1; a.stats2 = md.ws[0].st1;
+    RUN(PC_LN, 0, ln_fwd(a, 0, st));
+  }
+  for (int l = 0; l < L; ++l) {
+    const BlockP& q = md.bp[l];
+    BlockWS& w = md.ws[l];
+    const bool spatial = (l % 2 == 0);
+    const int mode = spatial ? 1 : 2;
+    int rc = linear_fwd(m, st, w.a1, P(m, fp, q.qkvw), P(m, fp, q.qkvb), w.qkv, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, 0, T, N);
+    if (rc) return rc;
+    if (spatial) RUN(PC_ATTN, 4.0 * B * T * N * N * C, attn_spatial_fwd(w.qkv, w.ao, B, T, N, C, H, st));
+    else RUN(PC_ATTN, 4.0 * B * N * (double)T * T * C, attn_temporal_fwd(w.qkv, w.ao, w.lse, B, T, N, C, H, st));
+    rc = linear_fwd(m, st, w.ao, P(m, fp, q.pw), P(m, fp, q.pb), w.x_mid, M, C, C, EPI_BIAS_RESID, nullptr, w.x_in,
+                    branch_mask(m, md, l, 0, B, m->train), mode, T, N);
+    if (rc) return rc;
+    {
+      LnFwdArgs a = {};
+      a.x = w.x_mid; a.M = (int)M; a.C = C;
+      a.g2 = P(m, fp, q.n2w); a.b2 = P(m, fp, q.n2b); a.eps2 = 1e-6f; a.y2 = w.a2; a.stats2 = w.st2;
+      RUN(PC_LN, 0, ln_fwd(a, 0, st));
+    }
+    rc = linear_fwd(m, st, w.a2, P(m, fp, q.f1w), P(m, fp, q.f1b), w.f, M, 2 * C, C, EPI_BIAS_GELU, w.z, nullptr, nullptr, 0, T, N);
+    if (rc) return rc;
+    rc = linear_fwd(m, st, w.f, P(m, fp, q.f2w), P(m, fp, q.f2b), w.x_out, M, C, 2 * C, EPI_BIAS_RESID, nullptr, w.x_mid,
+                    branch_mask(m, md, l, 1, B, m->train), mode, T, N);
+    if (rc) return rc;
+    // shared post-norm (mix_ste.py:143,154,166,170), Temporal_pos_embed after the first spatial block (:149),
+    // fused with the next block's norm1
+    LnFwdArgs a = {};
+    a.x = w.x_out; a.M = (int)M; a.C = C;
+    a.g1 = P(m, fp, spatial ? md.sn_w : md.tn_w); a.b1 = P(m, fp, spatial ? md.sn_b : md.tn_b); a.eps1 = 1e-6f;
+    a.pos = (l == 0) ? P(m, fp, md.tpos) : nullptr; a.T = T; a.J = N;
+    a.x1 = (l + 1 < L) ? md.ws[l + 1].x_in : md.x_final;
+    a.stats1 = w.stp;
+    if (l + 1 < L) {
+      a.g2 = P(m, fp, md.bp[l + 1].n1w); a.b2 = P(m, fp, md.bp[l + 1].n1b); a.eps2 = 1e-6f;
+      a.y2 = md.ws[l + 1].a1; a.stats2 = md.ws[l + 1].st1;
+    }
+    RUN(PC_LN, 0, ln_fwd(a, 0, st));
+  }
+  return MP_OK;
+}
+
+// on entry m->g holds dL/d x_final; on exit m->g holds dL/d (embedding output)
+static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int B, hipStream_t st) {
+  const int T = m->cfg.num_frame, N = md.N, C = md.C, H = md.H, L = 2 * md.depth;
+  const long M = (long)B * T * N;
+  float* g = m->g;
+  for (int l = L - 1; l >= 0; --l) {
+    const BlockP& q = md.bp[l];
+    BlockWS& w = md.ws[l];
+    const bool spatial = (l % 2 == 0);
+    const int mode = spatial ? 1 : 2;
+    // (a) shared post-norm (+ Temporal_pos_embed gradient behind block 0)
+    if (l == 0) RUN(PC_OTHER, 0, tpos_grad(g, G(m, fg, md.tpos), B, T, N, C, st));
+    RUN(PC_LN, 0, ln_bwd(g, w.x_out, w.stp, P(m, fp, spatial ? md.sn_w : md.tn_w), nullptr, g, G(m, fg, spatial ? md.sn_w : md.tn_w),
+                         G(m, fg, spatial ? md.sn_b : md.tn_b), (int)M, C, m->small, m->small_floats, st));
+    // (b) mlp branch: fc2
+    const float* mk2 = branch_mask(m, md, l, 1, B, m->train);
+    const float* gb = g;
+    if (mk2) {
+      RUN(PC_OTHER, 0, scale_rows(g, mk2, mode, m->tmpMask, (int)M, C, T, N, st));
+      gb = m->tmpMask;
+    }
+    int rc = linear_wgrad(m, st, gb, w.f, G(m, fg, q.f2w), G(m, fg, q.f2b), M, C, 2 * C);
+    if (rc) return rc;
+    rc = linear_dgrad(m, st, gb, P(m, fp, q.f2w), m->tmp2C, M, C, 2 * C, w.z);
+    if (rc) return rc;
+    // (c) fc1
+    rc = linear_wgrad(m, st, m->tmp2C, w.a2, G(m, fg, q.f1w), G(m, fg, q.f1b), M, 2 * C, C);
+    if (rc) return rc;
+    rc = linear_dgrad(m, st, m->tmp2C, P(m, fp, q.f1w), m->tmpC, M, 2 * C, C, nullptr);
+    if (rc) return rc;
+    // (d) norm2 + skip
+    RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, G(m, fg, q.n2w), G(m, fg, q.n2b), (int)M, C, m->small,
+                         m->small_floats, st));
+    // (e) attention branch: proj
+    const float* mk1 = branch_mask(m, md, l, 0, B, m->train);
+    gb = g;
+    if (mk1) {
+      RUN(PC_OTHER, 0, scale_rows(g, mk1, mode, m->tmpMask, (int)M, C, T, N, st));
+      gb = m->tmpMask;
+    }
+    rc = linear_wgrad(m, st, gb, w.ao, G(m, fg, q.pw), G(m, fg, q.pb), M, C, C);
+    if (rc) return rc;
+    rc = linear_dgrad(m, st, gb, P(m, fp, q.pw), m->tmpC, M, C, C, nullptr);
+    if (rc) return rc;
+    // (f) attention core
+    if (spatial) RUN(PC_ATTN, 10.0 * B * T * N * N * C, attn_spatial_bwd(w.qkv, m->tmpC, m->tmp3C, B, T, N, C, H, st));
+    else RUN(PC_ATTN, 10.0 * B * N * (double)T * T * C, attn_temporal_bwd(w.qkv, w.ao, m->tmpC, w.lse, m->delta, m->tmp3C, B, T, N, C, H, st));
+    // (g) qkv
+    rc = linear_wgrad(m, st, m->tmp3C, w.a1, G(m, fg, q.qkvw), G(m, fg, q.qkvb), M, 3 * C, C);
+    if (rc) return rc;
+    rc = linear_dgrad(m, st, m->tmp3C, P(m, fp, q.qkvw), m->tmpC, M, 3 * C, C, nullptr);
+    if (rc) return rc;
+    // (h) norm1 + skip
+    RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_in, w.st1, P(m, fp, q.n1w), g, g, G(m, fg, q.n1w), G(m, fg, q.n1b), (int)M, C, m->small,
+                         m->small_floats, st));
+  }
+  return MP_OK;
+}
+
+static void head_params(const mp_model* m, const Module& md, const float* fp, HeadParams& hp) {
+  for (int k = 0; k < md.K; ++k) {
+    hp.gamma[k] = P(m, fp, md.hg[k]); hp.beta[k] = P(m, fp, md.hb[k]); hp.W[k] = P(m, fp, md.hw[k]); hp.b[k] = P(m, fp, md.hbias[k]);
+  }
+}
+static void head_grads(const mp_model* m, const Module& md, float* fg, HeadGrads& hg) {
+  for (int k = 0; k < md.K; ++k) {
+    hg.gamma[k] = G(m, fg, md.hg[k]); hg.beta[k] = G(m, fg, md.hb[k]); hg.W[k] = G(m, fg, md.hw[k]); hg.b[k] = G(m, fg, md.hbias[k]);
+  }
+}
+
+}  // namespace mp
+
+// =================================================================================================
+// C ABI: model engine
+// =================================================================================================
+extern "C" {
+
+int mp_model_create(const mp_model_config* cfg, mp_model** out) {
+  MP_CHECK(cfg != nullptr && out != nullptr, MP_ERR_ARG, "mp_model_create: null argument");
+  MP_CHECK(cfg->arch == 0 || cfg->arch == 1, MP_ERR_ARG, "mp_model_create: arch %d (0 rmcl_manifold, 1 manifold)", cfg->arch);
+  MP_CHECK(cfg->precision == 0, MP_ERR_ARG, "mp_model_create: precision %d not built in this version (0 = fp32)", cfg->precision);
+  MP_CHECK(cfg->num_joints == 17 && cfg->num_bones == 16, MP_ERR_ARG, "mp_model_create: the decoder is built for the 17-joint H36M tree");
+  MP_CHECK(cfg->num_frame >= 2 && cfg->max_batch >= 1, MP_ERR_ARG, "mp_model_create: num_frame >= 2, max_batch >= 1");
+  MP_CHECK(cfg->embed_dim_rot % cfg->num_heads_rot == 0 && cfg->embed_dim_seg % cfg->num_heads_seg == 0, MP_ERR_ARG,
+           "mp_model_create: embed dim must be divisible by heads");
+  MP_CHECK(cfg->arch == 1 || (cfg->n_hyp >= 1 && cfg->n_hyp <= 8), MP_ERR_ARG, "mp_model_create: n_hyp in 1..8");
+  mp_model* m = new mp_model();
+  m->cfg = *cfg;
+  if (cfg->arch == 1) m->cfg.n_hyp = 1;
+  m->rot.prefix = "rotations_module."; m->rot.is_rot = true;
+  m->rot.N = cfg->num_joints; m->rot.C = cfg->embed_dim_rot; m->rot.H = cfg->num_heads_rot; m->rot.depth = cfg->depth_rot;
+  m->rot.K = m->cfg.n_hyp; m->rot.O = (cfg->arch == 0) ? 7 : 6;
+  m->seg.prefix = "segments_module."; m->seg.is_rot = false;
+  m->seg.N = cfg->num_bones; m->seg.C = cfg->embed_dim_seg; m->seg.H = cfg->num_heads_seg; m->seg.depth = cfg->depth_seg;
+  m->seg.K = 1; m->seg.O = 1;
+  build_module_params(m, m->rot);
+  build_module_params(m, m->seg);
+  m->rot.mask_base = 0;
+  m->seg.mask_base = (int)m->rot.masks.size();
+  Bump dry;
+  carve_all(m, dry);
+  m->arena_bytes = dry.off;
+  hipError_t e = hipMalloc((void**)&m->arena, m->arena_bytes);
+  if (e != hipSuccess) {
+    set_error("mp_model_create: hipMalloc(%zu bytes) failed: %s", m->arena_bytes, hipGetErrorString(e));
+    delete m;
+    return MP_ERR_HIP;
+  }
+  Bump real;
+  real.base = m->arena;
+  carve_all(m, real);
+  e = hipMemset(m->dscore_zero, 0, sizeof(float) * (size_t)cfg->max_batch * m->rot.K * cfg->num_frame);
+  if (e != hipSuccess) {
+    set_error("mp_model_create: hipMemset failed: %s", hipGetErrorString(e));
+    (void)hipFree(m->arena);
+    delete m;
+    return MP_ERR_HIP;
+  }
+  *out = m;
+  return MP_OK;
+}
+
+void mp_model_destroy(mp_model* m) {
+  if (!m) return;
+  for (auto& e : m->ev) (void)hipEventDestroy(e);
+  if (m->arena) (void)hipFree(m->arena);
+  delete m;
+}
+
+int64_t mp_model_workspace_bytes(const mp_model* m) { return m ? (int64_t)m->arena_bytes : 0; }
+int mp_model_num_params(const mp_model* m) { return m ? (int)m->params.size() : 0; }
+int64_t mp_model_flat_size(const mp_model* m) { return m ? m->flat_size : 0; }
+
+int mp_model_param_info(const mp_model* m, int index, char* name, int name_cap, int64_t* offset, int64_t* numel) {
+  MP_CHECK(m && index >= 0 && index < (int)m->params.size(), MP_ERR_ARG, "mp_model_param_info: bad index %d", index);
+  const ParamDesc& d = m->params[index];
+  if (name && name_cap > 0) snprintf(name, name_cap, "%s", d.name.c_str());
+  if (offset) *offset = d.offset;
+  if (numel) *numel = d.numel;
+  return MP_OK;
+}
+
+int mp_model_num_mask_branches(const mp_model* m) { return m ? (int)(m->rot.masks.size() + m->seg.masks.size()) : 0; }
+
+int mp_model_mask_info(const mp_model* m, int B, int index, char* name, int name_cap, int64_t* offset, int64_t* count,
+                       float* keep_prob) {
+  MP_CHECK(m && index >= 0 && index < mp_model_num_mask_branches(m), MP_ERR_ARG, "mp_model_mask_info: bad index %d", index);
+  long off = 0;
+  int i = 0;
+  const Module* mods[2] = {&m->rot, &m->seg};
+  for (const Module* q : mods) {
+    for (const auto& b : q->masks) {
+      const long cnt = b.spatial ? (long)B * m->cfg.num_frame : (long)B * q->N;
+      if (i == index) {
+        if (name && name_cap > 0) snprintf(name, name_cap, "%s", b.name.c_str());
+        if (offset) *offset = off;
+        if (count) *count = cnt;
+        if (keep_prob) *keep_prob = b.keep;
+        return MP_OK;
+      }
+      off += cnt;
+      ++i;
+    }
+  }
+  return MP_ERR_ARG;
+}
+
+int64_t mp_model_mask_floats(const mp_model* m, int B) {
+  if (!m) return 0;
+  long off = 0;
+  const Module* mods[2] = {&m->rot, &m->seg};
+  for (const Module* q : mods)
+    for (const auto& b : q->masks) off += b.spatial ? (long)B * m->cfg.num_frame : (long)B * q->N;
+  return off;
+}
+
+int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float* poses, float* scores, int train,
+                     const float* masks_override, uint64_t seed, uint64_t step, void* stream) {
+  MP_CHECK(m && fp && x && poses, MP_ERR_ARG, "mp_model_forward: null argument");
+  MP_CHECK(B >= 1 && B <= m->cfg.max_batch, MP_ERR_ARG, "mp_model_forward: batch %d outside 1..max_batch=%d", B, m->cfg.max_batch);
+  MP_CHECK(m->cfg.arch == 1 || scores != nullptr, MP_ERR_ARG, "mp_model_forward: scores buffer required for rmcl_manifold");
+  hipStream_t st = (hipStream_t)stream;
+  const int T = m->cfg.num_frame, J = m->cfg.num_joints, S = m->cfg.num_bones, K = m->rot.K;
+  m->B = B;
+  m->train = train != 0 && m->cfg.drop_path_rate > 0.f;
+  m->x_in = x;
+  if (m->train) {
+    if (masks_override) {
+      MP_HIP(hipMemcpyAsync(m->maskbuf, masks_override, sizeof(float) * mp_model_mask_floats(m, B), hipMemcpyDeviceToDevice, st));
+    } else {
+      std::vector<MaskDesc> ds;
+      long off = 0;
+      const Module* mods[2] = {&m->rot, &m->seg};
+      for (const Module* q : mods)
+        for (const auto& b : q->masks) {
+          const int cnt = b.spatial ? B * T : B * q->N;
+          ds.push_back({(int)off, cnt, b.keep});
+          off += cnt;
+        }
+      RUN(PC_OTHER, 0, droppath_masks(m->maskbuf, ds.data(), (int)ds.size(), seed, step, st));
+    }
+  }
+  // rotations backbone (mix_ste.py:128-173)
+  const long Mr = (long)B * T * J, Ms = (long)B * T * S;
+  RUN(PC_OTHER, 0, embed_fwd(x, P(m, fp, m->rot.emb_w), P(m, fp, m->rot.emb_b), P(m, fp, m->rot.spos), m->rot.ws[0].x_in, (int)Mr,
+                             m->rot.C, J, st));
+  int rc = backbone_fwd(m, m->rot, fp, B, st);
+  if (rc) return rc;
+  HeadParams hp;
+  head_params(m, m->rot, fp, hp);
+  RUN(PC_OTHER, 0, heads_fwd(m->rot.x_final, hp, K, m->rot.O, m->rot.headout, m->rot.hstats, (int)Mr, m->rot.C, st));
+  if (m->cfg.arch == 0) {
+    ScoreParams sp;
+    for (int k = 0; k < K; ++k) { sp.w[k] = P(m, fp, m->rot.sw[k]); sp.b[k] = P(m, fp, m->rot.sb[k]); }
+    RUN(PC_OTHER, 0, scores_fwd(m->rot.headout, sp, K, m->rot.O, scores, B, T, J, st));
+  }
+  // bones net (manifold_mix_ste.py:139-154)
+  RUN(PC_OTHER, 0, bones_embed_fwd(x, P(m, fp, m->seg.emb_w), P(m, fp, m->seg.emb_b), P(m, fp, m->seg.spos), m->seg.ws[0].x_in,
+                                   B * T, J * 2, S * m->seg.C, st));
+  rc = backbone_fwd(m, m->seg, fp, B, st);
+  if (rc) return rc;
+  HeadParams hs;
+  head_params(m, m->seg, fp, hs);
+  RUN(PC_OTHER, 0, heads_fwd(m->seg.x_final, hs, 1, 1, m->seg.headout, m->seg.hstats, (int)Ms, m->seg.C, st));
+  RUN(PC_OTHER, 0, bones_mean_fwd(m->seg.headout, m->lengths, B, T, S, st));
+  // manifold decoder (pose_decoder.py:32-55)
+  RUN(PC_OTHER, 0, fk_decode_fwd(m->rot.headout, m->rot.O, m->lengths, poses, B, K, T, st));
+  return MP_OK;
+}
+
+int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_poses, const float* d_scores, void* stream) {
+  MP_CHECK(m && fp && fg && d_poses, MP_ERR_ARG, "mp_model_backward: null argument");
+  MP_CHECK(m->B >= 1, MP_ERR_STATE, "mp_model_backward: no forward has been run");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = m->B, T = m->cfg.num_frame, J = m->cfg.num_joints, S = m->cfg.num_bones, K = m->rot.K;
+  const long Mr = (long)B * T * J, Ms = (long)B * T * S;
+  // decoder
+  RUN(PC_OTHER, 0, fk_decode_bwd(m->rot.headout, m->rot.O, m->lengths, d_poses, m->rot.dheadout, m->dlen_pose, B, K, T, st));
+  if (m->cfg.arch == 0) {
+    ScoreParams sp;
+    ScoreGrads sg;
+    for (int k = 0; k < K; ++k) {
+      sp.w[k] = P(m, fp, m->rot.sw[k]); sp.b[k] = P(m, fp, m->rot.sb[k]);
+      sg.w[k] = G(m, fg, m->rot.sw[k]); sg.b[k] = G(m, fg, m->rot.sb[k]);
+    }
+    // scores are recomputed into tmpC-sized scratch? no: softmax outputs are cheap to recompute from the head output
+    float* sc = m->tmp2C;   // (B,K,T) scratch, free at this point of the backward
+    RUN(PC_OTHER, 0, scores_fwd(m->rot.headout, sp, K, m->rot.O, sc, B, T, J, st));
+    RUN(PC_OTHER, 0, scores_bwd(m->rot.headout, sc, d_scores ? d_scores : m->dscore_zero, sp, sg, K, m->rot.O, m->rot.dheadout, B, T, J,
+                                m->small, m->small_floats, st));
+  }
+  // rotations module
+  HeadParams hp;
+  HeadGrads hg;
+  head_params(m, m->rot, fp, hp);
+  head_grads(m, m->rot, fg, hg);
+  RUN(PC_OTHER, 0, heads_bwd(m->rot.x_final, m->rot.hstats, hp, hg, K, m->rot.O, m->rot.dheadout, m->g, (int)Mr, m->rot.C, m->small,
+                             m->small_floats, st));
+  int rc = backbone_bwd(m, m->rot, fp, fg, B, st);
+  if (rc) return rc;
+  RUN(PC_OTHER, 0, embed_bwd(m->g, m->x_in, G(m, fg, m->rot.emb_w), G(m, fg, m->rot.emb_b), G(m, fg, m->rot.spos), (int)Mr, m->rot.C, J,
+                             m->small, m->small_floats, st));
+  // segments module
+  RUN(PC_OTHER, 0, bones_mean_bwd(m->dlen_pose, K * T, nullptr, m->seg.dheadout, B, T, S, st));
+  HeadParams hs;
+  HeadGrads hgs;
+  head_params(m, m->seg, fp, hs);
+  head_grads(m, m->seg, fg, hgs);
+  RUN(PC_OTHER, 0, heads_bwd(m->seg.x_final, m->seg.hstats, hs, hgs, 1, 1, m->seg.dheadout, m->g, (int)Ms, m->seg.C, m->small,
+                             m->small_floats, st));
+  rc = backbone_bwd(m, m->seg, fp, fg, B, st);
+  if (rc) return rc;
+  RUN(PC_OTHER, 0, bones_embed_bwd(m->g, m->x_in, G(m, fg, m->seg.emb_w), G(m, fg, m->seg.emb_b), G(m, fg, m->seg.spos), B * T, J * 2,
+                                   S * m->seg.C, m->small, m->small_floats, st));
+  return MP_OK;
+}
+
+int mp_model_peek(const mp_model* m, int which, const float** ptr, int64_t* numel) {
+  MP_CHECK(m && ptr && numel && m->B >= 1, MP_ERR_ARG, "mp_model_peek: bad argument or no forward yet");
+  const long Mr = (long)m->B * m->cfg.num_frame * m->cfg.num_joints;
+  if (which == 0) { *ptr = m->rot.headout; *numel = (long)m->rot.K * Mr * m->rot.O; return MP_OK; }
+  if (which == 1) { *ptr = m->lengths; *numel = (long)m->B * m->cfg.num_bones; return MP_OK; }
+  MP_CHECK(false, MP_ERR_ARG, "mp_model_peek: which=%d", which);
+}
+
+int mp_prof_enable(mp_model* m, int on) {
+  MP_CHECK(m, MP_ERR_ARG, "mp_prof_enable: null model");
+  if (on && m->ev.empty()) {
+    m->ev.resize(131072);
+    for (auto& e : m->ev) MP_HIP(hipEventCreate(&e));
+  }
+  m->prof = on != 0;
+  m->ev_used = 0;
+  m->ev_cls.clear();
+  m->ev_flops.clear();
+  return MP_OK;
+}
+
+int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops) {
+  MP_CHECK(m && ms && launches && flops, MP_ERR_ARG, "mp_prof_collect: null argument");
+  for (int c = 0; c < MP_PROF_CLASSES; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; }
+  for (size_t i = 0; i < m->ev_cls.size() && 2 * i + 1 < m->ev_used; ++i) {
+    MP_HIP(hipEventSynchronize(m->ev[2 * i + 1]));
+    float t = 0.f;
+    MP_HIP(hipEventElapsedTime(&t, m->ev[2 * i], m->ev[2 * i + 1]));
+    const int c = m->ev_cls[i];
+    ms[c] += t;
+    launches[c] += 1;
+    flops[c] += m->ev_flops[i];
+  }
+  m->ev_used = 0;
+  m->ev_cls.clear();
+  m->ev_flops.clear();
+  return MP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,396 @@
+// Output heads of the lifting model:
+//   * K hypothesis heads, MCLHead.forward (rmcl_manifold_mix_ste.py:291-298): LayerNorm(C, eps 1e-5) -> Linear(C, 7);
+//     the plain MixSTE head Sequential(LayerNorm, Linear(C, out_dim)) (mix_ste.py:123-126) is the K = 1 case.
+//     One wave per token: x-hat is computed once and shared by all K heads.
+//   * score head: Linear over the JOINT axis of the 7th channel + softmax over K (rmcl_manifold_mix_ste.py:294-297, :262)
+//   * bones net tail: mean over T of the per-frame segment lengths (manifold_mix_ste.py:153)
+#include "common.h"
+#include "kernels.h"
+
+namespace mp {
+
+constexpr int HV = 2;        // float4 per lane -> C <= 512
+constexpr int HMAXO = 8;     // out features per head <= 8
+
+__device__ __forceinline__ void head_row_xhat(const float* __restrict__ xr, int lane, int C, float eps, bool have_stats,
+                                              float& mean, float& rstd, float4 (&xh)[HV]) {
+#pragma unroll
+  for (int i = 0; i < HV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    xh[i] = (c < C) ? ld4(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (!have_stats) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < HV; ++i) s += (xh[i].x + xh[i].y) + (xh[i].z + xh[i].w);   // padding lanes hold zeros
+    mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < HV; ++i)
+      if (lane * 4 + 256 * i < C) {
+        const float a = xh[i].x - mean, b = xh[i].y - mean, c = xh[i].z - mean, d = xh[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+      }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  }
+#pragma unroll
+  for (int i = 0; i < HV; ++i) {
+    if (lane * 4 + 256 * i < C) {
+      xh[i].x = (xh[i].x - mean) * rstd; xh[i].y = (xh[i].y - mean) * rstd;
+      xh[i].z = (xh[i].z - mean) * rstd; xh[i].w = (xh[i].w - mean) * rstd;
+    }
+  }
+}
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ x, HeadParams p, int K, int O,
+                                                         float* __restrict__ out, float* __restrict__ stats, int M, int C) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int m = wave; m < M; m += nwaves) {
+    float mean, rstd;
+    float4 xh[HV];
+    head_row_xhat(x + (long)m * C, lane, C, 1e-5f, false, mean, rstd, xh);
+    if (lane == 0) {
+      stats[2 * (long)m] = mean;
+      stats[2 * (long)m + 1] = rstd;
+    }
+    for (int k = 0; k < K; ++k) {
+      float4 y[HV];
+#pragma unroll
+      for (int i = 0; i < HV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < C) {
+          const float4 g = ld4(p.gamma[k] + c), b = ld4(p.beta[k] + c);
+          y[i] = make_float4(xh[i].x * g.x + b.x, xh[i].y * g.y + b.y, xh[i].z * g.z + b.z, xh[i].w * g.w + b.w);
+        } else {
+          y[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      for (int o = 0; o < O; ++o) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < HV; ++i) {
+          const int c = lane * 4 + 256 * i;
+          if (c < C) s += dot4(y[i], ld4(p.W[k] + (long)o * C + c));
+        }
+        s = wave_sum(s);
+        if (lane == 0) out[((long)k * M + m) * O + o] = s + p.b[k][o];
+      }
+    }
+  }
+}
+
+int heads_fwd(const float* x, const HeadParams& p, int K, int O, float* out, float* stats, int M, int C, hipStream_t st) {
+  MP_CHECK(K >= 1 && K <= 8 && O >= 1 && O <= HMAXO && C % 4 == 0 && C <= 256 * HV, MP_ERR_ARG,
+           "heads_fwd: K=%d O=%d C=%d unsupported", K, O, C);
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3(max(1, min(cdiv(M, 4), 2048))), dim3(256), 0, st, x, p, K, O, out, stats, M, C);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// dx = LN'( sum_k gamma_k * (W_k^T dout_k) )
+__global__ __launch_bounds__(256) void heads_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                            HeadParams p, int K, int O, const float* __restrict__ dout,
+                                                            float* __restrict__ dx, int M, int C) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int m0 = wave; m0 < M; m0 += nwaves) {
+    const int m = __builtin_amdgcn_readfirstlane(m0);
+    float mean = stats[2 * (long)m], rstd = stats[2 * (long)m + 1];
+    float4 xh[HV], d[HV];
+    head_row_xhat(x + (long)m * C, lane, C, 1e-5f, true, mean, rstd, xh);
+#pragma unroll
+    for (int i = 0; i < HV; ++i) d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < K; ++k) {
+      float4 dy[HV];
+#pragma unroll
+      for (int i = 0; i < HV; ++i) dy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int o = 0; o < O; ++o) {
+        const float g = dout[((long)k * M + m) * O + o];
+#pragma unroll
+        for (int i = 0; i < HV; ++i) {
+          const int c = lane * 4 + 256 * i;
+          if (c < C) {
+            const float4 w = ld4(p.W[k] + (long)o * C + c);
+            dy[i].x += g * w.x; dy[i].y += g * w.y; dy[i].z += g * w.z; dy[i].w += g * w.w;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < HV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < C) {
+          const float4 gm = ld4(p.gamma[k] + c);
+          d[i].x += dy[i].x * gm.x; d[i].y += dy[i].y * gm.y; d[i].z += dy[i].z * gm.z; d[i].w += dy[i].w * gm.w;
+        }
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < HV; ++i) {
+      s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+      s2 += dot4(d[i], xh[i]);
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < HV; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < C)
+        st4(dx + (long)m * C + c, make_float4(rstd * (d[i].x - s1 - xh[i].x * s2), rstd * (d[i].y - s1 - xh[i].y * s2),
+                                              rstd * (d[i].z - s1 - xh[i].z * s2), rstd * (d[i].w - s1 - xh[i].w * s2)));
+    }
+  }
+}
+
+// parameter gradients of head k = blockIdx.y; each wave writes its own partial row [dW (O*C) | db (O) | dgamma (C) | dbeta (C)]
+template <int O>
+__global__ __launch_bounds__(256) void heads_bwd_param_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                               HeadParams p, int K, const float* __restrict__ dout,
+                                                               float* __restrict__ partial, int M, int C) {
+  const int lane = threadIdx.x & 63, k = blockIdx.y;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  float4 W[O][HV], dW[O][HV], gm[HV], bt[HV], dg[HV], dbt[HV];
+  float db[O];
+#pragma unroll
+  for (int i = 0; i < HV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    const bool ok = c < C;
+    gm[i] = ok ? ld4(p.gamma[k] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bt[i] = ok ? ld4(p.beta[k] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    dg[i] = dbt[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      W[o][i] = ok ? ld4(p.W[k] + (long)o * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dW[o][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < O; ++o) db[o] = 0.f;
+  for (int m0 = wave; m0 < M; m0 += nwaves) {
+    const int m = __builtin_amdgcn_readfirstlane(m0);
+    float mean = stats[2 * (long)m], rstd = stats[2 * (long)m + 1];
+    float4 xh[HV], dy[HV];
+    head_row_xhat(x + (long)m * C, lane, C, 1e-5f, true, mean, rstd, xh);
+#pragma unroll
+    for (int i = 0; i < HV; ++i) dy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      const float g = dout[((long)k * M + m) * O + o];
+      db[o] += g;
+#pragma unroll
+      for (int i = 0; i < HV; ++i) {
+        const float4 y = make_float4(xh[i].x * gm[i].x + bt[i].x, xh[i].y * gm[i].y + bt[i].y, xh[i].z * gm[i].z + bt[i].z,
+                                     xh[i].w * gm[i].w + bt[i].w);
+        dW[o][i].x += g * y.x; dW[o][i].y += g * y.y; dW[o][i].z += g * y.z; dW[o][i].w += g * y.w;
+        dy[i].x += g * W[o][i].x; dy[i].y += g * W[o][i].y; dy[i].z += g * W[o][i].z; dy[i].w += g * W[o][i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < HV; ++i) {
+      dg[i].x += dy[i].x * xh[i].x; dg[i].y += dy[i].y * xh[i].y; dg[i].z += dy[i].z * xh[i].z; dg[i].w += dy[i].w * xh[i].w;
+      dbt[i].x += dy[i].x; dbt[i].y += dy[i].y; dbt[i].z += dy[i].z; dbt[i].w += dy[i].w;
+    }
+  }
+  const long nk = (long)O * C + O + 2 * C;
+  float* pr = partial + ((long)wave * K + k) * nk;
+#pragma unroll
+  for (int i = 0; i < HV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < C) {
+#pragma unroll
+      for (int o = 0; o < O; ++o) st4(pr + (long)o * C + c, dW[o][i]);
+      st4(pr + (long)O * C + O + c, dg[i]);
+      st4(pr + (long)O * C + O + C + c, dbt[i]);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int o = 0; o < O; ++o) pr[(long)O * C + o] = db[o];
+  }
+}
+
+__global__ void heads_reduce_kernel(const float* __restrict__ partial, int P, int K, int O, int C, HeadGrads g) {
+  const int k = blockIdx.y;
+  const int nk = O * C + O + 2 * C;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nk) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += partial[((long)p * K + k) * nk + i];
+  if (i < O * C) g.W[k][i] += s;
+  else if (i < O * C + O) g.b[k][i - O * C] += s;
+  else if (i < O * C + O + C) g.gamma[k][i - O * C - O] += s;
+  else g.beta[k][i - O * C - O - C] += s;
+}
+
+constexpr int HB_GRID = 32;   // 128 waves -> 128 partial rows per head
+
+int heads_bwd(const float* x, const float* stats, const HeadParams& p, const HeadGrads& gp, int K, int O, const float* dout,
+              float* dx, int M, int C, float* scratch, long scratch_floats, hipStream_t st) {
+  MP_CHECK(K >= 1 && K <= 8 && O >= 1 && O <= HMAXO && C % 4 == 0 && C <= 256 * HV, MP_ERR_ARG,
+           "heads_bwd: K=%d O=%d C=%d unsupported", K, O, C);
+  hipLaunchKernelGGL(heads_bwd_dx_kernel, dim3(max(1, min(cdiv(M, 4), 2048))), dim3(256), 0, st, x, stats, p, K, O, dout, dx, M,
+                     C);
+  MP_LAUNCH_CHECK();
+  const int grid = max(1, min(cdiv(M, 4), HB_GRID));
+  const int P = grid * 4;
+  const long nk = (long)O * C + O + 2 * C;
+  MP_CHECK(scratch_floats >= (long)P * K * nk, MP_ERR_ARG, "heads_bwd: scratch too small");
+  dim3 g2(grid, K);
+  switch (O) {
+    case 1: hipLaunchKernelGGL(heads_bwd_param_kernel<1>, g2, dim3(256), 0, st, x, stats, p, K, dout, scratch, M, C); break;
+    case 3: hipLaunchKernelGGL(heads_bwd_param_kernel<3>, g2, dim3(256), 0, st, x, stats, p, K, dout, scratch, M, C); break;
+    case 6: hipLaunchKernelGGL(heads_bwd_param_kernel<6>, g2, dim3(256), 0, st, x, stats, p, K, dout, scratch, M, C); break;
+    case 7: hipLaunchKernelGGL(heads_bwd_param_kernel<7>, g2, dim3(256), 0, st, x, stats, p, K, dout, scratch, M, C); break;
+    default: MP_CHECK(false, MP_ERR_ARG, "heads_bwd: out features %d unsupported (1,3,6,7)", O);
+  }
+  MP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(heads_reduce_kernel, dim3(cdiv(nk, 256), K), dim3(256), 0, st, scratch, P, K, O, C, gp);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// score head + softmax over K
+// ---------------------------------------------------------------------------------------------
+__global__ void scores_fwd_kernel(const float* __restrict__ headout, ScoreParams p, int K, int O, float* __restrict__ scores,
+                                  int B, int T, int J) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;   // frame (b,t)
+  if (f >= B * T) return;
+  const long M = (long)B * T * J;
+  float lg[8];
+  float mx = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    float s = p.b[k][0];
+    for (int j = 0; j < J; ++j) s += p.w[k][j] * headout[((long)k * M + (long)f * J + j) * O + (O - 1)];
+    lg[k] = s;
+    mx = fmaxf(mx, s);
+  }
+  float sum = 0.f;
+  for (int k = 0; k < K; ++k) {
+    lg[k] = expf(lg[k] - mx);
+    sum += lg[k];
+  }
+  const int b = f / T, t = f % T;
+  for (int k = 0; k < K; ++k) scores[((long)b * K + k) * T + t] = lg[k] / sum;
+}
+
+int scores_fwd(const float* headout, const ScoreParams& p, int K, int O, float* scores, int B, int T, int J, hipStream_t st) {
+  MP_CHECK(K >= 1 && K <= 8, MP_ERR_ARG, "scores_fwd: K=%d unsupported", K);
+  hipLaunchKernelGGL(scores_fwd_kernel, dim3(cdiv(B * T, 128)), dim3(128), 0, st, headout, p, K, O, scores, B, T, J);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// dlogit = s * (ds - sum_k s ds); d(emb) = dlogit * w_k[j] written into channel O-1 of dheadout
+__global__ void scores_bwd_kernel(const float* __restrict__ scores, const float* __restrict__ dscores, ScoreParams p, int K, int O,
+                                  float* __restrict__ dheadout, float* __restrict__ dlogit, int B, int T, int J) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= B * T) return;
+  const long M = (long)B * T * J;
+  const int b = f / T, t = f % T;
+  float s[8], d[8];
+  float dot = 0.f;
+  for (int k = 0; k < K; ++k) {
+    s[k] = scores[((long)b * K + k) * T + t];
+    d[k] = dscores[((long)b * K + k) * T + t];
+    dot += s[k] * d[k];
+  }
+  for (int k = 0; k < K; ++k) {
+    const float dl = s[k] * (d[k] - dot);
+    dlogit[(long)k * B * T + f] = dl;
+    for (int j = 0; j < J; ++j) dheadout[((long)k * M + (long)f * J + j) * O + (O - 1)] = dl * p.w[k][j];
+  }
+}
+
+// grid K, block 256: dw_k[j] += sum_f dlogit[k][f] * emb[k][f][j]; db_k += sum_f dlogit[k][f]   (J <= 32)
+__global__ __launch_bounds__(256) void scores_param_kernel(const float* __restrict__ headout, const float* __restrict__ dlogit,
+                                                            ScoreGrads g, int K, int O, int B, int T, int J) {
+  __shared__ float red[256];
+  const int k = blockIdx.x;
+  const long M = (long)B * T * J;
+  const int F = B * T;
+  for (int j = 0; j <= J; ++j) {   // j == J -> bias
+    float s = 0.f;
+    for (int f = threadIdx.x; f < F; f += 256) {
+      const float dl = dlogit[(long)k * F + f];
+      s += (j < J) ? dl * headout[((long)k * M + (long)f * J + j) * O + (O - 1)] : dl;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      if (j < J) g.w[k][j] += red[0];
+      else g.b[k][0] += red[0];
+    }
+    __syncthreads();
+  }
+}
+
+int scores_bwd(const float* headout, const float* scores, const float* dscores, const ScoreParams& p, const ScoreGrads& gp, int K,
+               int O, float* dheadout, int B, int T, int J, float* scratch, long scratch_floats, hipStream_t st) {
+  MP_CHECK(K >= 1 && K <= 8 && J <= 32, MP_ERR_ARG, "scores_bwd: K=%d J=%d unsupported", K, J);
+  MP_CHECK(scratch_floats >= (long)K * B * T, MP_ERR_ARG, "scores_bwd: scratch too small");
+  hipLaunchKernelGGL(scores_bwd_kernel, dim3(cdiv(B * T, 128)), dim3(128), 0, st, scores, dscores, p, K, O, dheadout, scratch, B, T,
+                     J);
+  MP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scores_param_kernel, dim3(K), dim3(256), 0, st, headout, scratch, gp, K, O, B, T, J);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bones tail: lengths[b][s] = mean_t headout[(b,t,s)]
+// ---------------------------------------------------------------------------------------------
+__global__ void bones_mean_fwd_kernel(const float* __restrict__ headout, float* __restrict__ lengths, int B, int T, int S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * S) return;
+  const int b = i / S, s = i % S;
+  float a = 0.f;
+  for (int t = 0; t < T; ++t) a += headout[((long)b * T + t) * S + s];
+  lengths[i] = a / (float)T;
+}
+
+int bones_mean_fwd(const float* headout, float* lengths, int B, int T, int S, hipStream_t st) {
+  hipLaunchKernelGGL(bones_mean_fwd_kernel, dim3(cdiv(B * S, 64)), dim3(64), 0, st, headout, lengths, B, T, S);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// block per batch item: dlengths[b][s] = sum over the item's KT decoded poses; dheadout[(b,t,s)] = dlengths / T
+__global__ __launch_bounds__(256) void bones_mean_bwd_kernel(const float* __restrict__ dlen_pose, int KT, float* __restrict__ dlengths,
+                                                              float* __restrict__ dheadout, int T, int S) {
+  __shared__ float red[256];
+  __shared__ float tot[32];
+  const int b = blockIdx.x, s = threadIdx.x % S, sub = threadIdx.x / S, nsub = 256 / S;
+  float a = 0.f;
+  if (sub < nsub)
+    for (int i = sub; i < KT; i += nsub) a += dlen_pose[((long)b * KT + i) * S + s];
+  red[threadIdx.x] = (sub < nsub) ? a : 0.f;
+  __syncthreads();
+  if (threadIdx.x < S) {
+    float t = 0.f;
+    for (int u = 0; u < nsub; ++u) t += red[u * S + threadIdx.x];
+    tot[threadIdx.x] = t;
+    if (dlengths != nullptr) dlengths[b * S + threadIdx.x] = t;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < T * S; i += 256) dheadout[(long)b * T * S + i] = tot[i % S] / (float)T;
+}
+
+int bones_mean_bwd(const float* dlen_pose, int KT, float* dlengths, float* dheadout, int B, int T, int S, hipStream_t st) {
+  MP_CHECK(S <= 32, MP_ERR_ARG, "bones_mean_bwd: S=%d > 32", S);
+  hipLaunchKernelGGL(bones_mean_bwd_kernel, dim3(B), dim3(256), 0, st, dlen_pose, KT, dlengths, dheadout, T, S);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+}  // namespace mp

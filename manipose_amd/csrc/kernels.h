@@ -1,0 +1,105 @@
+// Internal launcher declarations shared by the engine and the C-ABI shims.  All pointers are device
+// pointers; all launchers enqueue on `st` and return MP_OK or an error code with mp::set_error() filled in.
+#pragma once
+#include "common.h"
+
+namespace mp {
+
+// ---------------------------------------------------------------- GEMM (gemm_f32.hip)
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_DGELU = 3, EPI_SLAB = 4 };
+struct GemmF32Args {
+  const float* A;
+  const float* B;
+  float* C;
+  long lda, ldb, ldc;
+  int M, N, K;
+  const float* bias;   // per output column, may be null
+  float* Z;            // EPI_BIAS_GELU: pre-activation (written); EPI_DGELU: pre-activation (read)
+  const float* R;      // EPI_BIAS_RESID: residual stream (read)
+  const float* mask;   // EPI_BIAS_RESID: DropPath multipliers per sample, may be null
+  int mask_mode, T, J; // see droppath_scale()
+  float* bias_slab;    // EPI_SLAB
+  int k_per_split;     // EPI_SLAB
+};
+int gemm_f32(int AL, int BL, int EPI, GemmF32Args g, hipStream_t st);
+int wgrad_f32(const float* dY, long lddy, const float* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
+              float* slab, long slab_floats, hipStream_t st);
+
+// ---------------------------------------------------------------- elementwise.hip
+struct LnFwdArgs {
+  const float* x;        // [M][C] input
+  int M, C;
+  // stage 1 (optional, g1 != null): x1 = LN(x; g1,b1,eps1) (+ pos[t(m)]) written fp32
+  const float* g1; const float* b1; float eps1;
+  const float* pos; int T, J;          // pos: [T][C] temporal positional table or null
+  float* x1; float* stats1;            // stats: [M][2] = (mean, rstd)
+  // stage 2 (optional, g2 != null): y2 = LN(stage-1 output or x; g2,b2,eps2)
+  const float* g2; const float* b2; float eps2;
+  void* y2; float* stats2;
+};
+int ln_fwd(const LnFwdArgs& a, int out_bf16, hipStream_t st);
+// dx = [dskip +] LN'(dy); partial param grads are reduced and ADDED into dgamma/dbeta.
+int ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx,
+           float* dgamma, float* dbeta, int M, int C, float* scratch, long scratch_floats, hipStream_t st);
+
+int embed_fwd(const float* xin, const float* W, const float* b, const float* spos, float* out, int M, int C, int J,
+              hipStream_t st);
+int embed_bwd(const float* g, const float* xin, float* dW, float* db, float* dspos, int M, int C, int J, float* scratch,
+              long scratch_floats, hipStream_t st);
+int bones_embed_fwd(const float* xin, const float* W, const float* b, const float* spos, float* out, int BT, int IN, int O,
+                    hipStream_t st);
+int bones_embed_bwd(const float* g, const float* xin, float* dW, float* db, float* dspos, int BT, int IN, int O,
+                    float* scratch, long scratch_floats, hipStream_t st);
+int tpos_grad(const float* g, float* dtpos, int B, int T, int J, int C, hipStream_t st);
+int scale_rows(const float* g, const float* mask, int mask_mode, float* out, int M, int C, int T, int J, hipStream_t st);
+int adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1, float beta2, float eps,
+              float weight_decay, float grad_scale, hipStream_t st);
+struct MaskDesc { int offset, count; float keep; };
+int droppath_masks(float* masks, const MaskDesc* descs, int ndesc, unsigned long long seed, unsigned long long step,
+                   hipStream_t st);
+
+// ---------------------------------------------------------------- attention.hip
+// qkv: [M][3C] (q | k | v, head-major inside each), out: [M][C]; token layout m = (b*T + t)*J + j
+int attn_spatial_fwd(const float* qkv, float* out, int B, int T, int J, int C, int H, hipStream_t st);
+int attn_spatial_bwd(const float* qkv, const float* dout, float* dqkv, int B, int T, int J, int C, int H, hipStream_t st);
+int attn_temporal_fwd(const float* qkv, float* out, float* lse, int B, int T, int J, int C, int H, hipStream_t st);
+int attn_temporal_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv,
+                      int B, int T, int J, int C, int H, hipStream_t st);
+
+// ---------------------------------------------------------------- heads.hip
+// K heads of LayerNorm(C, eps 1e-5) + Linear(C, O): out[k][m][o]
+struct HeadParams { const float* gamma[8]; const float* beta[8]; const float* W[8]; const float* b[8]; };
+struct HeadGrads { float* gamma[8]; float* beta[8]; float* W[8]; float* b[8]; };
+int heads_fwd(const float* x, const HeadParams& p, int K, int O, float* out, float* stats, int M, int C, hipStream_t st);
+int heads_bwd(const float* x, const float* stats, const HeadParams& p, const HeadGrads& gp, int K, int O, const float* dout,
+              float* dx, int M, int C, float* scratch, long scratch_floats, hipStream_t st);
+// score head: logit[b,k,t] = sum_j ws_k[j] * headout[k][(b,t,j)][O-1] + bs_k ; scores = softmax_k
+struct ScoreParams { const float* w[8]; const float* b[8]; };
+struct ScoreGrads { float* w[8]; float* b[8]; };
+int scores_fwd(const float* headout, const ScoreParams& p, int K, int O, float* scores, int B, int T, int J, hipStream_t st);
+int scores_bwd(const float* headout, const float* scores, const float* dscores, const ScoreParams& p, const ScoreGrads& gp,
+               int K, int O, float* dheadout, int B, int T, int J, float* scratch, long scratch_floats, hipStream_t st);
+int bones_mean_fwd(const float* headout, float* lengths, int B, int T, int S, hipStream_t st);
+int bones_mean_bwd(const float* dlen_pose, int KT, float* dlengths, float* dheadout, int B, int T, int S, hipStream_t st);
+
+// ---------------------------------------------------------------- fk_decode.hip
+// rot: element (k, m, c) at rot[(k*M + m)*rot_stride + c], m = (b*T+t)*J + j, c < 6; lengths [B][16]; poses [B][K][T][17][3]
+int fk_decode_fwd(const float* rot, int rot_stride, const float* lengths, float* poses, int B, int K, int T, hipStream_t st);
+int fk_decode_bwd(const float* rot, int rot_stride, const float* lengths, const float* dposes, float* drot,
+                  float* dlen_pose, int B, int K, int T, hipStream_t st);
+
+// ---------------------------------------------------------------- wta_loss.hip
+struct LossCfg { float beta, vel_w, smooth_w; int use_joint_weights; };
+// terms[4] = (wloss, score_reg, vloss, sreg); total = sum. dposes/dscores (may be null) receive d total / d input.
+int wta_loss(const float* poses, const float* scores, const float* y, const LossCfg& cfg, float* terms, int* argmin,
+             float* dposes, float* dscores, int B, int K, int T, float* scratch, long scratch_floats, hipStream_t st);
+// single-hypothesis loss (ManifoldMixSTE): terms[3] = (wloss, vloss, sreg)
+int single_loss(const float* poses, const float* y, const LossCfg& cfg, float* terms, float* dposes, int B, int T,
+                float* scratch, long scratch_floats, hipStream_t st);
+// eval: aggregate + MPJPE sums. mode 0 weighted_ave, 1 best_score, 2 oracle
+int aggregate_poses(const float* poses, const float* scores, const float* y, int mode, float* out, int B, int K, int T,
+                    hipStream_t st);
+int mpjpe_sum(const float* pred, const float* gt, long njoints, float* out_sum, float* scratch, long scratch_floats,
+              hipStream_t st);
+
+}  // namespace mp

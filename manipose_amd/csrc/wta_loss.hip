@@ -1,0 +1,245 @@
+// Fused Winner-Take-All multi-hypothesis training loss, forward AND gradient in one pass over the poses:
+//   wloss     = mean_{b,t} min_k mean_j w_j |p_kj - y_j|                       losses.py:104-138 (+ :14-43)
+//   score_reg = beta * BCE(scores, onehot(argmin_k))                            losses.py:141-170
+//   vloss     = vel_w * mean_{b,k,t<T-1,j} |d_t p - d_t y|   (ALL hypotheses)   losses.py:75-101, axis = 2
+//   sreg      = smooth_w * mean_{b,k,t<T-1,j,c} w_j (d_t p)^2                   regularizations.py:160-174
+// assembled as main_h36m_lifting.py:101-209 does (the reference evaluates the WTA part twice per step and
+// syncs the host 5 times; here it is one kernel + a 1-block finalize and no host sync).
+// One thread per frame (b,t).  K = 1 with scores == nullptr is the single-hypothesis loss of ManifoldMixSTE.
+#include "common.h"
+#include "kernels.h"
+
+namespace mp {
+
+constexpr int LJ = 17;
+__constant__ float c_w[LJ] = {1, 1, 2.5f, 2.5f, 1, 2.5f, 2.5f, 1, 1, 1, 1.5f, 1.5f, 4, 4, 1.5f, 4, 4};   // losses.py:6-8
+
+struct LossScales { float wta, bce, vel, smooth; };
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void wta_loss_kernel(const float* __restrict__ poses, const float* __restrict__ scores,
+                                                        const float* __restrict__ y, int use_w, LossScales sc,
+                                                        float* __restrict__ partial, int* __restrict__ argmin,
+                                                        float* __restrict__ dposes, float* __restrict__ dscores, int B, int K,
+                                                        int T) {
+  __shared__ float red[4];
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = f < B * T;
+  const int b = valid ? f / T : 0, t = valid ? f % T : 0;
+  const float* yr = y + ((long)b * T + t) * LJ * 3;
+  float lw = 0.f, lb = 0.f, lv = 0.f, ls = 0.f;
+  if (valid) {
+    // ---- pass 1: per-hypothesis weighted MPJPE and the winner ----
+    float best = INFINITY;
+    int kb = 0;
+    for (int k = 0; k < K; ++k) {
+      const float* pr = poses + (((long)b * K + k) * T + t) * LJ * 3;
+      float e = 0.f;
+      for (int j = 0; j < LJ; ++j) {
+        const float dx = pr[3 * j] - yr[3 * j], dy = pr[3 * j + 1] - yr[3 * j + 1], dz = pr[3 * j + 2] - yr[3 * j + 2];
+        e += (use_w ? c_w[j] : 1.0f) * sqrtf(dx * dx + dy * dy + dz * dz);
+      }
+      e /= (float)LJ;
+      if (e < best) { best = e; kb = k; }
+    }
+    lw = best * sc.wta;
+    if (argmin != nullptr) argmin[f] = kb;
+    // ---- scoring BCE (torch clamps log at -100; backward divides by max(s(1-s), 1e-12)) ----
+    if (scores != nullptr) {
+      for (int k = 0; k < K; ++k) {
+        const float s = scores[((long)b * K + k) * T + t];
+        const float gt = (k == kb) ? 1.0f : 0.0f;
+        const float l1 = fmaxf(logf(s), -100.0f), l0 = fmaxf(logf(1.0f - s), -100.0f);
+        lb -= (gt * l1 + (1.0f - gt) * l0) * sc.bce;
+        if (dscores != nullptr) dscores[((long)b * K + k) * T + t] = sc.bce * (s - gt) / fmaxf(s * (1.0f - s), 1e-12f);
+      }
+    }
+    // ---- pass 2: velocity / smoothness terms and all pose gradients ----
+    const bool has_prev = t > 0, has_next = t < T - 1;
+    for (int k = 0; k < K; ++k) {
+      const long fo = (((long)b * K + k) * T + t) * LJ * 3;
+      const float* pr = poses + fo;
+      for (int j = 0; j < LJ; ++j) {
+        const float wj = use_w ? c_w[j] : 1.0f;
+        const float p0 = pr[3 * j], p1 = pr[3 * j + 1], p2 = pr[3 * j + 2];
+        const float y0 = yr[3 * j], y1 = yr[3 * j + 1], y2 = yr[3 * j + 2];
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (k == kb) {
+          const float dx = p0 - y0, dy = p1 - y1, dz = p2 - y2;
+          const float n = sqrtf(dx * dx + dy * dy + dz * dz);
+          if (n > 0.f) {
+            const float c = sc.wta * wj / ((float)LJ * n);
+            g0 += c * dx; g1 += c * dy; g2 += c * dz;
+          }
+        }
+        if (has_next) {
+          const float s0 = pr[LJ * 3 + 3 * j] - p0, s1 = pr[LJ * 3 + 3 * j + 1] - p1, s2 = pr[LJ * 3 + 3 * j + 2] - p2;
+          const float u0 = s0 - (yr[LJ * 3 + 3 * j] - y0), u1 = s1 - (yr[LJ * 3 + 3 * j + 1] - y1),
+                      u2 = s2 - (yr[LJ * 3 + 3 * j + 2] - y2);
+          const float n = sqrtf(u0 * u0 + u1 * u1 + u2 * u2);
+          lv += n * sc.vel;
+          ls += wj * (s0 * s0 + s1 * s1 + s2 * s2) * sc.smooth;
+          if (n > 0.f) {
+            const float c = sc.vel / n;
+            g0 -= c * u0; g1 -= c * u1; g2 -= c * u2;
+          }
+          const float c2 = 2.0f * sc.smooth * wj;
+          g0 -= c2 * s0; g1 -= c2 * s1; g2 -= c2 * s2;
+        }
+        if (has_prev) {
+          const float s0 = p0 - pr[-LJ * 3 + 3 * j], s1 = p1 - pr[-LJ * 3 + 3 * j + 1], s2 = p2 - pr[-LJ * 3 + 3 * j + 2];
+          const float u0 = s0 - (y0 - yr[-LJ * 3 + 3 * j]), u1 = s1 - (y1 - yr[-LJ * 3 + 3 * j + 1]),
+                      u2 = s2 - (y2 - yr[-LJ * 3 + 3 * j + 2]);
+          const float n = sqrtf(u0 * u0 + u1 * u1 + u2 * u2);
+          if (n > 0.f) {
+            const float c = sc.vel / n;
+            g0 += c * u0; g1 += c * u1; g2 += c * u2;
+          }
+          const float c2 = 2.0f * sc.smooth * wj;
+          g0 += c2 * s0; g1 += c2 * s1; g2 += c2 * s2;
+        }
+        if (dposes != nullptr) {
+          dposes[fo + 3 * j] = g0; dposes[fo + 3 * j + 1] = g1; dposes[fo + 3 * j + 2] = g2;
+        }
+      }
+    }
+  }
+  const float a = block_sum_256(lw, red), bb = block_sum_256(lb, red), c = block_sum_256(lv, red), d = block_sum_256(ls, red);
+  if (threadIdx.x == 0) {
+    partial[4 * blockIdx.x] = a; partial[4 * blockIdx.x + 1] = bb; partial[4 * blockIdx.x + 2] = c; partial[4 * blockIdx.x + 3] = d;
+  }
+}
+
+// one block: terms[i] = sum_p partial[p][i] for i < 4
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partial, int P, float* __restrict__ terms,
+                                                             int nterms_out, int skip_bce) {
+  __shared__ float red[4];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int p = threadIdx.x; p < P; p += 256)
+    for (int i = 0; i < 4; ++i) s[i] += partial[4 * p + i];
+  float tot[4];
+  for (int i = 0; i < 4; ++i) tot[i] = block_sum_256(s[i], red);
+  if (threadIdx.x == 0) {
+    if (skip_bce) { terms[0] = tot[0]; terms[1] = tot[2]; terms[2] = tot[3]; }
+    else { terms[0] = tot[0]; terms[1] = tot[1]; terms[2] = tot[2]; terms[3] = tot[3]; }
+  }
+  (void)nterms_out;
+}
+
+static int loss_impl(const float* poses, const float* scores, const float* y, const LossCfg& cfg, float* terms, int* argmin,
+                     float* dposes, float* dscores, int B, int K, int T, float* scratch, long scratch_floats, int skip_bce,
+                     hipStream_t st) {
+  MP_CHECK(B > 0 && K >= 1 && K <= 8 && T >= 2, MP_ERR_ARG, "wta_loss: B=%d K=%d T=%d unsupported (T >= 2, K <= 8)", B, K, T);
+  const int grid = cdiv(B * T, 256);
+  MP_CHECK(scratch_floats >= 4L * grid, MP_ERR_ARG, "wta_loss: scratch too small");
+  LossScales sc;
+  sc.wta = 1.0f / ((float)B * T);
+  sc.bce = (scores != nullptr) ? cfg.beta / ((float)B * K * T) : 0.f;
+  sc.vel = cfg.vel_w / ((float)B * K * (T - 1) * LJ);
+  sc.smooth = cfg.smooth_w / ((float)B * K * (T - 1) * LJ * 3);
+  hipLaunchKernelGGL(wta_loss_kernel, dim3(grid), dim3(256), 0, st, poses, scores, y, cfg.use_joint_weights, sc, scratch, argmin,
+                     dposes, dscores, B, K, T);
+  MP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, grid, terms, 4, skip_bce);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+int wta_loss(const float* poses, const float* scores, const float* y, const LossCfg& cfg, float* terms, int* argmin, float* dposes,
+             float* dscores, int B, int K, int T, float* scratch, long scratch_floats, hipStream_t st) {
+  MP_CHECK(scores != nullptr, MP_ERR_ARG, "wta_loss: scores required");
+  return loss_impl(poses, scores, y, cfg, terms, argmin, dposes, dscores, B, K, T, scratch, scratch_floats, 0, st);
+}
+
+int single_loss(const float* poses, const float* y, const LossCfg& cfg, float* terms, float* dposes, int B, int T, float* scratch,
+                long scratch_floats, hipStream_t st) {
+  return loss_impl(poses, nullptr, y, cfg, terms, nullptr, dposes, nullptr, B, 1, T, scratch, scratch_floats, 1, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// eval-time aggregation (RMCLManifoldMixSTE.aggregate, rmcl_manifold_mix_ste.py:141-185) and MPJPE
+// (mean_joint_errors.py:31-36).  mode 0 weighted_ave, 1 best_score, 2 oracle (unweighted argmin vs y)
+// ---------------------------------------------------------------------------------------------
+__global__ void aggregate_kernel(const float* __restrict__ poses, const float* __restrict__ scores, const float* __restrict__ y,
+                                 int mode, float* __restrict__ out, int B, int K, int T) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= B * T) return;
+  const int b = f / T, t = f % T;
+  float* o = out + (long)f * LJ * 3;
+  if (mode == 0) {
+    for (int i = 0; i < LJ * 3; ++i) {
+      float a = 0.f;
+      for (int k = 0; k < K; ++k) a += poses[(((long)b * K + k) * T + t) * LJ * 3 + i] * scores[((long)b * K + k) * T + t];
+      o[i] = a;
+    }
+    return;
+  }
+  int kb = 0;
+  if (mode == 1) {
+    float best = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      const float s = scores[((long)b * K + k) * T + t];
+      if (s > best) { best = s; kb = k; }
+    }
+  } else {
+    float best = INFINITY;
+    const float* yr = y + (long)f * LJ * 3;
+    for (int k = 0; k < K; ++k) {
+      const float* pr = poses + (((long)b * K + k) * T + t) * LJ * 3;
+      float e = 0.f;
+      for (int j = 0; j < LJ; ++j) {
+        const float dx = pr[3 * j] - yr[3 * j], dy = pr[3 * j + 1] - yr[3 * j + 1], dz = pr[3 * j + 2] - yr[3 * j + 2];
+        e += sqrtf(dx * dx + dy * dy + dz * dz);
+      }
+      if (e < best) { best = e; kb = k; }
+    }
+  }
+  const float* pr = poses + (((long)b * K + kb) * T + t) * LJ * 3;
+  for (int i = 0; i < LJ * 3; ++i) o[i] = pr[i];
+}
+
+int aggregate_poses(const float* poses, const float* scores, const float* y, int mode, float* out, int B, int K, int T,
+                    hipStream_t st) {
+  MP_CHECK(mode >= 0 && mode <= 2, MP_ERR_ARG, "aggregate_poses: mode %d (0 weighted_ave, 1 best_score, 2 oracle)", mode);
+  MP_CHECK(mode == 2 ? y != nullptr : scores != nullptr, MP_ERR_ARG, "aggregate_poses: missing scores / ground truth");
+  hipLaunchKernelGGL(aggregate_kernel, dim3(cdiv(B * T, 128)), dim3(128), 0, st, poses, scores, y, mode, out, B, K, T);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+__global__ __launch_bounds__(256) void mpjpe_partial_kernel(const float* __restrict__ pred, const float* __restrict__ gt, long n,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float dx = pred[3 * i] - gt[3 * i], dy = pred[3 * i + 1] - gt[3 * i + 1], dz = pred[3 * i + 2] - gt[3 * i + 2];
+    s += sqrtf(dx * dx + dy * dy + dz * dz);
+  }
+  const float tot = block_sum_256(s, red);
+  if (threadIdx.x == 0) {
+    partial[4 * blockIdx.x] = tot;
+    partial[4 * blockIdx.x + 1] = 0.f; partial[4 * blockIdx.x + 2] = 0.f; partial[4 * blockIdx.x + 3] = 0.f;
+  }
+}
+
+int mpjpe_sum(const float* pred, const float* gt, long njoints, float* out_sum, float* scratch, long scratch_floats,
+              hipStream_t st) {
+  const int grid = (int)max(1L, min((njoints + 255) / 256, 1024L));
+  MP_CHECK(scratch_floats >= 4L * grid + 4, MP_ERR_ARG, "mpjpe_sum: scratch too small");
+  hipLaunchKernelGGL(mpjpe_partial_kernel, dim3(grid), dim3(256), 0, st, pred, gt, njoints, scratch);
+  MP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, grid, scratch + 4L * grid, 4, 0);
+  MP_LAUNCH_CHECK();
+  MP_HIP(hipMemcpyAsync(out_sum, scratch + 4L * grid, sizeof(float), hipMemcpyDeviceToDevice, st));
+  return MP_OK;
+}
+
+}  // namespace mp

@@ -1,0 +1,65 @@
+"""Fused Adam over the model's flat parameter buffer (mp_adam_step; reference: torch.optim.Adam(lr=4e-5,
+weight_decay=1e-6), hpe/main_h36m_lifting.py:234-238) and the data-parallel gradient exchange."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam:
+    """One kernel launch per step over all parameters.  ``state_dict``/``load_state_dict`` keep the moments so that
+    checkpoints (params_{tag}.pth of the reference, main_h36m_lifting.py:75-98) can be resumed."""
+
+    def __init__(self, model, lr: float = 4e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-6):
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.exp_avg: Optional[torch.Tensor] = None
+        self.exp_avg_sq: Optional[torch.Tensor] = None
+        self.param_groups = [{"lr": lr}]          # so torch lr schedulers' bookkeeping style code can read/modify lr
+
+    def _flat_grad(self) -> torch.Tensor:
+        m = self.model
+        flat = m.flat_parameters()
+        g = m._last_flat_grad
+        ok = g is not None and all(p.grad is not None and p.grad.data_ptr() == g.data_ptr() + 4 * off
+                                   for (off, _), p in zip(m._slots, m._plist))
+        if ok:
+            return g
+        g = torch.zeros_like(flat)            # gradients were accumulated/replaced by the caller: gather them
+        for (off, n), p in zip(m._slots, m._plist):
+            if p.grad is not None:
+                g[off:off + n].copy_(p.grad.reshape(-1))
+        return g
+
+    def step(self, flat_grad: Optional[torch.Tensor] = None, grad_scale: float = 1.0) -> None:
+        lib = _lib.load()
+        flat = self.model.flat_parameters()
+        g = flat_grad if flat_grad is not None else self._flat_grad()
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(flat)
+            self.exp_avg_sq = torch.zeros_like(flat)
+        self.step_count += 1
+        lr = self.param_groups[0]["lr"]
+        _lib.check(lib.mp_adam_step(_lib.ptr(flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                    flat.numel(), self.step_count, lr, self.betas[0], self.betas[1], self.eps,
+                                    self.weight_decay, grad_scale, _lib.stream_ptr()), "mp_adam_step")
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for p in self.model.parameters():
+            p.grad = None
+        self.model._last_flat_grad = None
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.param_groups[0]["lr"] = sd.get("lr", self.lr)
+        dev = self.model.flat_parameters().device
+        self.exp_avg = sd["exp_avg"].to(dev) if sd["exp_avg"] is not None else None
+        self.exp_avg_sq = sd["exp_avg_sq"].to(dev) if sd["exp_avg_sq"] is not None else None

@@ -1,0 +1,363 @@
+"""GPU parity tests: every HIP kernel and the whole model (forward, loss, backward, Adam) through the C ABI against
+the CPU oracle (oracle/manipose_ref.py) and the committed golden fixtures.  Run with ``pytest -m gpu`` on an MI355X.
+
+Tolerances: the path is fp32 end to end in the default (parity) precision; the north-star bound is 1e-4 m on MPJPE.
+Kernel-level comparisons use rtol/atol a few fp32 ulps above the CPU oracle's own reassociation noise.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import manipose_ref as orc
+from helpers import fixture_masks, fixture_state, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+MPJPE_TOL_M = 1e-4      # BASELINE.json north_star: outputs within 1e-4 on MPJPE
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from manipose_amd import _lib
+    assert torch.cuda.is_available(), "the gpu-marked tests need an MI355X"
+    return _lib.load()
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def close(got, want, rtol=1e-4, atol=1e-5, msg=""):
+    np.testing.assert_allclose(got.detach().cpu().numpy() if torch.is_tensor(got) else got,
+                               want.detach().cpu().numpy() if torch.is_tensor(want) else want, rtol=rtol, atol=atol,
+                               err_msg=msg)
+
+
+# --------------------------------------------------------------------------------------------- decoder
+def test_fk_decode_forward_backward_vs_reference_fixture(lib):
+    from manipose_amd import _lib
+    fx = load_fixture("decoder")
+    rot = dev(fx["rot6d"])                      # (B*L, 17, 6) rows ordered (b, l)
+    B, L = 3, 7
+    lengths = dev(fx["bones"].reshape(B, 16))
+    poses = torch.empty(B, 1, L, 17, 3, device="cuda")
+    _lib.check(lib.mp_fk_decode_fwd(rot.data_ptr(), 6, lengths.data_ptr(), poses.data_ptr(), B, 1, L, st()))
+    close(poses.view(B * L, 17, 3), fx["poses"], rtol=1e-5, atol=2e-6)
+    assert bool((poses[..., 0, :] == 0).all())
+    gp = dev(fx["gpos"]).view(B, 1, L, 17, 3).contiguous()
+    drot = torch.zeros_like(rot)
+    dlen = torch.zeros(B * L, 16, device="cuda")
+    _lib.check(lib.mp_fk_decode_bwd(rot.data_ptr(), 6, lengths.data_ptr(), gp.data_ptr(), drot.data_ptr(), dlen.data_ptr(),
+                                    B, 1, L, st()))
+    want = fx["g_rot6d"]
+    finite = np.isfinite(want)                  # the reference's autograd yields NaN at the two degenerate joints
+    assert (~finite).sum() == 12
+    got = drot.cpu().numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got[finite], want[finite], rtol=2e-4, atol=2e-5)
+    close(dlen.view(B, L, 16).sum(1), fx["g_bones"].reshape(B, 16), rtol=2e-4, atol=2e-5)
+
+
+def test_fk_decode_known_answer_tpose_and_autograd_module(lib):
+    from manipose_amd.architectures import PoseDecoder
+    from manipose_amd.data import h36m_skeleton
+    fx = load_fixture("decoder")
+    dec = PoseDecoder(h36m_skeleton())
+    ident = torch.tensor([1., 0, 0, 0, 1, 0], device="cuda").repeat(1, 17, 1)
+    tp = dec(ident, dev(fx["tpose_lens"]), torch.zeros(1, 3, device="cuda"))
+    close(tp, fx["tpose"], atol=1e-7)
+    rot = dev(fx["rot6d"][2:]).requires_grad_(True)            # skip the rows holding the degenerate joints
+    bl = dev(fx["bones"]).requires_grad_(True)
+    rot_full = torch.cat([dev(fx["rot6d"][:2]), rot], 0)
+    poses = dec(rot_full, bl)
+    (poses * dev(fx["gpos"])).sum().backward()
+    close(rot.grad, fx["g_rot6d"][2:], rtol=2e-4, atol=2e-5)
+    close(bl.grad, fx["g_bones"], rtol=2e-4, atol=2e-5)
+
+
+# --------------------------------------------------------------------------------------------- loss
+def test_wta_loss_terms_and_gradients_vs_reference_fixture(lib):
+    from manipose_amd.metrics import rmcl_training_loss
+    fx = load_fixture("loss")
+    poses = dev(fx["poses"]).requires_grad_(True)
+    scores = dev(fx["scores"]).requires_grad_(True)
+    total, terms = rmcl_training_loss(poses, scores, dev(fx["y"]))
+    total.backward()
+    got = np.array([terms[k].item() for k in ("wloss", "score_reg", "vloss", "sreg")])
+    np.testing.assert_allclose(got, fx["loss_terms"], rtol=2e-5)
+    close(poses.grad, fx["g_poses"], rtol=1e-4, atol=1e-8)
+    close(scores.grad, fx["g_scores"], rtol=1e-4, atol=1e-8)
+
+
+def test_reference_named_loss_functions(lib):
+    from manipose_amd import metrics as M
+    fx = load_fixture("loss")
+    poses, scores, y = dev(fx["poses"]), dev(fx["scores"]), dev(fx["y"])
+    w = M.STANDARD_H36M_WEIGHTS
+    cp, cy = torch.from_numpy(fx["poses"]), torch.from_numpy(fx["y"])
+    val, idx = M.wta_l2_loss_and_activate_head(poses, y, weights=w)
+    oval, oidx = orc.wta_l2_loss_and_activate_head(cp, cy, w)
+    assert torch.equal(idx.cpu(), oidx)
+    close(val, oval, rtol=1e-5, atol=1e-7)
+    close(M.mean_velocity_error(poses, y, axis=2), orc.mean_velocity_error(cp, cy, axis=2), rtol=1e-5)
+    close(M.smoothness_regularization(poses, w, axis=2), orc.smoothness_regularization(cp, w, axis=2), rtol=1e-5)
+    both, reg = M.wta_with_scoring_loss(poses, scores, y, beta=0.1, weights=w)
+    oboth, oreg = orc.wta_with_scoring_loss(cp, torch.from_numpy(fx["scores"]), cy, 0.1, w)
+    close(both, oboth, rtol=1e-5)
+    close(reg, oreg, rtol=1e-5)
+    close(M.mpjpe_error(poses[:, 0], y, "average"), orc.mpjpe_error(cp[:, 0], cy), rtol=1e-5)
+
+
+# --------------------------------------------------------------------------------------------- building blocks
+@pytest.mark.parametrize("M,C", [(37, 32), (306, 128), (4131, 512)])
+def test_layernorm_forward_backward(lib, M, C):
+    from manipose_amd import _lib
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    dy, dskip = torch.randn(M, C, generator=g), torch.randn(M, C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-6)
+    (y_ref * dy).sum().backward()
+    xd, y, stats = x.cuda(), torch.empty(M, C, device="cuda"), torch.empty(M, 2, device="cuda")
+    _lib.check(lib.mp_layernorm_fwd(xd.data_ptr(), gamma.cuda().data_ptr(), beta.cuda().data_ptr(), 1e-6, y.data_ptr(),
+                                    stats.data_ptr(), M, C, st()))
+    close(y, y_ref, rtol=1e-5, atol=2e-6)
+    dx = torch.empty(M, C, device="cuda")
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    scratch = torch.empty(512 * 2 * C + 16, device="cuda")
+    _lib.check(lib.mp_layernorm_bwd(dy.cuda().data_ptr(), xd.data_ptr(), stats.data_ptr(), gamma.cuda().data_ptr(),
+                                    dskip.cuda().data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M, C,
+                                    scratch.data_ptr(), scratch.numel(), st()))
+    close(dx, xr.grad + dskip, rtol=1e-4, atol=1e-5)
+    close(dg, gr.grad, rtol=1e-4, atol=1e-4)
+    close(db, br.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(306, 96, 32), (130, 48, 16), (4131, 1536, 512), (1000, 512, 1024)])
+def test_linear_forward_epilogues_and_backward(lib, M, N, K):
+    from manipose_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    r, dy = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    xd, Wd, bd = x.cuda(), W.cuda(), b.cuda()
+    ref = (x.double() @ W.double().T + b.double())
+    tol = dict(rtol=2e-5, atol=2e-5 * max(1.0, (K / 64) ** 0.5))
+    y = torch.empty(M, N, device="cuda")
+    _lib.check(lib.mp_linear_fwd(xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), y.data_ptr(), None, None, M, N, K, 0, st()))
+    close(y, ref.float(), **tol)
+    z = torch.empty(M, N, device="cuda")
+    _lib.check(lib.mp_linear_fwd(xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), y.data_ptr(), z.data_ptr(), None, M, N, K, 1, st()))
+    close(z, ref.float(), **tol)
+    close(y, torch.nn.functional.gelu(ref).float(), **tol)
+    _lib.check(lib.mp_linear_fwd(xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), y.data_ptr(), None, r.cuda().data_ptr(), M, N, K, 2, st()))
+    close(y, (ref + r.double()).float(), **tol)
+    # backward: dx = dy W, dW += dy^T x (accumulating), db += colsum(dy)
+    dx = torch.empty(M, K, device="cuda")
+    dW, db = torch.ones(N, K, device="cuda"), torch.ones(N, device="cuda")
+    slab = torch.empty(int(lib.mp_linear_bwd_slab_floats(N, K)), device="cuda")
+    _lib.check(lib.mp_linear_bwd(dy.cuda().data_ptr(), xd.data_ptr(), Wd.data_ptr(), dx.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                                 M, N, K, slab.data_ptr(), slab.numel(), st()))
+    tolb = dict(rtol=5e-5, atol=5e-5 * max(1.0, (M / 64) ** 0.5))
+    close(dx, (dy.double() @ W.double()).float(), rtol=5e-5, atol=5e-5 * max(1.0, (N / 64) ** 0.5))
+    close(dW, (1 + dy.double().T @ x.double()).float(), **tolb)
+    close(db, (1 + dy.double().sum(0)).float(), **tolb)
+
+
+def _attn_ref(qkv, B, T, J, C, H, temporal):
+    """mix_ste.py:255-279 restated on the (b,t,j) token layout for one fused qkv buffer."""
+    d = C // H
+    q, k, v = qkv.view(B, T, J, 3, H, d).unbind(3)                        # (B,T,J,H,d)
+    if temporal:
+        q, k, v = (t.permute(0, 2, 3, 1, 4) for t in (q, k, v))           # (B,J,H,T,d)
+    else:
+        q, k, v = (t.permute(0, 1, 3, 2, 4) for t in (q, k, v))           # (B,T,H,J,d)
+    a = ((q @ k.transpose(-2, -1)) * d ** -0.5).softmax(-1) @ v
+    a = a.permute(0, 3, 1, 2, 4) if temporal else a.permute(0, 1, 3, 2, 4)
+    return a.reshape(B * T * J, C)
+
+
+@pytest.mark.parametrize("temporal,B,T,J,C,H", [(0, 2, 9, 17, 32, 4), (0, 1, 27, 16, 128, 8), (0, 1, 5, 17, 512, 8),
+                                                (1, 2, 9, 17, 32, 4), (1, 1, 27, 16, 128, 8), (1, 1, 243, 17, 64, 1),
+                                                (1, 1, 243, 2, 512, 8), (1, 1, 300, 3, 16, 4)])
+def test_attention_forward_backward(lib, temporal, B, T, J, C, H):
+    from manipose_amd import _lib
+    g = torch.Generator().manual_seed(T * 7 + C)
+    M = B * T * J
+    qkv = torch.randn(M, 3 * C, generator=g).requires_grad_(True)
+    dout = torch.randn(M, C, generator=g)
+    ref = _attn_ref(qkv, B, T, J, C, H, temporal)
+    (ref * dout).sum().backward()
+    qd = qkv.detach().cuda()
+    out = torch.empty(M, C, device="cuda")
+    lse = torch.empty(B * J * H * T, device="cuda")
+    _lib.check(lib.mp_attention_fwd(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), temporal, B, T, J, C, H, st()))
+    close(out, ref, rtol=2e-5, atol=2e-6)
+    dq = torch.zeros(M, 3 * C, device="cuda")
+    delta = torch.empty(B * J * H * T, device="cuda")
+    _lib.check(lib.mp_attention_bwd(qd.data_ptr(), out.data_ptr(), dout.cuda().data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                    dq.data_ptr(), temporal, B, T, J, C, H, st()))
+    close(dq, qkv.grad, rtol=1e-4, atol=2e-6)
+
+
+def test_adam_step_vs_reference_fixture(lib):
+    from manipose_amd import _lib
+    fx = load_fixture("rmcl_tiny")
+    for k in [k[7:] for k in fx if k.startswith("adam1::")]:
+        p, g = dev(fx["w::" + k]).clone(), dev(fx["g::" + k])
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        _lib.check(lib.mp_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 1, 4e-5, 0.9, 0.999,
+                                    1e-8, 1e-6, 1.0, st()))
+        close(p, fx["adam1::" + k], rtol=1e-6, atol=1e-9)
+
+
+# --------------------------------------------------------------------------------------------- whole model
+def _build(fx, drop_path_rate=0.0):
+    from manipose_amd import ManifoldMixSTE, RMCLManifoldMixSTE, h36m_skeleton
+    c = fx["cfg"]
+    kw = dict(skeleton=h36m_skeleton(), num_frame=c["T"], embed_dim_rot=c["C_rot"], depth_rot=c["depth_rot"],
+              num_heads_rot=c["heads_rot"], embed_dim_seg=c["C_seg"], depth_seg=c["depth_seg"], num_heads_seg=c["heads_seg"],
+              drop_path_rate=drop_path_rate)
+    model = RMCLManifoldMixSTE(n_hyp=c["n_hyp"], **kw) if c["n_hyp"] > 0 else ManifoldMixSTE(**kw)
+    model.load_state_dict(fixture_state(fx), strict=True)
+    return model.cuda()
+
+
+def _check_grads(model, fx, rtol=2e-3, atol=2e-6):
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        want = fx["g::" + k]
+        got = p.grad.detach().cpu().numpy()
+        assert got.shape == want.shape, k
+        scale = np.abs(want).max() + 1e-12
+        err = np.abs(got - want).max() / scale
+        if err > worst[1]:
+            worst = (k, err)
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=atol + 1e-4 * scale, err_msg=k)
+    return worst
+
+
+@pytest.mark.parametrize("name", ["rmcl_tiny", "rmcl_small"])
+def test_rmcl_model_forward_loss_backward_vs_reference(lib, name):
+    from manipose_amd.metrics import mpjpe_error, rmcl_training_loss
+    fx = load_fixture(name)
+    model = _build(fx).eval()
+    X, y = dev(fx["X"]), dev(fx["y"])
+    poses, scores = model(X)
+    assert poses.shape == fx["poses"].shape and scores.shape == fx["scores"].shape
+    mp = mpjpe_error(poses, dev(fx["poses"]), "average").item()
+    assert mp <= MPJPE_TOL_M, f"MPJPE vs reference {mp:.3e} m"
+    close(poses, fx["poses"], rtol=1e-4, atol=2e-5)
+    close(scores, fx["scores"], rtol=1e-4, atol=1e-6)
+    assert bool((poses[..., 0, :] == 0).all())
+    close(scores.sum(1), torch.ones_like(scores.sum(1)), atol=1e-6)
+    if "rot6d" in fx:                                         # intermediates: head output and segment lengths
+        K, (B, T) = fx["cfg"]["n_hyp"], X.shape[:2]
+        ho = model._engine.peek(0).view(K, B, T, 17, 7)
+        close(ho[..., :6].permute(1, 0, 2, 3, 4), fx["rot6d"], rtol=1e-4, atol=2e-5)
+        close(model._engine.peek(1).view(B, 16, 1), fx["bones"], rtol=1e-4, atol=2e-6)
+    total, terms = rmcl_training_loss(poses, scores, y)
+    got = np.array([terms[k].item() for k in ("wloss", "score_reg", "vloss", "sreg")])
+    np.testing.assert_allclose(got, fx["loss_terms"], rtol=1e-4)
+    total.backward()
+    _check_grads(model, fx)
+    # eval-time aggregation modes against the reference's outputs
+    close(model.aggregate(poses, scores, "weighted_ave"), fx["agg_weighted"], rtol=1e-4, atol=2e-5)
+    close(model.aggregate(poses, scores, "best_score"), fx["agg_best"], rtol=1e-4, atol=2e-5)
+    oe, op = model.aggregate(poses, mode="oracle", ground_truth=y)
+    close(op, fx["agg_oracle"], rtol=1e-4, atol=2e-5)
+    close(oe, fx["agg_oracle_err"], rtol=1e-4, atol=2e-6)
+    with pytest.raises(ValueError):
+        model.aggregate(poses, scores, mode="median")
+
+
+def test_manifold_single_hypothesis_model_vs_reference(lib):
+    from manipose_amd.metrics import manifold_training_loss
+    fx = load_fixture("manifold_k1")
+    model = _build(fx).eval()
+    pred = model(dev(fx["X"]))
+    close(pred, fx["poses"], rtol=1e-4, atol=2e-5)
+    total, terms = manifold_training_loss(pred, dev(fx["y"]))
+    got = np.array([terms[k].item() for k in ("wloss", "vloss", "sreg")])
+    np.testing.assert_allclose(got, fx["loss_terms"], rtol=1e-4)
+    total.backward()
+    _check_grads(model, fx)
+
+
+def test_droppath_train_mode_with_injected_masks_vs_reference(lib):
+    from manipose_amd.metrics import rmcl_training_loss
+    fx = load_fixture("rmcl_tiny_droppath")
+    model = _build(fx, drop_path_rate=float(fx["drop_path_rate"])).train()
+    model.set_droppath_masks({k: v.cuda() for k, v in fixture_masks(fx).items()})
+    poses, scores = model(dev(fx["X"]))
+    close(poses, fx["poses"], rtol=1e-4, atol=2e-5)
+    total, _ = rmcl_training_loss(poses, scores, dev(fx["y"]))
+    np.testing.assert_allclose(total.item(), float(fx["loss_total"]), rtol=1e-4)
+    total.backward()
+    _check_grads(model, fx)
+
+
+def test_droppath_engine_rng_statistics(lib):
+    """Engine-drawn masks: eval == no drop; train differs from eval and the keep frequency matches the rate."""
+    fx = load_fixture("rmcl_tiny")
+    model = _build(fx, drop_path_rate=0.5)
+    X = dev(np.tile(fx["X"], (16, 1, 1, 1)))
+    with torch.no_grad():
+        p_eval, _ = model.eval()(X)
+        p_tr1, _ = model.train()(X)
+        p_tr2, _ = model.train()(X)
+    close(p_eval[:2], fx["poses"], rtol=1e-4, atol=2e-5)
+    assert not torch.allclose(p_eval, p_tr1) and not torch.allclose(p_tr1, p_tr2)
+    layout = model._engine.mask_layout(X.shape[0])
+    assert [n for n, *_ in layout][:2] == ["rotations_module.STEblocks.0.attn", "rotations_module.STEblocks.0.mlp"]
+    assert abs(layout[4][3] - 0.5) < 1e-6 and layout[0][3] == 1.0      # linspace(0, .5, 2) -> keep 1.0, 0.5
+
+
+def test_full_size_model_T243_K5_vs_oracle_and_manifold_property(lib):
+    """BASELINE config: T=243, J=17, K=5, C=512, depth 8 at B=1: MPJPE vs the CPU oracle <= 1e-4 m, parameter
+    gradients vs the oracle's autograd, and the size-independent manifold property (exact segment lengths)."""
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    from manipose_amd.metrics import mpjpe_error, rmcl_training_loss
+    cfg = orc.FULL_CFG
+    st_ = orc.make_state(cfg, seed=3)
+    model = RMCLManifoldMixSTE(h36m_skeleton(), drop_path_rate=0.0)
+    model.load_state_dict(st_, strict=True)
+    model = model.cuda().eval()
+    X, y = orc.synthetic_batch(1, 243, seed=42)
+    poses, scores = model(X.cuda())
+    req = {k: v.clone().requires_grad_(True) for k, v in st_.items()}
+    o_poses, o_scores = orc.rmcl_manifold_forward(X, req, orc.oracle_cfg(cfg))
+    mp = mpjpe_error(poses, o_poses.detach().cuda(), "average").item()
+    assert mp <= MPJPE_TOL_M, f"full-size MPJPE vs oracle {mp:.3e} m"
+    close(scores, o_scores.detach(), rtol=1e-3, atol=1e-5)
+    total, terms = rmcl_training_loss(poses, scores, y.cuda())
+    o_total, o_terms = orc.rmcl_training_loss(o_poses, o_scores, y)
+    np.testing.assert_allclose(total.item(), o_total.item(), rtol=1e-4)
+    total.backward()
+    o_total.backward()
+    bad = []
+    for k, p in model.named_parameters():
+        want = req[k].grad
+        err = (p.grad.cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+        if err > 5e-3:
+            bad.append((k, err))
+    assert not bad, bad[:5]
+    # manifold property at full size: every hypothesis/frame has exactly the predicted segment lengths
+    par = torch.tensor(orc.H36M_PARENTS[1:], device="cuda")
+    seg = (poses[..., 1:, :] - poses[..., par, :]).norm(dim=-1)
+    lens = model._engine.peek(1).view(1, 1, 1, 16).abs()
+    close(seg, lens.expand_as(seg), rtol=1e-4, atol=2e-6)
+
+
+def test_cpu_tensor_is_refused_loudly(lib):
+    fx = load_fixture("rmcl_tiny")
+    model = _build(fx)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.from_numpy(fx["X"]))
