@@ -146,6 +146,8 @@ int mp_model_backward(mp_model* m, const float* flat_params, float* flat_grads, 
 /* intermediate outputs of the last forward (device pointers owned by the model): 0 = head output
  * (K, B*T*17, O), 1 = segment lengths (B, 16) */
 int mp_model_peek(const mp_model* m, int which, const float** ptr, int64_t* numel);
+/* copy `numel` floats of intermediate `which` into dst (device) on `stream` */
+int mp_model_peek_copy(const mp_model* m, int which, float* dst, int64_t numel, void* stream);
 
 /* per-kernel-class device timing (HIP events on `stream`): classes 0 gemm_fwd, 1 gemm_dgrad, 2 gemm_wgrad,
  * 3 attention, 4 layernorm, 5 other.  collect() synchronises the events, adds up elapsed ms / launch counts /

@@ -18,6 +18,7 @@ class _LiftFunction(torch.autograd.Function):
         model._step_counter += 1
         poses, scores = eng.forward(model._flat, x, train=train, masks=masks, seed=model._seed, step=model._step_counter)
         ctx.model = model
+        ctx.save_for_backward(x)          # the engine reads x again in the embedding backward: keep it alive
         ctx.has_scores = scores is not None
         ctx.fwd_id = model._step_counter
         if scores is None:

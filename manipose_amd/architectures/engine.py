@@ -92,9 +92,8 @@ class LiftEngine:
         p, n = C.c_void_p(), C.c_int64()
         _lib.check(self.lib.mp_model_peek(self.handle, which, C.byref(p), C.byref(n)), "mp_model_peek")
         out = torch.empty(int(n.value), dtype=torch.float32, device=self.device)
-        rc = torch.cuda.cudart().cudaMemcpy(out.data_ptr(), p.value, int(n.value) * 4, 3)   # 3 = device to device
-        if int(rc) != 0:
-            raise RuntimeError(f"hipMemcpy failed with code {rc}")
+        _lib.check(self.lib.mp_model_peek_copy(self.handle, which, _lib.ptr(out), out.numel(), _lib.stream_ptr()),
+                   "mp_model_peek_copy")
         return out
 
     def prof_enable(self, on: bool = True) -> None:

@@ -596,6 +596,16 @@ int mp_model_peek(const mp_model* m, int which, const float** ptr, int64_t* nume
   MP_CHECK(false, MP_ERR_ARG, "mp_model_peek: which=%d", which);
 }
 
+int mp_model_peek_copy(const mp_model* m, int which, float* dst, int64_t numel, void* stream) {
+  const float* src = nullptr;
+  int64_t n = 0;
+  int rc = mp_model_peek(m, which, &src, &n);
+  if (rc) return rc;
+  MP_CHECK(dst && numel == n, MP_ERR_ARG, "mp_model_peek_copy: expected %ld floats", (long)n);
+  MP_HIP(hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MP_OK;
+}
+
 int mp_prof_enable(mp_model* m, int on) {
   MP_CHECK(m, MP_ERR_ARG, "mp_prof_enable: null model");
   if (on && m->ev.empty()) {

@@ -66,19 +66,30 @@ __device__ __forceinline__ void cross3(const float* u, const float* v, float* o)
 
 // Gram-Schmidt: returns R with columns x | y | z; also the intermediates needed by the backward
 struct GS { float x[3], y[3], z[3], na, nz; };
+// The Gram-Schmidt step is evaluated with the reference's operation order and one rounding per operation
+// (no FMA contraction, true divisions): for (near-)degenerate inputs (colinear 6-D halves) the result is
+// ill-conditioned and only the same rounding sequence reproduces the reference's joints.
+__device__ __forceinline__ void cross3_exact(const float* u, const float* v, float* o) {
+  o[0] = __fsub_rn(__fmul_rn(u[1], v[2]), __fmul_rn(u[2], v[1]));
+  o[1] = __fsub_rn(__fmul_rn(u[2], v[0]), __fmul_rn(u[0], v[2]));
+  o[2] = __fsub_rn(__fmul_rn(u[0], v[1]), __fmul_rn(u[1], v[0]));
+}
+__device__ __forceinline__ float norm3_exact(const float* v) {
+  return __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(v[0], v[0]), __fmul_rn(v[1], v[1])), __fmul_rn(v[2], v[2])));
+}
 __device__ __forceinline__ GS gram_schmidt(const float* r6) {
   GS g;
-  const float na = sqrtf(r6[0] * r6[0] + r6[1] * r6[1] + r6[2] * r6[2]);
+  const float na = norm3_exact(r6);
   g.na = na;
-  const float ia = 1.0f / fmaxf(na, GS_EPS);
-  g.x[0] = r6[0] * ia; g.x[1] = r6[1] * ia; g.x[2] = r6[2] * ia;
+  const float da = fmaxf(na, GS_EPS);
+  g.x[0] = __fdiv_rn(r6[0], da); g.x[1] = __fdiv_rn(r6[1], da); g.x[2] = __fdiv_rn(r6[2], da);
   float zc[3];
-  cross3(g.x, r6 + 3, zc);
-  const float nz = sqrtf(zc[0] * zc[0] + zc[1] * zc[1] + zc[2] * zc[2]);
+  cross3_exact(g.x, r6 + 3, zc);
+  const float nz = norm3_exact(zc);
   g.nz = nz;
-  const float iz = 1.0f / fmaxf(nz, GS_EPS);
-  g.z[0] = zc[0] * iz; g.z[1] = zc[1] * iz; g.z[2] = zc[2] * iz;
-  cross3(g.z, g.x, g.y);
+  const float dz = fmaxf(nz, GS_EPS);
+  g.z[0] = __fdiv_rn(zc[0], dz); g.z[1] = __fdiv_rn(zc[1], dz); g.z[2] = __fdiv_rn(zc[2], dz);
+  cross3_exact(g.z, g.x, g.y);
   return g;
 }
 __device__ __forceinline__ M3 gs_matrix(const GS& g) {
