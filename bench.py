@@ -20,13 +20,25 @@ TRAIN_GFLOP_PER_POSE = {243: 3.705, 81: 3.562, 27: 3.513}      # SURVEY.md 8d (3
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}                  # MI355X_MICROARCH.md: dense matrix peaks
 
 
+def host_cores():
+    """CPU cores this job may actually use: cgroup quota (cpu.max) if set, else the affinity mask, else cpu_count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("MANIPOSE_CPU_THREADS", "64"))))
+
+
 def cpu_baseline(T, K, steps=3):
     """Oracle (CPU restatement of the reference, fp32, torch autograd + torch.optim.Adam) on a bounded sample:
     B=1 window of the same workload, 1 warm-up + `steps` timed training steps."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import manipose_ref as orc
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
     cfg = dict(orc.FULL_CFG, T=T, n_hyp=K)
     st = {k: v.requires_grad_(True) for k, v in orc.make_state(cfg, seed=0).items()}
     opt = torch.optim.Adam(list(st.values()), lr=4e-5, weight_decay=1e-6)
@@ -57,7 +69,22 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("MANIPOSE_PRECISION", "fp32"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) time the CPU oracle and print its JSON")
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.frames, args.hyp)), flush=True)
+        return
+    cpu_json = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+        # timed in a child process BEFORE this process touches the GPU, with a hard wall-clock bound
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--frames", str(args.frames),
+                                "--hyp", str(args.hyp)], capture_output=True, text=True, timeout=240)
+            cpu_json = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:       # noqa: BLE001
+            cpu_json = {"value": None, "unit": "poses/s", "cores": host_cores(), "kind": "port",
+                        "sample": f"CPU oracle did not finish inside its 240 s bound ({type(e).__name__})"}
 
     import torch
     import torch.distributed as dist
@@ -93,9 +120,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    log(f"model built, B={B} T={T} precision={args.precision}")
+    for i in range(args.warmup):
         terms = trainer.train_step(X, y)
+        if i == 0:
+            torch.cuda.synchronize()
+            log(f"first step done, workspace {model._engine.workspace_bytes / 2**30:.1f} GiB")
     barrier()
+    log("warmup done")
     eng = model._engine
     if not args.no_prof:
         eng.prof_enable(True)
@@ -104,6 +140,7 @@ def main():
         terms = trainer.train_step(X, y)
     barrier()
     dt = time.perf_counter() - t0
+    log(f"timed region done: {dt:.3f} s")
     prof = eng.prof_collect() if not args.no_prof else None
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -131,8 +168,8 @@ def main():
             out["kernel_classes"] = {n: {"ms_per_step": v["ms"] / args.steps, "share": v["ms"] / tot if tot else 0.0,
                                          "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}
                                      for n, v in prof.items()}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(T, args.hyp)
+        if cpu_json is not None:
+            out["cpu_baseline"] = cpu_json
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -609,7 +609,7 @@ int mp_model_peek_copy(const mp_model* m, int which, float* dst, int64_t numel, 
 int mp_prof_enable(mp_model* m, int on) {
   MP_CHECK(m, MP_ERR_ARG, "mp_prof_enable: null model");
   if (on && m->ev.empty()) {
-    m->ev.resize(131072);
+    m->ev.resize(16384);
     for (auto& e : m->ev) MP_HIP(hipEventCreate(&e));
   }
   m->prof = on != 0;
