@@ -112,7 +112,7 @@ typedef struct mp_model_config {
   int embed_dim_seg, depth_seg, num_heads_seg;
   int n_hyp;           /* K (ignored for arch 1) */
   float drop_path_rate;/* stochastic depth: linspace(0, rate, depth) per module (mix_ste.py:70) */
-  int max_batch;       /* workspace is sized for this many windows */
+  int max_batch;       /* workspace is sized for this many windows; 0 = layout-only handle (no device memory) */
   int precision;       /* 0 = fp32 matrix cores (parity mode), 1 = bf16 matrix cores / fp32 accumulate */
 } mp_model_config;
 

@@ -98,11 +98,22 @@ class FusedLiftingMixin:
         self._flat = flat
 
     def flat_parameters(self) -> torch.Tensor:
-        """The single contiguous fp32 buffer all parameters live in (engine layout); build it if needed."""
-        if self._flat is None:
-            p = next(self.parameters())
+        """The single contiguous fp32 buffer all parameters live in (engine layout); build it if needed.  On a CPU
+        model this only lays the parameters out (layout-only engine handle): compute still requires a ROCm device."""
+        p = next(self.parameters())
+        if p.device.type != "cuda":
+            if self._flat is None or self._flat.device != p.device or not self._views_intact():
+                self._engine = LiftEngine(arch=self._arch, max_batch=0, precision=self.precision, **self._engine_cfg)
+                self._flatten(self._engine, p.device)
+            return self._flat
+        if self._flat is None or self._flat.device != p.device or not self._views_intact():
             self._ensure_engine(max(1, self.max_batch_hint), p.device)
         return self._flat
+
+    def flat_layout(self):
+        """[(state-dict key, offset, numel)] of the flat buffer."""
+        self.flat_parameters()
+        return list(self._engine.layout)
 
     def set_droppath_masks(self, masks: Optional[Dict[str, torch.Tensor]]):
         """Inject DropPath multipliers (branch name -> per-sample tensor) for the next train-mode forwards

@@ -29,7 +29,7 @@ class LiftEngine:
         self.arch = arch
         self.K = max(1, n_hyp) if arch == "rmcl_manifold" else 1
         self.max_batch = max_batch
-        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device("cuda", torch.cuda.current_device()) if max_batch > 0 else torch.device("cpu")
         h = C.c_void_p()
         _lib.check(self.lib.mp_model_create(C.byref(self.cfg), C.byref(h)), "mp_model_create")
         self.handle = h

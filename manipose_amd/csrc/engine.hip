@@ -393,7 +393,7 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   MP_CHECK(cfg->arch == 0 || cfg->arch == 1, MP_ERR_ARG, "mp_model_create: arch %d (0 rmcl_manifold, 1 manifold)", cfg->arch);
   MP_CHECK(cfg->precision == 0, MP_ERR_ARG, "mp_model_create: precision %d not built in this version (0 = fp32)", cfg->precision);
   MP_CHECK(cfg->num_joints == 17 && cfg->num_bones == 16, MP_ERR_ARG, "mp_model_create: the decoder is built for the 17-joint H36M tree");
-  MP_CHECK(cfg->num_frame >= 2 && cfg->max_batch >= 1, MP_ERR_ARG, "mp_model_create: num_frame >= 2, max_batch >= 1");
+  MP_CHECK(cfg->num_frame >= 2 && cfg->max_batch >= 0, MP_ERR_ARG, "mp_model_create: num_frame >= 2, max_batch >= 0");
   MP_CHECK(cfg->embed_dim_rot % cfg->num_heads_rot == 0 && cfg->embed_dim_seg % cfg->num_heads_seg == 0, MP_ERR_ARG,
            "mp_model_create: embed dim must be divisible by heads");
   MP_CHECK(cfg->arch == 1 || (cfg->n_hyp >= 1 && cfg->n_hyp <= 8), MP_ERR_ARG, "mp_model_create: n_hyp in 1..8");
@@ -410,6 +410,10 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   build_module_params(m, m->seg);
   m->rot.mask_base = 0;
   m->seg.mask_base = (int)m->rot.masks.size();
+  if (cfg->max_batch == 0) {   // layout-only handle (parameter / mask layout queries, no device needed)
+    *out = m;
+    return MP_OK;
+  }
   Bump dry;
   carve_all(m, dry);
   m->arena_bytes = dry.off;

@@ -13,6 +13,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from .distributed import allreduce_gradients
 from .optim import FusedAdam
 
 
@@ -73,7 +74,7 @@ class LiftingTrainer:
         if self.world > 1:
             # one collective per step over the single flat gradient buffer (137.8 MB fp32 at full size); RCCL picks the
             # all-links algorithm over the xGMI mesh.  Averaging is folded into the Adam kernel (grad_scale).
-            dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+            allreduce_gradients(self.flat_grads, self.pg)
         self.opt.step(self.flat_grads, grad_scale=1.0 / self.world)
         return bf["terms"]
 

@@ -222,6 +222,10 @@ def main():
     gen_model_fixture(ref, "rmcl_tiny_droppath", tiny, B=3, seed=14, drop_path_rate=0.5, train=True)
     gen_decoder_fixture(ref)
     gen_loss_fixture(ref)
+    # default initialisation under seed 42 (the product's constructors must consume the RNG identically)
+    torch.manual_seed(42)
+    m0 = build_ref_model(ref, small, 0.1)
+    np.savez_compressed(os.path.join(OUT, "init_seed42_small.npz"), **{k: v.numpy() for k, v in m0.state_dict().items()})
     # parameter-count known answers
     counts = {}
     for nm, T, K in (("rmcl_T243_K5", 243, 5), ("rmcl_T81_K5", 81, 5), ("manifold_T27", 27, 0)):

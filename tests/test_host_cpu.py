@@ -1,0 +1,147 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every declared symbol, the parameter layout and
+initialisation match the reference, the product refuses to compute on CPU, and the 2-rank data-parallel exchange
+(gloo) reproduces the single-process gradient."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import manipose_ref as orc
+from helpers import fixture_state, load_fixture
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tiny_model(fx):
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    c = fx["cfg"]
+    m = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=c["T"], embed_dim_rot=c["C_rot"], depth_rot=c["depth_rot"],
+                           num_heads_rot=c["heads_rot"], embed_dim_seg=c["C_seg"], depth_seg=c["depth_seg"],
+                           num_heads_seg=c["heads_seg"], n_hyp=c["n_hyp"], drop_path_rate=0.0)
+    m.load_state_dict(fixture_state(fx), strict=True)
+    return m
+
+
+def test_library_exports_every_declared_symbol():
+    from manipose_amd import _lib
+    lib = _lib.load()
+    names = _lib.declared_symbols()
+    assert len(names) >= 30 and "mp_model_forward" in names and "mp_fk_decode_fwd" in names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/manipose_hip.h but not exported"
+        assert n in _lib._SIGNATURES, f"{n} has no ctypes signature in manipose_amd/_lib.py"
+    assert lib.mp_abi_version() == 1
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    from manipose_amd import ManifoldMixSTE, RMCLManifoldMixSTE, h36m_skeleton
+    m = RMCLManifoldMixSTE(h36m_skeleton())
+    got = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in m.state_dict().items())
+    assert got == open(golden_dir + "/state_dict_keys_T243_K5.txt").read().split()
+    z = np.load(golden_dir + "/param_counts.npz")
+    assert sum(p.numel() for p in m.parameters()) == int(z["rmcl_T243_K5"]) == 34440062
+    m27 = ManifoldMixSTE(h36m_skeleton(), num_frame=27)
+    assert sum(p.numel() for p in m27.parameters()) == int(z["manifold_T27"])
+    # engine layout (flat buffer) covers exactly the state-dict, 16-byte aligned, non-overlapping
+    lay = m.flat_layout()
+    assert {n for n, _, _ in lay} == set(m.state_dict())
+    ends = 0
+    for n, off, num in lay:
+        assert off % 4 == 0 and off >= ends
+        ends = off + num
+    flat = m.flat_parameters()
+    name, off, num = lay[5]
+    assert torch.equal(flat[off:off + num], dict(m.named_parameters())[name].detach().reshape(-1))
+    assert isinstance(m, RMCLManifoldMixSTE) and isinstance(m, ManifoldMixSTE)     # reference isinstance dispatch
+
+
+def test_default_init_consumes_rng_like_reference(golden_dir):
+    """Same seed -> same initial weights as the reference constructor (fixture made by oracle/gen_golden.py)."""
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    z = np.load(golden_dir + "/init_seed42_small.npz")
+    torch.manual_seed(42)
+    m = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=27, embed_dim_rot=64, depth_rot=2, embed_dim_seg=32, depth_seg=2,
+                           n_hyp=5, drop_path_rate=0.1)
+    for k, v in m.state_dict().items():
+        np.testing.assert_array_equal(v.numpy(), z[k], err_msg=k)
+
+
+def test_no_cpu_fallback_and_argument_errors():
+    from manipose_amd import _lib
+    from manipose_amd.metrics import rmcl_training_loss
+    fx = load_fixture("rmcl_tiny")
+    model = _tiny_model(fx)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.from_numpy(fx["X"]))
+    with pytest.raises(AssertionError):
+        model(torch.zeros(2, 5, 17, 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rmcl_training_loss(torch.from_numpy(fx["poses"]), torch.from_numpy(fx["scores"]), torch.from_numpy(fx["y"]))
+    lib = _lib.load()
+    rc = lib.mp_fk_decode_fwd(None, 6, None, None, 1, 1, 1, None)       # argument validation happens before any launch
+    assert rc == 1 and b"null" in lib.mp_last_error()
+    cfg = _lib.ModelConfig(arch=7, num_frame=9, num_joints=17, num_bones=16, embed_dim_rot=32, depth_rot=1,
+                           num_heads_rot=4, embed_dim_seg=16, depth_seg=1, num_heads_seg=4, n_hyp=3, max_batch=0)
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.mp_model_create(C.byref(cfg), C.byref(h)) == 1 and b"arch" in lib.mp_last_error()
+
+
+def test_skeleton_tables():
+    from manipose_amd.data import h36m_skeleton
+    sk = h36m_skeleton()
+    assert sk.num_joints == 17 and sk.num_bones == 16
+    assert list(sk.has_children.astype(int)) == [1, 1, 1, 0, 1, 1, 0, 1, 1, 1, 0, 1, 1, 0, 1, 1, 0]
+    assert sk.bones_left == (3, 4, 5, 10, 11, 12) and sk.bones_right == (0, 1, 2, 13, 14, 15)
+    assert sk.bones[0] == (1, 0) and sk.children[8] == [9, 11, 14]
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(2)
+    from manipose_amd.distributed import allreduce_gradients, broadcast_parameters, init_from_env, shard_windows
+    r, w, _ = init_from_env("gloo")
+    fx = load_fixture("rmcl_tiny")
+    model = _tiny_model(fx)
+    flat = model.flat_parameters()                       # CPU layout-only engine
+    if r != 0:
+        flat.zero_()                                     # prove the broadcast brings rank 0's weights
+    broadcast_parameters(flat)
+    X, y = orc.synthetic_batch(4, fx["cfg"]["T"], seed=5)
+    idx = list(shard_windows(4, r, w))
+    st = {k: p for k, p in model.named_parameters()}    # views of the flat buffer
+    poses, scores = orc.rmcl_manifold_forward(X[idx], st, orc.oracle_cfg(fx["cfg"]))   # oracle = stand-in compute on CPU
+    total, _ = orc.rmcl_training_loss(poses, scores, y[idx])
+    total.backward()
+    g = torch.zeros_like(flat)
+    for (off, n), p in zip(model._slots, model._plist):
+        g[off:off + n] = p.grad.reshape(-1)
+    allreduce_gradients(g)
+    if r == 0:
+        torch.save({"g": g / w, "layout": model.flat_layout()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange_equals_full_batch(tmp_path):
+    """world_size-2 gloo run of the product's exchange path (flat layout + broadcast + SUM all-reduce + 1/world):
+    averaged shard gradients == gradient of the concatenated batch."""
+    out = str(tmp_path / "dp.pt")
+    port = 29600 + os.getpid() % 200
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    fx = load_fixture("rmcl_tiny")
+    st = {k: v.requires_grad_(True) for k, v in fixture_state(fx).items()}
+    X, y = orc.synthetic_batch(4, fx["cfg"]["T"], seed=5)
+    poses, scores = orc.rmcl_manifold_forward(X, st, orc.oracle_cfg(fx["cfg"]))
+    orc.rmcl_training_loss(poses, scores, y)[0].backward()
+    for name, off, n in res["layout"]:
+        np.testing.assert_allclose(res["g"][off:off + n].numpy(), st[name].grad.reshape(-1).numpy(), rtol=2e-4, atol=2e-6,
+                                   err_msg=name)
