@@ -90,6 +90,12 @@ int mp_linear_fwd(const float* x, const float* W, const float* b, float* y, floa
 int64_t mp_linear_bwd_slab_floats(int N, int K);
 int mp_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, int M, int N, int K,
                   float* slab, int64_t slab_floats, void* stream);
+/* bf16 matrix-core variants (precision 1 of the engine).  x, W, dy are bf16 unless *_f32 says fp32; y/z bf16, dx fp32
+ * or bf16 (dx_f32); r and the residual output y of epilogue 2 are fp32; dW/db fp32 (accumulated). */
+int mp_linear_fwd_bf16(const void* x, const void* W, const float* b, void* y, void* z, const float* r, int M, int N, int K,
+                       int epilogue, void* stream);
+int mp_linear_bwd_bf16(const void* dy, int dy_f32, const void* x, const void* W, void* dx, int dx_f32, float* dW, float* db,
+                       int M, int N, int K, float* slab, int64_t slab_floats, void* stream);
 /* Attention core of Attention.forward (architectures/mix_ste.py:271-279) on a fused qkv buffer (M, 3C).
  * temporal = 0: attends over the J tokens of a frame; 1: over the T frames of a joint. */
 int mp_attention_fwd(const float* qkv, float* out, float* lse, int temporal, int B, int T, int J, int C, int H, void* stream);

@@ -46,6 +46,8 @@ _SIGNATURES = {
     "mp_linear_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mp_linear_bwd_slab_floats": (i64, [i32, i32]),
     "mp_linear_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i64, vp]),
+    "mp_linear_fwd_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mp_linear_bwd_bf16": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, i64, vp]),
     "mp_attention_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mp_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mp_model_create": (i32, [C.POINTER(ModelConfig), C.POINTER(vp)]),

@@ -22,8 +22,8 @@ static int spatial_lds_floats_host(bool bwd, int N, int D) {
   return ((bwd ? (N * D + N * DP + N * DP + N * D + 2 * N * NP) : (N * D + N * DP + N * D + N * NP)) + 3) & ~3;   // 16-B aligned per wave
 }
 
-template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void attn_spatial_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+template <int WPB, typename TS>
+__global__ __launch_bounds__(WPB * 64) void attn_spatial_fwd_kernel(const TS* __restrict__ qkv, TS* __restrict__ out,
                                                                      int F, int N, int C, int H, int D, float scale) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_spatial_fwd_kernel(const float*
   if (active) {
     for (int idx = lane; idx < N * D4; idx += 64) {
       const int i = idx / D4, c = (idx - i * D4) * 4;
-      const float* r = qkv + (m0 + i) * C3 + h * D + c;
+      const TS* r = qkv + (m0 + i) * C3 + h * D + c;
       *reinterpret_cast<float4*>(q + i * D + c) = ld4(r);
       *reinterpret_cast<float4*>(k + i * DP + c) = ld4(r + C);
       *reinterpret_cast<float4*>(v + i * D + c) = ld4(r + 2 * C);
@@ -88,9 +88,9 @@ __global__ __launch_bounds__(WPB * 64) void attn_spatial_fwd_kernel(const float*
   }
 }
 
-template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void attn_spatial_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                                     float* __restrict__ dqkv, int F, int N, int C, int H, int D,
+template <int WPB, typename TS>
+__global__ __launch_bounds__(WPB * 64) void attn_spatial_bwd_kernel(const TS* __restrict__ qkv, const TS* __restrict__ dout,
+                                                                     TS* __restrict__ dqkv, int F, int N, int C, int H, int D,
                                                                      float scale) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_spatial_bwd_kernel(const float*
   if (active) {
     for (int idx = lane; idx < N * D4; idx += 64) {
       const int i = idx / D4, c = (idx - i * D4) * 4;
-      const float* r = qkv + (m0 + i) * C3 + h * D + c;
+      const TS* r = qkv + (m0 + i) * C3 + h * D + c;
       *reinterpret_cast<float4*>(q + i * D + c) = ld4(r);
       *reinterpret_cast<float4*>(k + i * DP + c) = ld4(r + C);
       *reinterpret_cast<float4*>(v + i * DP + c) = ld4(r + 2 * C);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_spatial_bwd_kernel(const float*
         dk.x += sji * qj.x; dk.y += sji * qj.y; dk.z += sji * qj.z; dk.w += sji * qj.w;
         dv.x += pji * gj.x; dv.y += pji * gj.y; dv.z += pji * gj.z; dv.w += pji * gj.w;
       }
-      float* r = dqkv + (m0 + i) * C3 + h * D + c;
+      TS* r = dqkv + (m0 + i) * C3 + h * D + c;
       st4(r, dq);
       st4(r + C, dk);
       st4(r + 2 * C, dv);
@@ -177,28 +177,38 @@ __global__ __launch_bounds__(WPB * 64) void attn_spatial_bwd_kernel(const float*
 
 static float qk_scale(int D) { return 1.0f / sqrtf((float)D); }   // head_dim ** -0.5, mix_ste.py:243-244
 
-int attn_spatial_fwd(const float* qkv, float* out, int B, int T, int J, int C, int H, hipStream_t st) {
-  MP_CHECK(C % H == 0 && (C / H) % 4 == 0 && J <= 32, MP_ERR_ARG, "attn_spatial_fwd: C=%d H=%d J=%d unsupported", C, H, J);
+template <typename TS>
+static int spatial_fwd_t(const TS* qkv, TS* out, int B, int T, int J, int C, int H, hipStream_t st) {
   const int D = C / H, F = B * T;
   constexpr int WPB = 4;
   const size_t lds = (size_t)WPB * spatial_lds_floats_host(false, J, D) * sizeof(float);
   MP_CHECK(lds <= 160 * 1024, MP_ERR_ARG, "attn_spatial_fwd: LDS %zu too large", lds);
-  hipLaunchKernelGGL(attn_spatial_fwd_kernel<WPB>, dim3(cdiv((long)F * H, WPB)), dim3(WPB * 64), lds, st, qkv, out, F, J, C, H,
+  hipLaunchKernelGGL((attn_spatial_fwd_kernel<WPB, TS>), dim3(cdiv((long)F * H, WPB)), dim3(WPB * 64), lds, st, qkv, out, F, J, C, H,
                      D, qk_scale(D));
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
-
-int attn_spatial_bwd(const float* qkv, const float* dout, float* dqkv, int B, int T, int J, int C, int H, hipStream_t st) {
-  MP_CHECK(C % H == 0 && (C / H) % 4 == 0 && J <= 32, MP_ERR_ARG, "attn_spatial_bwd: C=%d H=%d J=%d unsupported", C, H, J);
+template <typename TS>
+static int spatial_bwd_t(const TS* qkv, const TS* dout, TS* dqkv, int B, int T, int J, int C, int H, hipStream_t st) {
   const int D = C / H, F = B * T;
   constexpr int WPB = 2;
   const size_t lds = (size_t)WPB * spatial_lds_floats_host(true, J, D) * sizeof(float);
   MP_CHECK(lds <= 160 * 1024, MP_ERR_ARG, "attn_spatial_bwd: LDS %zu too large", lds);
-  hipLaunchKernelGGL(attn_spatial_bwd_kernel<WPB>, dim3(cdiv((long)F * H, WPB)), dim3(WPB * 64), lds, st, qkv, dout, dqkv, F, J, C,
-                     H, D, qk_scale(D));
+  hipLaunchKernelGGL((attn_spatial_bwd_kernel<WPB, TS>), dim3(cdiv((long)F * H, WPB)), dim3(WPB * 64), lds, st, qkv, dout, dqkv, F, J,
+                     C, H, D, qk_scale(D));
   MP_LAUNCH_CHECK();
   return MP_OK;
+}
+
+int attn_spatial_fwd(const void* qkv, void* out, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st) {
+  MP_CHECK(C % H == 0 && (C / H) % 4 == 0 && J <= 32, MP_ERR_ARG, "attn_spatial_fwd: C=%d H=%d J=%d unsupported", C, H, J);
+  return is_bf16 ? spatial_fwd_t<bf16>((const bf16*)qkv, (bf16*)out, B, T, J, C, H, st)
+                 : spatial_fwd_t<float>((const float*)qkv, (float*)out, B, T, J, C, H, st);
+}
+int attn_spatial_bwd(const void* qkv, const void* dout, void* dqkv, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st) {
+  MP_CHECK(C % H == 0 && (C / H) % 4 == 0 && J <= 32, MP_ERR_ARG, "attn_spatial_bwd: C=%d H=%d J=%d unsupported", C, H, J);
+  return is_bf16 ? spatial_bwd_t<bf16>((const bf16*)qkv, (const bf16*)dout, (bf16*)dqkv, B, T, J, C, H, st)
+                 : spatial_bwd_t<float>((const float*)qkv, (const float*)dout, (float*)dqkv, B, T, J, C, H, st);
 }
 
 // =============================================================================================
@@ -207,8 +217,8 @@ int attn_spatial_bwd(const float* qkv, const float* dout, float* dqkv, int B, in
 // =============================================================================================
 constexpr int KT = 16;
 
-template <int D>
-__device__ __forceinline__ void load_rows_tile(float* __restrict__ S, const float* __restrict__ base, long row_stride, int r0,
+template <int D, typename TS>
+__device__ __forceinline__ void load_rows_tile(float* __restrict__ S, const TS* __restrict__ base, long row_stride, int r0,
                                                int R, int tid) {
   constexpr int D4 = D / 4;
   for (int idx = tid; idx < KT * D4; idx += 256) {
@@ -219,8 +229,8 @@ __device__ __forceinline__ void load_rows_tile(float* __restrict__ S, const floa
   }
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_temporal_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+template <int D, typename TS>
+__global__ __launch_bounds__(256) void attn_temporal_fwd_kernel(const TS* __restrict__ qkv, TS* __restrict__ out,
                                                                  float* __restrict__ lse, int T, int J, int C, int H,
                                                                  float scale) {
   __shared__ __attribute__((aligned(16))) float Ks[KT * D];
@@ -228,8 +238,8 @@ __global__ __launch_bounds__(256) void attn_temporal_fwd_kernel(const float* __r
   const int unit = blockIdx.x, h = unit % H, bj = unit / H, j = bj % J, b = bj / J;
   const int t = blockIdx.y * 256 + threadIdx.x;
   const bool active = t < T;
-  const long rs3 = (long)J * 3 * C, rs1 = (long)J * C;
-  const float* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;   // row of frame 0
+  const long rs3 = (long)J * 3 * C;
+  const TS* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;   // row of frame 0
   float q[D], o[D];
 #pragma unroll
   for (int c = 0; c < D; c += 4) {
@@ -276,19 +286,18 @@ __global__ __launch_bounds__(256) void attn_temporal_fwd_kernel(const float* __r
   }
   if (active) {
     const float inv = 1.0f / l;
-    float* orow = out + ((long)(b * T + t) * J + j) * C + h * D;
+    TS* orow = out + ((long)(b * T + t) * J + j) * C + h * D;
 #pragma unroll
     for (int c = 0; c < D; c += 4) st4(orow + c, make_float4(o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv));
     lse[(long)unit * T + t] = mrun + logf(l);
   }
-  (void)rs1;
 }
 
 // dQ pass (thread per query); also writes delta[unit][t] = sum_c dO*O for the dK/dV pass
-template <int D>
-__global__ __launch_bounds__(256) void attn_temporal_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
-                                                                    const float* __restrict__ dout, const float* __restrict__ lse,
-                                                                    float* __restrict__ delta, float* __restrict__ dqkv, int T,
+template <int D, typename TS>
+__global__ __launch_bounds__(256) void attn_temporal_bwd_dq_kernel(const TS* __restrict__ qkv, const TS* __restrict__ out,
+                                                                    const TS* __restrict__ dout, const float* __restrict__ lse,
+                                                                    float* __restrict__ delta, TS* __restrict__ dqkv, int T,
                                                                     int J, int C, int H, float scale) {
   __shared__ __attribute__((aligned(16))) float Ks[KT * D];
   __shared__ __attribute__((aligned(16))) float Vs[KT * D];
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(256) void attn_temporal_bwd_dq_kernel(const float* 
   const int t = blockIdx.y * 256 + threadIdx.x;
   const bool active = t < T;
   const long rs3 = (long)J * 3 * C;
-  const float* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;
+  const TS* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;
   const long orow = ((long)(b * T + t) * J + j) * C + h * D;
   float q[D], g[D], dq[D];
   float dl = 0.f;
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(256) void attn_temporal_bwd_dq_kernel(const float* 
     }
   }
   if (active) {
-    float* r = dqkv + ((long)(b * T + t) * J + j) * 3 * C + h * D;
+    TS* r = dqkv + ((long)(b * T + t) * J + j) * 3 * C + h * D;
 #pragma unroll
     for (int c = 0; c < D; c += 4)
       st4(r + c, make_float4(dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale));
@@ -348,10 +357,10 @@ __global__ __launch_bounds__(256) void attn_temporal_bwd_dq_kernel(const float* 
 }
 
 // dK/dV pass (thread per key); queries, dO, lse and delta stream through LDS
-template <int D>
-__global__ __launch_bounds__(256) void attn_temporal_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+template <int D, typename TS>
+__global__ __launch_bounds__(256) void attn_temporal_bwd_dkv_kernel(const TS* __restrict__ qkv, const TS* __restrict__ dout,
                                                                      const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                     float* __restrict__ dqkv, int T, int J, int C, int H,
+                                                                     TS* __restrict__ dqkv, int T, int J, int C, int H,
                                                                      float scale) {
   __shared__ __attribute__((aligned(16))) float Qs[KT * D];
   __shared__ __attribute__((aligned(16))) float Gs[KT * D];
@@ -360,8 +369,8 @@ __global__ __launch_bounds__(256) void attn_temporal_bwd_dkv_kernel(const float*
   const int t = blockIdx.y * 256 + threadIdx.x;   // key index
   const bool active = t < T;
   const long rs3 = (long)J * 3 * C, rs1 = (long)J * C;
-  const float* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;
-  const float* gb = dout + ((long)b * T * J + j) * C + h * D;
+  const TS* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;
+  const TS* gb = dout + ((long)b * T * J + j) * C + h * D;
   float k[D], v[D], dk[D], dv[D];
 #pragma unroll
   for (int c = 0; c < D; c += 4) {
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(256) void attn_temporal_bwd_dkv_kernel(const float*
     }
   }
   if (active) {
-    float* r = dqkv + ((long)(b * T + t) * J + j) * 3 * C + h * D;
+    TS* r = dqkv + ((long)(b * T + t) * J + j) * 3 * C + h * D;
 #pragma unroll
     for (int c = 0; c < D; c += 4) {
       st4(r + C + c, make_float4(dk[c] * scale, dk[c + 1] * scale, dk[c + 2] * scale, dk[c + 3] * scale));
@@ -427,28 +436,40 @@ __global__ __launch_bounds__(256) void attn_temporal_bwd_dkv_kernel(const float*
     default: MP_CHECK(false, MP_ERR_ARG, "temporal attention: head dim %d unsupported (4,8,16,32,64)", D); \
   }
 
-int attn_temporal_fwd(const float* qkv, float* out, float* lse, int B, int T, int J, int C, int H, hipStream_t st) {
-  MP_CHECK(C % H == 0, MP_ERR_ARG, "attn_temporal_fwd: C %% H");
+template <typename TS>
+static int temporal_fwd_t(const TS* qkv, TS* out, float* lse, int B, int T, int J, int C, int H, hipStream_t st) {
   const int D = C / H;
   dim3 grid(B * J * H, cdiv(T, 256));
-  MP_DISPATCH_D(D, hipLaunchKernelGGL(attn_temporal_fwd_kernel<DD>, grid, dim3(256), 0, st, qkv, out, lse, T, J, C, H, qk_scale(D)));
+  MP_DISPATCH_D(D, hipLaunchKernelGGL((attn_temporal_fwd_kernel<DD, TS>), grid, dim3(256), 0, st, qkv, out, lse, T, J, C, H, qk_scale(D)));
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+template <typename TS>
+static int temporal_bwd_t(const TS* qkv, const TS* out, const TS* dout, const float* lse, float* delta, TS* dqkv, int B, int T, int J,
+                          int C, int H, hipStream_t st) {
+  const int D = C / H;
+  dim3 grid(B * J * H, cdiv(T, 256));
+  // k is pre-multiplied by `scale` in the dK/dV kernel and q in the dQ kernel, so that a = scale * q.k in both
+  MP_DISPATCH_D(D, hipLaunchKernelGGL((attn_temporal_bwd_dq_kernel<DD, TS>), grid, dim3(256), 0, st, qkv, out, dout, lse, delta, dqkv,
+                                      T, J, C, H, qk_scale(D)));
+  MP_LAUNCH_CHECK();
+  MP_DISPATCH_D(D, hipLaunchKernelGGL((attn_temporal_bwd_dkv_kernel<DD, TS>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, T, J,
+                                      C, H, qk_scale(D)));
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
 
-int attn_temporal_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv, int B,
-                      int T, int J, int C, int H, hipStream_t st) {
+int attn_temporal_fwd(const void* qkv, void* out, float* lse, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st) {
+  MP_CHECK(C % H == 0, MP_ERR_ARG, "attn_temporal_fwd: C %% H");
+  return is_bf16 ? temporal_fwd_t<bf16>((const bf16*)qkv, (bf16*)out, lse, B, T, J, C, H, st)
+                 : temporal_fwd_t<float>((const float*)qkv, (float*)out, lse, B, T, J, C, H, st);
+}
+int attn_temporal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int is_bf16,
+                      int B, int T, int J, int C, int H, hipStream_t st) {
   MP_CHECK(C % H == 0, MP_ERR_ARG, "attn_temporal_bwd: C %% H");
-  const int D = C / H;
-  dim3 grid(B * J * H, cdiv(T, 256));
-  // note k is pre-multiplied by `scale` in the dK/dV kernel and q in the dQ kernel, so that a = scale * q.k in both
-  MP_DISPATCH_D(D, hipLaunchKernelGGL(attn_temporal_bwd_dq_kernel<DD>, grid, dim3(256), 0, st, qkv, out, dout, lse, delta, dqkv, T,
-                                      J, C, H, qk_scale(D)));
-  MP_LAUNCH_CHECK();
-  MP_DISPATCH_D(D, hipLaunchKernelGGL(attn_temporal_bwd_dkv_kernel<DD>, grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, T, J,
-                                      C, H, qk_scale(D)));
-  MP_LAUNCH_CHECK();
-  return MP_OK;
+  return is_bf16 ? temporal_bwd_t<bf16>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, B, T, J, C, H, st)
+                 : temporal_bwd_t<float>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, B, T, J, C,
+                                         H, st);
 }
 
 }  // namespace mp

@@ -99,16 +99,37 @@ int mp_linear_bwd(const float* dy, const float* x, const float* W, float* dx, fl
   return wgrad_f32(dy, N, x, K, M, N, K, dW, db, slab, slab_floats, (hipStream_t)stream);
 }
 
+int mp_linear_fwd_bf16(const void* x, const void* W, const float* b, void* y, void* z, const float* r, int M, int N, int K,
+                       int epilogue, void* stream) {
+  MP_CHECK(x && W && y && epilogue >= 0 && epilogue <= 2, MP_ERR_ARG, "mp_linear_fwd_bf16: bad argument");
+  MP_CHECK((epilogue != 1 || z) && (epilogue != 2 || r), MP_ERR_ARG, "mp_linear_fwd_bf16: epilogue operand missing");
+  GemmB16Args g = {};
+  g.A = x; g.lda = K; g.B = W; g.ldb = K; g.C = y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b; g.Z = z; g.R = r;
+  const int epi = epilogue == 0 ? EPI_BIAS : (epilogue == 1 ? EPI_BIAS_GELU : EPI_BIAS_RESID);
+  return gemm_bf16(g, 0, 0, 0, epilogue == 2, epi, (hipStream_t)stream);
+}
+int mp_linear_bwd_bf16(const void* dy, int dy_f32, const void* x, const void* W, void* dx, int dx_f32, float* dW, float* db,
+                       int M, int N, int K, float* slab, int64_t slab_floats, void* stream) {
+  MP_CHECK(dy && x && W && dW && slab, MP_ERR_ARG, "mp_linear_bwd_bf16: null pointer");
+  if (dx) {
+    GemmB16Args g = {};
+    g.A = dy; g.lda = N; g.B = W; g.ldb = K; g.C = dx; g.ldc = K; g.M = M; g.N = K; g.K = N;
+    int rc = gemm_bf16(g, dy_f32, 0, 1, dx_f32, EPI_BIAS, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return wgrad_bf16(dy, dy_f32, N, (const bf16*)x, K, M, N, K, dW, db, slab, slab_floats, (hipStream_t)stream);
+}
+
 int mp_attention_fwd(const float* qkv, float* out, float* lse, int temporal, int B, int T, int J, int C, int H, void* stream) {
   MP_CHECK(qkv && out && (!temporal || lse), MP_ERR_ARG, "mp_attention_fwd: null pointer");
-  return temporal ? attn_temporal_fwd(qkv, out, lse, B, T, J, C, H, (hipStream_t)stream)
-                  : attn_spatial_fwd(qkv, out, B, T, J, C, H, (hipStream_t)stream);
+  return temporal ? attn_temporal_fwd(qkv, out, lse, 0, B, T, J, C, H, (hipStream_t)stream)
+                  : attn_spatial_fwd(qkv, out, 0, B, T, J, C, H, (hipStream_t)stream);
 }
 int mp_attention_bwd(const float* qkv, const float* out, const float* d_out, const float* lse, float* delta, float* d_qkv,
                      int temporal, int B, int T, int J, int C, int H, void* stream) {
   MP_CHECK(qkv && d_out && d_qkv && (!temporal || (out && lse && delta)), MP_ERR_ARG, "mp_attention_bwd: null pointer");
-  return temporal ? attn_temporal_bwd(qkv, out, d_out, lse, delta, d_qkv, B, T, J, C, H, (hipStream_t)stream)
-                  : attn_spatial_bwd(qkv, d_out, d_qkv, B, T, J, C, H, (hipStream_t)stream);
+  return temporal ? attn_temporal_bwd(qkv, out, d_out, lse, delta, d_qkv, 0, B, T, J, C, H, (hipStream_t)stream)
+                  : attn_spatial_bwd(qkv, d_out, d_qkv, 0, B, T, J, C, H, (hipStream_t)stream);
 }
 
 }  // extern "C"

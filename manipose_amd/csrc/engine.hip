@@ -15,7 +15,7 @@ long wgrad_f32_slab_floats(int Mtok, int Nout, int Kin);
 
 struct ParamDesc { std::string name; long offset, numel; };
 struct BlockP { int n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b; };
-struct BlockWS { float *x_in, *st1, *a1, *qkv, *lse, *ao, *x_mid, *st2, *a2, *z, *f, *x_out, *stp; };
+struct BlockWS { float *x_in, *st1, *lse, *x_mid, *st2, *x_out, *stp; void *a1, *qkv, *ao, *a2, *z, *f; };   // void*: fp32 or bf16 by precision
 struct MaskBranch { std::string name; float keep; int spatial; };
 
 struct Module {
@@ -44,7 +44,9 @@ struct mp_model {
   // workspace
   char* arena = nullptr;
   size_t arena_bytes = 0;
-  float *g = nullptr, *tmpC = nullptr, *tmpMask = nullptr, *tmp2C = nullptr, *tmp3C = nullptr, *delta = nullptr;
+  float *g = nullptr, *tmpC = nullptr, *tmpMask = nullptr, *delta = nullptr;
+  void *tmp2C = nullptr, *tmp3C = nullptr;   // dz / dqkv: fp32 or bf16 by precision
+  bf16* wbf = nullptr;                       // bf16 shadow of the flat parameter buffer (precision 1)
   float *slab = nullptr, *small = nullptr, *lengths = nullptr, *dlen_pose = nullptr, *maskbuf = nullptr, *dscore_zero = nullptr;
   long slab_floats = 0, small_floats = 0;
   // state of the last forward
@@ -134,14 +136,15 @@ struct Bump {
   }
 };
 
-static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax) {
+static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int half) {
   const long C = md.C;
+  auto act = [&](long n) -> void* { return bp.take(half ? (n + 1) / 2 : n); };   // bf16 activations take half the floats
   md.ws.resize(2 * md.depth);
   for (auto& w : md.ws) {
-    w.x_in = bp.take(M * C);   w.st1 = bp.take(M * 2);     w.a1 = bp.take(M * C);   w.qkv = bp.take(M * 3 * C);
+    w.x_in = bp.take(M * C);   w.st1 = bp.take(M * 2);     w.a1 = act(M * C);   w.qkv = act(M * 3 * C);
     w.lse = bp.take((long)Bmax * md.N * md.H * T);
-    w.ao = bp.take(M * C);     w.x_mid = bp.take(M * C);   w.st2 = bp.take(M * 2);  w.a2 = bp.take(M * C);
-    w.z = bp.take(M * 2 * C);  w.f = bp.take(M * 2 * C);   w.x_out = bp.take(M * C); w.stp = bp.take(M * 2);
+    w.ao = act(M * C);         w.x_mid = bp.take(M * C);   w.st2 = bp.take(M * 2);  w.a2 = act(M * C);
+    w.z = act(M * 2 * C);      w.f = act(M * 2 * C);       w.x_out = bp.take(M * C); w.stp = bp.take(M * 2);
   }
   md.x_final = bp.take(M * C);
   md.hstats = bp.take(M * 2);
@@ -162,21 +165,23 @@ static long small_scratch_floats(const mp_model* m) {
 static void carve_all(mp_model* m, Bump& bp) {
   const int Bm = m->cfg.max_batch, T = m->cfg.num_frame;
   const long Mr = (long)Bm * T * m->rot.N, Ms = (long)Bm * T * m->seg.N;
-  carve_module(m->rot, bp, Mr, T, Bm);
-  carve_module(m->seg, bp, Ms, T, Bm);
+  const int half = m->cfg.precision == 1;
+  carve_module(m->rot, bp, Mr, T, Bm, half);
+  carve_module(m->seg, bp, Ms, T, Bm, half);
+  if (half) m->wbf = reinterpret_cast<bf16*>(bp.take((m->flat_size + 1) / 2));
   const long MC = max(Mr * m->rot.C, Ms * m->seg.C);
   m->g = bp.take(MC);
   m->tmpC = bp.take(MC);
   m->tmpMask = bp.take(MC);
-  m->tmp2C = bp.take(2 * MC);
-  m->tmp3C = bp.take(3 * MC);
+  m->tmp2C = bp.take(half ? MC : 2 * MC);
+  m->tmp3C = bp.take(half ? (3 * MC + 1) / 2 : 3 * MC);
   m->delta = bp.take(max((long)Bm * m->rot.N * m->rot.H * T, (long)Bm * m->seg.N * m->seg.H * T));
   long slab = 0;
   const Module* mods[2] = {&m->rot, &m->seg};
   for (const Module* md : mods) {
     const long M = (long)Bm * T * md->N;
     const int C = md->C;
-    slab = max(slab, wgrad_f32_slab_floats((int)M, 3 * C, C));
+    slab = max(slab, wgrad_f32_slab_floats((int)M, 3 * C, C));   // same tile-derived bound for the bf16 kernels
     slab = max(slab, wgrad_f32_slab_floats((int)M, C, C));
     slab = max(slab, wgrad_f32_slab_floats((int)M, 2 * C, C));
     slab = max(slab, wgrad_f32_slab_floats((int)M, C, 2 * C));
@@ -225,23 +230,44 @@ enum { PC_GEMM_FWD = 0, PC_GEMM_DGRAD = 1, PC_GEMM_WGRAD = 2, PC_ATTN = 3, PC_LN
 static const float* P(const mp_model* m, const float* flat, int idx) { return flat + m->params[idx].offset; }
 static float* G(const mp_model* m, float* flat, int idx) { return flat + m->params[idx].offset; }
 
-static int linear_fwd(mp_model* m, hipStream_t st, const float* A, const float* W, const float* b, float* Cc, long M, int N, int K,
-                      int epi, float* Z, const float* R, const float* mask, int mask_mode, int T, int J) {
-  GemmF32Args g = {};
-  g.A = A; g.lda = K; g.B = W; g.ldb = K; g.C = Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
-  g.bias = b; g.Z = Z; g.R = R; g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
-  RUN(PC_GEMM_FWD, 2.0 * M * N * K, gemm_f32(0, 0, epi, g, st));
+// Linear layers: precision 0 -> fp32 matrix cores on fp32 buffers; precision 1 -> bf16 matrix cores, bf16 activations /
+// shadow weights, fp32 residual stream and fp32 gradient stream (converted to bf16 while staging).
+static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* A, int widx, int bidx, void* Cc, long M, int N, int K,
+                      int epi, void* Z, const float* R, const float* mask, int mask_mode, int T, int J) {
+  if (m->cfg.precision == 0) {
+    GemmF32Args g = {};
+    g.A = (const float*)A; g.lda = K; g.B = P(m, fp, widx); g.ldb = K; g.C = (float*)Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
+    g.bias = P(m, fp, bidx); g.Z = (float*)Z; g.R = R; g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
+    RUN(PC_GEMM_FWD, 2.0 * M * N * K, gemm_f32(0, 0, epi, g, st));
+    return MP_OK;
+  }
+  GemmB16Args g = {};
+  g.A = A; g.lda = K; g.B = m->wbf + m->params[widx].offset; g.ldb = K; g.C = Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
+  g.bias = P(m, fp, bidx); g.Z = Z; g.R = R; g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
+  RUN(PC_GEMM_FWD, 2.0 * M * N * K, gemm_bf16(g, 0, 0, 0, epi == EPI_BIAS_RESID ? 1 : 0, epi, st));
   return MP_OK;
 }
-// dX[M,K] = dY[M,N] W[N,K]  (optionally * gelu'(Z))
-static int linear_dgrad(mp_model* m, hipStream_t st, const float* dY, const float* W, float* dX, long M, int N, int K, float* Z) {
-  GemmF32Args g = {};
-  g.A = dY; g.lda = N; g.B = W; g.ldb = K; g.C = dX; g.ldc = K; g.M = (int)M; g.N = K; g.K = N; g.Z = Z;
-  RUN(PC_GEMM_DGRAD, 2.0 * M * N * K, gemm_f32(0, 1, Z ? EPI_DGELU : EPI_BIAS, g, st));
+// dX[M,K] = dY[M,N] W[N,K]  (optionally * gelu'(Z)).  dy_f32 / dx_f32: storage of dY / dX in bf16 mode.
+static int linear_dgrad(mp_model* m, hipStream_t st, const float* fp, const void* dY, int dy_f32, int widx, void* dX, int dx_f32,
+                        long M, int N, int K, void* Z) {
+  if (m->cfg.precision == 0) {
+    GemmF32Args g = {};
+    g.A = (const float*)dY; g.lda = N; g.B = P(m, fp, widx); g.ldb = K; g.C = (float*)dX; g.ldc = K; g.M = (int)M; g.N = K; g.K = N;
+    g.Z = (float*)Z;
+    RUN(PC_GEMM_DGRAD, 2.0 * M * N * K, gemm_f32(0, 1, Z ? EPI_DGELU : EPI_BIAS, g, st));
+    return MP_OK;
+  }
+  GemmB16Args g = {};
+  g.A = dY; g.lda = N; g.B = m->wbf + m->params[widx].offset; g.ldb = K; g.C = dX; g.ldc = K; g.M = (int)M; g.N = K; g.K = N; g.Z = Z;
+  RUN(PC_GEMM_DGRAD, 2.0 * M * N * K, gemm_bf16(g, dy_f32, 0, 1, dx_f32, Z ? EPI_DGELU : EPI_BIAS, st));
   return MP_OK;
 }
-static int linear_wgrad(mp_model* m, hipStream_t st, const float* dY, const float* X, float* dW, float* db, long M, int N, int K) {
-  RUN(PC_GEMM_WGRAD, 2.0 * M * N * K, wgrad_f32(dY, N, X, K, (int)M, N, K, dW, db, m->slab, m->slab_floats, st));
+static int linear_wgrad(mp_model* m, hipStream_t st, const void* dY, int dy_f32, const void* X, float* dW, float* db, long M, int N,
+                        int K) {
+  if (m->cfg.precision == 0)
+    RUN(PC_GEMM_WGRAD, 2.0 * M * N * K, wgrad_f32((const float*)dY, N, (const float*)X, K, (int)M, N, K, dW, db, m->slab, m->slab_floats, st));
+  else
+    RUN(PC_GEMM_WGRAD, 2.0 * M * N * K, wgrad_bf16(dY, dy_f32, N, (const bf16*)X, K, (int)M, N, K, dW, db, m->slab, m->slab_floats, st));
   return MP_OK;
 }
 
@@ -263,35 +289,36 @@ static const float* branch_mask(const mp_model* m, const Module& md, int l, int 
 
 static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStream_t st) {
   const int T = m->cfg.num_frame, N = md.N, C = md.C, H = md.H, L = 2 * md.depth;
+  const int half = m->cfg.precision == 1;
   const long M = (long)B * T * N;
   // norm1 of block 0 (the input embedding has already been written to ws[0].x_in)
   {
     LnFwdArgs a = {};
     a.x = md.ws[0].x_in; a.M = (int)M; a.C = C;
     a.g2 = P(m, fp, md.bp[0].n1w); a.b2 = P(m, fp, md.bp[0].n1b); a.eps2 = 1e-6f; a.y2 = md.ws[0].a1; a.stats2 = md.ws[0].st1;
-    RUN(PC_LN, 0, ln_fwd(a, 0, st));
+    RUN(PC_LN, 0, ln_fwd(a, half, st));
   }
   for (int l = 0; l < L; ++l) {
     const BlockP& q = md.bp[l];
     BlockWS& w = md.ws[l];
     const bool spatial = (l % 2 == 0);
     const int mode = spatial ? 1 : 2;
-    int rc = linear_fwd(m, st, w.a1, P(m, fp, q.qkvw), P(m, fp, q.qkvb), w.qkv, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, 0, T, N);
+    int rc = linear_fwd(m, st, fp, w.a1, q.qkvw, q.qkvb, w.qkv, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, 0, T, N);
     if (rc) return rc;
-    if (spatial) RUN(PC_ATTN, 4.0 * B * T * N * N * C, attn_spatial_fwd(w.qkv, w.ao, B, T, N, C, H, st));
-    else RUN(PC_ATTN, 4.0 * B * N * (double)T * T * C, attn_temporal_fwd(w.qkv, w.ao, w.lse, B, T, N, C, H, st));
-    rc = linear_fwd(m, st, w.ao, P(m, fp, q.pw), P(m, fp, q.pb), w.x_mid, M, C, C, EPI_BIAS_RESID, nullptr, w.x_in,
+    if (spatial) RUN(PC_ATTN, 4.0 * B * T * N * N * C, attn_spatial_fwd(w.qkv, w.ao, half, B, T, N, C, H, st));
+    else RUN(PC_ATTN, 4.0 * B * N * (double)T * T * C, attn_temporal_fwd(w.qkv, w.ao, w.lse, half, B, T, N, C, H, st));
+    rc = linear_fwd(m, st, fp, w.ao, q.pw, q.pb, w.x_mid, M, C, C, EPI_BIAS_RESID, nullptr, w.x_in,
                     branch_mask(m, md, l, 0, B, m->train), mode, T, N);
     if (rc) return rc;
     {
       LnFwdArgs a = {};
       a.x = w.x_mid; a.M = (int)M; a.C = C;
       a.g2 = P(m, fp, q.n2w); a.b2 = P(m, fp, q.n2b); a.eps2 = 1e-6f; a.y2 = w.a2; a.stats2 = w.st2;
-      RUN(PC_LN, 0, ln_fwd(a, 0, st));
+      RUN(PC_LN, 0, ln_fwd(a, half, st));
     }
-    rc = linear_fwd(m, st, w.a2, P(m, fp, q.f1w), P(m, fp, q.f1b), w.f, M, 2 * C, C, EPI_BIAS_GELU, w.z, nullptr, nullptr, 0, T, N);
+    rc = linear_fwd(m, st, fp, w.a2, q.f1w, q.f1b, w.f, M, 2 * C, C, EPI_BIAS_GELU, w.z, nullptr, nullptr, 0, T, N);
     if (rc) return rc;
-    rc = linear_fwd(m, st, w.f, P(m, fp, q.f2w), P(m, fp, q.f2b), w.x_out, M, C, 2 * C, EPI_BIAS_RESID, nullptr, w.x_mid,
+    rc = linear_fwd(m, st, fp, w.f, q.f2w, q.f2b, w.x_out, M, C, 2 * C, EPI_BIAS_RESID, nullptr, w.x_mid,
                     branch_mask(m, md, l, 1, B, m->train), mode, T, N);
     if (rc) return rc;
     // shared post-norm (mix_ste.py:143,154,166,170), Temporal_pos_embed after the first spatial block (:149),
@@ -306,7 +333,7 @@ static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStre
       a.g2 = P(m, fp, md.bp[l + 1].n1w); a.b2 = P(m, fp, md.bp[l + 1].n1b); a.eps2 = 1e-6f;
       a.y2 = md.ws[l + 1].a1; a.stats2 = md.ws[l + 1].st1;
     }
-    RUN(PC_LN, 0, ln_fwd(a, 0, st));
+    RUN(PC_LN, 0, ln_fwd(a, half, st));
   }
   return MP_OK;
 }
@@ -315,6 +342,7 @@ static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStre
 static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int B, hipStream_t st) {
   const int T = m->cfg.num_frame, N = md.N, C = md.C, H = md.H, L = 2 * md.depth;
   const long M = (long)B * T * N;
+  const int half = m->cfg.precision == 1;
   float* g = m->g;
   for (int l = L - 1; l >= 0; --l) {
     const BlockP& q = md.bp[l];
@@ -332,14 +360,14 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
       RUN(PC_OTHER, 0, scale_rows(g, mk2, mode, m->tmpMask, (int)M, C, T, N, st));
       gb = m->tmpMask;
     }
-    int rc = linear_wgrad(m, st, gb, w.f, G(m, fg, q.f2w), G(m, fg, q.f2b), M, C, 2 * C);
+    int rc = linear_wgrad(m, st, gb, 1, w.f, G(m, fg, q.f2w), G(m, fg, q.f2b), M, C, 2 * C);
     if (rc) return rc;
-    rc = linear_dgrad(m, st, gb, P(m, fp, q.f2w), m->tmp2C, M, C, 2 * C, w.z);
+    rc = linear_dgrad(m, st, fp, gb, 1, q.f2w, m->tmp2C, 0, M, C, 2 * C, w.z);
     if (rc) return rc;
     // (c) fc1
-    rc = linear_wgrad(m, st, m->tmp2C, w.a2, G(m, fg, q.f1w), G(m, fg, q.f1b), M, 2 * C, C);
+    rc = linear_wgrad(m, st, m->tmp2C, 0, w.a2, G(m, fg, q.f1w), G(m, fg, q.f1b), M, 2 * C, C);
     if (rc) return rc;
-    rc = linear_dgrad(m, st, m->tmp2C, P(m, fp, q.f1w), m->tmpC, M, 2 * C, C, nullptr);
+    rc = linear_dgrad(m, st, fp, m->tmp2C, 0, q.f1w, m->tmpC, 1, M, 2 * C, C, nullptr);
     if (rc) return rc;
     // (d) norm2 + skip
     RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, G(m, fg, q.n2w), G(m, fg, q.n2b), (int)M, C, m->small,
@@ -351,17 +379,17 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
       RUN(PC_OTHER, 0, scale_rows(g, mk1, mode, m->tmpMask, (int)M, C, T, N, st));
       gb = m->tmpMask;
     }
-    rc = linear_wgrad(m, st, gb, w.ao, G(m, fg, q.pw), G(m, fg, q.pb), M, C, C);
+    rc = linear_wgrad(m, st, gb, 1, w.ao, G(m, fg, q.pw), G(m, fg, q.pb), M, C, C);
     if (rc) return rc;
-    rc = linear_dgrad(m, st, gb, P(m, fp, q.pw), m->tmpC, M, C, C, nullptr);
+    rc = linear_dgrad(m, st, fp, gb, 1, q.pw, m->tmpC, 0, M, C, C, nullptr);          // d(attention out): bf16 in bf16 mode
     if (rc) return rc;
     // (f) attention core
-    if (spatial) RUN(PC_ATTN, 10.0 * B * T * N * N * C, attn_spatial_bwd(w.qkv, m->tmpC, m->tmp3C, B, T, N, C, H, st));
-    else RUN(PC_ATTN, 10.0 * B * N * (double)T * T * C, attn_temporal_bwd(w.qkv, w.ao, m->tmpC, w.lse, m->delta, m->tmp3C, B, T, N, C, H, st));
+    if (spatial) RUN(PC_ATTN, 10.0 * B * T * N * N * C, attn_spatial_bwd(w.qkv, m->tmpC, m->tmp3C, half, B, T, N, C, H, st));
+    else RUN(PC_ATTN, 10.0 * B * N * (double)T * T * C, attn_temporal_bwd(w.qkv, w.ao, m->tmpC, w.lse, m->delta, m->tmp3C, half, B, T, N, C, H, st));
     // (g) qkv
-    rc = linear_wgrad(m, st, m->tmp3C, w.a1, G(m, fg, q.qkvw), G(m, fg, q.qkvb), M, 3 * C, C);
+    rc = linear_wgrad(m, st, m->tmp3C, 0, w.a1, G(m, fg, q.qkvw), G(m, fg, q.qkvb), M, 3 * C, C);
     if (rc) return rc;
-    rc = linear_dgrad(m, st, m->tmp3C, P(m, fp, q.qkvw), m->tmpC, M, 3 * C, C, nullptr);
+    rc = linear_dgrad(m, st, fp, m->tmp3C, 0, q.qkvw, m->tmpC, 1, M, 3 * C, C, nullptr);
     if (rc) return rc;
     // (h) norm1 + skip
     RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_in, w.st1, P(m, fp, q.n1w), g, g, G(m, fg, q.n1w), G(m, fg, q.n1b), (int)M, C, m->small,
@@ -391,7 +419,9 @@ extern "C" {
 int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   MP_CHECK(cfg != nullptr && out != nullptr, MP_ERR_ARG, "mp_model_create: null argument");
   MP_CHECK(cfg->arch == 0 || cfg->arch == 1, MP_ERR_ARG, "mp_model_create: arch %d (0 rmcl_manifold, 1 manifold)", cfg->arch);
-  MP_CHECK(cfg->precision == 0, MP_ERR_ARG, "mp_model_create: precision %d not built in this version (0 = fp32)", cfg->precision);
+  MP_CHECK(cfg->precision == 0 || cfg->precision == 1, MP_ERR_ARG, "mp_model_create: precision %d (0 = fp32, 1 = bf16)", cfg->precision);
+  MP_CHECK(cfg->precision == 0 || (cfg->embed_dim_rot % 8 == 0 && cfg->embed_dim_seg % 8 == 0), MP_ERR_ARG,
+           "mp_model_create: bf16 precision needs embedding widths that are multiples of 8");
   MP_CHECK(cfg->num_joints == 17 && cfg->num_bones == 16, MP_ERR_ARG, "mp_model_create: the decoder is built for the 17-joint H36M tree");
   MP_CHECK(cfg->num_frame >= 2 && cfg->max_batch >= 0, MP_ERR_ARG, "mp_model_create: num_frame >= 2, max_batch >= 0");
   MP_CHECK(cfg->embed_dim_rot % cfg->num_heads_rot == 0 && cfg->embed_dim_seg % cfg->num_heads_seg == 0, MP_ERR_ARG,
@@ -517,6 +547,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
       RUN(PC_OTHER, 0, droppath_masks(m->maskbuf, ds.data(), (int)ds.size(), seed, step, st));
     }
   }
+  if (m->cfg.precision == 1) RUN(PC_OTHER, 0, cast_to_bf16(fp, m->wbf, m->flat_size, st));
   // rotations backbone (mix_ste.py:128-173)
   const long Mr = (long)B * T * J, Ms = (long)B * T * S;
   RUN(PC_OTHER, 0, embed_fwd(x, P(m, fp, m->rot.emb_w), P(m, fp, m->rot.emb_b), P(m, fp, m->rot.spos), m->rot.ws[0].x_in, (int)Mr,
@@ -561,7 +592,7 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
       sg.w[k] = G(m, fg, m->rot.sw[k]); sg.b[k] = G(m, fg, m->rot.sb[k]);
     }
     // scores are recomputed into tmpC-sized scratch? no: softmax outputs are cheap to recompute from the head output
-    float* sc = m->tmp2C;   // (B,K,T) scratch, free at this point of the backward
+    float* sc = m->tmpC;    // (B,K,T) scratch, free at this point of the backward
     RUN(PC_OTHER, 0, scores_fwd(m->rot.headout, sp, K, m->rot.O, sc, B, T, J, st));
     RUN(PC_OTHER, 0, scores_bwd(m->rot.headout, sc, d_scores ? d_scores : m->dscore_zero, sp, sg, K, m->rot.O, m->rot.dheadout, B, T, J,
                                 m->small, m->small_floats, st));

@@ -25,6 +25,26 @@ int gemm_f32(int AL, int BL, int EPI, GemmF32Args g, hipStream_t st);
 int wgrad_f32(const float* dY, long lddy, const float* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
               float* slab, long slab_floats, hipStream_t st);
 
+// ---------------------------------------------------------------- gemm_bf16.hip
+struct GemmB16Args {
+  const void* A;
+  const void* B;
+  void* C;
+  long lda, ldb, ldc;
+  int M, N, K;
+  const float* bias;
+  void* Z;             // pre-activation, element type of C
+  const float* R;      // fp32 residual stream
+  const float* mask;
+  int mask_mode, T, J;
+  float* bias_slab;
+  int k_per_split;
+};
+int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, hipStream_t st);
+int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
+               float* slab, long slab_floats, hipStream_t st);
+int cast_to_bf16(const float* src, bf16* dst, long n, hipStream_t st);
+
 // ---------------------------------------------------------------- elementwise.hip
 struct LnFwdArgs {
   const float* x;        // [M][C] input
@@ -60,10 +80,10 @@ int droppath_masks(float* masks, const MaskDesc* descs, int ndesc, unsigned long
 
 // ---------------------------------------------------------------- attention.hip
 // qkv: [M][3C] (q | k | v, head-major inside each), out: [M][C]; token layout m = (b*T + t)*J + j
-int attn_spatial_fwd(const float* qkv, float* out, int B, int T, int J, int C, int H, hipStream_t st);
-int attn_spatial_bwd(const float* qkv, const float* dout, float* dqkv, int B, int T, int J, int C, int H, hipStream_t st);
-int attn_temporal_fwd(const float* qkv, float* out, float* lse, int B, int T, int J, int C, int H, hipStream_t st);
-int attn_temporal_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv,
+int attn_spatial_fwd(const void* qkv, void* out, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st);
+int attn_spatial_bwd(const void* qkv, const void* dout, void* dqkv, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st);
+int attn_temporal_fwd(const void* qkv, void* out, float* lse, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st);
+int attn_temporal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int is_bf16,
                       int B, int T, int J, int C, int H, hipStream_t st);
 
 // ---------------------------------------------------------------- heads.hip

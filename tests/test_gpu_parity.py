@@ -374,3 +374,73 @@ def test_cpu_tensor_is_refused_loudly(lib):
     model = _build(fx)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model(torch.from_numpy(fx["X"]))
+
+
+# --------------------------------------------------------------------------------------------- bf16 precision (throughput mode)
+BF16_MPJPE_TOL_M = 1e-2     # documented drift bound of the bf16 matrix-core mode vs the fp32 reference
+
+
+@pytest.mark.parametrize("M,N,K", [(306, 96, 32), (130, 48, 16), (4131, 1536, 512), (1000, 512, 1024)])
+def test_bf16_linear_forward_and_backward(lib, M, N, K):
+    """bf16 MFMA GEMMs (N/T operand layouts incl. the hardware-transpose-read path) against an fp64 product of the SAME
+    bf16-rounded operands: only accumulation order and output rounding differ."""
+    from manipose_amd import _lib
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    r, dy = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    xb, Wb, dyb = x.bfloat16().cuda(), W.bfloat16().cuda(), dy.bfloat16().cuda()
+    bd, rd, dyd = b.cuda(), r.cuda(), dy.cuda()
+    ref = xb.double().cpu() @ Wb.double().cpu().T + b.double()
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.mp_linear_fwd_bf16(xb.data_ptr(), Wb.data_ptr(), bd.data_ptr(), y.data_ptr(), None, None, M, N, K, 0, st()))
+    close(y.float(), ref.float(), rtol=1e-2, atol=1e-2)
+    z = torch.empty_like(y)
+    _lib.check(lib.mp_linear_fwd_bf16(xb.data_ptr(), Wb.data_ptr(), bd.data_ptr(), y.data_ptr(), z.data_ptr(), None, M, N, K, 1, st()))
+    close(z.float(), ref.float(), rtol=1e-2, atol=1e-2)
+    close(y.float(), torch.nn.functional.gelu(ref).float(), rtol=1e-2, atol=1e-2)
+    y32 = torch.empty(M, N, device="cuda")
+    _lib.check(lib.mp_linear_fwd_bf16(xb.data_ptr(), Wb.data_ptr(), bd.data_ptr(), y32.data_ptr(), None, rd.data_ptr(), M, N, K, 2, st()))
+    close(y32, (ref + r.double()).float(), rtol=1e-4, atol=1e-4 * max(1.0, (K / 64) ** 0.5))
+    slab = torch.empty(int(lib.mp_linear_bwd_slab_floats(N, K)), device="cuda")
+    for dy_f32 in (0, 1):
+        dyin = dyd if dy_f32 else dyb
+        dyr = (dyd.bfloat16() if dy_f32 else dyb).double().cpu()       # fp32 dY is rounded to bf16 while staging
+        dx = torch.empty(M, K, device="cuda")
+        dW, db = torch.ones(N, K, device="cuda"), torch.ones(N, device="cuda")
+        _lib.check(lib.mp_linear_bwd_bf16(dyin.data_ptr(), dy_f32, xb.data_ptr(), Wb.data_ptr(), dx.data_ptr(), 1, dW.data_ptr(),
+                                          db.data_ptr(), M, N, K, slab.data_ptr(), slab.numel(), st()))
+        close(dx, (dyr @ Wb.double().cpu()).float(), rtol=1e-4, atol=1e-4 * max(1.0, (N / 64) ** 0.5))
+        close(dW, (1 + dyr.T @ xb.double().cpu()).float(), rtol=1e-4, atol=2e-4 * max(1.0, (M / 64) ** 0.5))
+        close(db, (1 + dyr.sum(0)).float(), rtol=1e-4, atol=2e-4 * max(1.0, (M / 64) ** 0.5))
+    dxb = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+    dW, db = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+    _lib.check(lib.mp_linear_bwd_bf16(dyd.data_ptr(), 1, xb.data_ptr(), Wb.data_ptr(), dxb.data_ptr(), 0, dW.data_ptr(),
+                                      db.data_ptr(), M, N, K, slab.data_ptr(), slab.numel(), st()))
+    close(dxb.float(), (dyd.bfloat16().double().cpu() @ Wb.double().cpu()).float(), rtol=1e-2, atol=1e-2 * max(1.0, (N / 64) ** 0.5))
+
+
+def _cos(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("name", ["rmcl_tiny", "rmcl_small"])
+def test_bf16_precision_model_drift_vs_reference(lib, name):
+    """Throughput precision (bf16 matrix cores, fp32 accumulate / residual stream / norms / softmax): drift vs the fp32
+    reference is bounded and reported; gradients stay aligned with the reference's."""
+    from manipose_amd.metrics import mpjpe_error, rmcl_training_loss
+    fx = load_fixture(name)
+    model = _build(fx)
+    model.precision = "bf16"
+    model = model.eval()
+    poses, scores = model(dev(fx["X"]))
+    mp = mpjpe_error(poses, dev(fx["poses"]), "average").item()
+    print(f"\n[bf16 drift] {name}: MPJPE vs fp32 reference = {mp * 1e3:.4f} mm")
+    assert mp <= BF16_MPJPE_TOL_M
+    total, _ = rmcl_training_loss(poses, scores, dev(fx["y"]))
+    assert abs(total.item() - float(fx["loss_total"])) <= 2e-2 * abs(float(fx["loss_total"]))
+    total.backward()
+    cs = {k: _cos(p.grad.cpu(), torch.from_numpy(fx["g::" + k])) for k, p in model.named_parameters()}
+    worst = min(cs.items(), key=lambda kv: kv[1])
+    print(f"[bf16 drift] {name}: worst gradient cosine {worst[1]:.5f} at {worst[0]}")
+    assert worst[1] > 0.98, worst
