@@ -102,6 +102,11 @@ int mp_attention_fwd(const float* qkv, float* out, float* lse, int temporal, int
 int mp_attention_bwd(const float* qkv, const float* out, const float* d_out, const float* lse, float* delta, float* d_qkv,
                      int temporal, int B, int T, int J, int C, int H, void* stream);
 
+/* bf16 storage variants of the two calls above (temporal: MFMA kernels when T <= 256 and head dim in {64, 16}) */
+int mp_attention_fwd_bf16(const void* qkv, void* out, float* lse, int temporal, int B, int T, int J, int C, int H, void* stream);
+int mp_attention_bwd_bf16(const void* qkv, const void* out, const void* d_out, const float* lse, float* delta, void* d_qkv,
+                          int temporal, int B, int T, int J, int C, int H, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Model engine: RMCLManifoldMixSTE / ManifoldMixSTE forward + backward as one native launch sequence
  * (replaces RMCLManifoldMixSTE.forward, architectures/rmcl_manifold_mix_ste.py:83-106 and everything it

@@ -50,6 +50,8 @@ _SIGNATURES = {
     "mp_linear_bwd_bf16": (i32, [vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, i64, vp]),
     "mp_attention_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mp_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mp_attention_fwd_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mp_attention_bwd_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mp_model_create": (i32, [C.POINTER(ModelConfig), C.POINTER(vp)]),
     "mp_model_destroy": (None, [vp]),
     "mp_model_workspace_bytes": (i64, [vp]),

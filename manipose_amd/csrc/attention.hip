@@ -459,14 +459,22 @@ static int temporal_bwd_t(const TS* qkv, const TS* out, const TS* dout, const fl
   return MP_OK;
 }
 
+bool attn_tmfma_supported(int T, int D);
+int attn_tmfma_fwd(const bf16* qkv, bf16* out, float* lse, int B, int T, int J, int C, int H, hipStream_t st);
+int attn_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, const float* lse, bf16* dqkv, int B, int T, int J, int C, int H,
+                   hipStream_t st);
+
 int attn_temporal_fwd(const void* qkv, void* out, float* lse, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st) {
   MP_CHECK(C % H == 0, MP_ERR_ARG, "attn_temporal_fwd: C %% H");
+  if (is_bf16 && attn_tmfma_supported(T, C / H)) return attn_tmfma_fwd((const bf16*)qkv, (bf16*)out, lse, B, T, J, C, H, st);
   return is_bf16 ? temporal_fwd_t<bf16>((const bf16*)qkv, (bf16*)out, lse, B, T, J, C, H, st)
                  : temporal_fwd_t<float>((const float*)qkv, (float*)out, lse, B, T, J, C, H, st);
 }
 int attn_temporal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int is_bf16,
                       int B, int T, int J, int C, int H, hipStream_t st) {
   MP_CHECK(C % H == 0, MP_ERR_ARG, "attn_temporal_bwd: C %% H");
+  if (is_bf16 && attn_tmfma_supported(T, C / H))
+    return attn_tmfma_bwd((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, B, T, J, C, H, st);
   return is_bf16 ? temporal_bwd_t<bf16>((const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, B, T, J, C, H, st)
                  : temporal_bwd_t<float>((const float*)qkv, (const float*)out, (const float*)dout, lse, delta, (float*)dqkv, B, T, J, C,
                                          H, st);

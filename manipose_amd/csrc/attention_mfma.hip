@@ -1,0 +1,350 @@
+// Temporal attention of the MixSTE blocks on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16), forward and backward,
+// for windows of T <= 256 frames (H36M: 243, 3DHP: 81/27) and head dims 64 (rotations net) / 16 (bones net).
+//
+// One workgroup per (window b, joint j, head h): its K/V (and in the backward Q/dO) rows - strided by J*3C in HBM,
+// 128 B contiguous each - are staged ONCE into LDS in their natural [t][d] layout (rows padded by 16 B), and every
+// matrix product of the layer reads them from there:
+//   * products reducing over d (S = Q K^T, dP = dO V^T) take both operands as 16-byte row reads (ds_read_b128);
+//   * products reducing over t (O = P V, dQ = dS K, dV = P^T dO, dK = dS^T Q) take the LDS operand through the
+//     gfx950 hardware transpose read (ds_read_b64_tr_b16) and the P / dS operand STRAIGHT FROM THE ACCUMULATORS of the
+//     previous product: the score tile is computed in the orientation whose accumulator layout (column on the lane,
+//     4 rows in registers) is the B-fragment layout of the next MFMA up to a fixed permutation of the reduction index,
+//     which is applied to the other operand's transpose-read addresses instead (no LDS round trip, no shuffles).
+// Softmax is exact (not online): a wave holds a 16-query x 256-key score strip in 64 accumulator registers.
+// fp32 accumulation, fp32 softmax statistics; log-sum-exp saved for the backward.
+#include "common.h"
+#include "kernels.h"
+
+namespace mp {
+
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TP = 256;            // padded frames
+constexpr int NTILE = TP / 16;
+
+template <int D> struct ACfg {
+  static constexpr int ROWB = 2 * D + 16;              // LDS bytes per frame row
+  static constexpr int KS = (D + 31) / 32;             // k-steps of the d-reductions
+  static constexpr int DB = D / 16;                    // 16-wide d blocks of the t-reductions
+  static constexpr int CH = D / 8;                     // 16-byte chunks per row
+};
+
+// stage `rows` (frames) x D of a strided bf16 matrix into LDS, zero-filling frames >= T
+template <int D, int NTHREADS>
+__device__ __forceinline__ void stage_rows(char* __restrict__ S, const bf16* __restrict__ base, long row_stride, int T, int tid) {
+  constexpr int CH = ACfg<D>::CH, ROWB = ACfg<D>::ROWB;
+  for (int idx = tid; idx < TP * CH; idx += NTHREADS) {
+    const int t = idx / CH, c = idx - t * CH;
+    uint4 x = make_uint4(0u, 0u, 0u, 0u);
+    if (t < T) x = *reinterpret_cast<const uint4*>(base + (long)t * row_stride + c * 8);
+    *reinterpret_cast<uint4*>(S + t * ROWB + c * 16) = x;
+  }
+}
+
+// 8 consecutive d (d = 32*ks + 8*(lane>>4) ...) of frame row0 + (lane & 15): A operand [row][d] or B operand [d][col=row]
+template <int D>
+__device__ __forceinline__ bf16x8_t frag_rows(const char* __restrict__ S, int row0, int ks, int lane) {
+  const int g = lane >> 4;
+  const int d0 = 32 * ks + 8 * g;
+  bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (D < 32 && d0 >= D) return z;                       // head dim 16: upper half of the 32-deep step is zero padding
+  return *reinterpret_cast<const bf16x8_t*>(S + (row0 + (lane & 15)) * ACfg<D>::ROWB + d0 * 2);
+}
+
+// A operand [d = 16*db + (lane&15)][kappa] of a product reducing over 32 frames starting at t0, with the reduction index
+// permuted as kappa = 8g + i  <->  frame t0 + 4g + i (i < 4), t0 + 16 + 4g + (i - 4) (i >= 4): exactly the frames whose
+// scores lane group g holds in the accumulators of the two 16-frame score tiles (pack_acc below).
+template <int D>
+__device__ __forceinline__ bf16x8_t frag_cols_perm(const char* __restrict__ S, int t0, int db, int lane) {
+  typedef bf16x4_t __attribute__((address_space(3))) * lds_ptr;
+  const int li = lane & 15, q = li >> 2, p = li & 3, g = lane >> 4;
+  const char* a0 = S + (t0 + 4 * g + q) * ACfg<D>::ROWB + (16 * db + 4 * p) * 2;
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
+  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0 + 16 * ACfg<D>::ROWB));
+  bf16x8_t f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+// two 16x16 accumulator tiles (rows 4g+r of frames [t0, t0+16) and [t0+16, t0+32), column on the lane) -> B fragment
+__device__ __forceinline__ bf16x8_t pack_acc(const f32x4& a, const f32x4& b) {
+  union { uint4 u; bf16x8_t v; } r;
+  r.u.x = pack_bf16x2(a[0], a[1]); r.u.y = pack_bf16x2(a[2], a[3]);
+  r.u.z = pack_bf16x2(b[0], b[1]); r.u.w = pack_bf16x2(b[2], b[3]);
+  return r.v;
+}
+
+__device__ __forceinline__ float group_max(float v) {      // over the 4 lane groups (lane>>4) that share a column
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+__device__ __forceinline__ void store4(bf16* p, const f32x4& v, float s) {
+  uint2 r;
+  r.x = pack_bf16x2(v[0] * s, v[1] * s);
+  r.y = pack_bf16x2(v[2] * s, v[3] * s);
+  *reinterpret_cast<uint2*>(p) = r;
+}
+
+// =============================================================================================
+// forward: O = softmax(scale Q K^T) V ; lse = log sum exp of the scaled scores
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void attn_tmfma_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                              float* __restrict__ lse, int T, int J, int C, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB;
+  char* Ks = sm;
+  char* Vs = sm + TP * ROWB;
+  const int unit = blockIdx.x, h = unit % H, bj = unit / H, j = bj % J, b = bj / J;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const long rs3 = (long)J * 3 * C;
+  const bf16* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;
+  stage_rows<D, 256>(Ks, qb + C, rs3, T, tid);
+  stage_rows<D, 256>(Vs, qb + 2 * C, rs3, T, tid);
+  __syncthreads();
+  const int ntile = (T + 15) >> 4;
+  for (int qt = wave; qt < ntile; qt += 4) {
+    const int tq = qt * 16 + l15;                      // this lane's query (column of every tile below)
+    bf16x8_t bq[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = 32 * ks + 8 * g;
+      bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+      bq[ks] = (tq < T && d0 < D) ? *reinterpret_cast<const bf16x8_t*>(qb + (long)tq * rs3 + d0) : z;
+    }
+    // scores^T strip: s[kt][r] = scale * K[kt*16 + 4g + r] . Q[tq]
+    f32x4 s[NTILE];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NTILE; ++kt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (kt < ntile) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<D>(Ks, kt * 16, ks, lane), bq[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = (kt * 16 + 4 * g + r < T) ? acc[r] * scale : -INFINITY;
+        acc[r] = v;
+        mx = fmaxf(mx, v);
+      }
+      s[kt] = acc;
+    }
+    mx = group_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NTILE; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[kt][r] - mx);
+        s[kt][r] = e;
+        sum += e;
+      }
+    sum = group_sum(sum);
+    // O^T[d][tq] = sum_t V[t][d] P[tq][t]
+    f32x4 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kp = 0; kp < NTILE / 2; ++kp) {
+      if (2 * kp < ntile) {
+        const bf16x8_t bp = pack_acc(s[2 * kp], s[2 * kp + 1]);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_perm<D>(Vs, kp * 32, db, lane), bp, o[db], 0, 0, 0);
+      }
+    }
+    if (tq < T) {
+      const float inv = 1.0f / sum;
+      bf16* orow = out + ((long)(b * T + tq) * J + j) * C + h * D;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) store4(orow + 16 * db + 4 * g, o[db], inv);
+      if (g == 0) lse[(long)unit * T + tq] = mx + __logf(sum);
+    }
+  }
+}
+
+// =============================================================================================
+// backward: dQ, dK, dV from Q, K, V, O, dO and the saved log-sum-exp
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(512) void attn_tmfma_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                              const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                              bf16* __restrict__ dqkv, int T, int J, int C, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB;
+  char* Qs = sm;
+  char* Ks = Qs + TP * ROWB;
+  char* Vs = Ks + TP * ROWB;
+  char* Gs = Vs + TP * ROWB;                           // dO
+  float* Ls = reinterpret_cast<float*>(Gs + TP * ROWB);  // log-sum-exp per query (+inf for padding -> p = 0)
+  float* Dl = Ls + TP;                                 // delta = sum_d dO * O per query
+  const int unit = blockIdx.x, h = unit % H, bj = unit / H, j = bj % J, b = bj / J;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const long rs3 = (long)J * 3 * C, rs1 = (long)J * C;
+  const bf16* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;
+  const bf16* ob = out + ((long)b * T * J + j) * C + h * D;
+  const bf16* gb = dout + ((long)b * T * J + j) * C + h * D;
+  stage_rows<D, 512>(Qs, qb, rs3, T, tid);
+  stage_rows<D, 512>(Ks, qb + C, rs3, T, tid);
+  stage_rows<D, 512>(Vs, qb + 2 * C, rs3, T, tid);
+  stage_rows<D, 512>(Gs, gb, rs1, T, tid);
+  if (tid < TP) {
+    float dl = 0.f;
+    if (tid < T) {
+#pragma unroll
+      for (int c = 0; c < D; c += 4) {
+        const float4 a = ld4(gb + (long)tid * rs1 + c), o4 = ld4(ob + (long)tid * rs1 + c);
+        dl += (a.x * o4.x + a.y * o4.y) + (a.z * o4.z + a.w * o4.w);
+      }
+    }
+    Dl[tid] = dl;
+    Ls[tid] = (tid < T) ? lse[(long)unit * T + tid] : INFINITY;
+  }
+  __syncthreads();
+  const int ntile = (T + 15) >> 4;
+  bf16* dq_base = dqkv + ((long)b * T * J + j) * 3 * C + h * D;
+
+  // ---- phase A: dQ, one 16-query strip per wave iteration (scores in the [key][query] orientation) ----
+  for (int qt = wave; qt < ntile; qt += 8) {
+    const int tq = qt * 16 + l15;
+    bf16x8_t bq[KS], bg[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bq[ks] = frag_rows<D>(Qs, qt * 16, ks, lane);
+      bg[ks] = frag_rows<D>(Gs, qt * 16, ks, lane);
+    }
+    const float L = Ls[tq], dl = Dl[tq];
+    f32x4 dq[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kp = 0; 2 * kp < ntile; ++kp) {
+      f32x4 ds2[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int kt = 2 * kp + hf;
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<D>(Ks, kt * 16, ks, lane), bq[ks], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<D>(Vs, kt * 16, ks, lane), bg[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = (kt * 16 + 4 * g + r < T) ? __expf(sa[r] * scale - L) : 0.f;
+          ds2[hf][r] = p * (dp[r] - dl);
+        }
+      }
+      const bf16x8_t bds = pack_acc(ds2[0], ds2[1]);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_perm<D>(Ks, kp * 32, db, lane), bds, dq[db], 0, 0, 0);
+    }
+    if (tq < T) {
+#pragma unroll
+      for (int db = 0; db < DB; ++db) store4(dq_base + (long)tq * rs3 + 16 * db + 4 * g, dq[db], scale);
+    }
+  }
+
+  // ---- phase B: dK, dV, one 16-key strip per wave iteration (scores in the [query][key] orientation) ----
+  for (int kt = wave; kt < ntile; kt += 8) {
+    const int tk = kt * 16 + l15;
+    bf16x8_t bk[KS], bv[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bk[ks] = frag_rows<D>(Ks, kt * 16, ks, lane);
+      bv[ks] = frag_rows<D>(Vs, kt * 16, ks, lane);
+    }
+    f32x4 dk[DB], dv[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      dk[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int qp = 0; 2 * qp < ntile; ++qp) {
+      f32x4 p2[2], ds2[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int qt = 2 * qp + hf;
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<D>(Qs, qt * 16, ks, lane), bk[ks], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<D>(Gs, qt * 16, ks, lane), bv[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int tq = qt * 16 + 4 * g + r;            // rows of this orientation are queries
+          const float p = __expf(sa[r] * scale - Ls[tq]);   // Ls = +inf on padded queries -> 0
+          p2[hf][r] = p;
+          ds2[hf][r] = p * (dp[r] - Dl[tq]);
+        }
+      }
+      const bf16x8_t bp = pack_acc(p2[0], p2[1]), bds = pack_acc(ds2[0], ds2[1]);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_perm<D>(Gs, qp * 32, db, lane), bp, dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_perm<D>(Qs, qp * 32, db, lane), bds, dk[db], 0, 0, 0);
+      }
+    }
+    if (tk < T) {
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        store4(dq_base + C + (long)tk * rs3 + 16 * db + 4 * g, dk[db], scale);
+        store4(dq_base + 2 * C + (long)tk * rs3 + 16 * db + 4 * g, dv[db], 1.0f);
+      }
+    }
+  }
+}
+
+bool attn_tmfma_supported(int T, int D) { return T <= TP && (D == 64 || D == 16); }
+
+int attn_tmfma_fwd(const bf16* qkv, bf16* out, float* lse, int B, int T, int J, int C, int H, hipStream_t st) {
+  const int D = C / H;
+  MP_CHECK(attn_tmfma_supported(T, D) && C % 8 == 0, MP_ERR_ARG, "attn_tmfma_fwd: T=%d D=%d unsupported", T, D);
+  const float scale = 1.0f / sqrtf((float)D);
+  const int units = B * J * H;
+  if (D == 64) {
+    const size_t lds = 2 * TP * ACfg<64>::ROWB;
+    static bool attr_set = false;
+    if (!attr_set) {
+      MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_tmfma_fwd_kernel<64>, dim3(units), dim3(256), lds, st, qkv, out, lse, T, J, C, H, scale);
+  } else {
+    const size_t lds = 2 * TP * ACfg<16>::ROWB;
+    hipLaunchKernelGGL(attn_tmfma_fwd_kernel<16>, dim3(units), dim3(256), lds, st, qkv, out, lse, T, J, C, H, scale);
+  }
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+int attn_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, const float* lse, bf16* dqkv, int B, int T, int J, int C, int H,
+                   hipStream_t st) {
+  const int D = C / H;
+  MP_CHECK(attn_tmfma_supported(T, D) && C % 8 == 0, MP_ERR_ARG, "attn_tmfma_bwd: T=%d D=%d unsupported", T, D);
+  const float scale = 1.0f / sqrtf((float)D);
+  const int units = B * J * H;
+  if (D == 64) {
+    const size_t lds = 4 * TP * ACfg<64>::ROWB + 2 * TP * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_tmfma_bwd_kernel<64>, dim3(units), dim3(512), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale);
+  } else {
+    const size_t lds = 4 * TP * ACfg<16>::ROWB + 2 * TP * sizeof(float);
+    hipLaunchKernelGGL(attn_tmfma_bwd_kernel<16>, dim3(units), dim3(512), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale);
+  }
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+}  // namespace mp

@@ -132,4 +132,16 @@ int mp_attention_bwd(const float* qkv, const float* out, const float* d_out, con
                   : attn_spatial_bwd(qkv, d_out, d_qkv, 0, B, T, J, C, H, (hipStream_t)stream);
 }
 
+int mp_attention_fwd_bf16(const void* qkv, void* out, float* lse, int temporal, int B, int T, int J, int C, int H, void* stream) {
+  MP_CHECK(qkv && out && (!temporal || lse), MP_ERR_ARG, "mp_attention_fwd_bf16: null pointer");
+  return temporal ? attn_temporal_fwd(qkv, out, lse, 1, B, T, J, C, H, (hipStream_t)stream)
+                  : attn_spatial_fwd(qkv, out, 1, B, T, J, C, H, (hipStream_t)stream);
+}
+int mp_attention_bwd_bf16(const void* qkv, const void* out, const void* d_out, const float* lse, float* delta, void* d_qkv,
+                          int temporal, int B, int T, int J, int C, int H, void* stream) {
+  MP_CHECK(qkv && d_out && d_qkv && (!temporal || (out && lse && delta)), MP_ERR_ARG, "mp_attention_bwd_bf16: null pointer");
+  return temporal ? attn_temporal_bwd(qkv, out, d_out, lse, delta, d_qkv, 1, B, T, J, C, H, (hipStream_t)stream)
+                  : attn_spatial_bwd(qkv, d_out, d_qkv, 1, B, T, J, C, H, (hipStream_t)stream);
+}
+
 }  // extern "C"

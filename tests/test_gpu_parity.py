@@ -444,3 +444,65 @@ def test_bf16_precision_model_drift_vs_reference(lib, name):
     worst = min(cs.items(), key=lambda kv: kv[1])
     print(f"[bf16 drift] {name}: worst gradient cosine {worst[1]:.5f} at {worst[0]}")
     assert worst[1] > 0.98, worst
+
+
+@pytest.mark.parametrize("temporal,B,T,J,C,H", [(1, 2, 243, 3, 128, 2), (1, 1, 81, 17, 512, 8), (1, 2, 27, 16, 128, 8),
+                                                (1, 1, 256, 2, 64, 1), (1, 1, 17, 2, 32, 2), (1, 1, 300, 2, 128, 2),
+                                                (0, 1, 9, 17, 128, 2)])
+def test_bf16_attention_forward_backward(lib, temporal, B, T, J, C, H):
+    """bf16-storage attention (temporal: MFMA kernels for T <= 256 and head dim 64/16, VALU kernels otherwise) against the
+    fp32 formula evaluated on the same bf16-rounded q/k/v and dO."""
+    from manipose_amd import _lib
+    g = torch.Generator().manual_seed(T * 11 + C)
+    M = B * T * J
+    qkv_b = torch.randn(M, 3 * C, generator=g).bfloat16()
+    dout_b = torch.randn(M, C, generator=g).bfloat16()
+    qkv = qkv_b.float().requires_grad_(True)
+    ref = _attn_ref(qkv, B, T, J, C, H, temporal)
+    (ref * dout_b.float()).sum().backward()
+    qd, dod = qkv_b.cuda(), dout_b.cuda()
+    out = torch.empty(M, C, device="cuda", dtype=torch.bfloat16)
+    lse = torch.zeros(B * J * H * T, device="cuda")
+    _lib.check(lib.mp_attention_fwd_bf16(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), temporal, B, T, J, C, H, st()))
+    close(out.float(), ref, rtol=2e-2, atol=2e-2)
+    dq = torch.zeros(M, 3 * C, device="cuda", dtype=torch.bfloat16)
+    delta = torch.empty(B * J * H * T, device="cuda")
+    _lib.check(lib.mp_attention_bwd_bf16(qd.data_ptr(), out.data_ptr(), dod.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                         dq.data_ptr(), temporal, B, T, J, C, H, st()))
+    got, want = dq.float().cpu(), qkv.grad
+    assert _cos(got, want) > 0.999, _cos(got, want)
+    close(got, want, rtol=5e-2, atol=5e-2 * float(want.abs().max()))
+
+
+def test_bf16_full_size_model_drift_vs_oracle(lib):
+    """BASELINE config #3 (T=243 K=5 C=512 depth 8, bf16 matrix cores incl. the MFMA attention kernels) at B=1 against
+    the fp32 CPU oracle: reports the MPJPE drift of the throughput precision and checks gradient alignment."""
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    from manipose_amd.metrics import mpjpe_error, rmcl_training_loss
+    cfg = orc.FULL_CFG
+    st_ = orc.make_state(cfg, seed=3)
+    model = RMCLManifoldMixSTE(h36m_skeleton(), drop_path_rate=0.0)
+    model.load_state_dict(st_, strict=True)
+    model.precision = "bf16"
+    model = model.cuda().eval()
+    X, y = orc.synthetic_batch(1, 243, seed=42)
+    poses, scores = model(X.cuda())
+    req = {k: v.clone().requires_grad_(True) for k, v in st_.items()}
+    o_poses, o_scores = orc.rmcl_manifold_forward(X, req, orc.oracle_cfg(cfg))
+    mp = mpjpe_error(poses, o_poses.detach().cuda(), "average").item()
+    print(f"\n[bf16 drift] full size T=243 K=5: MPJPE vs fp32 oracle = {mp * 1e3:.4f} mm")
+    assert mp <= BF16_MPJPE_TOL_M
+    total, _ = rmcl_training_loss(poses, scores, y.cuda())
+    o_total, _ = orc.rmcl_training_loss(o_poses, o_scores, y)
+    assert abs(total.item() - o_total.item()) <= 2e-2 * abs(o_total.item())
+    total.backward()
+    o_total.backward()
+    cs = {k: _cos(p.grad.cpu(), req[k].grad) for k, p in model.named_parameters()}
+    worst = min(cs.items(), key=lambda kv: kv[1])
+    mean = sum(cs.values()) / len(cs)
+    print(f"[bf16 drift] full size: gradient cosine mean {mean:.5f}, worst {worst[1]:.5f} at {worst[0]}")
+    assert worst[1] > 0.9 and mean > 0.99, (worst, mean)
+    par = torch.tensor(orc.H36M_PARENTS[1:], device="cuda")
+    seg = (poses[..., 1:, :] - poses[..., par, :]).norm(dim=-1)       # the manifold property is exact in any precision
+    lens = model._engine.peek(1).view(1, 1, 1, 16).abs()
+    close(seg, lens.expand_as(seg), rtol=1e-4, atol=2e-6)
