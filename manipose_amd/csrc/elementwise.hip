@@ -129,8 +129,8 @@ constexpr int LNB_GRID = 512;
 
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                      const float* dskip, float* dx, float* __restrict__ partial, int M,
-                                                      int C) {
+                                                      const float* dskip, float* dx, bf16* __restrict__ dx_b16,
+                                                      float* __restrict__ partial, int M, int C) {
   __shared__ float red[4 * 2 * 1024];  // [wave][dgamma|dbeta][C<=1024]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
           o.x += k.x; o.y += k.y; o.z += k.z; o.w += k.w;
         }
         st4(dx + (long)m * C + c, o);
+        if (dx_b16 != nullptr) st4(dx_b16 + (long)m * C + c, o);   // bf16 copy: A operand of the next dgrad/wgrad GEMMs
       }
     }
   }
@@ -201,25 +202,43 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 
 // out segment j (<=4): dst[j][i] += sum_p partial[p][off_j + i]
 struct ReduceDst { float* dst[4]; int off[5]; int stride[4]; };
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int P, int n, ReduceDst d) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int p = 0; p < P; ++p) s += partial[(long)p * n + i];
+// block = 32 outputs x 8 row groups: each thread sums P/8 partial rows (4 independent chains), LDS-combines the 8 groups
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int P, int n, ReduceDst d) {
+  __shared__ float red[8][33];
+  const int oi = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + oi;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int p = grp;
+    for (; p + 24 < P; p += 32) {
+      s0 += partial[(long)p * n + i];
+      s1 += partial[(long)(p + 8) * n + i];
+      s2 += partial[(long)(p + 16) * n + i];
+      s3 += partial[(long)(p + 24) * n + i];
+    }
+    for (; p < P; p += 8) s0 += partial[(long)p * n + i];
+  }
+  red[grp][oi] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && i < n) {
+    float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (i >= d.off[j] && i < d.off[j + 1] && d.dst[j] != nullptr) d.dst[j][(long)(i - d.off[j]) * d.stride[j]] += s;
+    for (int k = 0; k < 8; ++k) s += red[k][oi];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i >= d.off[j] && i < d.off[j + 1] && d.dst[j] != nullptr) d.dst[j][(long)(i - d.off[j]) * d.stride[j]] += s;
+  }
 }
 
-int ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx,
+int ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
            float* dgamma, float* dbeta, int M, int C, float* scratch, long scratch_floats, hipStream_t st) {
   MP_CHECK(C % 4 == 0 && C <= 1024, MP_ERR_ARG, "ln_bwd: C=%d unsupported", C);
   const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
   MP_CHECK(scratch_floats >= (long)grid * 2 * C, MP_ERR_ARG, "ln_bwd: scratch too small");
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, st, dy, x, stats, gamma, dskip, dx, scratch, M, C);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, st, dy, x, stats, gamma, dskip, dx, (bf16*)dx_b16, scratch, M, C);
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dgamma, dbeta, nullptr, nullptr}, {0, C, 2 * C, 2 * C, 2 * C}, {1, 1, 1, 1}};
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, scratch, grid, 2 * C, d);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, scratch, grid, 2 * C, d);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -294,7 +313,7 @@ int embed_bwd(const float* g, const float* xin, float* dW, float* db, float* dsp
                      M, C, J);
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dW, db, dspos, nullptr}, {0, 2 * C, 3 * C, n, n}, {1, 1, 1, 1}};
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, scratch, chunks, n, d);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 32)), dim3(256), 0, st, scratch, chunks, n, d);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -376,10 +395,10 @@ int bones_embed_bwd(const float* g, const float* xin, float* dW, float* db, floa
   MP_LAUNCH_CHECK();
   // the positional table is added exactly like the bias (index o = s*Cs + c), so dspos == db contribution
   ReduceDst d = {{dW, db, nullptr, nullptr}, {0, O * BE_IN, n, n, n}, {1, 1, 1, 1}};
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, scratch, chunks, n, d);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 32)), dim3(256), 0, st, scratch, chunks, n, d);
   MP_LAUNCH_CHECK();
   ReduceDst d2 = {{nullptr, dspos, nullptr, nullptr}, {0, O * BE_IN, n, n, n}, {1, 1, 1, 1}};
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, scratch, chunks, n, d2);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 32)), dim3(256), 0, st, scratch, chunks, n, d2);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -403,7 +422,8 @@ int tpos_grad(const float* g, float* dtpos, int B, int T, int J, int C, hipStrea
 }
 
 // out[m][:] = mask(m) * g[m][:]  (DropPath backward on a branch gradient)
-__global__ void scale_rows_kernel(const float* __restrict__ g, const float* __restrict__ mask, int mode, float* __restrict__ out,
+template <typename TO>
+__global__ void scale_rows_kernel(const float* __restrict__ g, const float* __restrict__ mask, int mode, TO* __restrict__ out,
                                   int M, int C, int T, int J) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c4 = C / 4;
@@ -415,9 +435,12 @@ __global__ void scale_rows_kernel(const float* __restrict__ g, const float* __re
   st4(out + i * 4, v);
 }
 
-int scale_rows(const float* g, const float* mask, int mask_mode, float* out, int M, int C, int T, int J, hipStream_t st) {
+int scale_rows(const float* g, const float* mask, int mask_mode, void* out, int out_bf16, int M, int C, int T, int J, hipStream_t st) {
   const long n = (long)M * (C / 4);
-  hipLaunchKernelGGL(scale_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, g, mask, mask_mode, out, M, C, T, J);
+  if (out_bf16)
+    hipLaunchKernelGGL(scale_rows_kernel<bf16>, dim3(cdiv(n, 256)), dim3(256), 0, st, g, mask, mask_mode, (bf16*)out, M, C, T, J);
+  else
+    hipLaunchKernelGGL(scale_rows_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, st, g, mask, mask_mode, (float*)out, M, C, T, J);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

@@ -45,6 +45,7 @@ struct mp_model {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   float *g = nullptr, *tmpC = nullptr, *tmpMask = nullptr, *delta = nullptr;
+  bf16* g_b16 = nullptr;                     // bf16 copy of the gradient stream (A operand of dgrad/wgrad in precision 1)
   void *tmp2C = nullptr, *tmp3C = nullptr;   // dz / dqkv: fp32 or bf16 by precision
   bf16* wbf = nullptr;                       // bf16 shadow of the flat parameter buffer (precision 1)
   float *slab = nullptr, *small = nullptr, *lengths = nullptr, *dlen_pose = nullptr, *maskbuf = nullptr, *dscore_zero = nullptr;
@@ -173,6 +174,7 @@ static void carve_all(mp_model* m, Bump& bp) {
   m->g = bp.take(MC);
   m->tmpC = bp.take(MC);
   m->tmpMask = bp.take(MC);
+  if (half) m->g_b16 = reinterpret_cast<bf16*>(bp.take((MC + 1) / 2));
   m->tmp2C = bp.take(half ? MC : 2 * MC);
   m->tmp3C = bp.take(half ? (3 * MC + 1) / 2 : 3 * MC);
   m->delta = bp.take(max((long)Bm * m->rot.N * m->rot.H * T, (long)Bm * m->seg.N * m->seg.H * T));
@@ -351,18 +353,19 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
     const int mode = spatial ? 1 : 2;
     // (a) shared post-norm (+ Temporal_pos_embed gradient behind block 0)
     if (l == 0) RUN(PC_OTHER, 0, tpos_grad(g, G(m, fg, md.tpos), B, T, N, C, st));
-    RUN(PC_LN, 0, ln_bwd(g, w.x_out, w.stp, P(m, fp, spatial ? md.sn_w : md.tn_w), nullptr, g, G(m, fg, spatial ? md.sn_w : md.tn_w),
-                         G(m, fg, spatial ? md.sn_b : md.tn_b), (int)M, C, m->small, m->small_floats, st));
-    // (b) mlp branch: fc2
+    RUN(PC_LN, 0, ln_bwd(g, w.x_out, w.stp, P(m, fp, spatial ? md.sn_w : md.tn_w), nullptr, g, m->g_b16,
+                         G(m, fg, spatial ? md.sn_w : md.tn_w), G(m, fg, spatial ? md.sn_b : md.tn_b), (int)M, C, m->small,
+                         m->small_floats, st));
+    // (b) mlp branch: fc2.  gb = branch gradient (DropPath-scaled), bf16 copy in precision 1
     const float* mk2 = branch_mask(m, md, l, 1, B, m->train);
-    const float* gb = g;
+    const void* gb = half ? (const void*)m->g_b16 : (const void*)g;
     if (mk2) {
-      RUN(PC_OTHER, 0, scale_rows(g, mk2, mode, m->tmpMask, (int)M, C, T, N, st));
+      RUN(PC_OTHER, 0, scale_rows(g, mk2, mode, m->tmpMask, half, (int)M, C, T, N, st));
       gb = m->tmpMask;
     }
-    int rc = linear_wgrad(m, st, gb, 1, w.f, G(m, fg, q.f2w), G(m, fg, q.f2b), M, C, 2 * C);
+    int rc = linear_wgrad(m, st, gb, 0, w.f, G(m, fg, q.f2w), G(m, fg, q.f2b), M, C, 2 * C);
     if (rc) return rc;
-    rc = linear_dgrad(m, st, fp, gb, 1, q.f2w, m->tmp2C, 0, M, C, 2 * C, w.z);
+    rc = linear_dgrad(m, st, fp, gb, 0, q.f2w, m->tmp2C, 0, M, C, 2 * C, w.z);
     if (rc) return rc;
     // (c) fc1
     rc = linear_wgrad(m, st, m->tmp2C, 0, w.a2, G(m, fg, q.f1w), G(m, fg, q.f1b), M, 2 * C, C);
@@ -370,18 +373,18 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
     rc = linear_dgrad(m, st, fp, m->tmp2C, 0, q.f1w, m->tmpC, 1, M, 2 * C, C, nullptr);
     if (rc) return rc;
     // (d) norm2 + skip
-    RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, G(m, fg, q.n2w), G(m, fg, q.n2b), (int)M, C, m->small,
-                         m->small_floats, st));
+    RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, m->g_b16, G(m, fg, q.n2w), G(m, fg, q.n2b), (int)M, C,
+                         m->small, m->small_floats, st));
     // (e) attention branch: proj
     const float* mk1 = branch_mask(m, md, l, 0, B, m->train);
-    gb = g;
+    gb = half ? (const void*)m->g_b16 : (const void*)g;
     if (mk1) {
-      RUN(PC_OTHER, 0, scale_rows(g, mk1, mode, m->tmpMask, (int)M, C, T, N, st));
+      RUN(PC_OTHER, 0, scale_rows(g, mk1, mode, m->tmpMask, half, (int)M, C, T, N, st));
       gb = m->tmpMask;
     }
-    rc = linear_wgrad(m, st, gb, 1, w.ao, G(m, fg, q.pw), G(m, fg, q.pb), M, C, C);
+    rc = linear_wgrad(m, st, gb, 0, w.ao, G(m, fg, q.pw), G(m, fg, q.pb), M, C, C);
     if (rc) return rc;
-    rc = linear_dgrad(m, st, fp, gb, 1, q.pw, m->tmpC, 0, M, C, C, nullptr);          // d(attention out): bf16 in bf16 mode
+    rc = linear_dgrad(m, st, fp, gb, 0, q.pw, m->tmpC, 0, M, C, C, nullptr);          // d(attention out): bf16 in bf16 mode
     if (rc) return rc;
     // (f) attention core
     if (spatial) RUN(PC_ATTN, 10.0 * B * T * N * N * C, attn_spatial_bwd(w.qkv, m->tmpC, m->tmp3C, half, B, T, N, C, H, st));
@@ -392,8 +395,8 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
     rc = linear_dgrad(m, st, fp, m->tmp3C, 0, q.qkvw, m->tmpC, 1, M, 3 * C, C, nullptr);
     if (rc) return rc;
     // (h) norm1 + skip
-    RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_in, w.st1, P(m, fp, q.n1w), g, g, G(m, fg, q.n1w), G(m, fg, q.n1b), (int)M, C, m->small,
-                         m->small_floats, st));
+    RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_in, w.st1, P(m, fp, q.n1w), g, g, nullptr, G(m, fg, q.n1w), G(m, fg, q.n1b), (int)M, C,
+                         m->small, m->small_floats, st));
   }
   return MP_OK;
 }

@@ -106,7 +106,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmB16Args g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so give every XCD a
+  // CONTIGUOUS run of tiles (n fastest): the tiles that share an activation row panel then share one L2.
+  int tm, tn;
+  {
+    const int nwg = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    tm = wg / gridDim.x;
+    tn = wg - tm * gridDim.x;
+  }
+  const int m0 = tm * GBM, n0 = tn * GBN;
   const int kbeg = blockIdx.z * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
 
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmB16Args g) {
       load_op<TB, TRB>(B, g.ldb, n0, k0 + GBK, g.N, kend, tid, vb);
     }
     if (EPI == EPI_SLAB && TRA == 1) {
-      if (blockIdx.x == 0 && tid < GBM) {
+      if (tn == 0 && tid < GBM) {
         for (int r = 0; r < GBK; ++r)
           bsum += __uint_as_float((unsigned)(*reinterpret_cast<const unsigned short*>(As + r * T_ROWB + tid * 2)) << 16);
       }
@@ -146,41 +156,47 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmB16Args g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile
     }
   }
 
-  // ---- epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg ----
+  // ---- epilogue.  The MFMA was issued with the operands swapped, i.e. it produced the TRANSPOSED 16x16 tile: lane holds
+  // C[m = tile row (lane & 15)][n = tile col 4*(lane>>4) + r], r = 0..3 -> four consecutive output columns per lane,
+  // so bias / residual / pre-activation traffic and the stores are 16-byte (fp32) or 8-byte (bf16) vector accesses. ----
   TC* C = reinterpret_cast<TC*>(g.C);
   if (EPI == EPI_SLAB) {
     C += (long)blockIdx.z * g.M * g.ldc;
-    if (TRA == 1 && blockIdx.x == 0 && tid < GBM && m0 + tid < g.M && g.bias_slab != nullptr)
+    if (TRA == 1 && tn == 0 && tid < GBM && m0 + tid < g.M && g.bias_slab != nullptr)
       g.bias_slab[(long)blockIdx.z * g.M + m0 + tid] = bsum;
   }
   TC* Z = reinterpret_cast<TC*>(g.Z);
+  const int l15 = lane & 15, gq = lane >> 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    const int row = m0 + wr * 64 + i * 16 + l15;
+    if (row >= g.M) continue;
+    const float dscale = (EPI == EPI_BIAS_RESID) ? droppath_scale(g.mask, g.mask_mode, row, g.T, g.J) : 1.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wc * 64 + j * 16 + (lane & 15);
+      const int col = n0 + wc * 64 + j * 16 + 4 * gq;
       if (col >= g.N) continue;
-      const float bias = (EPI != EPI_SLAB && EPI != EPI_DGELU && g.bias != nullptr) ? g.bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
-        if (row >= g.M) continue;
-        const long o = (long)row * g.ldc + col;
-        float v = acc[i][j][r] + bias;
-        if (EPI == EPI_BIAS_GELU) {
-          store_c<TC>(Z + o, v);
-          v = gelu_f(v);
-        } else if (EPI == EPI_BIAS_RESID) {
-          v = g.R[o] + droppath_scale(g.mask, g.mask_mode, row, g.T, g.J) * v;
-        } else if (EPI == EPI_DGELU) {
-          v *= gelu_grad_f(to_f(Z[o]));
-        }
-        store_c<TC>(C + o, v);
+      const long o = (long)row * g.ldc + col;
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (EPI != EPI_SLAB && EPI != EPI_DGELU && g.bias != nullptr) {
+        const float4 b = ld4(g.bias + col);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
       }
+      if (EPI == EPI_BIAS_GELU) {
+        st4(Z + o, v);
+        v = make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
+      } else if (EPI == EPI_BIAS_RESID) {
+        const float4 r = ld4(g.R + o);
+        v = make_float4(r.x + dscale * v.x, r.y + dscale * v.y, r.z + dscale * v.z, r.w + dscale * v.w);
+      } else if (EPI == EPI_DGELU) {
+        const float4 z = ld4(Z + o);
+        v = make_float4(v.x * gelu_grad_fast(z.x), v.y * gelu_grad_fast(z.y), v.z * gelu_grad_fast(z.z), v.w * gelu_grad_fast(z.w));
+      }
+      st4(C + o, v);
     }
   }
 }
@@ -204,7 +220,8 @@ static int launch_b16(const GemmB16Args& g, int splits, hipStream_t st) {
 // C[M,N] = A(i,r) B(r,j): a_f32/c_f32 select fp32 instead of bf16 storage; a_tr/b_tr select the "T" layouts.
 int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, hipStream_t st) {
   MP_CHECK(g.M > 0 && g.N > 0 && g.K > 0, MP_ERR_ARG, "gemm_bf16: empty problem");
-  MP_CHECK((a_tr ? g.M : g.K) % 8 == 0 && (b_tr ? g.N : g.K) % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0, MP_ERR_ARG,
+  MP_CHECK((a_tr ? g.M : g.K) % 8 == 0 && (b_tr ? g.N : g.K) % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.N % 4 == 0 &&
+               g.ldc % 4 == 0, MP_ERR_ARG,
            "gemm_bf16: contiguous operand dimensions and leading dimensions must be multiples of 8 (M=%d N=%d K=%d)", g.M, g.N, g.K);
   g.k_per_split = ((g.K + GBK - 1) / GBK) * GBK;
   if (!a_f32 && !a_tr && !b_tr && !c_f32 && epi == EPI_BIAS) return launch_b16<bf16, 0, bf16, 0, bf16, EPI_BIAS>(g, 1, st);
@@ -212,6 +229,8 @@ int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, 
   if (!a_f32 && !a_tr && !b_tr && c_f32 && epi == EPI_BIAS_RESID) return launch_b16<bf16, 0, bf16, 0, float, EPI_BIAS_RESID>(g, 1, st);
   if (!a_f32 && !a_tr && !b_tr && !c_f32 && epi == EPI_BIAS_GELU) return launch_b16<bf16, 0, bf16, 0, bf16, EPI_BIAS_GELU>(g, 1, st);
   if (a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_DGELU) return launch_b16<float, 0, bf16, 1, bf16, EPI_DGELU>(g, 1, st);
+  if (!a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_DGELU) return launch_b16<bf16, 0, bf16, 1, bf16, EPI_DGELU>(g, 1, st);
+  if (!a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_BIAS) return launch_b16<bf16, 0, bf16, 1, bf16, EPI_BIAS>(g, 1, st);
   if (a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_BIAS) return launch_b16<float, 0, bf16, 1, bf16, EPI_BIAS>(g, 1, st);
   if (!a_f32 && !a_tr && b_tr && c_f32 && epi == EPI_BIAS) return launch_b16<bf16, 0, bf16, 1, float, EPI_BIAS>(g, 1, st);
   if (a_f32 && !a_tr && b_tr && c_f32 && epi == EPI_BIAS) return launch_b16<float, 0, bf16, 1, float, EPI_BIAS>(g, 1, st);

@@ -59,7 +59,7 @@ struct LnFwdArgs {
 };
 int ln_fwd(const LnFwdArgs& a, int out_bf16, hipStream_t st);
 // dx = [dskip +] LN'(dy); partial param grads are reduced and ADDED into dgamma/dbeta.
-int ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx,
+int ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
            float* dgamma, float* dbeta, int M, int C, float* scratch, long scratch_floats, hipStream_t st);
 
 int embed_fwd(const float* xin, const float* W, const float* b, const float* spos, float* out, int M, int C, int J,
@@ -71,7 +71,7 @@ int bones_embed_fwd(const float* xin, const float* W, const float* b, const floa
 int bones_embed_bwd(const float* g, const float* xin, float* dW, float* db, float* dspos, int BT, int IN, int O,
                     float* scratch, long scratch_floats, hipStream_t st);
 int tpos_grad(const float* g, float* dtpos, int B, int T, int J, int C, hipStream_t st);
-int scale_rows(const float* g, const float* mask, int mask_mode, float* out, int M, int C, int T, int J, hipStream_t st);
+int scale_rows(const float* g, const float* mask, int mask_mode, void* out, int out_bf16, int M, int C, int T, int J, hipStream_t st);
 int adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1, float beta2, float eps,
               float weight_decay, float grad_scale, hipStream_t st);
 struct MaskDesc { int offset, count; float keep; };
