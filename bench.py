@@ -18,6 +18,9 @@ sys.path.insert(0, ROOT)
 
 TRAIN_GFLOP_PER_POSE = {243: 3.705, 81: 3.562, 27: 3.513}      # SURVEY.md 8d (3 x forward GEMM+attention FLOPs)
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}                  # MI355X_MICROARCH.md: dense matrix peaks
+# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction of
+# MI355X_MICROARCH.md section HBM, + WRITE_SIZE), see profiles/README.md; keyed by (precision, windows per GPU).
+PMC_TRAFFIC_PER_LAUNCH = {("bf16", 32): 620.4e6}   # profiles/r01_bf16_B32_pmc_hbm_traffic.csv (forward-GEMM class average)
 
 
 def host_cores():
@@ -63,10 +66,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("MANIPOSE_BENCH_BATCH", "16")), help="windows per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MANIPOSE_BENCH_BATCH", "32")), help="windows per GPU")
     ap.add_argument("--frames", type=int, default=243)
     ap.add_argument("--hyp", type=int, default=5)
-    ap.add_argument("--precision", default=os.environ.get("MANIPOSE_PRECISION", "fp32"))
+    ap.add_argument("--precision", default=os.environ.get("MANIPOSE_PRECISION", "bf16"), choices=["bf16", "fp32"],
+                    help="bf16 = BASELINE config #3 (bf16 matrix cores, fp32 accumulate/residual/softmax); fp32 = parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) time the CPU oracle and print its JSON")
@@ -161,8 +165,11 @@ def main():
             k = prof["gemm_fwd"]
             ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
             peak = PEAK_TFLOPS[args.precision]
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<AL=0,BL=0> (forward Linear GEMMs)",
-                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            kname = ("gemm_bf16_kernel<bf16,N,bf16,N,*> (forward Linear GEMMs, v_mfma_f32_16x16x32_bf16)" if args.precision == "bf16"
+                     else "gemm_f32_kernel<AL=0,BL=0,*> (forward Linear GEMMs, v_mfma_f32_32x32x2_f32)")
+            out["roofline"] = {"bound": "mfma", "kernel": kname,
+                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                               "traffic": PMC_TRAFFIC_PER_LAUNCH.get((args.precision, B)),
                                "avg_launch_ms": k["ms"] / max(1, k["launches"]), "launches": k["launches"]}
             tot = sum(v["ms"] for v in prof.values())
             out["kernel_classes"] = {n: {"ms_per_step": v["ms"] / args.steps, "share": v["ms"] / tot if tot else 0.0,

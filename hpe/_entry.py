@@ -1,0 +1,170 @@
+"""Shared implementation of the two lifting entry points (counterparts of the reference's Hydra scripts
+hpe/main_h36m_lifting.py:711-1270 and hpe/main_3dhp.py:662-1063): same `group.key=value` override grammar, same config
+keys (hpe/conf/config.yaml), same model construction (_instantiate_model :613-670), loss assembly (make_loss :101-178),
+optimizer / scheduler (:227-270), checkpoint names (save_state :75-98: model{tag}.pth / params{tag}.pth) and the MPJPE
+evaluation of evaluate() (hpe/eval_utils.py:16-223: weighted-average, best-score and oracle aggregation, millimetres).
+The dataset pipelines are out of scope: without `data.data_dir` the script trains / evaluates on
+synthetic H36M-shaped windows so that the whole MI355X path (engine, fused loss, RCCL data parallelism, fused Adam) runs.
+Launch on N GPUs with `python -m torch.distributed.run --nproc-per-node N hpe/main_h36m_lifting.py ...`.
+"""
+from __future__ import annotations
+
+import copy
+import os
+import sys
+
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+    @staticmethod
+    def wrap(d):
+        return Cfg({k: Cfg.wrap(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+
+def load_config(argv, extra_defaults=None):
+    with open(os.path.join(ROOT, "hpe", "conf", "config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    for k, v in (extra_defaults or {}).items():
+        grp, key = k.split(".")
+        cfg[grp][key] = v
+    for arg in argv:
+        if "=" not in arg:
+            raise SystemExit(f"expected group.key=value overrides, got {arg!r}")
+        path, val = arg.lstrip("+").split("=", 1)
+        grp, key = path.split(".", 1)
+        if grp not in cfg:
+            raise SystemExit(f"unknown config group {grp!r}")
+        cfg[grp][key] = yaml.safe_load(val)
+    return Cfg.wrap(cfg)
+
+
+def instantiate_model(cfg):
+    from manipose_amd import ManifoldMixSTE, RMCLManifoldMixSTE, h36m_skeleton
+    sk = h36m_skeleton()
+    kw = dict(skeleton=sk, num_frame=cfg.data.seq_len, num_joints=sk.num_joints, num_bones=sk.num_bones, in_chans=2,
+              rot_rep_dim=cfg.model.rot_dim, num_heads_rot=cfg.model.nheads, depth_rot=cfg.model.layers,
+              embed_dim_rot=cfg.model.channels, num_heads_seg=cfg.model.nheads_seg, depth_seg=cfg.model.layers_seg,
+              embed_dim_seg=cfg.model.channels_seg, drop_path_rate=cfg.model.drop_path_rate, mup=cfg.model.mup)
+    if cfg.model.arch == "rmcl_manifold":
+        model = RMCLManifoldMixSTE(n_hyp=cfg.multi_hyp.n_hyp, **kw)
+    elif cfg.model.arch == "manifold":
+        model = ManifoldMixSTE(**kw)
+    else:
+        raise ValueError("Only Manifold-MixSTE and RMCL-Manifold-MixSTE are accelerated on MI355X. "
+                         f"Got option {cfg.model.arch}.")
+    model.precision = cfg.model.precision
+    return model
+
+
+def synthetic_windows(n, T, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    X = (0.3 * torch.randn(n, T, 17, 2, device=device, generator=g)).clamp(-1, 1)
+    y = 0.3 * torch.randn(n, T, 17, 3, device=device, generator=g)
+    y[:, :, 0] = 0
+    return X, y
+
+
+@torch.no_grad()
+def evaluate(model, X, y, batch):
+    """MPJPE (mm) of the aggregated / best-score / oracle hypotheses (eval_utils.py:16-223, without flip-TTA)."""
+    from manipose_amd import RMCLManifoldMixSTE
+    from manipose_amd.metrics import mpjpe_error
+    model.eval()
+    sums = {"mpjpe": 0.0, "ps_oracle_mpjpe": 0.0, "oracle_mpjpe": 0.0}
+    n = 0
+    for i in range(0, X.shape[0], batch):
+        xb, yb = X[i:i + batch], y[i:i + batch]
+        out = model(xb)
+        if isinstance(model, RMCLManifoldMixSTE):
+            poses, scores = out
+            sums["mpjpe"] += mpjpe_error(model.aggregate(poses, scores, "weighted_ave"), yb, "sum").item()
+            sums["ps_oracle_mpjpe"] += mpjpe_error(model.aggregate(poses, scores, "best_score"), yb, "sum").item()
+            sums["oracle_mpjpe"] += mpjpe_error(model.aggregate(poses, mode="oracle", ground_truth=yb)[1], yb, "sum").item()
+        else:
+            sums["mpjpe"] += mpjpe_error(out, yb, "sum").item()
+        n += yb.numel() // 3
+    return {k: 1000.0 * v / n for k, v in sums.items() if v > 0}
+
+
+def save_state(model, trainer, scheduler_state, epoch, folder, tag=None):
+    tag = f"_{tag}" if tag else ""
+    torch.save(model.state_dict(), os.path.join(folder, f"model{tag}.pth"))
+    torch.save({"optimizer": trainer.opt.state_dict(), "scheduler": scheduler_state, "epoch": epoch},
+               os.path.join(folder, f"params{tag}.pth"))
+
+
+def run(argv, extra_defaults=None):
+    from manipose_amd.distributed import broadcast_parameters, init_from_env
+    from manipose_amd.training import LiftingTrainer
+    cfg = load_config(argv, extra_defaults)
+    rank, world, local = init_from_env()
+    if not torch.cuda.is_available():
+        raise RuntimeError("the lifting entry points need an MI355X (ROCm device); there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(cfg.run.seed)
+    model = instantiate_model(cfg)
+    if cfg.run.checkpoint_model:
+        ck = torch.load(cfg.run.checkpoint_model, map_location="cpu")
+        model.load_state_dict(ck["model_pos"] if "model_pos" in ck else ck)
+    model.max_batch_hint = max(cfg.train.batch_size, cfg.train.batch_size_test)
+    model = model.to(dev)
+    trainer = LiftingTrainer(model, lr=cfg.train.lr, weight_decay=1e-6, w_loss=cfg.train.w_loss, vel_loss=cfg.train.vel_loss,
+                             smooth_reg=cfg.train.smooth_reg, rmcl_score_reg=cfg.train.rmcl_score_reg, seed=cfg.run.seed)
+    broadcast_parameters(model.flat_parameters())
+    start_epoch = 0
+    if cfg.run.checkpoint_params:
+        st = torch.load(cfg.run.checkpoint_params, map_location="cpu")
+        trainer.opt.load_state_dict(st["optimizer"])
+        start_epoch = st["epoch"]
+    if cfg.data.data_dir:
+        raise NotImplementedError("dataset loading (hpe/mh_so3_hpe/data of the reference) is outside this repository's scope; "
+                                  "leave data.data_dir empty to run on synthetic H36M-shaped windows")
+    T, B = cfg.data.seq_len, cfg.train.batch_size
+    out_dir = os.path.join(os.getcwd(), cfg.run.experiment)
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+    Xv, yv = synthetic_windows(4 * cfg.train.batch_size_test, T, dev, seed=10_000)
+    best_val, bad_epochs, lr = 1e10, 0, cfg.train.lr
+    if cfg.run.train:
+        for epoch in range(start_epoch, cfg.train.epochs):
+            model.train()
+            acc = torch.zeros(4, device=dev)
+            for it in range(cfg.train.steps_per_epoch):
+                X, y = synthetic_windows(B, T, dev, seed=cfg.run.seed + 7919 * (epoch * cfg.train.steps_per_epoch + it) + rank)
+                acc += trainer.train_step(X, y)                      # device-side accumulation: no per-step host sync
+            terms = (acc / cfg.train.steps_per_epoch).tolist()
+            if (epoch + 1) % cfg.train.valid_epoch_interval == 0:
+                model.eval()
+                val = sum(trainer.eval_loss(Xv[i:i + cfg.train.batch_size_test], yv[i:i + cfg.train.batch_size_test]).sum().item()
+                          for i in range(0, Xv.shape[0], cfg.train.batch_size_test))
+                if val < best_val * (1 - cfg.train.lr_threshold):     # ReduceLROnPlateau(mode=min, rel threshold)
+                    bad_epochs = 0
+                else:
+                    bad_epochs += 1
+                if val < best_val:
+                    best_val = val
+                    if rank == 0:
+                        save_state(model, trainer, {"best": best_val, "bad_epochs": bad_epochs}, epoch, out_dir, "best_val")
+                if cfg.train.lr_scheduler == "plateau" and bad_epochs > cfg.train.lr_patience:
+                    lr = max(lr * 0.5, cfg.train.lr_min)
+                    trainer.opt.param_groups[0]["lr"] = lr
+                    bad_epochs = 0
+            if rank == 0:
+                print(f"epoch {epoch}: tr_loss {sum(terms):.5f} wloss {terms[0]:.5f} score_reg {terms[1]:.5f} vloss {terms[2]:.5f} "
+                      f"sreg {terms[3]:.5f} | best val {best_val:.5f} lr {lr:.2e}", flush=True)
+            if (epoch + 1) % cfg.train.mpjpe_epoch_interval == 0 and rank == 0:
+                print("   eval:", {k: round(v, 3) for k, v in evaluate(model, Xv, yv, cfg.train.batch_size_test).items()}, flush=True)
+        if rank == 0:
+            save_state(model, trainer, {"best": best_val, "bad_epochs": bad_epochs}, cfg.train.epochs, out_dir, "end")
+    if cfg.run.test and rank == 0:
+        print("test:", {k: round(v, 3) for k, v in evaluate(model, Xv, yv, cfg.train.batch_size_test).items()}, flush=True)
+    return best_val
