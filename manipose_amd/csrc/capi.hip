@@ -82,11 +82,7 @@ int mp_linear_fwd(const float* x, const float* W, const float* b, float* y, floa
   g.A = x; g.lda = K; g.B = W; g.ldb = K; g.C = y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b; g.Z = z; g.R = r;
   return gemm_f32(0, 0, epilogue == 0 ? EPI_BIAS : (epilogue == 1 ? EPI_BIAS_GELU : EPI_BIAS_RESID), g, (hipStream_t)stream);
 }
-int64_t mp_linear_bwd_slab_floats(int N, int K) {
-  const int tiles = cdiv(N, 128) * cdiv(K, 128);
-  const int splits = max(1, min(64, (1024 + tiles - 1) / tiles));
-  return ((int64_t)N * K + N) * (splits + 1);
-}
+int64_t mp_linear_bwd_slab_floats(int N, int K) { return wgrad_f32_slab_floats(0, N, K) + (int64_t)N * K + N; }
 int mp_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, int M, int N, int K,
                   float* slab, int64_t slab_floats, void* stream) {
   MP_CHECK(dy && x && W && dW && slab, MP_ERR_ARG, "mp_linear_bwd: null pointer");

@@ -13,6 +13,7 @@
 //       read ds_read_b64_tr_b16 (two per fragment), so no transposed copies of activations or weights ever
 //       exist in HBM.
 // fp32 operands (the fp32 residual-gradient stream) are converted to bf16 while staging.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -201,6 +202,214 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmB16Args g) {
   }
 }
 
+// =================================================================================================================
+// All-bf16 operands: direct-to-LDS staging (global_load_lds_dwordx4, no VGPR / ds_write round trip), two LDS stages,
+// ONE barrier per k-tile; the DMA of tile t+1 overlaps the MFMAs of tile t.
+// The DMA writes LDS linearly (wave-uniform base + lane*16), so the bank-conflict swizzles are applied to each lane's
+// SOURCE address instead and undone by the fragment reads:
+//   "N" operand: 128-B rows [row][8 chunks]; LDS slot s of row r holds k-chunk  s ^ (r & 7)
+//   "T" operand: 256-B rows [red][16 chunks]; LDS slot s of row r holds out-chunk s ^ 2*((r&3) + 4*((r>>3)&1))
+// Both keep full 128/256-byte HBM lines per row (the XOR only permutes chunks inside a row) and make every ds_read_b128 /
+// ds_read_b64_tr_b16 of the fragment loads conflict-free.  Out-of-range chunks are sourced from a 16-byte zero page.
+// =================================================================================================================
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ int t_swz(int r) { return 2 * ((r & 3) + 4 * ((r >> 3) & 1)); }
+
+// ROWS = 128 or 256 output indices of this operand in the tile; every wave issues 4 DMA instructions (1 KiB each)
+template <int TR, int ROWS, int NWAVES>
+__device__ __forceinline__ void glds_tile(char* __restrict__ S, const bf16* __restrict__ P, long ld, int out0, int r0, int OUT, int r_end,
+                                          int lane, int wave) {
+  typedef __attribute__((address_space(3))) void* lptr;
+  typedef const __attribute__((address_space(1))) void* gptr;
+  constexpr int NINST = ROWS * 8 / 64 / NWAVES;      // == 4 for (128 rows, 4 waves) and (256 rows, 8 waves)
+  constexpr int CPR = ROWS / 8;                      // chunks per reduction row of a "T" image
+#pragma unroll
+  for (int n4 = 0; n4 < NINST; ++n4) {
+    const int n = wave * NINST + n4;                 // wave-uniform instruction index
+    const int c = 64 * n + lane;
+    const bf16* src;
+    bool ok;
+    if (TR == 0) {
+      const int row = c >> 3, kg = (c & 7) ^ (row & 7);
+      const int o = out0 + row, r = r0 + kg * 8;
+      ok = o < OUT && r < r_end;
+      src = P + (long)o * ld + r;
+    } else {
+      const int rr = c / CPR, oc = (c % CPR) ^ t_swz(rr);
+      const int r = r0 + rr, o = out0 + oc * 8;
+      ok = r < r_end && o < OUT;
+      src = P + (long)r * ld + o;
+    }
+    if (!ok) src = reinterpret_cast<const bf16*>(g_zero_page);
+    __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(S + n * 1024), 16, 0, 0);
+  }
+}
+
+template <int TR, int ROWS>
+__device__ __forceinline__ bf16x8_t read_frag2(const char* __restrict__ S, int ob, int ks, int lane) {
+  if (TR == 0) {
+    const int row = ob + (lane & 15), kg = ks * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8_t*>(S + row * 128 + ((kg ^ (row & 7)) << 4));
+  } else {
+    typedef bf16x4_t __attribute__((address_space(3))) * lds_ptr;
+    constexpr int ROWB = ROWS * 2;
+    const int li = lane & 15, q = li >> 2, p = li & 3;
+    const int r = ks * 32 + (lane >> 4) * 8 + q, col = ob + 4 * p;
+    const int oc = col >> 3, hf = (col >> 2) & 1, sw = t_swz(r);   // t_swz(r + 4) == t_swz(r) for q < 4
+    const char* a0 = S + r * ROWB + ((oc ^ sw) << 4) + hf * 8;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0 + 4 * ROWB));
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  }
+}
+
+// BT x BT output tile (BT = 128: 4 waves, 256: 8 waves); waves laid out 2 x (BT/64); each wave (BT/2) x 64.
+template <int TRA, int TRB, typename TC, int EPI, int BT>
+__global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = BT / 32, WN = BT / 64, MI = BT / 32, OPB = BT * 128, STAGE = 2 * OPB;
+  const bf16* A = reinterpret_cast<const bf16*>(g.A);
+  const bf16* B = reinterpret_cast<const bf16*>(g.B);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  int tm, tn;
+  {
+    const int nwg = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    tm = wg / gridDim.x;
+    tn = wg - tm * gridDim.x;
+  }
+  const int m0 = tm * BT, n0 = tn * BT;
+  const int kbeg = blockIdx.z * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+
+  f32x4 acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  glds_tile<TRA, BT, NW>(smem, A, g.lda, m0, kbeg, g.M, kend, lane, wave);
+  glds_tile<TRB, BT, NW>(smem + OPB, B, g.ldb, n0, kbeg, g.N, kend, lane, wave);
+  int stage = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += GBK, stage ^= 1) {
+    __syncthreads();   // (vmcnt(0) + barrier): tile k0 has landed for every wave; nobody still reads the other stage
+    const char* As = smem + stage * STAGE;
+    const char* Bs = As + OPB;
+    if (k0 + GBK < kend && !(g.debug & 2)) {
+      char* nx = smem + (stage ^ 1) * STAGE;
+      glds_tile<TRA, BT, NW>(nx, A, g.lda, m0, k0 + GBK, g.M, kend, lane, wave);
+      glds_tile<TRB, BT, NW>(nx + OPB, B, g.ldb, n0, k0 + GBK, g.N, kend, lane, wave);
+    }
+    if (g.debug & 1) continue;
+    if (EPI == EPI_SLAB && TRA == 1) {
+      if (tn == 0 && tid < BT) {
+        const int oc = tid >> 3, wi = tid & 7;
+        for (int r = 0; r < GBK; ++r)
+          bsum += __uint_as_float((unsigned)(*reinterpret_cast<const unsigned short*>(As + r * (BT * 2) + ((oc ^ t_swz(r)) << 4) + wi * 2)) << 16);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < GBK / 32; ++ks) {
+      bf16x8_t bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = read_frag2<TRB, BT>(Bs, wc * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const bf16x8_t af = read_frag2<TRA, BT>(As, wr * (BT / 2) + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[i][j], 0, 0, 0);   // C^T tile
+      }
+    }
+  }
+
+  if ((g.debug & 4) && acc[0][0][0] != 12345.678f) return;
+  // ---- epilogue through LDS: the accumulators (transposed-tile layout: lane = row, 4 consecutive columns per register
+  // group) are written to a wave-private 64 x 64 fp32 image (16-byte chunks XOR-swizzled by the row) and read back row-major,
+  // so bias / residual / pre-activation loads and the output stores are full 128/256-byte lines, 16 lanes per row. ----
+  TC* C = reinterpret_cast<TC*>(g.C);
+  if (EPI == EPI_SLAB) {
+    C += (long)blockIdx.z * g.M * g.ldc;
+    if (TRA == 1 && tn == 0 && tid < BT && m0 + tid < g.M && g.bias_slab != nullptr)
+      g.bias_slab[(long)blockIdx.z * g.M + m0 + tid] = bsum;
+  }
+  TC* Z = reinterpret_cast<TC*>(g.Z);
+  __syncthreads();                                   // every wave is done with the operand stages: reuse them
+  float* img = reinterpret_cast<float*>(smem + wave * 16384);
+  const int l15 = lane & 15, gq = lane >> 4;
+  const int col = n0 + wc * 64 + 4 * l15;            // read-back mapping: 16 lanes cover the 64 columns of a row
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (EPI != EPI_SLAB && EPI != EPI_DGELU && g.bias != nullptr && col < g.N) bias4 = ld4(g.bias + col);
+#pragma unroll
+  for (int hp = 0; hp < MI / 4; ++hp) {              // 64 rows of the wave tile per pass
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int lr = ii * 16 + l15;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ch = (4 * j + gq) ^ (lr & 15);
+        *reinterpret_cast<f32x4*>(img + lr * 64 + ch * 4) = acc[hp * 4 + ii][j];
+      }
+    }
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int lr = it * 4 + gq;
+      const int row = m0 + wr * (BT / 2) + hp * 64 + lr;
+      float4 v = *reinterpret_cast<const float4*>(img + lr * 64 + ((l15 ^ (lr & 15)) << 2));
+      if (row >= g.M || col >= g.N) continue;
+      const long o = (long)row * g.ldc + col;
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      if (EPI == EPI_BIAS_GELU) {
+        st4(Z + o, v);
+        v = make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
+      } else if (EPI == EPI_BIAS_RESID) {
+        const float dscale = droppath_scale(g.mask, g.mask_mode, row, g.T, g.J);
+        const float4 r = ld4(g.R + o);
+        v = make_float4(r.x + dscale * v.x, r.y + dscale * v.y, r.z + dscale * v.z, r.w + dscale * v.w);
+      } else if (EPI == EPI_DGELU) {
+        const float4 z = ld4(Z + o);
+        v = make_float4(v.x * gelu_grad_fast(z.x), v.y * gelu_grad_fast(z.y), v.z * gelu_grad_fast(z.z), v.w * gelu_grad_fast(z.w));
+      }
+      st4(C + o, v);
+    }
+  }
+}
+
+static bool g_force_small_tile = false;    // test hook: exercise the 128x128 instantiation on big shapes too
+void gemm_bf16_force_small_tile(bool on) { g_force_small_tile = on; }
+
+template <int TRA, int TRB, typename TC, int EPI, int BT>
+static int launch_glds_bt(const GemmB16Args& g, int splits, hipStream_t st) {
+  constexpr size_t lds = 2 * 2 * BT * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MP_HIP(hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<TRA, TRB, TC, EPI, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(g.N, BT), cdiv(g.M, BT), splits);
+  hipLaunchKernelGGL((gemm_bf16_glds_kernel<TRA, TRB, TC, EPI, BT>), grid, dim3(BT * 2), lds, st, g);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+// 256x256 tiles (1 workgroup of 8 waves per CU: 2x the MFMA work per byte moved through the CU's vector-memory path and
+// LDS) whenever the problem is wide enough; 128x128 tiles for the narrow bones-net layers.
+static bool use_big_tile(const GemmB16Args& g) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MANIPOSE_GEMM_TILE"); env = e ? atoi(e) : 0; }
+  if (env == 128 || g_force_small_tile) return false;
+  return g.M >= 256 && g.N >= 256 && g.N % 256 == 0;
+}
+template <int TRA, int TRB, typename TC, int EPI>
+static int launch_glds(const GemmB16Args& g, int splits, hipStream_t st) {
+  return use_big_tile(g) ? launch_glds_bt<TRA, TRB, TC, EPI, 256>(g, splits, st) : launch_glds_bt<TRA, TRB, TC, EPI, 128>(g, splits, st);
+}
+
 __global__ void reduce_slabs_b16_kernel(const float* __restrict__ slab, float* __restrict__ out, long n, int S) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -219,27 +428,29 @@ static int launch_b16(const GemmB16Args& g, int splits, hipStream_t st) {
 
 // C[M,N] = A(i,r) B(r,j): a_f32/c_f32 select fp32 instead of bf16 storage; a_tr/b_tr select the "T" layouts.
 int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, hipStream_t st) {
+  { const char* e = getenv("MANIPOSE_GEMM_DEBUG"); g.debug = e ? atoi(e) : 0; }   // timing ablations only (1 no MFMA, 2 no DMA, 4 no epilogue)
   MP_CHECK(g.M > 0 && g.N > 0 && g.K > 0, MP_ERR_ARG, "gemm_bf16: empty problem");
   MP_CHECK((a_tr ? g.M : g.K) % 8 == 0 && (b_tr ? g.N : g.K) % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.N % 4 == 0 &&
                g.ldc % 4 == 0, MP_ERR_ARG,
            "gemm_bf16: contiguous operand dimensions and leading dimensions must be multiples of 8 (M=%d N=%d K=%d)", g.M, g.N, g.K);
   g.k_per_split = ((g.K + GBK - 1) / GBK) * GBK;
-  if (!a_f32 && !a_tr && !b_tr && !c_f32 && epi == EPI_BIAS) return launch_b16<bf16, 0, bf16, 0, bf16, EPI_BIAS>(g, 1, st);
-  if (!a_f32 && !a_tr && !b_tr && c_f32 && epi == EPI_BIAS) return launch_b16<bf16, 0, bf16, 0, float, EPI_BIAS>(g, 1, st);
-  if (!a_f32 && !a_tr && !b_tr && c_f32 && epi == EPI_BIAS_RESID) return launch_b16<bf16, 0, bf16, 0, float, EPI_BIAS_RESID>(g, 1, st);
-  if (!a_f32 && !a_tr && !b_tr && !c_f32 && epi == EPI_BIAS_GELU) return launch_b16<bf16, 0, bf16, 0, bf16, EPI_BIAS_GELU>(g, 1, st);
+  if (!a_f32 && !a_tr && !b_tr && !c_f32 && epi == EPI_BIAS) return launch_glds<0, 0, bf16, EPI_BIAS>(g, 1, st);
+  if (!a_f32 && !a_tr && !b_tr && c_f32 && epi == EPI_BIAS) return launch_glds<0, 0, float, EPI_BIAS>(g, 1, st);
+  if (!a_f32 && !a_tr && !b_tr && c_f32 && epi == EPI_BIAS_RESID) return launch_glds<0, 0, float, EPI_BIAS_RESID>(g, 1, st);
+  if (!a_f32 && !a_tr && !b_tr && !c_f32 && epi == EPI_BIAS_GELU) return launch_glds<0, 0, bf16, EPI_BIAS_GELU>(g, 1, st);
   if (a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_DGELU) return launch_b16<float, 0, bf16, 1, bf16, EPI_DGELU>(g, 1, st);
-  if (!a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_DGELU) return launch_b16<bf16, 0, bf16, 1, bf16, EPI_DGELU>(g, 1, st);
-  if (!a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_BIAS) return launch_b16<bf16, 0, bf16, 1, bf16, EPI_BIAS>(g, 1, st);
+  if (!a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_DGELU) return launch_glds<0, 1, bf16, EPI_DGELU>(g, 1, st);
+  if (!a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_BIAS) return launch_glds<0, 1, bf16, EPI_BIAS>(g, 1, st);
   if (a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_BIAS) return launch_b16<float, 0, bf16, 1, bf16, EPI_BIAS>(g, 1, st);
-  if (!a_f32 && !a_tr && b_tr && c_f32 && epi == EPI_BIAS) return launch_b16<bf16, 0, bf16, 1, float, EPI_BIAS>(g, 1, st);
+  if (!a_f32 && !a_tr && b_tr && c_f32 && epi == EPI_BIAS) return launch_glds<0, 1, float, EPI_BIAS>(g, 1, st);
   if (a_f32 && !a_tr && b_tr && c_f32 && epi == EPI_BIAS) return launch_b16<float, 0, bf16, 1, float, EPI_BIAS>(g, 1, st);
   MP_CHECK(false, MP_ERR_ARG, "gemm_bf16: unsupported variant a_f32=%d a_tr=%d b_tr=%d c_f32=%d epi=%d", a_f32, a_tr, b_tr, c_f32, epi);
 }
 
-static void wgrad_split_b16(int Mtok, int Nout, int Kin, int& splits, int& kper) {
-  const int tiles = cdiv(Nout, GBM) * cdiv(Kin, GBN);
-  splits = max(1, min(64, (1024 + tiles - 1) / tiles));
+static void wgrad_split_b16(int Mtok, int Nout, int Kin, int bt, int& splits, int& kper) {
+  const int tiles = cdiv(Nout, bt) * cdiv(Kin, bt);
+  const int target = (bt == 256) ? 512 : 1024;            // workgroups in flight: 2 (256^2) / 4 (128^2) per CU
+  splits = max(1, min(64, (target + tiles - 1) / tiles));
   kper = ((cdiv(Mtok, splits) + GBK - 1) / GBK) * GBK;
   splits = cdiv(Mtok, kper);
 }
@@ -248,18 +459,18 @@ static void wgrad_split_b16(int Mtok, int Nout, int Kin, int& splits, int& kper)
 int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
                float* slab, long slab_floats, hipStream_t st) {
   MP_CHECK(Mtok > 0 && Nout % 8 == 0 && Kin % 8 == 0, MP_ERR_ARG, "wgrad_bf16: bad dims %d %d %d", Mtok, Nout, Kin);
-  int splits, kper;
-  wgrad_split_b16(Mtok, Nout, Kin, splits, kper);
-  const long per = (long)Nout * Kin + Nout;
-  MP_CHECK(slab_floats >= per * splits, MP_ERR_ARG, "wgrad_bf16: slab too small (%ld < %ld)", slab_floats, per * splits);
   GemmB16Args g = {};
   g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx;
   g.M = Nout; g.N = Kin; g.K = Mtok;
+  int splits, kper;
+  wgrad_split_b16(Mtok, Nout, Kin, (!dy_f32 && use_big_tile(g)) ? 256 : 128, splits, kper);
+  const long per = (long)Nout * Kin + Nout;
+  MP_CHECK(slab_floats >= per * splits, MP_ERR_ARG, "wgrad_bf16: slab too small (%ld < %ld)", slab_floats, per * splits);
   g.C = slab; g.ldc = Kin;
   g.bias_slab = (db != nullptr) ? slab + (long)splits * Nout * Kin : nullptr;
   g.k_per_split = kper;
   int rc = dy_f32 ? launch_b16<float, 1, bf16, 1, float, EPI_SLAB>(g, splits, st)
-                  : launch_b16<bf16, 1, bf16, 1, float, EPI_SLAB>(g, splits, st);
+                  : launch_glds<1, 1, float, EPI_SLAB>(g, splits, st);
   if (rc) return rc;
   const long n = (long)Nout * Kin;
   hipLaunchKernelGGL(reduce_slabs_b16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, slab, dW, n, splits);

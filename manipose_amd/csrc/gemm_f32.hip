@@ -189,8 +189,10 @@ static void wgrad_split(int Mtok, int Nout, int Kin, int& splits, int& kper) {
 }
 long wgrad_f32_slab_floats(int Mtok, int Nout, int Kin) {
   (void)Mtok;   // upper bound over every token count: the split count never exceeds the tile-derived target
-  const int tiles = cdiv(Nout, BM) * cdiv(Kin, BN);
-  return ((long)Nout * Kin + Nout) * max(1, min(64, (1024 + tiles - 1) / tiles));
+  const int tiles = cdiv(Nout, BM) * cdiv(Kin, BN);                  // 128x128 tiles (fp32 and narrow bf16 layers)
+  const int tiles256 = cdiv(Nout, 256) * cdiv(Kin, 256);             // 256x256 tiles of the bf16 direct-to-LDS kernel
+  const int s128 = max(1, min(64, (1024 + tiles - 1) / tiles)), s256 = max(1, min(64, (512 + tiles256 - 1) / tiles256));
+  return ((long)Nout * Kin + Nout) * max(s128, s256);
 }
 
 // dW[N',K'] += dY[Mtok,N']^T X[Mtok,K'] ; db[N'] += colsum(dY).  slab: >= splits*(N'*K' + N') floats.
