@@ -200,13 +200,20 @@ static int spatial_bwd_t(const TS* qkv, const TS* dout, TS* dqkv, int B, int T, 
   return MP_OK;
 }
 
+bool attn_smfma_supported(int N, int D, int H);
+int attn_smfma_fwd(const bf16* qkv, bf16* out, int B, int T, int J, int C, int H, hipStream_t st);
+int attn_smfma_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, int B, int T, int J, int C, int H, hipStream_t st);
+
 int attn_spatial_fwd(const void* qkv, void* out, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st) {
   MP_CHECK(C % H == 0 && (C / H) % 4 == 0 && J <= 32, MP_ERR_ARG, "attn_spatial_fwd: C=%d H=%d J=%d unsupported", C, H, J);
+  if (is_bf16 && attn_smfma_supported(J, C / H, H)) return attn_smfma_fwd((const bf16*)qkv, (bf16*)out, B, T, J, C, H, st);
   return is_bf16 ? spatial_fwd_t<bf16>((const bf16*)qkv, (bf16*)out, B, T, J, C, H, st)
                  : spatial_fwd_t<float>((const float*)qkv, (float*)out, B, T, J, C, H, st);
 }
 int attn_spatial_bwd(const void* qkv, const void* dout, void* dqkv, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st) {
   MP_CHECK(C % H == 0 && (C / H) % 4 == 0 && J <= 32, MP_ERR_ARG, "attn_spatial_bwd: C=%d H=%d J=%d unsupported", C, H, J);
+  if (is_bf16 && attn_smfma_supported(J, C / H, H))
+    return attn_smfma_bwd((const bf16*)qkv, (const bf16*)dout, (bf16*)dqkv, B, T, J, C, H, st);
   return is_bf16 ? spatial_bwd_t<bf16>((const bf16*)qkv, (const bf16*)dout, (bf16*)dqkv, B, T, J, C, H, st)
                  : spatial_bwd_t<float>((const float*)qkv, (const float*)dout, (float*)dqkv, B, T, J, C, H, st);
 }

@@ -302,6 +302,266 @@ __global__ __launch_bounds__(512) void attn_tmfma_bwd_kernel(const bf16* __restr
   }
 }
 
+// =============================================================================================
+// spatial attention on the matrix cores: the N = 17 joints (16 bones) of ONE frame attend to each other.
+// One workgroup per frame, one wave per head: the frame's whole fused qkv block (N x 3C bf16, contiguous in HBM: 52 KB
+// at C = 512) is staged into LDS in one coalesced sweep, each wave then works on its head's 64-wide (16-wide) slices.
+// N is padded to 32 inside the MFMA tiles by CLAMPING the token index of the padding lanes (finite duplicate data, their
+// probabilities are masked to exactly 0), so no zero rows are stored.
+// =============================================================================================
+template <int D>
+__device__ __forceinline__ bf16x8_t frag_tok(const char* __restrict__ S, int pitch, int off, int tok0, int ks, int lane, int N) {
+  const int g = lane >> 4, d0 = 32 * ks + 8 * g;
+  bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (D < 32 && d0 >= D) return z;
+  const int tok = min(tok0 + (lane & 15), N - 1);
+  return *reinterpret_cast<const bf16x8_t*>(S + tok * pitch + off + d0 * 2);
+}
+// A operand [d = 16 db + (lane & 15)][kappa] over the 32 (padded) tokens, kappa permuted like pack_acc's rows
+template <int D>
+__device__ __forceinline__ bf16x8_t frag_tokT(const char* __restrict__ S, int pitch, int off, int db, int lane, int N) {
+  typedef bf16x4_t __attribute__((address_space(3))) * lds_ptr;
+  const int li = lane & 15, q = li >> 2, p = li & 3, g = lane >> 4;
+  const int r1 = min(4 * g + q, N - 1), r2 = min(16 + 4 * g + q, N - 1);
+  const int cb = off + (16 * db + 4 * p) * 2;
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(S + r1 * pitch + cb));
+  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(S + r2 * pitch + cb));
+  bf16x8_t f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+__device__ __forceinline__ void stage_block(char* __restrict__ S, int pitch, const bf16* __restrict__ src, int rows, int row_bytes,
+                                            int tid, int nthreads) {
+  const int cpr = row_bytes >> 4;
+  for (int c = tid; c < rows * cpr; c += nthreads) {
+    const int r = c / cpr, k = c - r * cpr;
+    *reinterpret_cast<uint4*>(S + r * pitch + k * 16) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src) + (long)r * row_bytes + k * 16);
+  }
+}
+
+// softmax over the (<= 32) keys of this lane's query column; s0/s1: accumulator tiles of keys 0..15 / 16..31 (raw q.k)
+__device__ __forceinline__ void col_softmax(f32x4& s0, f32x4& s1, int g, int N, float scale) {
+  float mx = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    s0[r] = (4 * g + r < N) ? s0[r] * scale : -INFINITY;
+    s1[r] = (16 + 4 * g + r < N) ? s1[r] * scale : -INFINITY;
+    mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+  }
+  mx = group_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    s0[r] = __expf(s0[r] - mx);
+    s1[r] = __expf(s1[r] - mx);
+    sum += s0[r] + s1[r];
+  }
+  const float inv = 1.0f / group_sum(sum);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { s0[r] *= inv; s1[r] *= inv; }
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void attn_smfma_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int N, int C, int H,
+                                                               float scale) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int KS = ACfg<D>::KS, DB = ACfg<D>::DB;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int pitch = 6 * C + 16;
+  stage_block(sm, pitch, qkv + (long)f * N * 3 * C, N, 6 * C, tid, blockDim.x);
+  __syncthreads();
+  const int oq = h * D * 2, ok = 2 * C + oq, ov = 4 * C + oq;
+  bf16x8_t qf[2][KS], kf[2][KS];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[t][ks] = frag_tok<D>(sm, pitch, oq, 16 * t, ks, lane, N);
+      kf[t][ks] = frag_tok<D>(sm, pitch, ok, 16 * t, ks, lane, N);
+    }
+  bf16x8_t vT[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db) vT[db] = frag_tokT<D>(sm, pitch, ov, db, lane, N);
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    if (qt * 16 >= N) break;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};      // S^T[key][query]: keys 0..15 / 16..31
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0][ks], qf[qt][ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1][ks], qf[qt][ks], s1, 0, 0, 0);
+    }
+    col_softmax(s0, s1, g, N, scale);
+    const bf16x8_t bp = pack_acc(s0, s1);
+    const int tq = qt * 16 + l15;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT[db], bp, o, 0, 0, 0);
+      if (tq < N) store4(out + ((long)f * N + tq) * C + h * D + 16 * db + 4 * g, o, 1.0f);
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void attn_smfma_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                               bf16* __restrict__ dqkv, int N, int C, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int KS = ACfg<D>::KS, DB = ACfg<D>::DB;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int pitch = 6 * C + 16, gpitch = 2 * C + 16;
+  char* gs = sm + N * pitch;                               // dO block of the frame
+  stage_block(sm, pitch, qkv + (long)f * N * 3 * C, N, 6 * C, tid, blockDim.x);
+  stage_block(gs, gpitch, dout + (long)f * N * C, N, 2 * C, tid, blockDim.x);
+  __syncthreads();
+  const int oq = h * D * 2, ok = 2 * C + oq, ov = 4 * C + oq, og = oq;
+  bf16x8_t qf[2][KS], kf[2][KS], vf[2][KS], gf[2][KS];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[t][ks] = frag_tok<D>(sm, pitch, oq, 16 * t, ks, lane, N);
+      kf[t][ks] = frag_tok<D>(sm, pitch, ok, 16 * t, ks, lane, N);
+      vf[t][ks] = frag_tok<D>(sm, pitch, ov, 16 * t, ks, lane, N);
+      gf[t][ks] = frag_tok<D>(gs, gpitch, og, 16 * t, ks, lane, N);
+    }
+  bf16* dbase = dqkv + (long)f * N * 3 * C + h * D;
+  // ---- pass A ([key][query] orientation): softmax statistics per query column, dQ ----
+  float mq[2], lq[2], dlq[2];                              // per query column (tile qt, lane & 15): max, 1/sum handled inside
+  f32x4 pA[2][2];                                          // normalised P^T tiles [qt][kt]
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0][ks], qf[qt][ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1][ks], qf[qt][ks], s1, 0, 0, 0);
+      d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0][ks], gf[qt][ks], d0, 0, 0, 0);   // dP^T[key][query]
+      d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[1][ks], gf[qt][ks], d1, 0, 0, 0);
+    }
+    // raw maxima / sums are needed again in pass B: recompute them there from the same scores via these two numbers
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s0[r] = (4 * g + r < N) ? s0[r] * scale : -INFINITY;
+      s1[r] = (16 + 4 * g + r < N) ? s1[r] * scale : -INFINITY;
+      mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+    }
+    mx = group_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s0[r] = __expf(s0[r] - mx);
+      s1[r] = __expf(s1[r] - mx);
+      sum += s0[r] + s1[r];
+    }
+    sum = group_sum(sum);
+    const float inv = 1.0f / sum;
+    float dl = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s0[r] *= inv; s1[r] *= inv;
+      dl += s0[r] * d0[r] + s1[r] * d1[r];
+    }
+    dl = group_sum(dl);
+    mq[qt] = mx; lq[qt] = inv; dlq[qt] = dl;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d0[r] = s0[r] * (d0[r] - dl);                        // dS^T
+      d1[r] = s1[r] * (d1[r] - dl);
+    }
+    pA[qt][0] = s0; pA[qt][1] = s1;
+    const bf16x8_t bds = pack_acc(d0, d1);
+    const int tq = qt * 16 + l15;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+      dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokT<D>(sm, pitch, ok, db, lane, N), bds, dq, 0, 0, 0);
+      if (tq < N) store4(dbase + (long)tq * 3 * C + 16 * db + 4 * g, dq, scale);
+    }
+  }
+  // ---- pass B ([query][key] orientation): dK, dV.  Row statistics come from pass A's column statistics by shuffle ----
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    if (kt * 16 >= N) break;
+    f32x4 p2[2], ds2[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt][ks], kf[kt][ks], sa, 0, 0, 0);   // S[query][key]
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[qt][ks], vf[kt][ks], dp, 0, 0, 0);   // dP[query][key]
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int src = 4 * g + r;                          // lane holding query (qt, 4g + r)'s column statistics
+        const float m = __shfl(mq[qt], src, 64), il = __shfl(lq[qt], src, 64), dl = __shfl(dlq[qt], src, 64);
+        const bool ok2 = (qt * 16 + 4 * g + r < N) && (kt * 16 + l15 < N);
+        const float p = ok2 ? __expf(sa[r] * scale - m) * il : 0.f;
+        p2[qt][r] = p;
+        ds2[qt][r] = p * (dp[r] - dl);
+      }
+    }
+    const bf16x8_t bp = pack_acc(p2[0], p2[1]), bds = pack_acc(ds2[0], ds2[1]);
+    const int tk = kt * 16 + l15;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dk = {0.f, 0.f, 0.f, 0.f};
+      dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokT<D>(gs, gpitch, og, db, lane, N), bp, dv, 0, 0, 0);
+      dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokT<D>(sm, pitch, oq, db, lane, N), bds, dk, 0, 0, 0);
+      if (tk < N) {
+        store4(dbase + C + (long)tk * 3 * C + 16 * db + 4 * g, dk, scale);
+        store4(dbase + 2 * C + (long)tk * 3 * C + 16 * db + 4 * g, dv, 1.0f);
+      }
+    }
+  }
+  (void)pA;
+}
+
+bool attn_smfma_supported(int N, int D, int H) { return N >= 16 && N <= 32 && (D == 64 || D == 16) && H >= 1 && H <= 8; }
+
+int attn_smfma_fwd(const bf16* qkv, bf16* out, int B, int T, int J, int C, int H, hipStream_t st) {
+  const int D = C / H;
+  MP_CHECK(attn_smfma_supported(J, D, H) && C % 8 == 0, MP_ERR_ARG, "attn_smfma_fwd: J=%d D=%d H=%d unsupported", J, D, H);
+  const float scale = 1.0f / sqrtf((float)D);
+  const size_t lds = (size_t)J * (6 * C + 16);
+  if (D == 64) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      MP_HIP(hipFuncSetAttribute((const void*)attn_smfma_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_smfma_fwd_kernel<64>, dim3(B * T), dim3(H * 64), lds, st, qkv, out, J, C, H, scale);
+  } else {
+    hipLaunchKernelGGL(attn_smfma_fwd_kernel<16>, dim3(B * T), dim3(H * 64), lds, st, qkv, out, J, C, H, scale);
+  }
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+int attn_smfma_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, int B, int T, int J, int C, int H, hipStream_t st) {
+  const int D = C / H;
+  MP_CHECK(attn_smfma_supported(J, D, H) && C % 8 == 0, MP_ERR_ARG, "attn_smfma_bwd: J=%d D=%d H=%d unsupported", J, D, H);
+  const float scale = 1.0f / sqrtf((float)D);
+  const size_t lds = (size_t)J * (6 * C + 16) + (size_t)J * (2 * C + 16);
+  if (D == 64) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      MP_HIP(hipFuncSetAttribute((const void*)attn_smfma_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_smfma_bwd_kernel<64>, dim3(B * T), dim3(H * 64), lds, st, qkv, dout, dqkv, J, C, H, scale);
+  } else {
+    hipLaunchKernelGGL(attn_smfma_bwd_kernel<16>, dim3(B * T), dim3(H * 64), lds, st, qkv, dout, dqkv, J, C, H, scale);
+  }
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
 bool attn_tmfma_supported(int T, int D) { return T <= TP && (D == 64 || D == 16); }
 
 int attn_tmfma_fwd(const bf16* qkv, bf16* out, float* lse, int B, int T, int J, int C, int H, hipStream_t st) {

@@ -130,6 +130,7 @@ constexpr int LNB_GRID = 512;
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
                                                       const float* dskip, float* dx, bf16* __restrict__ dx_b16,
+                                                      const float* __restrict__ mask, int mask_mode, int T, int J,
                                                       float* __restrict__ partial, int M, int C) {
   __shared__ float red[4 * 2 * 1024];  // [wave][dgamma|dbeta][C<=1024]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
     s1 = wave_sum(s1) / (float)C;
     s2 = wave_sum(s2) / (float)C;
+    const float ms = (dx_b16 != nullptr) ? droppath_scale(mask, mask_mode, __builtin_amdgcn_readfirstlane(m), T, J) : 1.0f;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = lane * 4 + 256 * i;
@@ -177,7 +179,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
           o.x += k.x; o.y += k.y; o.z += k.z; o.w += k.w;
         }
         st4(dx + (long)m * C + c, o);
-        if (dx_b16 != nullptr) st4(dx_b16 + (long)m * C + c, o);   // bf16 copy: A operand of the next dgrad/wgrad GEMMs
+        if (dx_b16 != nullptr)     // bf16 copy, pre-scaled by the consumer branch's DropPath mask: A operand of its GEMMs
+          st4(dx_b16 + (long)m * C + c, make_float4(o.x * ms, o.y * ms, o.z * ms, o.w * ms));
       }
     }
   }
@@ -231,11 +234,13 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 int ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
-           float* dgamma, float* dbeta, int M, int C, float* scratch, long scratch_floats, hipStream_t st) {
+           const float* mask, int mask_mode, int T, int J, float* dgamma, float* dbeta, int M, int C, float* scratch,
+           long scratch_floats, hipStream_t st) {
   MP_CHECK(C % 4 == 0 && C <= 1024, MP_ERR_ARG, "ln_bwd: C=%d unsupported", C);
   const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
   MP_CHECK(scratch_floats >= (long)grid * 2 * C, MP_ERR_ARG, "ln_bwd: scratch too small");
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, st, dy, x, stats, gamma, dskip, dx, (bf16*)dx_b16, scratch, M, C);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, st, dy, x, stats, gamma, dskip, dx, (bf16*)dx_b16, mask,
+                     mask ? mask_mode : 0, T, J, scratch, M, C);
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dgamma, dbeta, nullptr, nullptr}, {0, C, 2 * C, 2 * C, 2 * C}, {1, 1, 1, 1}};
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, scratch, grid, 2 * C, d);

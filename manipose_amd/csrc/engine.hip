@@ -353,14 +353,15 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
     const int mode = spatial ? 1 : 2;
     // (a) shared post-norm (+ Temporal_pos_embed gradient behind block 0)
     if (l == 0) RUN(PC_OTHER, 0, tpos_grad(g, G(m, fg, md.tpos), B, T, N, C, st));
-    RUN(PC_LN, 0, ln_bwd(g, w.x_out, w.stp, P(m, fp, spatial ? md.sn_w : md.tn_w), nullptr, g, m->g_b16,
+    // (b)'s branch gradient gb = DropPath-scaled g: in precision 1 the LN backward emits it directly as a bf16 copy
+    const float* mk2 = branch_mask(m, md, l, 1, B, m->train);
+    RUN(PC_LN, 0, ln_bwd(g, w.x_out, w.stp, P(m, fp, spatial ? md.sn_w : md.tn_w), nullptr, g, m->g_b16, mk2, mode, T, N,
                          G(m, fg, spatial ? md.sn_w : md.tn_w), G(m, fg, spatial ? md.sn_b : md.tn_b), (int)M, C, m->small,
                          m->small_floats, st));
-    // (b) mlp branch: fc2.  gb = branch gradient (DropPath-scaled), bf16 copy in precision 1
-    const float* mk2 = branch_mask(m, md, l, 1, B, m->train);
+    // (b) mlp branch: fc2
     const void* gb = half ? (const void*)m->g_b16 : (const void*)g;
-    if (mk2) {
-      RUN(PC_OTHER, 0, scale_rows(g, mk2, mode, m->tmpMask, half, (int)M, C, T, N, st));
+    if (mk2 && !half) {
+      RUN(PC_OTHER, 0, scale_rows(g, mk2, mode, m->tmpMask, 0, (int)M, C, T, N, st));
       gb = m->tmpMask;
     }
     int rc = linear_wgrad(m, st, gb, 0, w.f, G(m, fg, q.f2w), G(m, fg, q.f2b), M, C, 2 * C);
@@ -373,13 +374,13 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
     rc = linear_dgrad(m, st, fp, m->tmp2C, 0, q.f1w, m->tmpC, 1, M, 2 * C, C, nullptr);
     if (rc) return rc;
     // (d) norm2 + skip
-    RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, m->g_b16, G(m, fg, q.n2w), G(m, fg, q.n2b), (int)M, C,
-                         m->small, m->small_floats, st));
-    // (e) attention branch: proj
     const float* mk1 = branch_mask(m, md, l, 0, B, m->train);
+    RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, m->g_b16, mk1, mode, T, N, G(m, fg, q.n2w), G(m, fg, q.n2b),
+                         (int)M, C, m->small, m->small_floats, st));
+    // (e) attention branch: proj
     gb = half ? (const void*)m->g_b16 : (const void*)g;
-    if (mk1) {
-      RUN(PC_OTHER, 0, scale_rows(g, mk1, mode, m->tmpMask, half, (int)M, C, T, N, st));
+    if (mk1 && !half) {
+      RUN(PC_OTHER, 0, scale_rows(g, mk1, mode, m->tmpMask, 0, (int)M, C, T, N, st));
       gb = m->tmpMask;
     }
     rc = linear_wgrad(m, st, gb, 0, w.ao, G(m, fg, q.pw), G(m, fg, q.pb), M, C, C);
@@ -395,8 +396,8 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
     rc = linear_dgrad(m, st, fp, m->tmp3C, 0, q.qkvw, m->tmpC, 1, M, 3 * C, C, nullptr);
     if (rc) return rc;
     // (h) norm1 + skip
-    RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_in, w.st1, P(m, fp, q.n1w), g, g, nullptr, G(m, fg, q.n1w), G(m, fg, q.n1b), (int)M, C,
-                         m->small, m->small_floats, st));
+    RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_in, w.st1, P(m, fp, q.n1w), g, g, nullptr, nullptr, 0, T, N, G(m, fg, q.n1w), G(m, fg, q.n1b),
+                         (int)M, C, m->small, m->small_floats, st));
   }
   return MP_OK;
 }

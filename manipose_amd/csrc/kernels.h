@@ -61,7 +61,8 @@ struct LnFwdArgs {
 int ln_fwd(const LnFwdArgs& a, int out_bf16, hipStream_t st);
 // dx = [dskip +] LN'(dy); partial param grads are reduced and ADDED into dgamma/dbeta.
 int ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
-           float* dgamma, float* dbeta, int M, int C, float* scratch, long scratch_floats, hipStream_t st);
+           const float* mask, int mask_mode, int T, int J, float* dgamma, float* dbeta, int M, int C, float* scratch,
+           long scratch_floats, hipStream_t st);
 
 int embed_fwd(const float* xin, const float* W, const float* b, const float* spos, float* out, int M, int C, int J,
               hipStream_t st);

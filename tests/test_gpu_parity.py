@@ -448,7 +448,8 @@ def test_bf16_precision_model_drift_vs_reference(lib, name):
 
 @pytest.mark.parametrize("temporal,B,T,J,C,H", [(1, 2, 243, 3, 128, 2), (1, 1, 81, 17, 512, 8), (1, 2, 27, 16, 128, 8),
                                                 (1, 1, 256, 2, 64, 1), (1, 1, 17, 2, 32, 2), (1, 1, 300, 2, 128, 2),
-                                                (0, 1, 9, 17, 128, 2)])
+                                                (0, 1, 9, 17, 128, 2), (0, 2, 5, 17, 512, 8), (0, 1, 7, 16, 128, 8),
+                                                (0, 1, 3, 17, 64, 4)])
 def test_bf16_attention_forward_backward(lib, temporal, B, T, J, C, H):
     """bf16-storage attention (temporal: MFMA kernels for T <= 256 and head dim 64/16, VALU kernels otherwise) against the
     fp32 formula evaluated on the same bf16-rounded q/k/v and dO."""
@@ -506,3 +507,25 @@ def test_bf16_full_size_model_drift_vs_oracle(lib):
     seg = (poses[..., 1:, :] - poses[..., par, :]).norm(dim=-1)       # the manifold property is exact in any precision
     lens = model._engine.peek(1).view(1, 1, 1, 16).abs()
     close(seg, lens.expand_as(seg), rtol=1e-4, atol=2e-6)
+
+
+def test_bf16_droppath_train_mode_with_injected_masks(lib):
+    """Train-mode DropPath in the bf16 precision (mask scaling folded into GEMM epilogues and the LN-backward bf16 copy)."""
+    from manipose_amd.metrics import mpjpe_error, rmcl_training_loss
+    fx = load_fixture("rmcl_tiny_droppath")
+    model = _build(fx, drop_path_rate=float(fx["drop_path_rate"]))
+    model.precision = "bf16"
+    model = model.train()
+    model.set_droppath_masks({k: v.cuda() for k, v in fixture_masks(fx).items()})
+    poses, scores = model(dev(fx["X"]))
+    # keep = 0.5 doubles the surviving branches, so this fixture's poses (joints up to 1.3 m from the root) amplify the bf16
+    # rounding noise: bound the drift relative to the mean joint distance instead of in absolute millimetres
+    ref = dev(fx["poses"])
+    rel = mpjpe_error(poses, ref, "average").item() / ref.norm(dim=-1).mean().item()
+    assert rel <= 0.03, rel
+    total, _ = rmcl_training_loss(poses, scores, dev(fx["y"]))
+    assert abs(total.item() - float(fx["loss_total"])) <= 2e-2 * abs(float(fx["loss_total"]))
+    total.backward()
+    cs = {k: _cos(p.grad.cpu(), torch.from_numpy(fx["g::" + k])) for k, p in model.named_parameters()}
+    worst = min(cs.items(), key=lambda kv: kv[1])
+    assert worst[1] > 0.98, worst
