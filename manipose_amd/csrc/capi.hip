@@ -69,7 +69,7 @@ int mp_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
 int mp_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx,
                      float* dgamma, float* dbeta, int M, int C, float* scratch, int64_t scratch_floats, void* stream) {
   MP_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta && scratch, MP_ERR_ARG, "mp_layernorm_bwd: null pointer");
-  return ln_bwd(dy, x, stats, gamma, dskip, dx, nullptr, nullptr, 0, 1, 1, dgamma, dbeta, M, C, scratch, scratch_floats, (hipStream_t)stream);
+  return ln_bwd(dy, 0, x, stats, gamma, dskip, dx, nullptr, nullptr, 0, 1, 1, dgamma, dbeta, M, C, scratch, scratch_floats, (hipStream_t)stream);
 }
 
 int mp_linear_fwd(const float* x, const float* W, const float* b, float* y, float* z, const float* r, int M, int N, int K,

@@ -127,7 +127,8 @@ int ln_fwd(const LnFwdArgs& a, int out_bf16, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 constexpr int LNB_GRID = 512;
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename TDY>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
                                                       const float* dskip, float* dx, bf16* __restrict__ dx_b16,
                                                       const float* __restrict__ mask, int mask_mode, int T, int J,
@@ -233,17 +234,138 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
-int ln_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
+int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
            const float* mask, int mask_mode, int T, int J, float* dgamma, float* dbeta, int M, int C, float* scratch,
            long scratch_floats, hipStream_t st) {
   MP_CHECK(C % 4 == 0 && C <= 1024, MP_ERR_ARG, "ln_bwd: C=%d unsupported", C);
   const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
   MP_CHECK(scratch_floats >= (long)grid * 2 * C, MP_ERR_ARG, "ln_bwd: scratch too small");
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, st, dy, x, stats, gamma, dskip, dx, (bf16*)dx_b16, mask,
-                     mask ? mask_mode : 0, T, J, scratch, M, C);
+  if (dy_bf16)
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dy, x, stats, gamma, dskip, dx, (bf16*)dx_b16, mask,
+                       mask ? mask_mode : 0, T, J, scratch, M, C);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, x, stats, gamma, dskip, dx, (bf16*)dx_b16,
+                       mask, mask ? mask_mode : 0, T, J, scratch, M, C);
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dgamma, dbeta, nullptr, nullptr}, {0, C, 2 * C, 2 * C, 2 * C}, {1, 1, 1, 1}};
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, scratch, grid, 2 * C, d);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// Fused pair of LayerNorm backwards across a block boundary (precision-independent, C <= 512):
+//   t  = dskip + LN1'(dy1; x1, stats1, gamma1)        (norm1 of block l+1, plus the residual skip gradient)
+//   dx = LN0'(t; x0, stats0, gamma0)                  (shared post-norm behind block l)
+// saving one fp32 write + read of the gradient stream per block.  Partials: [dgamma1 | dbeta1 | dgamma0 | dbeta0].
+template <typename TDY>
+__global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy1, const float* __restrict__ x1,
+                                                       const float* __restrict__ stats1, const float* __restrict__ gamma1,
+                                                       const float* dskip, const float* __restrict__ x0,
+                                                       const float* __restrict__ stats0, const float* __restrict__ gamma0, float* dx,
+                                                       bf16* __restrict__ dx_b16, const float* __restrict__ mask, int mask_mode, int T,
+                                                       int J, float* __restrict__ partial, int M, int C) {
+  constexpr int V = 2;
+  __shared__ float red[4 * 4 * 512];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  float4 acc[4][V], g1[V], g0[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = lane * 4 + 256 * i;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    g1[i] = (c < C) ? ld4(gamma1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    g0[i] = (c < C) ? ld4(gamma0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int m = wave; m < M; m += nwaves) {
+    float4 xh[V], d[V], t[V];
+    float s1 = 0.f, s2 = 0.f;
+    const float mean1 = stats1[2 * (long)m], rstd1 = stats1[2 * (long)m + 1];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = lane * 4 + 256 * i;
+      xh[i] = d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C) {
+        const float4 xv = ld4(x1 + (long)m * C + c), g = ld4(dy1 + (long)m * C + c);
+        xh[i] = make_float4((xv.x - mean1) * rstd1, (xv.y - mean1) * rstd1, (xv.z - mean1) * rstd1, (xv.w - mean1) * rstd1);
+        acc[0][i].x += g.x * xh[i].x; acc[0][i].y += g.y * xh[i].y; acc[0][i].z += g.z * xh[i].z; acc[0][i].w += g.w * xh[i].w;
+        acc[1][i].x += g.x; acc[1][i].y += g.y; acc[1][i].z += g.z; acc[1][i].w += g.w;
+        d[i] = make_float4(g.x * g1[i].x, g.y * g1[i].y, g.z * g1[i].z, g.w * g1[i].w);
+        s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+        s2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+    const float mean0 = stats0[2 * (long)m], rstd0 = stats0[2 * (long)m + 1];
+    float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = lane * 4 + 256 * i;
+      t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C) {
+        const float4 k = ld4(dskip + (long)m * C + c), xv = ld4(x0 + (long)m * C + c);
+        t[i].x = rstd1 * (d[i].x - s1 - xh[i].x * s2) + k.x;
+        t[i].y = rstd1 * (d[i].y - s1 - xh[i].y * s2) + k.y;
+        t[i].z = rstd1 * (d[i].z - s1 - xh[i].z * s2) + k.z;
+        t[i].w = rstd1 * (d[i].w - s1 - xh[i].w * s2) + k.w;
+        xh[i] = make_float4((xv.x - mean0) * rstd0, (xv.y - mean0) * rstd0, (xv.z - mean0) * rstd0, (xv.w - mean0) * rstd0);
+        acc[2][i].x += t[i].x * xh[i].x; acc[2][i].y += t[i].y * xh[i].y; acc[2][i].z += t[i].z * xh[i].z; acc[2][i].w += t[i].w * xh[i].w;
+        acc[3][i].x += t[i].x; acc[3][i].y += t[i].y; acc[3][i].z += t[i].z; acc[3][i].w += t[i].w;
+        d[i] = make_float4(t[i].x * g0[i].x, t[i].y * g0[i].y, t[i].z * g0[i].z, t[i].w * g0[i].w);
+        u1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+        u2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
+      }
+    }
+    u1 = wave_sum(u1) / (float)C;
+    u2 = wave_sum(u2) / (float)C;
+    const float ms = (dx_b16 != nullptr) ? droppath_scale(mask, mask_mode, __builtin_amdgcn_readfirstlane(m), T, J) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < C) {
+        const float4 o = make_float4(rstd0 * (d[i].x - u1 - xh[i].x * u2), rstd0 * (d[i].y - u1 - xh[i].y * u2),
+                                     rstd0 * (d[i].z - u1 - xh[i].z * u2), rstd0 * (d[i].w - u1 - xh[i].w * u2));
+        st4(dx + (long)m * C + c, o);
+        if (dx_b16 != nullptr) st4(dx_b16 + (long)m * C + c, make_float4(o.x * ms, o.y * ms, o.z * ms, o.w * ms));
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < C) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(&red[(wv * 4 + k) * 512 + c]) = acc[k][i];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * C; i += 256) {
+    const int which = i / C, c = i - which * C;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) sum += red[(w * 4 + which) * 512 + c];
+    partial[(long)blockIdx.x * 4 * C + i] = sum;
+  }
+}
+
+int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, const float* gamma1, const float* dskip,
+            const float* x0, const float* stats0, const float* gamma0, float* dx, void* dx_b16, const float* mask, int mask_mode, int T,
+            int J, float* dgamma1, float* dbeta1, float* dgamma0, float* dbeta0, int M, int C, float* scratch, long scratch_floats,
+            hipStream_t st) {
+  MP_CHECK(C % 4 == 0 && C <= 512, MP_ERR_ARG, "ln_bwd2: C=%d unsupported", C);
+  const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
+  MP_CHECK(scratch_floats >= (long)grid * 4 * C, MP_ERR_ARG, "ln_bwd2: scratch too small");
+  if (dy_bf16)
+    hipLaunchKernelGGL(ln_bwd2_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
+                       dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C);
+  else
+    hipLaunchKernelGGL(ln_bwd2_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
+                       dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C);
+  MP_LAUNCH_CHECK();
+  ReduceDst d = {{dgamma1, dbeta1, dgamma0, dbeta0}, {0, C, 2 * C, 3 * C, 4 * C}, {1, 1, 1, 1}};
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(4 * C, 32)), dim3(256), 0, st, scratch, grid, 4 * C, d);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

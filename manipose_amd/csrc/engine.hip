@@ -154,7 +154,7 @@ static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int half
 }
 
 static long small_scratch_floats(const mp_model* m) {
-  long s = 512L * 2 * 1024;                                                        // ln_bwd partials
+  long s = 512L * 4 * 1024;                                                        // ln_bwd / ln_bwd2 partials
   const Module* mods[2] = {&m->rot, &m->seg};
   for (const Module* md : mods) s = max(s, 128L * md->K * ((long)md->O * md->C + md->O + 2 * md->C));   // heads_bwd
   s = max(s, 128L * (3 + m->rot.N) * m->rot.C);                                   // embed_bwd
@@ -346,19 +346,23 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
   const long M = (long)B * T * N;
   const int half = m->cfg.precision == 1;
   float* g = m->g;
+  bool post_done = false;
   for (int l = L - 1; l >= 0; --l) {
     const BlockP& q = md.bp[l];
     BlockWS& w = md.ws[l];
     const bool spatial = (l % 2 == 0);
     const int mode = spatial ? 1 : 2;
-    // (a) shared post-norm (+ Temporal_pos_embed gradient behind block 0)
-    if (l == 0) RUN(PC_OTHER, 0, tpos_grad(g, G(m, fg, md.tpos), B, T, N, C, st));
-    // (b)'s branch gradient gb = DropPath-scaled g: in precision 1 the LN backward emits it directly as a bf16 copy
+    // (a) shared post-norm (+ Temporal_pos_embed gradient behind block 0); skipped when the previous iteration's fused
+    // norm1/post-norm backward (h) has already produced dL/d x_out[l]
     const float* mk2 = branch_mask(m, md, l, 1, B, m->train);
-    RUN(PC_LN, 0, ln_bwd(g, w.x_out, w.stp, P(m, fp, spatial ? md.sn_w : md.tn_w), nullptr, g, m->g_b16, mk2, mode, T, N,
-                         G(m, fg, spatial ? md.sn_w : md.tn_w), G(m, fg, spatial ? md.sn_b : md.tn_b), (int)M, C, m->small,
-                         m->small_floats, st));
-    // (b) mlp branch: fc2
+    if (!post_done) {
+      if (l == 0) RUN(PC_OTHER, 0, tpos_grad(g, G(m, fg, md.tpos), B, T, N, C, st));
+      RUN(PC_LN, 0, ln_bwd(g, 0, w.x_out, w.stp, P(m, fp, spatial ? md.sn_w : md.tn_w), nullptr, g, m->g_b16, mk2, mode, T, N,
+                           G(m, fg, spatial ? md.sn_w : md.tn_w), G(m, fg, spatial ? md.sn_b : md.tn_b), (int)M, C, m->small,
+                           m->small_floats, st));
+    }
+    post_done = false;
+    // (b) mlp branch: fc2 (gb = DropPath-scaled branch gradient; a bf16 copy emitted by the LN backward in precision 1)
     const void* gb = half ? (const void*)m->g_b16 : (const void*)g;
     if (mk2 && !half) {
       RUN(PC_OTHER, 0, scale_rows(g, mk2, mode, m->tmpMask, 0, (int)M, C, T, N, st));
@@ -371,12 +375,12 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
     // (c) fc1
     rc = linear_wgrad(m, st, m->tmp2C, 0, w.a2, G(m, fg, q.f1w), G(m, fg, q.f1b), M, 2 * C, C);
     if (rc) return rc;
-    rc = linear_dgrad(m, st, fp, m->tmp2C, 0, q.f1w, m->tmpC, 1, M, 2 * C, C, nullptr);
+    rc = linear_dgrad(m, st, fp, m->tmp2C, 0, q.f1w, m->tmpC, 0, M, 2 * C, C, nullptr);     // d(norm2 out): bf16 in precision 1
     if (rc) return rc;
     // (d) norm2 + skip
     const float* mk1 = branch_mask(m, md, l, 0, B, m->train);
-    RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, m->g_b16, mk1, mode, T, N, G(m, fg, q.n2w), G(m, fg, q.n2b),
-                         (int)M, C, m->small, m->small_floats, st));
+    RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, m->g_b16, mk1, mode, T, N, G(m, fg, q.n2w),
+                         G(m, fg, q.n2b), (int)M, C, m->small, m->small_floats, st));
     // (e) attention branch: proj
     gb = half ? (const void*)m->g_b16 : (const void*)g;
     if (mk1 && !half) {
@@ -393,11 +397,24 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
     // (g) qkv
     rc = linear_wgrad(m, st, m->tmp3C, 0, w.a1, G(m, fg, q.qkvw), G(m, fg, q.qkvb), M, 3 * C, C);
     if (rc) return rc;
-    rc = linear_dgrad(m, st, fp, m->tmp3C, 0, q.qkvw, m->tmpC, 1, M, 3 * C, C, nullptr);
+    rc = linear_dgrad(m, st, fp, m->tmp3C, 0, q.qkvw, m->tmpC, 0, M, 3 * C, C, nullptr);   // d(norm1 out): bf16 in precision 1
     if (rc) return rc;
-    // (h) norm1 + skip
-    RUN(PC_LN, 0, ln_bwd(m->tmpC, w.x_in, w.st1, P(m, fp, q.n1w), g, g, nullptr, nullptr, 0, T, N, G(m, fg, q.n1w), G(m, fg, q.n1b),
-                         (int)M, C, m->small, m->small_floats, st));
+    // (h) norm1 + skip; for l >= 2 fused with the shared post-norm backward of block l-1 (its (a) step)
+    if (l >= 2 && C <= 512) {
+      const BlockP& qp = md.bp[l - 1];
+      (void)qp;
+      BlockWS& wp = md.ws[l - 1];
+      const bool pspatial = ((l - 1) % 2 == 0);
+      const float* mkp = branch_mask(m, md, l - 1, 1, B, m->train);
+      RUN(PC_LN, 0, ln_bwd2(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, wp.x_out, wp.stp, P(m, fp, pspatial ? md.sn_w : md.tn_w), g,
+                            m->g_b16, mkp, pspatial ? 1 : 2, T, N, G(m, fg, q.n1w), G(m, fg, q.n1b),
+                            G(m, fg, pspatial ? md.sn_w : md.tn_w), G(m, fg, pspatial ? md.sn_b : md.tn_b), (int)M, C, m->small,
+                            m->small_floats, st));
+      post_done = true;
+    } else {
+      RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, g, nullptr, nullptr, 0, T, N, G(m, fg, q.n1w),
+                           G(m, fg, q.n1b), (int)M, C, m->small, m->small_floats, st));
+    }
   }
   return MP_OK;
 }
