@@ -449,8 +449,9 @@ int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, 
 
 static void wgrad_split_b16(int Mtok, int Nout, int Kin, int bt, int& splits, int& kper) {
   const int tiles = cdiv(Nout, bt) * cdiv(Kin, bt);
-  const int target = (bt == 256) ? 512 : 1024;            // workgroups in flight: 2 (256^2) / 4 (128^2) per CU
-  splits = max(1, min(64, (target + tiles - 1) / tiles));
+  // 256^2 tiles run one workgroup per CU: fill the 256 CUs exactly once (a 257th workgroup would double the kernel time);
+  // 128^2 tiles run 2-4 per CU.  Fewer splits also means fewer fp32 slabs to write and reduce.
+  splits = (bt == 256) ? max(1, min(64, 256 / tiles)) : max(1, min(64, (1024 + tiles - 1) / tiles));
   kper = ((cdiv(Mtok, splits) + GBK - 1) / GBK) * GBK;
   splits = cdiv(Mtok, kper);
 }
