@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("MANIPOSE_BENCH_BATCH", "32")), help="windows per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MANIPOSE_BENCH_BATCH", "64")), help="windows per GPU")
     ap.add_argument("--frames", type=int, default=243)
     ap.add_argument("--hyp", type=int, default=5)
     ap.add_argument("--precision", default=os.environ.get("MANIPOSE_PRECISION", "bf16"), choices=["bf16", "fp32"],
@@ -165,7 +165,7 @@ def main():
             k = prof["gemm_fwd"]
             ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
             peak = PEAK_TFLOPS[args.precision]
-            kname = ("gemm_bf16_kernel<bf16,N,bf16,N,*> (forward Linear GEMMs, v_mfma_f32_16x16x32_bf16)" if args.precision == "bf16"
+            kname = ("gemm_bf16_glds_kernel<N,N,*,256> (forward Linear GEMMs: direct-to-LDS, 256x256x64 tiles, v_mfma_f32_16x16x32_bf16)" if args.precision == "bf16"
                      else "gemm_f32_kernel<AL=0,BL=0,*> (forward Linear GEMMs, v_mfma_f32_32x32x2_f32)")
             out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,

@@ -287,6 +287,17 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   const int m0 = tm * BT, n0 = tn * BT;
   const int kbeg = blockIdx.z * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
+  if (BT == 256 && g.stagger > 0) {
+    // All tiles cost the same, so with one workgroup per CU every CU would reach its (HBM-write-bound) epilogue at the same
+    // moment and idle its matrix cores while the whole chip's stores queue up.  Phase-shift the FIRST wave of workgroups
+    // (later ones inherit the shift, a CU starts its next tile when the previous one retires) so epilogues of some CUs
+    // overlap main loops of others.
+    const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (id < 256) {
+      const int ph = (id >> 3) & 7;
+      for (int i = 0; i < ph * g.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+  }
 
   f32x4 acc[MI][4];
 #pragma unroll
@@ -315,16 +326,52 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
           bsum += __uint_as_float((unsigned)(*reinterpret_cast<const unsigned short*>(As + r * (BT * 2) + ((oc ^ t_swz(r)) << 4) + wi * 2)) << 16);
       }
     }
+    // software-pipelined fragment reads: the ds_reads of step s+1 are issued before the 8 MFMAs of step s
+    {
+      constexpr int HS = MI / 2, NSTEP = (GBK / 32) * HS;
+      bf16x8_t b_cur[4], b_nxt[4], a_cur[2], a_nxt[2];
 #pragma unroll
-    for (int ks = 0; ks < GBK / 32; ++ks) {
-      bf16x8_t bfr[4];
+      for (int j = 0; j < 4; ++j) b_cur[j] = read_frag2<TRB, BT>(Bs, wc * 64 + j * 16, 0, lane);
+      a_cur[0] = read_frag2<TRA, BT>(As, wr * (BT / 2), 0, lane);
+      a_cur[1] = read_frag2<TRA, BT>(As, wr * (BT / 2) + 16, 0, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = read_frag2<TRB, BT>(Bs, wc * 64 + j * 16, ks, lane);
+      for (int step = 0; step < NSTEP; ++step) {
+        const int ip = step % HS;
+        if (step + 1 < NSTEP) {
+          const int nks = (step + 1) / HS, nip = (step + 1) % HS;
+          a_nxt[0] = read_frag2<TRA, BT>(As, wr * (BT / 2) + (2 * nip) * 16, nks, lane);
+          a_nxt[1] = read_frag2<TRA, BT>(As, wr * (BT / 2) + (2 * nip + 1) * 16, nks, lane);
+          if (nip == 0) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const bf16x8_t af = read_frag2<TRA, BT>(As, wr * (BT / 2) + i * 16, ks, lane);
+            for (int j = 0; j < 4; ++j) b_nxt[j] = read_frag2<TRB, BT>(Bs, wc * 64 + j * 16, nks, lane);
+          }
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[i][j], 0, 0, 0);   // C^T tile
+        for (int j = 0; j < 4; ++j) acc[2 * ip][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[j], a_cur[0], acc[2 * ip][j], 0, 0, 0);   // C^T tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[2 * ip + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[j], a_cur[1], acc[2 * ip + 1][j], 0, 0, 0);
+        // pin the order "next step's LDS reads, then this step's 8 MFMAs" (hipcc otherwise sinks the reads behind the MFMAs
+        // and exposes their latency before every group)
+        if (step + 1 < NSTEP) {
+          if ((step + 1) % HS == 0) {            // A and B fragments of the next k-step
+            if (TRA && TRB) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+            else if (TRB) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+            else if (TRA) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+          } else {
+            if (TRA) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        if (step + 1 < NSTEP) {
+          a_cur[0] = a_nxt[0];
+          a_cur[1] = a_nxt[1];
+          if ((step + 1) % HS == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b_cur[j] = b_nxt[j];
+          }
+        }
       }
     }
   }
@@ -429,6 +476,7 @@ static int launch_b16(const GemmB16Args& g, int splits, hipStream_t st) {
 // C[M,N] = A(i,r) B(r,j): a_f32/c_f32 select fp32 instead of bf16 storage; a_tr/b_tr select the "T" layouts.
 int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, hipStream_t st) {
   { const char* e = getenv("MANIPOSE_GEMM_DEBUG"); g.debug = e ? atoi(e) : 0; }   // timing ablations only (1 no MFMA, 2 no DMA, 4 no epilogue)
+  { static int stg = -1; if (stg < 0) { const char* e = getenv("MANIPOSE_GEMM_STAGGER"); stg = e ? atoi(e) : 0; } g.stagger = stg; }
   MP_CHECK(g.M > 0 && g.N > 0 && g.K > 0, MP_ERR_ARG, "gemm_bf16: empty problem");
   MP_CHECK((a_tr ? g.M : g.K) % 8 == 0 && (b_tr ? g.N : g.K) % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.N % 4 == 0 &&
                g.ldc % 4 == 0, MP_ERR_ARG,
@@ -470,6 +518,7 @@ int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, i
   g.C = slab; g.ldc = Kin;
   g.bias_slab = (db != nullptr) ? slab + (long)splits * Nout * Kin : nullptr;
   g.k_per_split = kper;
+  g.stagger = 0;       // split-K wgrad: one workgroup per CU, nothing to desynchronise
   int rc = dy_f32 ? launch_b16<float, 1, bf16, 1, float, EPI_SLAB>(g, splits, st)
                   : launch_glds<1, 1, float, EPI_SLAB>(g, splits, st);
   if (rc) return rc;
