@@ -20,7 +20,7 @@ TRAIN_GFLOP_PER_POSE = {243: 3.705, 81: 3.562, 27: 3.513}      # SURVEY.md 8d (3
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}                  # MI355X_MICROARCH.md: dense matrix peaks
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction of
 # MI355X_MICROARCH.md section HBM, + WRITE_SIZE), see profiles/README.md; keyed by (precision, windows per GPU).
-PMC_TRAFFIC_PER_LAUNCH = {("bf16", 32): 620.4e6}   # profiles/r01_bf16_B32_pmc_hbm_traffic.csv (forward-GEMM class average)
+PMC_TRAFFIC_PER_LAUNCH = {("bf16", 32): 620.4e6, ("bf16", 64): 1245.4e6}   # profiles/r01_bf16_B{32,64}_pmc_hbm_traffic.csv (forward-GEMM class average)
 
 
 def host_cores():
