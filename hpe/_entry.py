@@ -73,23 +73,44 @@ def synthetic_windows(n, T, device, seed):
 
 
 @torch.no_grad()
-def evaluate(model, X, y, batch):
-    """MPJPE (mm) of the aggregated / best-score / oracle hypotheses (eval_utils.py:16-223, without flip-TTA)."""
+def evaluate(model, X, y, batch, tta=True):
+    """MPJPE (mm) of the aggregated / best-score / oracle hypotheses, with the reference's flip test-time augmentation
+    (hpe/eval_utils.py:16-223).  The flipped copy is batched with the original into ONE forward of 2B windows
+    instead of a second pass."""
     from manipose_amd import RMCLManifoldMixSTE
+    from manipose_amd.augmentations import pose_flip
     from manipose_amd.metrics import mpjpe_error
     model.eval()
+    sk = model.decoder.skeleton
+    rmcl = isinstance(model, RMCLManifoldMixSTE)
     sums = {"mpjpe": 0.0, "ps_oracle_mpjpe": 0.0, "oracle_mpjpe": 0.0}
     n = 0
     for i in range(0, X.shape[0], batch):
         xb, yb = X[i:i + batch], y[i:i + batch]
-        out = model(xb)
-        if isinstance(model, RMCLManifoldMixSTE):
-            poses, scores = out
-            sums["mpjpe"] += mpjpe_error(model.aggregate(poses, scores, "weighted_ave"), yb, "sum").item()
-            sums["ps_oracle_mpjpe"] += mpjpe_error(model.aggregate(poses, scores, "best_score"), yb, "sum").item()
-            sums["oracle_mpjpe"] += mpjpe_error(model.aggregate(poses, mode="oracle", ground_truth=yb)[1], yb, "sum").item()
+        nb = xb.shape[0]
+        if tta:
+            xin = torch.cat([xb, pose_flip((xb.clone(),), sk)[0]], dim=0)
         else:
-            sums["mpjpe"] += mpjpe_error(out, yb, "sum").item()
+            xin = xb
+        out = model(xin)
+        if rmcl:
+            poses, scores = out
+            pred = model.aggregate(poses[:nb], scores[:nb], "weighted_ave")
+            best = model.aggregate(poses[:nb], scores[:nb], "best_score")
+            orac = model.aggregate(poses[:nb], mode="oracle", ground_truth=yb)[1]
+            if tta:
+                hyp_f = pose_flip((poses[nb:].clone(),), sk)[0]          # flipped hypotheses mapped back to the original frame
+                pred = (pred + model.aggregate(hyp_f, scores[nb:], "weighted_ave")) / 2
+                best = (best + model.aggregate(hyp_f, scores[nb:], "best_score")) / 2
+                orac = (orac + model.aggregate(hyp_f, mode="oracle", ground_truth=yb)[1]) / 2
+            sums["mpjpe"] += mpjpe_error(pred, yb, "sum").item()
+            sums["ps_oracle_mpjpe"] += mpjpe_error(best, yb, "sum").item()
+            sums["oracle_mpjpe"] += mpjpe_error(orac, yb, "sum").item()
+        else:
+            pred = out[:nb]
+            if tta:
+                pred = (pred + pose_flip((out[nb:].clone(),), sk)[0]) / 2
+            sums["mpjpe"] += mpjpe_error(pred, yb, "sum").item()
         n += yb.numel() // 3
     return {k: 1000.0 * v / n for k, v in sums.items() if v > 0}
 
@@ -115,7 +136,7 @@ def run(argv, extra_defaults=None):
     if cfg.run.checkpoint_model:
         ck = torch.load(cfg.run.checkpoint_model, map_location="cpu")
         model.load_state_dict(ck["model_pos"] if "model_pos" in ck else ck)
-    model.max_batch_hint = max(cfg.train.batch_size, cfg.train.batch_size_test)
+    model.max_batch_hint = max(cfg.train.batch_size, 2 * cfg.train.batch_size_test)      # x2: flip-TTA batches the mirrored copy
     model = model.to(dev)
     trainer = LiftingTrainer(model, lr=cfg.train.lr, weight_decay=1e-6, w_loss=cfg.train.w_loss, vel_loss=cfg.train.vel_loss,
                              smooth_reg=cfg.train.smooth_reg, rmcl_score_reg=cfg.train.rmcl_score_reg, seed=cfg.run.seed)
@@ -162,9 +183,9 @@ def run(argv, extra_defaults=None):
                 print(f"epoch {epoch}: tr_loss {sum(terms):.5f} wloss {terms[0]:.5f} score_reg {terms[1]:.5f} vloss {terms[2]:.5f} "
                       f"sreg {terms[3]:.5f} | best val {best_val:.5f} lr {lr:.2e}", flush=True)
             if (epoch + 1) % cfg.train.mpjpe_epoch_interval == 0 and rank == 0:
-                print("   eval:", {k: round(v, 3) for k, v in evaluate(model, Xv, yv, cfg.train.batch_size_test).items()}, flush=True)
+                print("   eval:", {k: round(v, 3) for k, v in evaluate(model, Xv, yv, cfg.train.batch_size_test, tta=cfg.train.tta).items()}, flush=True)
         if rank == 0:
             save_state(model, trainer, {"best": best_val, "bad_epochs": bad_epochs}, cfg.train.epochs, out_dir, "end")
     if cfg.run.test and rank == 0:
-        print("test:", {k: round(v, 3) for k, v in evaluate(model, Xv, yv, cfg.train.batch_size_test).items()}, flush=True)
+        print("test:", {k: round(v, 3) for k, v in evaluate(model, Xv, yv, cfg.train.batch_size_test, tta=cfg.train.tta).items()}, flush=True)
     return best_val

@@ -156,7 +156,7 @@ static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int half
 static long small_scratch_floats(const mp_model* m) {
   long s = 512L * 4 * 1024;                                                        // ln_bwd / ln_bwd2 partials
   const Module* mods[2] = {&m->rot, &m->seg};
-  for (const Module* md : mods) s = max(s, 128L * md->K * ((long)md->O * md->C + md->O + 2 * md->C));   // heads_bwd
+  for (const Module* md : mods) s = max(s, 512L * md->K * ((long)md->O * md->C + md->O + 2 * md->C));   // heads_bwd
   s = max(s, 128L * (3 + m->rot.N) * m->rot.C);                                   // embed_bwd
   s = max(s, 33L * m->seg.N * m->seg.C * 35);                                     // bones_embed_bwd
   s = max(s, 8L * m->cfg.max_batch * m->cfg.num_frame + 64);                       // scores_bwd dlogit / loss partials

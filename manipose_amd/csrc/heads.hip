@@ -220,15 +220,23 @@ __global__ void heads_reduce_kernel(const float* __restrict__ partial, int P, in
   const int nk = O * C + O + 2 * C;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nk) return;
-  float s = 0.f;
-  for (int p = 0; p < P; ++p) s += partial[((long)p * K + k) * nk + i];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int p = 0;
+  for (; p + 3 < P; p += 4) {
+    s0 += partial[((long)p * K + k) * nk + i];
+    s1 += partial[((long)(p + 1) * K + k) * nk + i];
+    s2 += partial[((long)(p + 2) * K + k) * nk + i];
+    s3 += partial[((long)(p + 3) * K + k) * nk + i];
+  }
+  for (; p < P; ++p) s0 += partial[((long)p * K + k) * nk + i];
+  const float s = (s0 + s1) + (s2 + s3);
   if (i < O * C) g.W[k][i] += s;
   else if (i < O * C + O) g.b[k][i - O * C] += s;
   else if (i < O * C + O + C) g.gamma[k][i - O * C - O] += s;
   else g.beta[k][i - O * C - O - C] += s;
 }
 
-constexpr int HB_GRID = 32;   // 128 waves -> 128 partial rows per head
+constexpr int HB_GRID = 128;  // 512 waves -> 512 partial rows per head
 
 int heads_bwd(const float* x, const float* stats, const HeadParams& p, const HeadGrads& gp, int K, int O, const float* dout,
               float* dx, int M, int C, float* scratch, long scratch_floats, hipStream_t st) {

@@ -145,3 +145,29 @@ def test_two_rank_gradient_exchange_equals_full_batch(tmp_path):
     for name, off, n in res["layout"]:
         np.testing.assert_allclose(res["g"][off:off + n].numpy(), st[name].grad.reshape(-1).numpy(), rtol=2e-4, atol=2e-6,
                                    err_msg=name)
+
+
+def test_pose_flip_semantics():
+    """Flip = negate x + swap left/right joints, in place, tuple in/out (reference augmentations/functional.py:7-28);
+    an involution; aggregate-then-flip == flip-then-aggregate (what the batched flip-TTA relies on)."""
+    from manipose_amd.augmentations import pose_flip
+    from manipose_amd.data import h36m_skeleton
+    sk = h36m_skeleton()
+    g = torch.Generator().manual_seed(3)
+    p = torch.randn(2, 5, 17, 3, generator=g)
+    ref = p.clone()
+    ref[..., 0] *= -1
+    idx = list(range(17))
+    for l, r in zip(sk.joints_left, sk.joints_right):
+        idx[l], idx[r] = r, l
+    ref = ref[..., idx, :]
+    q = p.clone()
+    (out,) = pose_flip((q,), sk)
+    assert out is q and torch.equal(q, ref)
+    pose_flip((q,), sk)
+    assert torch.equal(q, p)
+    hyp = torch.randn(2, 3, 5, 17, 3, generator=g)
+    sc = torch.rand(2, 3, 5, 1, generator=g).softmax(1)
+    a = orc.aggregate(pose_flip((hyp.clone(),), sk)[0], sc)
+    b = pose_flip((orc.aggregate(hyp, sc),), sk)[0]
+    np.testing.assert_allclose(a.numpy(), b.numpy(), atol=1e-6)
