@@ -12,6 +12,7 @@
 //     which is applied to the other operand's transpose-read addresses instead (no LDS round trip, no shuffles).
 // Softmax is exact (not online): a wave holds a 16-query x 256-key score strip in 64 accumulator registers.
 // fp32 accumulation, fp32 softmax statistics; log-sum-exp saved for the backward.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -176,7 +177,8 @@ __global__ __launch_bounds__(256) void attn_tmfma_fwd_kernel(const bf16* __restr
 template <int D>
 __global__ __launch_bounds__(512) void attn_tmfma_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                               const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                              bf16* __restrict__ dqkv, int T, int J, int C, int H, float scale) {
+                                                              bf16* __restrict__ dqkv, int T, int J, int C, int H, float scale,
+                                                              int debug) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB;
   char* Qs = sm;
@@ -210,93 +212,120 @@ __global__ __launch_bounds__(512) void attn_tmfma_bwd_kernel(const bf16* __restr
   __syncthreads();
   const int ntile = (T + 15) >> 4;
   bf16* dq_base = dqkv + ((long)b * T * J + j) * 3 * C + h * D;
+  if (debug & 1) return;                                 // timing ablation: staging only
 
-  // ---- phase A: dQ, one 16-query strip per wave iteration (scores in the [key][query] orientation) ----
-  for (int qt = wave; qt < ntile; qt += 8) {
-    const int tq = qt * 16 + l15;
-    bf16x8_t bq[KS], bg[KS];
+  // ---- phase A: dQ.  Each wave iteration owns TWO 16-query strips so that every K / V fragment read from LDS feeds two
+  // MFMAs (scores in the [key][query] orientation: query on the lane, 4 keys per accumulator) ----
+  for (int qp0 = wave; 2 * qp0 < ntile; qp0 += 8) {
+    const int qtA = 2 * qp0, qtB = 2 * qp0 + 1;       // qtB may be an all-padding strip (Ls = +inf there)
+    const int tqA = qtA * 16 + l15, tqB = qtB * 16 + l15;
+    bf16x8_t bqA[KS], bgA[KS], bqB[KS], bgB[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bq[ks] = frag_rows<D>(Qs, qt * 16, ks, lane);
-      bg[ks] = frag_rows<D>(Gs, qt * 16, ks, lane);
+      bqA[ks] = frag_rows<D>(Qs, qtA * 16, ks, lane); bgA[ks] = frag_rows<D>(Gs, qtA * 16, ks, lane);
+      bqB[ks] = frag_rows<D>(Qs, qtB * 16, ks, lane); bgB[ks] = frag_rows<D>(Gs, qtB * 16, ks, lane);
     }
-    const float L = Ls[tq], dl = Dl[tq];
-    f32x4 dq[DB];
+    const float LA = Ls[tqA], dlA = Dl[tqA], LB = Ls[tqB], dlB = Dl[tqB];
+    f32x4 dqA[DB], dqB[DB];
 #pragma unroll
-    for (int db = 0; db < DB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int db = 0; db < DB; ++db) { dqA[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dqB[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int kp = 0; 2 * kp < ntile; ++kp) {
-      f32x4 ds2[2];
+      f32x4 dsA[2], dsB[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int kt = 2 * kp + hf;
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sA = {0.f, 0.f, 0.f, 0.f}, pA = {0.f, 0.f, 0.f, 0.f}, sB = {0.f, 0.f, 0.f, 0.f}, pB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<D>(Ks, kt * 16, ks, lane), bq[ks], sa, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<D>(Vs, kt * 16, ks, lane), bg[ks], dp, 0, 0, 0);
+          const bf16x8_t kf = frag_rows<D>(Ks, kt * 16, ks, lane), vf = frag_rows<D>(Vs, kt * 16, ks, lane);
+          sA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bqA[ks], sA, 0, 0, 0);
+          sB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bqB[ks], sB, 0, 0, 0);
+          pA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, bgA[ks], pA, 0, 0, 0);
+          pB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, bgB[ks], pB, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = (kt * 16 + 4 * g + r < T) ? __expf(sa[r] * scale - L) : 0.f;
-          ds2[hf][r] = p * (dp[r] - dl);
+          const bool kok = kt * 16 + 4 * g + r < T;
+          const float eA = kok ? __expf(sA[r] * scale - LA) : 0.f, eB = kok ? __expf(sB[r] * scale - LB) : 0.f;
+          dsA[hf][r] = eA * (pA[r] - dlA);
+          dsB[hf][r] = eB * (pB[r] - dlB);
         }
       }
-      const bf16x8_t bds = pack_acc(ds2[0], ds2[1]);
+      const bf16x8_t bA = pack_acc(dsA[0], dsA[1]), bB = pack_acc(dsB[0], dsB[1]);
 #pragma unroll
-      for (int db = 0; db < DB; ++db) dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_perm<D>(Ks, kp * 32, db, lane), bds, dq[db], 0, 0, 0);
+      for (int db = 0; db < DB; ++db) {
+        const bf16x8_t kT = frag_cols_perm<D>(Ks, kp * 32, db, lane);
+        dqA[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, bA, dqA[db], 0, 0, 0);
+        dqB[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, bB, dqB[db], 0, 0, 0);
+      }
     }
-    if (tq < T) {
 #pragma unroll
-      for (int db = 0; db < DB; ++db) store4(dq_base + (long)tq * rs3 + 16 * db + 4 * g, dq[db], scale);
+    for (int db = 0; db < DB; ++db) {
+      if (tqA < T) store4(dq_base + (long)tqA * rs3 + 16 * db + 4 * g, dqA[db], scale);
+      if (tqB < T) store4(dq_base + (long)tqB * rs3 + 16 * db + 4 * g, dqB[db], scale);
     }
   }
 
-  // ---- phase B: dK, dV, one 16-key strip per wave iteration (scores in the [query][key] orientation) ----
-  for (int kt = wave; kt < ntile; kt += 8) {
-    const int tk = kt * 16 + l15;
-    bf16x8_t bk[KS], bv[KS];
+  if (debug & 2) return;                                 // timing ablation: no dK/dV pass
+  // ---- phase B: dK, dV, two 16-key strips per wave iteration (scores in the [query][key] orientation) ----
+  for (int kp0 = wave; 2 * kp0 < ntile; kp0 += 8) {
+    const int ktA = 2 * kp0, ktB = 2 * kp0 + 1;
+    const int tkA = ktA * 16 + l15, tkB = ktB * 16 + l15;
+    bf16x8_t bkA[KS], bvA[KS], bkB[KS], bvB[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bk[ks] = frag_rows<D>(Ks, kt * 16, ks, lane);
-      bv[ks] = frag_rows<D>(Vs, kt * 16, ks, lane);
+      bkA[ks] = frag_rows<D>(Ks, ktA * 16, ks, lane); bvA[ks] = frag_rows<D>(Vs, ktA * 16, ks, lane);
+      bkB[ks] = frag_rows<D>(Ks, ktB * 16, ks, lane); bvB[ks] = frag_rows<D>(Vs, ktB * 16, ks, lane);
     }
-    f32x4 dk[DB], dv[DB];
+    f32x4 dkA[DB], dvA[DB], dkB[DB], dvB[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
-      dk[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dv[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dkA[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvA[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dkB[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvB[db] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int qp = 0; 2 * qp < ntile; ++qp) {
-      f32x4 p2[2], ds2[2];
+      f32x4 pA2[2], dA2[2], pB2[2], dB2[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int qt = 2 * qp + hf;
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sA = {0.f, 0.f, 0.f, 0.f}, gA = {0.f, 0.f, 0.f, 0.f}, sB = {0.f, 0.f, 0.f, 0.f}, gB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<D>(Qs, qt * 16, ks, lane), bk[ks], sa, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<D>(Gs, qt * 16, ks, lane), bv[ks], dp, 0, 0, 0);
+          const bf16x8_t qf = frag_rows<D>(Qs, qt * 16, ks, lane), gf = frag_rows<D>(Gs, qt * 16, ks, lane);
+          sA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, bkA[ks], sA, 0, 0, 0);
+          sB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, bkB[ks], sB, 0, 0, 0);
+          gA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, bvA[ks], gA, 0, 0, 0);
+          gB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, bvB[ks], gB, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int tq = qt * 16 + 4 * g + r;            // rows of this orientation are queries
-          const float p = __expf(sa[r] * scale - Ls[tq]);   // Ls = +inf on padded queries -> 0
-          p2[hf][r] = p;
-          ds2[hf][r] = p * (dp[r] - Dl[tq]);
+          const int tq = qt * 16 + 4 * g + r;            // rows of this orientation are queries; Ls = +inf on padding -> 0
+          const float L = Ls[tq], dl = Dl[tq];
+          const float eA = __expf(sA[r] * scale - L), eB = __expf(sB[r] * scale - L);
+          pA2[hf][r] = eA; dA2[hf][r] = eA * (gA[r] - dl);
+          pB2[hf][r] = eB; dB2[hf][r] = eB * (gB[r] - dl);
         }
       }
-      const bf16x8_t bp = pack_acc(p2[0], p2[1]), bds = pack_acc(ds2[0], ds2[1]);
+      const bf16x8_t bpA = pack_acc(pA2[0], pA2[1]), bdA = pack_acc(dA2[0], dA2[1]);
+      const bf16x8_t bpB = pack_acc(pB2[0], pB2[1]), bdB = pack_acc(dB2[0], dB2[1]);
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_perm<D>(Gs, qp * 32, db, lane), bp, dv[db], 0, 0, 0);
-        dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_perm<D>(Qs, qp * 32, db, lane), bds, dk[db], 0, 0, 0);
+        const bf16x8_t gT = frag_cols_perm<D>(Gs, qp * 32, db, lane), qT = frag_cols_perm<D>(Qs, qp * 32, db, lane);
+        dvA[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT, bpA, dvA[db], 0, 0, 0);
+        dvB[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT, bpB, dvB[db], 0, 0, 0);
+        dkA[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, bdA, dkA[db], 0, 0, 0);
+        dkB[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, bdB, dkB[db], 0, 0, 0);
       }
     }
-    if (tk < T) {
 #pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        store4(dq_base + C + (long)tk * rs3 + 16 * db + 4 * g, dk[db], scale);
-        store4(dq_base + 2 * C + (long)tk * rs3 + 16 * db + 4 * g, dv[db], 1.0f);
+    for (int db = 0; db < DB; ++db) {
+      if (tkA < T) {
+        store4(dq_base + C + (long)tkA * rs3 + 16 * db + 4 * g, dkA[db], scale);
+        store4(dq_base + 2 * C + (long)tkA * rs3 + 16 * db + 4 * g, dvA[db], 1.0f);
+      }
+      if (tkB < T) {
+        store4(dq_base + C + (long)tkB * rs3 + 16 * db + 4 * g, dkB[db], scale);
+        store4(dq_base + 2 * C + (long)tkB * rs3 + 16 * db + 4 * g, dvB[db], 1.0f);
       }
     }
   }
@@ -591,6 +620,8 @@ int attn_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, const flo
   MP_CHECK(attn_tmfma_supported(T, D) && C % 8 == 0, MP_ERR_ARG, "attn_tmfma_bwd: T=%d D=%d unsupported", T, D);
   const float scale = 1.0f / sqrtf((float)D);
   const int units = B * J * H;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("MANIPOSE_ATTN_DEBUG"); dbg = e ? atoi(e) : 0; }
   if (D == 64) {
     const size_t lds = 4 * TP * ACfg<64>::ROWB + 2 * TP * sizeof(float);
     static bool attr_set = false;
@@ -598,10 +629,10 @@ int attn_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, const flo
       MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;
     }
-    hipLaunchKernelGGL(attn_tmfma_bwd_kernel<64>, dim3(units), dim3(512), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale);
+    hipLaunchKernelGGL(attn_tmfma_bwd_kernel<64>, dim3(units), dim3(512), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg);
   } else {
     const size_t lds = 4 * TP * ACfg<16>::ROWB + 2 * TP * sizeof(float);
-    hipLaunchKernelGGL(attn_tmfma_bwd_kernel<16>, dim3(units), dim3(512), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale);
+    hipLaunchKernelGGL(attn_tmfma_bwd_kernel<16>, dim3(units), dim3(512), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg);
   }
   MP_LAUNCH_CHECK();
   return MP_OK;

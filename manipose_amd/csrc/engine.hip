@@ -50,6 +50,12 @@ struct mp_model {
   bf16* wbf = nullptr;                       // bf16 shadow of the flat parameter buffer (precision 1)
   float *slab = nullptr, *small = nullptr, *lengths = nullptr, *dlen_pose = nullptr, *maskbuf = nullptr, *dscore_zero = nullptr;
   long slab_floats = 0, small_floats = 0;
+  // The bones net runs concurrently with the rotations net on a second stream with its own scratch set; the host code stays
+  // sequential and simply swaps which set the fields above point at while it enqueues that module's kernels.
+  struct ScratchSet { float *g, *tmpC, *tmpMask, *delta, *slab, *small; bf16* g_b16; void *tmp2C, *tmp3C; long slab_floats, small_floats; };
+  ScratchSet sets[2];
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // state of the last forward
   int B = 0;
   bool train = false;
@@ -170,28 +176,29 @@ static void carve_all(mp_model* m, Bump& bp) {
   carve_module(m->rot, bp, Mr, T, Bm, half);
   carve_module(m->seg, bp, Ms, T, Bm, half);
   if (half) m->wbf = reinterpret_cast<bf16*>(bp.take((m->flat_size + 1) / 2));
-  const long MC = max(Mr * m->rot.C, Ms * m->seg.C);
-  m->g = bp.take(MC);
-  m->tmpC = bp.take(MC);
-  m->tmpMask = bp.take(MC);
-  if (half) m->g_b16 = reinterpret_cast<bf16*>(bp.take((MC + 1) / 2));
-  m->tmp2C = bp.take(half ? MC : 2 * MC);
-  m->tmp3C = bp.take(half ? (3 * MC + 1) / 2 : 3 * MC);
-  m->delta = bp.take(max((long)Bm * m->rot.N * m->rot.H * T, (long)Bm * m->seg.N * m->seg.H * T));
-  long slab = 0;
+  const int halfp = m->cfg.precision == 1;
   const Module* mods[2] = {&m->rot, &m->seg};
-  for (const Module* md : mods) {
-    const long M = (long)Bm * T * md->N;
+  for (int i = 0; i < 2; ++i) {
+    const Module* md = mods[i];
+    const long M = (i == 0) ? Mr : Ms, MC = M * md->C;
+    mp_model::ScratchSet& sc = m->sets[i];
+    sc.g = bp.take(MC);
+    sc.tmpC = bp.take(MC);
+    sc.tmpMask = bp.take(MC);
+    sc.g_b16 = halfp ? reinterpret_cast<bf16*>(bp.take((MC + 1) / 2)) : nullptr;
+    sc.tmp2C = bp.take(halfp ? MC : 2 * MC);
+    sc.tmp3C = bp.take(halfp ? (3 * MC + 1) / 2 : 3 * MC);
+    sc.delta = bp.take((long)Bm * md->N * md->H * T);
     const int C = md->C;
-    slab = max(slab, wgrad_f32_slab_floats((int)M, 3 * C, C));   // same tile-derived bound for the bf16 kernels
+    long slab = wgrad_f32_slab_floats((int)M, 3 * C, C);   // same tile-derived bound for the bf16 kernels
     slab = max(slab, wgrad_f32_slab_floats((int)M, C, C));
     slab = max(slab, wgrad_f32_slab_floats((int)M, 2 * C, C));
     slab = max(slab, wgrad_f32_slab_floats((int)M, C, 2 * C));
+    sc.slab_floats = slab;
+    sc.slab = bp.take(slab);
+    sc.small_floats = small_scratch_floats(m);
+    sc.small = bp.take(sc.small_floats);
   }
-  m->slab_floats = slab;
-  m->slab = bp.take(slab);
-  m->small_floats = small_scratch_floats(m);
-  m->small = bp.take(m->small_floats);
   m->lengths = bp.take((long)Bm * m->seg.N);
   m->dlen_pose = bp.take((long)Bm * m->rot.K * T * m->seg.N);
   long nm = 0;
@@ -199,6 +206,12 @@ static void carve_all(mp_model* m, Bump& bp) {
     for (const auto& b : md->masks) nm += b.spatial ? (long)Bm * T : (long)Bm * md->N;
   m->maskbuf = bp.take(nm + 64);
   m->dscore_zero = bp.take((long)Bm * m->rot.K * T);
+}
+
+static void use_scratch(mp_model* m, int i) {
+  const mp_model::ScratchSet& sc = m->sets[i];
+  m->g = sc.g; m->tmpC = sc.tmpC; m->tmpMask = sc.tmpMask; m->delta = sc.delta; m->slab = sc.slab; m->small = sc.small;
+  m->g_b16 = sc.g_b16; m->tmp2C = sc.tmp2C; m->tmp3C = sc.tmp3C; m->slab_floats = sc.slab_floats; m->small_floats = sc.small_floats;
 }
 
 // ---- profiling helpers -------------------------------------------------------------------------
@@ -477,6 +490,14 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   Bump real;
   real.base = m->arena;
   carve_all(m, real);
+  use_scratch(m, 0);
+  if (hipStreamCreateWithFlags(&m->st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {
+    set_error("mp_model_create: could not create the side stream / events");
+    (void)hipFree(m->arena);
+    delete m;
+    return MP_ERR_HIP;
+  }
   e = hipMemset(m->dscore_zero, 0, sizeof(float) * (size_t)cfg->max_batch * m->rot.K * cfg->num_frame);
   if (e != hipSuccess) {
     set_error("mp_model_create: hipMemset failed: %s", hipGetErrorString(e));
@@ -491,6 +512,9 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
 void mp_model_destroy(mp_model* m) {
   if (!m) return;
   for (auto& e : m->ev) (void)hipEventDestroy(e);
+  if (m->st2) { (void)hipStreamSynchronize(m->st2); (void)hipStreamDestroy(m->st2); }
+  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+  if (m->ev_join) (void)hipEventDestroy(m->ev_join);
   if (m->arena) (void)hipFree(m->arena);
   delete m;
 }
@@ -569,6 +593,10 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
     }
   }
   if (m->cfg.precision == 1) RUN(PC_OTHER, 0, cast_to_bf16(fp, m->wbf, m->flat_size, st));
+  // fork: the side stream may start once the masks / bf16 weights above are in place
+  MP_HIP(hipEventRecord(m->ev_fork, st));
+  MP_HIP(hipStreamWaitEvent(m->st2, m->ev_fork, 0));
+  use_scratch(m, 0);
   // rotations backbone (mix_ste.py:128-173)
   const long Mr = (long)B * T * J, Ms = (long)B * T * S;
   RUN(PC_OTHER, 0, embed_fwd(x, P(m, fp, m->rot.emb_w), P(m, fp, m->rot.emb_b), P(m, fp, m->rot.spos), m->rot.ws[0].x_in, (int)Mr,
@@ -583,15 +611,24 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
     for (int k = 0; k < K; ++k) { sp.w[k] = P(m, fp, m->rot.sw[k]); sp.b[k] = P(m, fp, m->rot.sb[k]); }
     RUN(PC_OTHER, 0, scores_fwd(m->rot.headout, sp, K, m->rot.O, scores, B, T, J, st));
   }
-  // bones net (manifold_mix_ste.py:139-154)
-  RUN(PC_OTHER, 0, bones_embed_fwd(x, P(m, fp, m->seg.emb_w), P(m, fp, m->seg.emb_b), P(m, fp, m->seg.spos), m->seg.ws[0].x_in,
-                                   B * T, J * 2, S * m->seg.C, st));
-  rc = backbone_fwd(m, m->seg, fp, B, st);
-  if (rc) return rc;
-  HeadParams hs;
-  head_params(m, m->seg, fp, hs);
-  RUN(PC_OTHER, 0, heads_fwd(m->seg.x_final, hs, 1, 1, m->seg.headout, m->seg.hstats, (int)Ms, m->seg.C, st));
-  RUN(PC_OTHER, 0, bones_mean_fwd(m->seg.headout, m->lengths, B, T, S, st));
+  // bones net (manifold_mix_ste.py:139-154) on the side stream, concurrently with the rotations net enqueued above
+  {
+    hipStream_t main_st = st;
+    st = m->st2;
+    use_scratch(m, 1);
+    RUN(PC_OTHER, 0, bones_embed_fwd(x, P(m, fp, m->seg.emb_w), P(m, fp, m->seg.emb_b), P(m, fp, m->seg.spos), m->seg.ws[0].x_in,
+                                     B * T, J * 2, S * m->seg.C, st));
+    rc = backbone_fwd(m, m->seg, fp, B, st);
+    if (rc) return rc;
+    HeadParams hs;
+    head_params(m, m->seg, fp, hs);
+    RUN(PC_OTHER, 0, heads_fwd(m->seg.x_final, hs, 1, 1, m->seg.headout, m->seg.hstats, (int)Ms, m->seg.C, st));
+    RUN(PC_OTHER, 0, bones_mean_fwd(m->seg.headout, m->lengths, B, T, S, st));
+    MP_HIP(hipEventRecord(m->ev_join, m->st2));
+    st = main_st;
+    use_scratch(m, 0);
+    MP_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
+  }
   // manifold decoder (pose_decoder.py:32-55)
   RUN(PC_OTHER, 0, fk_decode_fwd(m->rot.headout, m->rot.O, m->lengths, poses, B, K, T, st));
   return MP_OK;
@@ -603,6 +640,7 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   hipStream_t st = (hipStream_t)stream;
   const int B = m->B, T = m->cfg.num_frame, J = m->cfg.num_joints, S = m->cfg.num_bones, K = m->rot.K;
   const long Mr = (long)B * T * J, Ms = (long)B * T * S;
+  use_scratch(m, 0);
   // decoder
   RUN(PC_OTHER, 0, fk_decode_bwd(m->rot.headout, m->rot.O, m->lengths, d_poses, m->rot.dheadout, m->dlen_pose, B, K, T, st));
   if (m->cfg.arch == 0) {
@@ -618,6 +656,10 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     RUN(PC_OTHER, 0, scores_bwd(m->rot.headout, sc, d_scores ? d_scores : m->dscore_zero, sp, sg, K, m->rot.O, m->rot.dheadout, B, T, J,
                                 m->small, m->small_floats, st));
   }
+  // fork: the bones-net backward only needs the per-pose length gradients of the decoder backward
+  MP_HIP(hipEventRecord(m->ev_fork, st));
+  MP_HIP(hipStreamWaitEvent(m->st2, m->ev_fork, 0));
+  use_scratch(m, 0);
   // rotations module
   HeadParams hp;
   HeadGrads hg;
@@ -629,18 +671,27 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   if (rc) return rc;
   RUN(PC_OTHER, 0, embed_bwd(m->g, m->x_in, G(m, fg, m->rot.emb_w), G(m, fg, m->rot.emb_b), G(m, fg, m->rot.spos), (int)Mr, m->rot.C, J,
                              m->small, m->small_floats, st));
-  // segments module
-  RUN(PC_OTHER, 0, bones_mean_bwd(m->dlen_pose, K * T, nullptr, m->seg.dheadout, B, T, S, st));
-  HeadParams hs;
-  HeadGrads hgs;
-  head_params(m, m->seg, fp, hs);
-  head_grads(m, m->seg, fg, hgs);
-  RUN(PC_OTHER, 0, heads_bwd(m->seg.x_final, m->seg.hstats, hs, hgs, 1, 1, m->seg.dheadout, m->g, (int)Ms, m->seg.C, m->small,
-                             m->small_floats, st));
-  rc = backbone_bwd(m, m->seg, fp, fg, B, st);
-  if (rc) return rc;
-  RUN(PC_OTHER, 0, bones_embed_bwd(m->g, m->x_in, G(m, fg, m->seg.emb_w), G(m, fg, m->seg.emb_b), G(m, fg, m->seg.spos), B * T, J * 2,
-                                   S * m->seg.C, m->small, m->small_floats, st));
+  // segments module, on the side stream with its own scratch set
+  {
+    hipStream_t main_st = st;
+    st = m->st2;
+    use_scratch(m, 1);
+    RUN(PC_OTHER, 0, bones_mean_bwd(m->dlen_pose, K * T, nullptr, m->seg.dheadout, B, T, S, st));
+    HeadParams hs;
+    HeadGrads hgs;
+    head_params(m, m->seg, fp, hs);
+    head_grads(m, m->seg, fg, hgs);
+    RUN(PC_OTHER, 0, heads_bwd(m->seg.x_final, m->seg.hstats, hs, hgs, 1, 1, m->seg.dheadout, m->g, (int)Ms, m->seg.C, m->small,
+                               m->small_floats, st));
+    rc = backbone_bwd(m, m->seg, fp, fg, B, st);
+    if (rc) return rc;
+    RUN(PC_OTHER, 0, bones_embed_bwd(m->g, m->x_in, G(m, fg, m->seg.emb_w), G(m, fg, m->seg.emb_b), G(m, fg, m->seg.spos), B * T, J * 2,
+                                     S * m->seg.C, m->small, m->small_floats, st));
+    MP_HIP(hipEventRecord(m->ev_join, m->st2));
+    st = main_st;
+    use_scratch(m, 0);
+    MP_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
+  }
   return MP_OK;
 }
 
