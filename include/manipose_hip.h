@@ -83,7 +83,7 @@ int mp_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
                      void* stream);
 int mp_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx,
                      float* dgamma, float* dbeta, int M, int C, float* scratch, int64_t scratch_floats, void* stream);
-/* y = x W^T + b (nn.Linear); epilogue 0 none, 1 GELU (z receives the pre-activation), 2 residual: y = r + y */
+/* y = x W^T + b (nn.Linear); epilogue 0 none, 1 GELU (z receives gelu'(x W^T + b), which is all the backward needs), 2 residual: y = r + y */
 int mp_linear_fwd(const float* x, const float* W, const float* b, float* y, float* z, const float* r, int M, int N, int K,
                   int epilogue, void* stream);
 /* dx = dy W ; dW += dy^T x ; db += colsum(dy).  slab >= workspace reported by mp_linear_bwd_slab_floats */

@@ -2,6 +2,7 @@
 // RMCLManifoldMixSTE (rmcl_manifold_mix_ste.py:83-106) / ManifoldMixSTE (manifold_mix_ste.py:75-88) natively,
 // one kernel stream, no host synchronisation, no tensor transposes.  The Python nn.Module mirror
 // (manipose_amd/architectures) only hands over device pointers.
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include "common.h"
@@ -56,6 +57,11 @@ struct mp_model {
   ScratchSet sets[2];
   hipStream_t st2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // weight-gradient GEMMs of the rotations net do not feed the backward chain: they run on a third stream, ordered against the
+  // chain's scratch-buffer reuse by events (E = "operand ready", W = "wgrad done reading")
+  hipStream_t st3 = nullptr;
+  hipEvent_t evE[2][4] = {}, evW[2][4] = {};
+  bool wgrad_async = false;
   // state of the last forward
   int B = 0;
   bool train = false;
@@ -360,7 +366,15 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
   const int half = m->cfg.precision == 1;
   float* g = m->g;
   bool post_done = false;
-  for (int l = L - 1; l >= 0; --l) {
+  // asynchronous weight gradients (rotations net on the main stream only)
+  const bool wasync = m->wgrad_async && md.is_rot && st != m->st2;
+  hipStream_t sw = wasync ? m->st3 : st;
+  bool have_prev = false;       // a previous block's W events exist
+  int par = 0;
+#define E_READY(i) do { if (wasync) { MP_HIP(hipEventRecord(m->evE[par][i], st)); MP_HIP(hipStreamWaitEvent(sw, m->evE[par][i], 0)); } } while (0)
+#define W_DONE(i) do { if (wasync) MP_HIP(hipEventRecord(m->evW[par][i], sw)); } while (0)
+#define WAIT_W(p, i) do { if (wasync) MP_HIP(hipStreamWaitEvent(st, m->evW[p][i], 0)); } while (0)
+  for (int l = L - 1; l >= 0; --l, par ^= 1) {
     const BlockP& q = md.bp[l];
     BlockWS& w = md.ws[l];
     const bool spatial = (l % 2 == 0);
@@ -381,15 +395,21 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
       RUN(PC_OTHER, 0, scale_rows(g, mk2, mode, m->tmpMask, 0, (int)M, C, T, N, st));
       gb = m->tmpMask;
     }
-    int rc = linear_wgrad(m, st, gb, 0, w.f, G(m, fg, q.f2w), G(m, fg, q.f2b), M, C, 2 * C);
+    E_READY(0);                                                    // gb is ready
+    int rc = linear_wgrad(m, sw, gb, 0, w.f, G(m, fg, q.f2w), G(m, fg, q.f2b), M, C, 2 * C);
     if (rc) return rc;
+    W_DONE(0);
+    if (have_prev) WAIT_W(par ^ 1, 1);                             // previous block's fc1 wgrad still reads tmp2C
     rc = linear_dgrad(m, st, fp, gb, 0, q.f2w, m->tmp2C, 0, M, C, 2 * C, w.z);
     if (rc) return rc;
     // (c) fc1
-    rc = linear_wgrad(m, st, m->tmp2C, 0, w.a2, G(m, fg, q.f1w), G(m, fg, q.f1b), M, 2 * C, C);
+    E_READY(1);                                                    // dz (tmp2C) is ready
+    rc = linear_wgrad(m, sw, m->tmp2C, 0, w.a2, G(m, fg, q.f1w), G(m, fg, q.f1b), M, 2 * C, C);
     if (rc) return rc;
+    W_DONE(1);
     rc = linear_dgrad(m, st, fp, m->tmp2C, 0, q.f1w, m->tmpC, 0, M, 2 * C, C, nullptr);     // d(norm2 out): bf16 in precision 1
     if (rc) return rc;
+    WAIT_W(par, 0);                                                // the fc2 wgrad must be done with gb before (d) rewrites it
     // (d) norm2 + skip
     const float* mk1 = branch_mask(m, md, l, 0, B, m->train);
     RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, m->g_b16, mk1, mode, T, N, G(m, fg, q.n2w),
@@ -400,18 +420,25 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
       RUN(PC_OTHER, 0, scale_rows(g, mk1, mode, m->tmpMask, 0, (int)M, C, T, N, st));
       gb = m->tmpMask;
     }
-    rc = linear_wgrad(m, st, gb, 0, w.ao, G(m, fg, q.pw), G(m, fg, q.pb), M, C, C);
+    E_READY(2);                                                    // gb (second half of the block) is ready
+    rc = linear_wgrad(m, sw, gb, 0, w.ao, G(m, fg, q.pw), G(m, fg, q.pb), M, C, C);
     if (rc) return rc;
+    W_DONE(2);
     rc = linear_dgrad(m, st, fp, gb, 0, q.pw, m->tmpC, 0, M, C, C, nullptr);          // d(attention out): bf16 in bf16 mode
     if (rc) return rc;
+    if (have_prev) WAIT_W(par ^ 1, 3);                             // previous block's qkv wgrad still reads tmp3C
     // (f) attention core
     if (spatial) RUN(PC_ATTN, 10.0 * B * T * N * N * C, attn_spatial_bwd(w.qkv, m->tmpC, m->tmp3C, half, B, T, N, C, H, st));
     else RUN(PC_ATTN, 10.0 * B * N * (double)T * T * C, attn_temporal_bwd(w.qkv, w.ao, m->tmpC, w.lse, m->delta, m->tmp3C, half, B, T, N, C, H, st));
     // (g) qkv
-    rc = linear_wgrad(m, st, m->tmp3C, 0, w.a1, G(m, fg, q.qkvw), G(m, fg, q.qkvb), M, 3 * C, C);
+    E_READY(3);                                                    // dqkv (tmp3C) is ready
+    rc = linear_wgrad(m, sw, m->tmp3C, 0, w.a1, G(m, fg, q.qkvw), G(m, fg, q.qkvb), M, 3 * C, C);
     if (rc) return rc;
+    W_DONE(3);
     rc = linear_dgrad(m, st, fp, m->tmp3C, 0, q.qkvw, m->tmpC, 0, M, 3 * C, C, nullptr);   // d(norm1 out): bf16 in precision 1
     if (rc) return rc;
+    WAIT_W(par, 2);                                                // the proj wgrad must be done with gb before (h) rewrites it
+    have_prev = true;
     // (h) norm1 + skip; for l >= 2 fused with the shared post-norm backward of block l-1 (its (a) step)
     if (l >= 2 && C <= 512) {
       const BlockP& qp = md.bp[l - 1];
@@ -429,6 +456,13 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
                            G(m, fg, q.n1b), (int)M, C, m->small, m->small_floats, st));
     }
   }
+  if (wasync && have_prev) {    // the last block's fc1 / qkv weight gradients
+    WAIT_W(par ^ 1, 1);
+    WAIT_W(par ^ 1, 3);
+  }
+#undef E_READY
+#undef W_DONE
+#undef WAIT_W
   return MP_OK;
 }
 
@@ -498,6 +532,21 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
     delete m;
     return MP_ERR_HIP;
   }
+  {
+    const char* ev = getenv("MANIPOSE_WGRAD_STREAM");
+    m->wgrad_async = !(ev && atoi(ev) == 0);
+    bool ok = hipStreamCreateWithFlags(&m->st3, hipStreamNonBlocking) == hipSuccess;
+    for (int a = 0; a < 2 && ok; ++a)
+      for (int b = 0; b < 4 && ok; ++b)
+        ok = hipEventCreateWithFlags(&m->evE[a][b], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&m->evW[a][b], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      set_error("mp_model_create: could not create the wgrad stream / events");
+      (void)hipFree(m->arena);
+      delete m;
+      return MP_ERR_HIP;
+    }
+  }
   e = hipMemset(m->dscore_zero, 0, sizeof(float) * (size_t)cfg->max_batch * m->rot.K * cfg->num_frame);
   if (e != hipSuccess) {
     set_error("mp_model_create: hipMemset failed: %s", hipGetErrorString(e));
@@ -513,6 +562,12 @@ void mp_model_destroy(mp_model* m) {
   if (!m) return;
   for (auto& e : m->ev) (void)hipEventDestroy(e);
   if (m->st2) { (void)hipStreamSynchronize(m->st2); (void)hipStreamDestroy(m->st2); }
+  if (m->st3) { (void)hipStreamSynchronize(m->st3); (void)hipStreamDestroy(m->st3); }
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 4; ++b) {
+      if (m->evE[a][b]) (void)hipEventDestroy(m->evE[a][b]);
+      if (m->evW[a][b]) (void)hipEventDestroy(m->evW[a][b]);
+    }
   if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
   if (m->ev_join) (void)hipEventDestroy(m->ev_join);
   if (m->arena) (void)hipFree(m->arena);

@@ -188,14 +188,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmB16Args g) {
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
       }
       if (EPI == EPI_BIAS_GELU) {
-        st4(Z + o, v);
-        v = make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
+        float4 c, d;     // cdf / pdf parts: f = x cdf, f' = cdf + x pdf; Z keeps f' (all the backward needs from z)
+        gelu_parts_fast(v.x, c.x, d.x); gelu_parts_fast(v.y, c.y, d.y); gelu_parts_fast(v.z, c.z, d.z); gelu_parts_fast(v.w, c.w, d.w);
+        st4(Z + o, make_float4(c.x + v.x * d.x, c.y + v.y * d.y, c.z + v.z * d.z, c.w + v.w * d.w));
+        v = make_float4(v.x * c.x, v.y * c.y, v.z * c.z, v.w * c.w);
       } else if (EPI == EPI_BIAS_RESID) {
         const float4 r = ld4(g.R + o);
         v = make_float4(r.x + dscale * v.x, r.y + dscale * v.y, r.z + dscale * v.z, r.w + dscale * v.w);
       } else if (EPI == EPI_DGELU) {
         const float4 z = ld4(Z + o);
-        v = make_float4(v.x * gelu_grad_fast(z.x), v.y * gelu_grad_fast(z.y), v.z * gelu_grad_fast(z.z), v.w * gelu_grad_fast(z.w));
+        v = make_float4(v.x * z.x, v.y * z.y, v.z * z.z, v.w * z.w);      // Z holds gelu'(pre-activation)
       }
       st4(C + o, v);
     }
@@ -413,15 +415,17 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
       const long o = (long)row * g.ldc + col;
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
       if (EPI == EPI_BIAS_GELU) {
-        st4(Z + o, v);
-        v = make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
+        float4 c, d;     // cdf / pdf parts: f = x cdf, f' = cdf + x pdf; Z keeps f' (all the backward needs from z)
+        gelu_parts_fast(v.x, c.x, d.x); gelu_parts_fast(v.y, c.y, d.y); gelu_parts_fast(v.z, c.z, d.z); gelu_parts_fast(v.w, c.w, d.w);
+        st4(Z + o, make_float4(c.x + v.x * d.x, c.y + v.y * d.y, c.z + v.z * d.z, c.w + v.w * d.w));
+        v = make_float4(v.x * c.x, v.y * c.y, v.z * c.z, v.w * c.w);
       } else if (EPI == EPI_BIAS_RESID) {
         const float dscale = droppath_scale(g.mask, g.mask_mode, row, g.T, g.J);
         const float4 r = ld4(g.R + o);
         v = make_float4(r.x + dscale * v.x, r.y + dscale * v.y, r.z + dscale * v.z, r.w + dscale * v.w);
       } else if (EPI == EPI_DGELU) {
         const float4 z = ld4(Z + o);
-        v = make_float4(v.x * gelu_grad_fast(z.x), v.y * gelu_grad_fast(z.y), v.z * gelu_grad_fast(z.z), v.w * gelu_grad_fast(z.w));
+        v = make_float4(v.x * z.x, v.y * z.y, v.z * z.z, v.w * z.w);      // Z holds gelu'(pre-activation)
       }
       st4(C + o, v);
     }

@@ -136,12 +136,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
         const long o = (long)row * g.ldc + col;
         float v = acc[mi][ni][r] + bias;
         if (EPI == EPI_BIAS_GELU) {
-          g.Z[o] = v;
+          g.Z[o] = gelu_grad_f(v);      // Z keeps gelu'(z): all the backward needs from the pre-activation
           v = gelu_f(v);
         } else if (EPI == EPI_BIAS_RESID) {
           v = g.R[o] + droppath_scale(g.mask, g.mask_mode, row, g.T, g.J) * v;
         } else if (EPI == EPI_DGELU) {
-          v *= gelu_grad_f(g.Z[o]);
+          v *= g.Z[o];
         }
         C[o] = v;
       }

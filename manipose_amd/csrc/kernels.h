@@ -14,7 +14,7 @@ struct GemmF32Args {
   long lda, ldb, ldc;
   int M, N, K;
   const float* bias;   // per output column, may be null
-  float* Z;            // EPI_BIAS_GELU: pre-activation (written); EPI_DGELU: pre-activation (read)
+  float* Z;            // EPI_BIAS_GELU: gelu'(pre-activation) (written); EPI_DGELU: the same (read)
   const float* R;      // EPI_BIAS_RESID: residual stream (read)
   const float* mask;   // EPI_BIAS_RESID: DropPath multipliers per sample, may be null
   int mask_mode, T, J; // see droppath_scale()
@@ -33,7 +33,7 @@ struct GemmB16Args {
   long lda, ldb, ldc;
   int M, N, K;
   const float* bias;
-  void* Z;             // pre-activation, element type of C
+  void* Z;             // gelu'(pre-activation) kept for the backward, element type of C
   const float* R;      // fp32 residual stream
   const float* mask;
   int mask_mode, T, J;

@@ -167,7 +167,9 @@ def test_linear_forward_epilogues_and_backward(lib, M, N, K):
     close(y, ref.float(), **tol)
     z = torch.empty(M, N, device="cuda")
     _lib.check(lib.mp_linear_fwd(xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), y.data_ptr(), z.data_ptr(), None, M, N, K, 1, st()))
-    close(z, ref.float(), **tol)
+    refg = ref.clone().requires_grad_(True)
+    torch.nn.functional.gelu(refg).sum().backward()
+    close(z, refg.grad.float(), **tol)                   # z keeps gelu'(pre-activation)
     close(y, torch.nn.functional.gelu(ref).float(), **tol)
     _lib.check(lib.mp_linear_fwd(xd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), y.data_ptr(), None, rd.data_ptr(), M, N, K, 2, st()))
     close(y, (ref + r.double()).float(), **tol)
@@ -396,7 +398,9 @@ def test_bf16_linear_forward_and_backward(lib, M, N, K):
     close(y.float(), ref.float(), rtol=1e-2, atol=1e-2)
     z = torch.empty_like(y)
     _lib.check(lib.mp_linear_fwd_bf16(xb.data_ptr(), Wb.data_ptr(), bd.data_ptr(), y.data_ptr(), z.data_ptr(), None, M, N, K, 1, st()))
-    close(z.float(), ref.float(), rtol=1e-2, atol=1e-2)
+    refg = ref.clone().requires_grad_(True)
+    torch.nn.functional.gelu(refg).sum().backward()
+    close(z.float(), refg.grad.float(), rtol=1e-2, atol=1e-2)      # z keeps gelu'(pre-activation)
     close(y.float(), torch.nn.functional.gelu(ref).float(), rtol=1e-2, atol=1e-2)
     y32 = torch.empty(M, N, device="cuda")
     _lib.check(lib.mp_linear_fwd_bf16(xb.data_ptr(), Wb.data_ptr(), bd.data_ptr(), y32.data_ptr(), None, rd.data_ptr(), M, N, K, 2, st()))
