@@ -1,4 +1,5 @@
 // extern "C" shims of the stand-alone operators declared in include/manipose_hip.h
+#include <string.h>
 #include "common.h"
 #include "kernels.h"
 #include "../../include/manipose_hip.h"
@@ -138,6 +139,15 @@ int mp_attention_bwd_bf16(const void* qkv, const void* out, const void* d_out, c
   MP_CHECK(qkv && d_out && d_qkv && (!temporal || (out && lse && delta)), MP_ERR_ARG, "mp_attention_bwd_bf16: null pointer");
   return temporal ? attn_temporal_bwd(qkv, out, d_out, lse, delta, d_qkv, 1, B, T, J, C, H, (hipStream_t)stream)
                   : attn_spatial_bwd(qkv, d_out, d_qkv, 1, B, T, J, C, H, (hipStream_t)stream);
+}
+
+/* test / tuning hooks: "gemm_small_tile" (1 = 128x128 tiles everywhere), "gemm_persist_min_tiles" (tile count from which the
+ * persistent GEMM kernel runs; 0 = default) */
+int mp_set_option(const char* name, int value) {
+  MP_CHECK(name, MP_ERR_ARG, "mp_set_option: null name");
+  if (!strcmp(name, "gemm_small_tile")) { gemm_bf16_force_small_tile(value != 0); return MP_OK; }
+  if (!strcmp(name, "gemm_persist_min_tiles")) { gemm_bf16_persist_min_tiles(value); return MP_OK; }
+  MP_CHECK(false, MP_ERR_ARG, "mp_set_option: unknown option '%s'", name);
 }
 
 }  // extern "C"

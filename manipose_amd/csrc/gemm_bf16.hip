@@ -268,6 +268,59 @@ __device__ __forceinline__ bf16x8_t read_frag2(const char* __restrict__ S, int o
   }
 }
 
+// One k-tile (GBK = 64) of MFMAs for a wave's (BT/2) x 64 sub-tile, fragment reads software-pipelined: the ds_reads of
+// step s+1 are issued before the 8 MFMAs of step s.
+template <int TRA, int TRB, int BT>
+__device__ __forceinline__ void mma_stage(const char* __restrict__ As, const char* __restrict__ Bs, f32x4 (&acc)[BT / 32][4], int wr, int wc,
+                                          int lane) {
+  constexpr int MI = BT / 32;
+  constexpr int HS = MI / 2, NSTEP = (GBK / 32) * HS;
+  bf16x8_t b_cur[4], b_nxt[4], a_cur[2], a_nxt[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b_cur[j] = read_frag2<TRB, BT>(Bs, wc * 64 + j * 16, 0, lane);
+  a_cur[0] = read_frag2<TRA, BT>(As, wr * (BT / 2), 0, lane);
+  a_cur[1] = read_frag2<TRA, BT>(As, wr * (BT / 2) + 16, 0, lane);
+#pragma unroll
+  for (int step = 0; step < NSTEP; ++step) {
+    const int ip = step % HS;
+    if (step + 1 < NSTEP) {
+      const int nks = (step + 1) / HS, nip = (step + 1) % HS;
+      a_nxt[0] = read_frag2<TRA, BT>(As, wr * (BT / 2) + (2 * nip) * 16, nks, lane);
+      a_nxt[1] = read_frag2<TRA, BT>(As, wr * (BT / 2) + (2 * nip + 1) * 16, nks, lane);
+      if (nip == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b_nxt[j] = read_frag2<TRB, BT>(Bs, wc * 64 + j * 16, nks, lane);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[2 * ip][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[j], a_cur[0], acc[2 * ip][j], 0, 0, 0);   // C^T tile
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[2 * ip + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[j], a_cur[1], acc[2 * ip + 1][j], 0, 0, 0);
+    // pin the order "next step's LDS reads, then this step's 8 MFMAs" (hipcc otherwise sinks the reads behind the MFMAs
+    // and exposes their latency before every group)
+    if (step + 1 < NSTEP) {
+      if ((step + 1) % HS == 0) {            // A and B fragments of the next k-step
+        if (TRA && TRB) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+        else if (TRB) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+        else if (TRA) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+      } else {
+        if (TRA) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    if (step + 1 < NSTEP) {
+      a_cur[0] = a_nxt[0];
+      a_cur[1] = a_nxt[1];
+      if ((step + 1) % HS == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b_cur[j] = b_nxt[j];
+      }
+    }
+  }
+}
+
 // BT x BT output tile (BT = 128: 4 waves, 256: 8 waves); waves laid out 2 x (BT/64); each wave (BT/2) x 64.
 template <int TRA, int TRB, typename TC, int EPI, int BT>
 __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
@@ -328,54 +381,7 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
           bsum += __uint_as_float((unsigned)(*reinterpret_cast<const unsigned short*>(As + r * (BT * 2) + ((oc ^ t_swz(r)) << 4) + wi * 2)) << 16);
       }
     }
-    // software-pipelined fragment reads: the ds_reads of step s+1 are issued before the 8 MFMAs of step s
-    {
-      constexpr int HS = MI / 2, NSTEP = (GBK / 32) * HS;
-      bf16x8_t b_cur[4], b_nxt[4], a_cur[2], a_nxt[2];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b_cur[j] = read_frag2<TRB, BT>(Bs, wc * 64 + j * 16, 0, lane);
-      a_cur[0] = read_frag2<TRA, BT>(As, wr * (BT / 2), 0, lane);
-      a_cur[1] = read_frag2<TRA, BT>(As, wr * (BT / 2) + 16, 0, lane);
-#pragma unroll
-      for (int step = 0; step < NSTEP; ++step) {
-        const int ip = step % HS;
-        if (step + 1 < NSTEP) {
-          const int nks = (step + 1) / HS, nip = (step + 1) % HS;
-          a_nxt[0] = read_frag2<TRA, BT>(As, wr * (BT / 2) + (2 * nip) * 16, nks, lane);
-          a_nxt[1] = read_frag2<TRA, BT>(As, wr * (BT / 2) + (2 * nip + 1) * 16, nks, lane);
-          if (nip == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b_nxt[j] = read_frag2<TRB, BT>(Bs, wc * 64 + j * 16, nks, lane);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[2 * ip][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[j], a_cur[0], acc[2 * ip][j], 0, 0, 0);   // C^T tile
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[2 * ip + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[j], a_cur[1], acc[2 * ip + 1][j], 0, 0, 0);
-        // pin the order "next step's LDS reads, then this step's 8 MFMAs" (hipcc otherwise sinks the reads behind the MFMAs
-        // and exposes their latency before every group)
-        if (step + 1 < NSTEP) {
-          if ((step + 1) % HS == 0) {            // A and B fragments of the next k-step
-            if (TRA && TRB) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-            else if (TRB) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
-            else if (TRA) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-            else __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-          } else {
-            if (TRA) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-          }
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        if (step + 1 < NSTEP) {
-          a_cur[0] = a_nxt[0];
-          a_cur[1] = a_nxt[1];
-          if ((step + 1) % HS == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b_cur[j] = b_nxt[j];
-          }
-        }
-      }
-    }
+    mma_stage<TRA, TRB, BT>(As, Bs, acc, wr, wc, lane);
   }
 
   if ((g.debug & 4) && acc[0][0][0] != 12345.678f) return;
@@ -432,6 +438,207 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   }
 }
 
+// =================================================================================================================
+// Persistent form of the 256 x 256 direct-to-LDS kernel, for problems with many more tiles than CUs (the forward and
+// dgrad GEMMs of the token stream: K = 512..1536 is only 8..24 k-tiles, so the per-tile fixed costs - workgroup launch,
+// the latency of the first DMA, the store drain - are as long as the main loop).  One workgroup per CU walks the tiles
+// id, id + G, ...; the two-stage k pipeline runs ACROSS tiles (the DMA of the next tile's first k-tile is issued during
+// the last k-tile of the current one), and the epilogue transposes through a wave-private 4 KiB LDS image that lies
+// outside the operand stages, so its stores drain while the next tile's first k-tile is multiplied.
+// Tile order: workgroup w runs on XCD w & 7 (round-robin dispatch); in every round each XCD owns G/8 consecutive
+// row-major tiles, i.e. a few complete tile rows: the A rows are shared through that XCD's L2, the weights stay in it.
+// =================================================================================================================
+// Per-lane byte offsets of the 4 DMA instructions a wave issues per operand and k-tile, relative to the (wave-uniform)
+// address of the tile's first element of that k-tile; the same source swizzles as glds_tile.  Rows past the end of the
+// matrix are clamped to its last row (their products are never stored), so no lane needs a different base.
+template <int TR>
+__device__ __forceinline__ void persist_offsets(unsigned (&off)[4], long ld, int out0, int OUT, int lane, int wave) {
+#pragma unroll
+  for (int n4 = 0; n4 < 4; ++n4) {
+    const int c = 64 * (wave * 4 + n4) + lane;
+    if (TR == 0) {
+      const int row = c >> 3, kg = (c & 7) ^ (row & 7);
+      off[n4] = (unsigned)(min(row, OUT - 1 - out0) * (int)ld * 2 + kg * 16);
+    } else {
+      const int rr = c >> 5, oc = (c & 31) ^ t_swz(rr);      // OUT % 256 == 0 (launcher): every chunk is in range
+      off[n4] = (unsigned)(rr * (int)ld * 2 + oc * 16);
+    }
+  }
+}
+__device__ __forceinline__ void persist_dma(char* __restrict__ S, const char* __restrict__ base, const unsigned (&off)[4], int wave) {
+  typedef __attribute__((address_space(3))) void* lptr;
+  typedef const __attribute__((address_space(1))) void* gptr;
+#pragma unroll
+  for (int n4 = 0; n4 < 4; ++n4) __builtin_amdgcn_global_load_lds((gptr)(base + off[n4]), (lptr)(S + (wave * 4 + n4) * 1024), 16, 0, 0);
+}
+
+// Epilogue of one wave's 128 x 64 sub-tile: 16 rows per pass are written to the wave-private image in the accumulator layout
+// (lane = row, 4 consecutive columns; 16-byte chunks XOR-swizzled by the row) and read back row-major, so residual / gelu'
+// loads and the stores are full lines, 16 lanes per row.  FULL = the tile has no rows past M: no predicates, and the
+// loads of a pass are issued together ahead of its stores.
+template <typename TC, int EPI, bool FULL>
+__device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32x4 (&acc)[8][4], float* __restrict__ img, int row0, int col,
+                                                 const float4& bias4, TC* __restrict__ C, TC* __restrict__ Z, int l15, int gq) {
+  constexpr bool LOADS = (EPI == EPI_BIAS_RESID || EPI == EPI_DGELU);
+  const float* const mk = (EPI == EPI_BIAS_RESID && g.mask != nullptr && g.mask_mode != 0) ? g.mask : nullptr;
+  float4 in_nxt[4];
+  float ds_nxt[4];
+  // the residual / gelu' rows (and DropPath scales) of pass i+1 are requested BEFORE the stores of pass i are issued: memory
+  // operations retire in order, so a pass never waits for the previous pass's stores.
+  auto request = [&](int i) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = row0 + i * 16 + it * 4 + gq;
+      const int rc = FULL ? row : min(row, g.M - 1);
+      const long o = (long)rc * g.ldc + col;
+      if (LOADS) in_nxt[it] = (EPI == EPI_DGELU) ? ld4(Z + o) : ld4(g.R + o);
+      ds_nxt[it] = 1.0f;
+      if (EPI == EPI_BIAS_RESID && mk != nullptr)
+        ds_nxt[it] = mk[g.mask_mode == 1 ? rc / g.J : (rc / (g.T * g.J)) * g.J + rc % g.J];     // == droppath_scale
+    }
+  };
+  if (LOADS) request(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float4 in[4];
+    float ds[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { in[it] = in_nxt[it]; ds[it] = ds_nxt[it]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(img + l15 * 64 + (((4 * j + gq) ^ l15) << 2)) = acc[i][j];
+    if (LOADS && i + 1 < 8) request(i + 1);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int lr = it * 4 + gq;
+      const int row = row0 + i * 16 + lr;
+      float4 v = *reinterpret_cast<const float4*>(img + lr * 64 + ((l15 ^ lr) << 2));
+      const long o = (long)row * g.ldc + col;
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      if (EPI == EPI_BIAS_GELU) {
+        float4 c, d;     // cdf / pdf parts: f = x cdf, f' = cdf + x pdf; Z keeps f' (all the backward needs from z)
+        gelu_parts_fast(v.x, c.x, d.x); gelu_parts_fast(v.y, c.y, d.y); gelu_parts_fast(v.z, c.z, d.z); gelu_parts_fast(v.w, c.w, d.w);
+        if (FULL || row < g.M) st4(Z + o, make_float4(c.x + v.x * d.x, c.y + v.y * d.y, c.z + v.z * d.z, c.w + v.w * d.w));
+        v = make_float4(v.x * c.x, v.y * c.y, v.z * c.z, v.w * c.w);
+      } else if (EPI == EPI_BIAS_RESID) {
+        v = make_float4(in[it].x + ds[it] * v.x, in[it].y + ds[it] * v.y, in[it].z + ds[it] * v.z, in[it].w + ds[it] * v.w);
+      } else if (EPI == EPI_DGELU) {
+        v = make_float4(v.x * in[it].x, v.y * in[it].y, v.z * in[it].z, v.w * in[it].w);      // Z holds gelu'(pre-activation)
+      }
+      if (FULL || row < g.M) st4(C + o, v);
+    }
+  }
+}
+
+template <int TRB, typename TC, int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, int tiles_n, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BT = 256, WN = 4, MI = 8, OPB = BT * 128, STAGE = 2 * OPB;
+  const char* const A = reinterpret_cast<const char*>(g.A);
+  const char* const B = reinterpret_cast<const char*>(g.B);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  const int per_xcd = gridDim.x >> 3;                       // gridDim.x is a multiple of 8
+  int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (id >= ntiles) return;
+  const int nk = g.K / GBK;                                 // K % 64 == 0, nk >= 2 (launcher)
+  int m0 = (id / tiles_n) * BT, n0 = (id % tiles_n) * BT;
+  unsigned aoff[4], boff[4];
+  persist_offsets<0>(aoff, g.lda, m0, g.M, lane, wave);
+  persist_offsets<TRB>(boff, g.ldb, 0, BT, lane, wave);     // N % 256 == 0: the same for every tile
+  // byte address of (tile origin, reduction index k) of each operand
+  auto a_base = [&](int mm, int k) { return A + ((long)mm * g.lda + k) * 2; };
+  auto b_base = [&](int nn, int k) { return TRB ? B + ((long)k * g.ldb + nn) * 2 : B + ((long)nn * g.ldb + k) * 2; };
+  persist_dma(smem, a_base(m0, 0), aoff, wave);
+  persist_dma(smem + OPB, b_base(n0, 0), boff, wave);
+  int stage = 0;
+  bool landed = false;                                      // this tile's first k-tile was already waited for (before the previous epilogue)
+  TC* const C = reinterpret_cast<TC*>(g.C);
+  TC* const Z = reinterpret_cast<TC*>(g.Z);
+  float* const img = reinterpret_cast<float*>(smem + 2 * STAGE + wave * 4096);
+  const bool has_bias = EPI != EPI_DGELU && g.bias != nullptr;
+
+  while (true) {
+    const int idn = id + gridDim.x;
+    const bool has_next = idn < ntiles;
+    const int m0n = (idn / tiles_n) * BT, n0n = (idn % tiles_n) * BT;
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int ks = 0; ks < nk; ++ks, stage ^= 1) {
+      // k-tile ks has landed for every wave and nobody still reads the other stage.  On a tile's first k-tile the DMA was
+      // waited for before the previous epilogue: do not wait for that epilogue's stores here, they drain under this k-tile.
+      if (ks == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only
+      else __builtin_amdgcn_s_waitcnt(0x0070);                        // vmcnt(0) lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+      const char* As = smem + stage * STAGE;
+      const char* Bs = As + OPB;
+      char* nx = smem + (stage ^ 1) * STAGE;
+      const bool last = ks + 1 == nk;
+      if (!(g.debug & 2) && (!last || has_next)) {
+        if (last) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+        persist_dma(nx, a_base(last ? m0n : m0, last ? 0 : (ks + 1) * GBK), aoff, wave);
+        persist_dma(nx + OPB, b_base(last ? n0n : n0, last ? 0 : (ks + 1) * GBK), boff, wave);
+      }
+      if (last && has_bias) {      // this wave's 64 bias values -> its (idle) epilogue image, 4 bytes per lane; covered by the vmcnt(0) below
+        typedef __attribute__((address_space(3))) void* lptr;
+        typedef const __attribute__((address_space(1))) void* gptr;
+        __builtin_amdgcn_global_load_lds((gptr)(g.bias + n0 + wc * 64 + lane), (lptr)img, 4, 0, 0);
+      }
+      if (!(g.debug & 1)) mma_stage<0, TRB, BT>(As, Bs, acc, wr, wc, lane);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): the next tile's first k-tile (issued one k-tile ago)
+    landed = true;
+
+    // ---- epilogue, 16 rows of the wave's 128 x 64 sub-tile per pass through the wave-private image ----
+    if (!(g.debug & 4)) {
+      // the lane indices pass through an opaque move so that the epilogue's address arithmetic is redone per tile instead of
+      // being hoisted out of the tile loop, where it would sit in ~20 VGPRs across the main loop (the kernel runs at the
+      // 256-VGPR limit of two waves per SIMD)
+      int e15 = lane & 15, eq = lane >> 4;
+      asm volatile("" : "+v"(e15), "+v"(eq));
+      const int col = n0 + wc * 64 + 4 * e15;               // < N: N % 256 == 0
+      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_bias) bias4 = *reinterpret_cast<const float4*>(img + 4 * e15);
+      if (m0 + BT <= g.M) persist_epilogue<TC, EPI, true>(g, acc, img, m0 + wr * 128, col, bias4, C, Z, e15, eq);
+      else persist_epilogue<TC, EPI, false>(g, acc, img, m0 + wr * 128, col, bias4, C, Z, e15, eq);
+    }
+    if (!has_next) break;
+    id = idn; m0 = m0n; n0 = n0n;
+  }
+}
+
+static int g_persist_min_tiles = 0;        // test hook: 0 = default (2 tiles per workgroup), else the tile count from which the persistent kernel runs
+void gemm_bf16_persist_min_tiles(int n) { g_persist_min_tiles = n; }
+
+static int persist_workgroups() {
+  static int n = -1;
+  if (n < 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    const char* e = getenv("MANIPOSE_GEMM_PERSIST");      // 0 disables the persistent kernel (A/B timing)
+    n = (e && atoi(e) == 0) ? 0 : (cus / 8) * 8;
+  }
+  return n;
+}
+
+template <int TRB, typename TC, int EPI>
+static int launch_persist(const GemmB16Args& g, int wgs, hipStream_t st) {
+  constexpr size_t lds = 2 * 2 * 256 * 128 + 8 * 4096;     // two operand stages + the epilogue images = 160 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    MP_HIP(hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<TRB, TC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int tiles_n = cdiv(g.N, 256), ntiles = tiles_n * cdiv(g.M, 256);
+  hipLaunchKernelGGL((gemm_bf16_persist_kernel<TRB, TC, EPI>), dim3(wgs), dim3(512), lds, st, g, tiles_n, ntiles);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
 static bool g_force_small_tile = false;    // test hook: exercise the 128x128 instantiation on big shapes too
 void gemm_bf16_force_small_tile(bool on) { g_force_small_tile = on; }
 
@@ -458,6 +665,12 @@ static bool use_big_tile(const GemmB16Args& g) {
 }
 template <int TRA, int TRB, typename TC, int EPI>
 static int launch_glds(const GemmB16Args& g, int splits, hipStream_t st) {
+  if constexpr (TRA == 0 && EPI != EPI_SLAB) {
+    const int wgs = persist_workgroups();
+    if (wgs > 0 && splits == 1 && use_big_tile(g) && g.K >= 2 * GBK && g.K % GBK == 0 && (long)cdiv(g.N, 256) * cdiv(g.M, 256) >= (g_persist_min_tiles > 0 ? (long)g_persist_min_tiles : 2L * wgs) &&
+        256L * g.lda * 2 < (1L << 31) && 64L * g.ldb * 2 < (1L << 31) && 256L * g.ldb * 2 < (1L << 31))
+      return launch_persist<TRB, TC, EPI>(g, wgs, st);
+  }
   return use_big_tile(g) ? launch_glds_bt<TRA, TRB, TC, EPI, 256>(g, splits, st) : launch_glds_bt<TRA, TRB, TC, EPI, 128>(g, splits, st);
 }
 

@@ -46,6 +46,8 @@ int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, 
 int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
                float* slab, long slab_floats, hipStream_t st);
 int cast_to_bf16(const float* src, bf16* dst, long n, hipStream_t st);
+void gemm_bf16_force_small_tile(bool on);          // test hooks (mp_set_option)
+void gemm_bf16_persist_min_tiles(int n);
 
 // ---------------------------------------------------------------- elementwise.hip
 struct LnFwdArgs {

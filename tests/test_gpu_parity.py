@@ -382,7 +382,7 @@ def test_cpu_tensor_is_refused_loudly(lib):
 BF16_MPJPE_TOL_M = 1e-2     # documented drift bound of the bf16 matrix-core mode vs the fp32 reference
 
 
-@pytest.mark.parametrize("M,N,K", [(306, 96, 32), (130, 48, 16), (4131, 1536, 512), (1000, 512, 1024)])
+@pytest.mark.parametrize("M,N,K", [(306, 96, 32), (130, 48, 16), (4131, 1536, 512), (1000, 512, 1024), (66100, 512, 512)])
 def test_bf16_linear_forward_and_backward(lib, M, N, K):
     """bf16 MFMA GEMMs (N/T operand layouts incl. the hardware-transpose-read path) against an fp64 product of the SAME
     bf16-rounded operands: only accumulation order and output rounding differ."""
@@ -557,3 +557,36 @@ def test_batched_flip_tta_matches_two_pass_reference_procedure(lib):
     orac = (orc.aggregate(p0, mode="oracle", ground_truth=y)[1] + orc.aggregate(hyp_f, mode="oracle", ground_truth=y)[1]) / 2
     want_o = 1000.0 * orc.mpjpe_error(orac, y).item()
     assert abs(got["oracle_mpjpe"] - want_o) <= 1e-3 * want_o + 0.05, (got, want_o)
+
+
+def test_bf16_persistent_gemm_path_matches_tiled_path(lib):
+    """The persistent 256x256 GEMM kernel (used from 512 output tiles up, i.e. only at training batch sizes) forced on at
+    small sizes: forward outputs and every gradient of the train-mode (DropPath masks injected) bf16 model must agree with
+    the one-tile-per-workgroup kernels, which the fixtures above pin to the reference."""
+    from manipose_amd import RMCLManifoldMixSTE, _lib, h36m_skeleton
+    B, T = 6, 27
+    outs = []
+    for min_tiles in (0, 1):
+        _lib.check(lib.mp_set_option(b"gemm_persist_min_tiles", min_tiles))
+        try:
+            torch.manual_seed(7)
+            model = RMCLManifoldMixSTE(n_hyp=3, skeleton=h36m_skeleton(), num_frame=T, embed_dim_rot=256, depth_rot=2, num_heads_rot=4,
+                                       embed_dim_seg=256, depth_seg=2, num_heads_seg=4, drop_path_rate=0.3).cuda().train()
+            model.precision = "bf16"
+            x = torch.randn(B, T, 17, 2, generator=torch.Generator().manual_seed(3)).cuda()
+            model.flat_parameters()
+            model._ensure_engine(B, x.device)
+            gen = torch.Generator().manual_seed(11)
+            model.set_droppath_masks({name: (torch.rand(cnt, generator=gen) > 0.3).float() / 0.7
+                                      for name, _, cnt, _ in model._engine.mask_layout(B)})
+            poses, scores = model(x)
+            (poses.square().sum() + scores.square().sum()).backward()
+            outs.append((poses.detach().clone(), scores.detach().clone(),
+                         torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()))
+        finally:
+            _lib.check(lib.mp_set_option(b"gemm_persist_min_tiles", 0))
+    assert torch.isfinite(outs[1][2]).all()
+    close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-5)
+    close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-5)
+    assert _cos(outs[0][2], outs[1][2]) > 0.99999
+    assert (outs[0][2] - outs[1][2]).abs().max() <= 1e-4 * outs[0][2].abs().max()
