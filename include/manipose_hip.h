@@ -81,6 +81,7 @@ int mp_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
 /* Building blocks exposed for unit parity tests (same kernels the model engine launches). */
 int mp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* stats, int M, int C,
                      void* stream);
+/* scratch: >= 1024 * 2 * C floats (per-workgroup dgamma/dbeta partials, reduced deterministically) */
 int mp_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx,
                      float* dgamma, float* dbeta, int M, int C, float* scratch, int64_t scratch_floats, void* stream);
 /* y = x W^T + b (nn.Linear); epilogue 0 none, 1 GELU (z receives gelu'(x W^T + b), which is all the backward needs), 2 residual: y = r + y */

@@ -47,14 +47,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int C = a.C;
-  for (int m = wave; m < a.M; m += nwaves) {
-    float4 v[LN_MAXV];
+  auto load_row = [&](int m, float4 (&v)[LN_MAXV]) {
     const float* xr = a.x + (long)m * C;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = lane * 4 + 256 * i;
       if (c < C) v[i] = ld4(xr + c);
     }
+  };
+  auto finish_row = [&](int m, float4 (&v)[LN_MAXV]) {
     if (a.g1 != nullptr) {
       float mean, rstd;
       row_stats(v, lane, C, a.eps1, mean, rstd);
@@ -104,6 +105,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
         a.stats2[2 * (long)m + 1] = rstd;
       }
     }
+  };
+  // two rows in flight per wave: the second row's loads are outstanding while the first row is reduced and stored
+  for (int m = wave; m < a.M; m += 2 * nwaves) {
+    float4 va[LN_MAXV], vb[LN_MAXV];
+    const int mb = m + nwaves;
+    load_row(m, va);
+    if (mb < a.M) load_row(mb, vb);
+    finish_row(m, va);
+    if (mb < a.M) finish_row(mb, vb);
   }
 }
 
@@ -125,73 +135,95 @@ int ln_fwd(const LnFwdArgs& a, int out_bf16, hipStream_t st) {
 // dxhat = dy * gamma.  dgamma/dbeta: per-wave register sums -> per-block LDS sum -> partial rows
 // in scratch -> reduce_partials_kernel (deterministic, no atomics).
 // ---------------------------------------------------------------------------------------------
-constexpr int LNB_GRID = 512;
+constexpr int LNB_GRID = 1024;   // 4 workgroups (16 waves) per CU
 
-template <typename TDY>
+// V float4 per lane (C <= 256 V); R rows in flight per wave: every load of the R rows (x, dy, skip gradient, statistics, DropPath
+// scale) is issued before the first row is reduced.
+template <typename TDY, int V, int R>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
                                                       const float* dskip, float* dx, bf16* __restrict__ dx_b16,
                                                       const float* __restrict__ mask, int mask_mode, int T, int J,
                                                       float* __restrict__ partial, int M, int C) {
-  __shared__ float red[4 * 2 * 1024];  // [wave][dgamma|dbeta][C<=1024]
+  __shared__ float red[4 * 2 * 256 * V];  // [wave][dgamma|dbeta][C <= 256 V]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  float4 dg[LN_MAXV], db[LN_MAXV], gm[LN_MAXV];
+  float4 dg[V], db[V], gm[V];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < V; ++i) {
     dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int c = lane * 4 + 256 * i;
     gm[i] = (c < C) ? ld4(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int m = wave; m < M; m += nwaves) {
-    const float mean = stats[2 * (long)m], rstd = stats[2 * (long)m + 1];
-    float4 xh[LN_MAXV], d[LN_MAXV];
-    float s1 = 0.f, s2 = 0.f;
+  for (int m0 = wave; m0 < M; m0 += R * nwaves) {
+    float4 xv[R][V], g[R][V], k[R][V];
+    float mean[R], rstd[R], ms[R];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = lane * 4 + 256 * i;
-      if (c < C) {
-        const float4 xv = ld4(x + (long)m * C + c);
-        const float4 g = ld4(dy + (long)m * C + c);
-        xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-        dg[i].x += g.x * xh[i].x; dg[i].y += g.y * xh[i].y; dg[i].z += g.z * xh[i].z; dg[i].w += g.w * xh[i].w;
-        db[i].x += g.x; db[i].y += g.y; db[i].z += g.z; db[i].w += g.w;
-        d[i] = make_float4(g.x * gm[i].x, g.y * gm[i].y, g.z * gm[i].z, g.w * gm[i].w);
-        s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
-        s2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
+    for (int r = 0; r < R; ++r) {
+      const int m = m0 + r * nwaves;
+      if (m < M) {
+        mean[r] = stats[2 * (long)m];
+        rstd[r] = stats[2 * (long)m + 1];
+        ms[r] = (dx_b16 != nullptr) ? droppath_scale(mask, mask_mode, __builtin_amdgcn_readfirstlane(m), T, J) : 1.0f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const int c = lane * 4 + 256 * i;
+          if (c < C) {
+            xv[r][i] = ld4(x + (long)m * C + c);
+            g[r][i] = ld4(dy + (long)m * C + c);
+            k[r][i] = (dskip != nullptr) ? ld4(dskip + (long)m * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
       }
     }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
-    const float ms = (dx_b16 != nullptr) ? droppath_scale(mask, mask_mode, __builtin_amdgcn_readfirstlane(m), T, J) : 1.0f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = lane * 4 + 256 * i;
-      if (c < C) {
-        float4 o;
-        o.x = rstd * (d[i].x - s1 - xh[i].x * s2);
-        o.y = rstd * (d[i].y - s1 - xh[i].y * s2);
-        o.z = rstd * (d[i].z - s1 - xh[i].z * s2);
-        o.w = rstd * (d[i].w - s1 - xh[i].w * s2);
-        if (dskip != nullptr) {
-          const float4 k = ld4(dskip + (long)m * C + c);
-          o.x += k.x; o.y += k.y; o.z += k.z; o.w += k.w;
+    for (int r = 0; r < R; ++r) {
+      const int m = m0 + r * nwaves;
+      if (m >= M) break;
+      float4 xh[V], d[V];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < C) {
+          const float4 gg = g[r][i];
+          xh[i] = make_float4((xv[r][i].x - mean[r]) * rstd[r], (xv[r][i].y - mean[r]) * rstd[r], (xv[r][i].z - mean[r]) * rstd[r],
+                              (xv[r][i].w - mean[r]) * rstd[r]);
+          dg[i].x += gg.x * xh[i].x; dg[i].y += gg.y * xh[i].y; dg[i].z += gg.z * xh[i].z; dg[i].w += gg.w * xh[i].w;
+          db[i].x += gg.x; db[i].y += gg.y; db[i].z += gg.z; db[i].w += gg.w;
+          d[i] = make_float4(gg.x * gm[i].x, gg.y * gm[i].y, gg.z * gm[i].z, gg.w * gm[i].w);
+          s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+          s2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
         }
-        st4(dx + (long)m * C + c, o);
-        if (dx_b16 != nullptr)     // bf16 copy, pre-scaled by the consumer branch's DropPath mask: A operand of its GEMMs
-          st4(dx_b16 + (long)m * C + c, make_float4(o.x * ms, o.y * ms, o.z * ms, o.w * ms));
+      }
+      s1 = wave_sum(s1) / (float)C;
+      s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < C) {
+          float4 o;
+          o.x = rstd[r] * (d[i].x - s1 - xh[i].x * s2);
+          o.y = rstd[r] * (d[i].y - s1 - xh[i].y * s2);
+          o.z = rstd[r] * (d[i].z - s1 - xh[i].z * s2);
+          o.w = rstd[r] * (d[i].w - s1 - xh[i].w * s2);
+          if (dskip != nullptr) { o.x += k[r][i].x; o.y += k[r][i].y; o.z += k[r][i].z; o.w += k[r][i].w; }
+          st4(dx + (long)m * C + c, o);
+          if (dx_b16 != nullptr)     // bf16 copy, pre-scaled by the consumer branch's DropPath mask: A operand of its GEMMs
+            st4(dx_b16 + (long)m * C + c, make_float4(o.x * ms[r], o.y * ms[r], o.z * ms[r], o.w * ms[r]));
+        }
       }
     }
   }
   // block reduction of dgamma/dbeta
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < V; ++i) {
     const int c = lane * 4 + 256 * i;
     if (c < C) {
-      *reinterpret_cast<float4*>(&red[(wv * 2 + 0) * 1024 + c]) = dg[i];
-      *reinterpret_cast<float4*>(&red[(wv * 2 + 1) * 1024 + c]) = db[i];
+      *reinterpret_cast<float4*>(&red[(wv * 2 + 0) * 256 * V + c]) = dg[i];
+      *reinterpret_cast<float4*>(&red[(wv * 2 + 1) * 256 * V + c]) = db[i];
     }
   }
   __syncthreads();
@@ -199,7 +231,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     const int which = i / C, c = i - which * C;
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * 1024 + c];
+    for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * 256 * V + c];
     partial[(long)blockIdx.x * 2 * C + i] = s;
   }
 }
@@ -240,12 +272,12 @@ int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, cons
   MP_CHECK(C % 4 == 0 && C <= 1024, MP_ERR_ARG, "ln_bwd: C=%d unsupported", C);
   const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
   MP_CHECK(scratch_floats >= (long)grid * 2 * C, MP_ERR_ARG, "ln_bwd: scratch too small");
-  if (dy_bf16)
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dy, x, stats, gamma, dskip, dx, (bf16*)dx_b16, mask,
-                       mask ? mask_mode : 0, T, J, scratch, M, C);
-  else
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, x, stats, gamma, dskip, dx, (bf16*)dx_b16,
-                       mask, mask ? mask_mode : 0, T, J, scratch, M, C);
+#define MP_LN_BWD(TDY, V, R)                                                                                                             \
+  hipLaunchKernelGGL((ln_bwd_kernel<TDY, V, R>), dim3(grid), dim3(256), 0, st, (const TDY*)dy, x, stats, gamma, dskip, dx, (bf16*)dx_b16, \
+                     mask, mask ? mask_mode : 0, T, J, scratch, M, C)
+  if (C <= 512) { if (dy_bf16) MP_LN_BWD(bf16, 2, 2); else MP_LN_BWD(float, 2, 2); }
+  else          { if (dy_bf16) MP_LN_BWD(bf16, 4, 1); else MP_LN_BWD(float, 4, 1); }
+#undef MP_LN_BWD
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dgamma, dbeta, nullptr, nullptr}, {0, C, 2 * C, 2 * C, 2 * C}, {1, 1, 1, 1}};
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, scratch, grid, 2 * C, d);
@@ -281,13 +313,27 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy
   for (int m = wave; m < M; m += nwaves) {
     float4 xh[V], d[V], t[V];
     float s1 = 0.f, s2 = 0.f;
+    // every input of the row is requested up front (the second norm's operands used to be loaded behind the first reduction)
     const float mean1 = stats1[2 * (long)m], rstd1 = stats1[2 * (long)m + 1];
+    const float mean0 = stats0[2 * (long)m], rstd0 = stats0[2 * (long)m + 1];
+    const float ms = (dx_b16 != nullptr) ? droppath_scale(mask, mask_mode, __builtin_amdgcn_readfirstlane(m), T, J) : 1.0f;
+    float4 xv1[V], gy[V], kk[V], xv0[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < C) {
+        xv1[i] = ld4(x1 + (long)m * C + c);
+        gy[i] = ld4(dy1 + (long)m * C + c);
+        kk[i] = ld4(dskip + (long)m * C + c);
+        xv0[i] = ld4(x0 + (long)m * C + c);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const int c = lane * 4 + 256 * i;
       xh[i] = d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < C) {
-        const float4 xv = ld4(x1 + (long)m * C + c), g = ld4(dy1 + (long)m * C + c);
+        const float4 xv = xv1[i], g = gy[i];
         xh[i] = make_float4((xv.x - mean1) * rstd1, (xv.y - mean1) * rstd1, (xv.z - mean1) * rstd1, (xv.w - mean1) * rstd1);
         acc[0][i].x += g.x * xh[i].x; acc[0][i].y += g.y * xh[i].y; acc[0][i].z += g.z * xh[i].z; acc[0][i].w += g.w * xh[i].w;
         acc[1][i].x += g.x; acc[1][i].y += g.y; acc[1][i].z += g.z; acc[1][i].w += g.w;
@@ -298,14 +344,13 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy
     }
     s1 = wave_sum(s1) / (float)C;
     s2 = wave_sum(s2) / (float)C;
-    const float mean0 = stats0[2 * (long)m], rstd0 = stats0[2 * (long)m + 1];
     float u1 = 0.f, u2 = 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const int c = lane * 4 + 256 * i;
       t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < C) {
-        const float4 k = ld4(dskip + (long)m * C + c), xv = ld4(x0 + (long)m * C + c);
+        const float4 k = kk[i], xv = xv0[i];
         t[i].x = rstd1 * (d[i].x - s1 - xh[i].x * s2) + k.x;
         t[i].y = rstd1 * (d[i].y - s1 - xh[i].y * s2) + k.y;
         t[i].z = rstd1 * (d[i].z - s1 - xh[i].z * s2) + k.z;
@@ -320,7 +365,6 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy
     }
     u1 = wave_sum(u1) / (float)C;
     u2 = wave_sum(u2) / (float)C;
-    const float ms = (dx_b16 != nullptr) ? droppath_scale(mask, mask_mode, __builtin_amdgcn_readfirstlane(m), T, J) : 1.0f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const int c = lane * 4 + 256 * i;

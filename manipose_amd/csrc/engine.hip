@@ -166,7 +166,7 @@ static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int half
 }
 
 static long small_scratch_floats(const mp_model* m) {
-  long s = 512L * 4 * 1024;                                                        // ln_bwd / ln_bwd2 partials
+  long s = 1024L * 4 * 1024;                                                       // ln_bwd / ln_bwd2 partials (LNB_GRID rows)
   const Module* mods[2] = {&m->rot, &m->seg};
   for (const Module* md : mods) s = max(s, 512L * md->K * ((long)md->O * md->C + md->O + 2 * md->C));   // heads_bwd
   s = max(s, 128L * (3 + m->rot.N) * m->rot.C);                                   // embed_bwd

@@ -144,7 +144,7 @@ def test_layernorm_forward_backward(lib, M, C):
     close(y, y_ref, rtol=1e-5, atol=2e-6)
     dx = torch.empty(M, C, device="cuda")
     dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-    scratch = torch.empty(512 * 2 * C + 16, device="cuda")
+    scratch = torch.empty(1024 * 2 * C + 16, device="cuda")       # LN-backward partials: 1024 workgroups x [dgamma | dbeta]
     _lib.check(lib.mp_layernorm_bwd(dyd.data_ptr(), xd.data_ptr(), stats.data_ptr(), gd.data_ptr(),
                                     dsd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M, C,
                                     scratch.data_ptr(), scratch.numel(), st()))
