@@ -169,7 +169,8 @@ int mp_prof_enable(mp_model* m, int on);
 int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops);
 
 /* test / tuning hooks (no reference counterpart): "gemm_small_tile" (1 = 128x128 GEMM tiles everywhere),
- * "gemm_persist_min_tiles" (output-tile count from which the persistent GEMM kernel is used; 0 = default). */
+ * "gemm_persist_min_tiles" (output-tile count from which the persistent GEMM kernels are used; 0 = default),
+ * "gemm_persist_mode" (0 tiled kernels only, 1 = default: persistent kernel where it applies). */
 int mp_set_option(const char* name, int value);
 
 #ifdef __cplusplus

@@ -142,11 +142,12 @@ int mp_attention_bwd_bf16(const void* qkv, const void* out, const void* d_out, c
 }
 
 /* test / tuning hooks: "gemm_small_tile" (1 = 128x128 tiles everywhere), "gemm_persist_min_tiles" (tile count from which the
- * persistent GEMM kernel runs; 0 = default) */
+ * persistent GEMM kernels run; 0 = default), "gemm_persist_mode" (0 tiled kernels only, 1 persistent kernel where it applies) */
 int mp_set_option(const char* name, int value) {
   MP_CHECK(name, MP_ERR_ARG, "mp_set_option: null name");
   if (!strcmp(name, "gemm_small_tile")) { gemm_bf16_force_small_tile(value != 0); return MP_OK; }
   if (!strcmp(name, "gemm_persist_min_tiles")) { gemm_bf16_persist_min_tiles(value); return MP_OK; }
+  if (!strcmp(name, "gemm_persist_mode")) { gemm_bf16_persist_mode(value); return MP_OK; }
   MP_CHECK(false, MP_ERR_ARG, "mp_set_option: unknown option '%s'", name);
 }
 

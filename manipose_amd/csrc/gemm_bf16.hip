@@ -614,15 +614,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
 static int g_persist_min_tiles = 0;        // test hook: 0 = default (2 tiles per workgroup), else the tile count from which the persistent kernel runs
 void gemm_bf16_persist_min_tiles(int n) { g_persist_min_tiles = n; }
 
+// 0 tiled kernels only, 1 (default) the persistent kernel where it applies; env MANIPOSE_GEMM_PERSIST or
+// mp_set_option("gemm_persist_mode") for A/B timing and tests
+static int g_persist_mode = -1;
+void gemm_bf16_persist_mode(int mode) { g_persist_mode = mode; }
 static int persist_workgroups() {
   static int n = -1;
   if (n < 0) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-    const char* e = getenv("MANIPOSE_GEMM_PERSIST");      // 0 disables the persistent kernel (A/B timing)
-    n = (e && atoi(e) == 0) ? 0 : (cus / 8) * 8;
+    n = (cus / 8) * 8;
   }
-  return n;
+  if (g_persist_mode < 0) {
+    const char* e = getenv("MANIPOSE_GEMM_PERSIST");
+    g_persist_mode = e ? atoi(e) : 1;
+  }
+  return g_persist_mode == 0 ? 0 : n;
 }
 
 template <int TRB, typename TC, int EPI>

@@ -48,6 +48,7 @@ int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, i
 int cast_to_bf16(const float* src, bf16* dst, long n, hipStream_t st);
 void gemm_bf16_force_small_tile(bool on);          // test hooks (mp_set_option)
 void gemm_bf16_persist_min_tiles(int n);
+void gemm_bf16_persist_mode(int mode);
 
 // ---------------------------------------------------------------- elementwise.hip
 struct LnFwdArgs {

@@ -386,6 +386,20 @@ BF16_MPJPE_TOL_M = 1e-2     # documented drift bound of the bf16 matrix-core mod
 def test_bf16_linear_forward_and_backward(lib, M, N, K):
     """bf16 MFMA GEMMs (N/T operand layouts incl. the hardware-transpose-read path) against an fp64 product of the SAME
     bf16-rounded operands: only accumulation order and output rounding differ."""
+    _bf16_linear_case(lib, M, N, K)
+
+
+def test_bf16_linear_tiled_kernels_on_the_persistent_kernel_shape(lib):
+    """Same check on the large shape with the persistent kernel switched off (one tile per workgroup)."""
+    from manipose_amd import _lib
+    _lib.check(lib.mp_set_option(b"gemm_persist_mode", 0))
+    try:
+        _bf16_linear_case(lib, 66100, 512, 512)
+    finally:
+        _lib.check(lib.mp_set_option(b"gemm_persist_mode", 1))
+
+
+def _bf16_linear_case(lib, M, N, K):
     from manipose_amd import _lib
     g = torch.Generator().manual_seed(M * 3 + N + K)
     x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
@@ -566,7 +580,7 @@ def test_bf16_persistent_gemm_path_matches_tiled_path(lib):
     from manipose_amd import RMCLManifoldMixSTE, _lib, h36m_skeleton
     B, T = 6, 27
     outs = []
-    for min_tiles in (0, 1):
+    for min_tiles in (0, 1):                              # tiled kernels (too few tiles for the default rule) / persistent kernel forced
         _lib.check(lib.mp_set_option(b"gemm_persist_min_tiles", min_tiles))
         try:
             torch.manual_seed(7)
@@ -585,8 +599,9 @@ def test_bf16_persistent_gemm_path_matches_tiled_path(lib):
                          torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()))
         finally:
             _lib.check(lib.mp_set_option(b"gemm_persist_min_tiles", 0))
-    assert torch.isfinite(outs[1][2]).all()
-    close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-5)
-    close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-5)
-    assert _cos(outs[0][2], outs[1][2]) > 0.99999
-    assert (outs[0][2] - outs[1][2]).abs().max() <= 1e-4 * outs[0][2].abs().max()
+    for o in outs[1:]:
+        assert torch.isfinite(o[2]).all()
+        close(outs[0][0], o[0], rtol=1e-5, atol=1e-5)
+        close(outs[0][1], o[1], rtol=1e-5, atol=1e-5)
+        assert _cos(outs[0][2], o[2]) > 0.99999
+        assert (outs[0][2] - o[2]).abs().max() <= 1e-4 * outs[0][2].abs().max()
