@@ -26,7 +26,11 @@ constexpr int TP = 256;            // padded frames
 constexpr int NTILE = TP / 16;
 
 template <int D> struct ACfg {
-  static constexpr int ROWB = 2 * D + 16;              // LDS bytes per frame row
+  // LDS bytes per frame row.  Head dim 64: exactly 128 B, the 16-byte chunk index XOR-swizzled by (frame & 7) - conflict-free for
+  // both the row reads (ds_read_b128) and the transpose reads (ds_read_b64_tr_b16); a 16-byte pad (144 B rows) made both of them
+  // 2-way conflicted (45 % of the LDS cycles were conflict cycles).  Head dim 16: 32 B + 16 B pad.
+  static constexpr int ROWB = D == 64 ? 128 : 2 * D + 16;
+  static __device__ __forceinline__ int swz(int row) { return D == 64 ? (row & 7) : 0; }
   static constexpr int KS = (D + 31) / 32;             // k-steps of the d-reductions
   static constexpr int DB = D / 16;                    // 16-wide d blocks of the t-reductions
   static constexpr int CH = D / 8;                     // 16-byte chunks per row
@@ -40,34 +44,57 @@ __device__ __forceinline__ void stage_rows(char* __restrict__ S, const bf16* __r
     const int t = idx / CH, c = idx - t * CH;
     uint4 x = make_uint4(0u, 0u, 0u, 0u);
     if (t < T) x = *reinterpret_cast<const uint4*>(base + (long)t * row_stride + c * 8);
-    *reinterpret_cast<uint4*>(S + t * ROWB + c * 16) = x;
+    *reinterpret_cast<uint4*>(S + t * ROWB + ((c ^ ACfg<D>::swz(t)) << 4)) = x;
   }
 }
 
-// 8 consecutive d (d = 32*ks + 8*(lane>>4) ...) of frame row0 + (lane & 15): A operand [row][d] or B operand [d][col=row]
-template <int D>
-__device__ __forceinline__ bf16x8_t frag_rows(const char* __restrict__ S, int row0, int ks, int lane) {
-  const int g = lane >> 4;
-  const int d0 = 32 * ks + 8 * g;
-  bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (D < 32 && d0 >= D) return z;                       // head dim 16: upper half of the 32-deep step is zero padding
-  return *reinterpret_cast<const bf16x8_t*>(S + (row0 + (lane & 15)) * ACfg<D>::ROWB + d0 * 2);
-}
-
-// A operand [d = 16*db + (lane&15)][kappa] of a product reducing over 32 frames starting at t0, with the reduction index
-// permuted as kappa = 8g + i  <->  frame t0 + 4g + i (i < 4), t0 + 16 + 4g + (i - 4) (i >= 4): exactly the frames whose
-// scores lane group g holds in the accumulators of the two 16-frame score tiles (pack_acc below).
-template <int D>
-__device__ __forceinline__ bf16x8_t frag_cols_perm(const char* __restrict__ S, int t0, int db, int lane) {
-  typedef bf16x4_t __attribute__((address_space(3))) * lds_ptr;
-  const int li = lane & 15, q = li >> 2, p = li & 3, g = lane >> 4;
-  const char* a0 = S + (t0 + 4 * g + q) * ACfg<D>::ROWB + (16 * db + 4 * p) * 2;
-  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
-  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0 + 16 * ACfg<D>::ROWB));
-  bf16x8_t f;
-  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-  return f;
-}
+// Reader of one LDS image.  The per-lane byte offsets of its two access patterns are computed once, INCLUDING the image's base
+// offset, and made opaque to the optimizer: every LDS address in the hot loops is then one VGPR + a uniform row offset, instead
+// of a chain of adds re-deriving it from the lane id and an image base that does not fit the 16-bit DS offset field.
+//   rows(ks, row0): 8 consecutive d (d = 32 ks + 8 (lane >> 4) ...) of frame row0 + (lane & 15): the A operand [row][d] or the
+//                   B operand [d][col = row] of a product reducing over d;
+//   cols(db, t0):   the A operand [d = 16 db + (lane & 15)][kappa] of a product reducing over the 32 frames from t0, with the
+//                   reduction index permuted as kappa = 8g + i <-> frame t0 + 4g + i (i < 4), t0 + 16 + 4g + (i - 4) (i >= 4):
+//                   exactly the frames whose scores lane group g holds in the accumulators of two 16-frame score tiles
+//                   (pack_acc below); two hardware transpose reads (ds_read_b64_tr_b16).
+template <int D> struct ImgRd {
+  int fr[ACfg<D>::KS], tc[ACfg<D>::DB];
+  bool zero;                                           // head dim 16: the upper half of the 32-deep step is zero padding
+  __device__ __forceinline__ void init(const char* img, int lane) {
+    constexpr int ROWB = ACfg<D>::ROWB;
+    // 32-bit LDS address of the image (its relocated base folded in here, once, instead of an add per access)
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    const int img_off = (int)(unsigned)(size_t)((lds_cptr)img);
+    const int l15 = lane & 15, g = lane >> 4, q = l15 >> 2, p = l15 & 3;
+    zero = D < 32 && 8 * g >= D;
+#pragma unroll
+    for (int ks = 0; ks < ACfg<D>::KS; ++ks) {
+      fr[ks] = img_off + l15 * ROWB + (((4 * ks + g) ^ ACfg<D>::swz(l15)) << 4);
+      asm volatile("" : "+v"(fr[ks]));
+    }
+#pragma unroll
+    for (int db = 0; db < ACfg<D>::DB; ++db) {
+      const int row = 4 * g + q;                       // + t0 (a multiple of 8: same swizzle); the second read is 16 rows further
+      tc[db] = img_off + row * ROWB + (((2 * db + (p >> 1)) ^ ACfg<D>::swz(row)) << 4) + (p & 1) * 8;
+      asm volatile("" : "+v"(tc[db]));
+    }
+  }
+  __device__ __forceinline__ bf16x8_t rows(int ks, int row0) const {
+    typedef const bf16x8_t __attribute__((address_space(3))) * lds_ptr8;
+    bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (D < 32 && zero) return z;
+    return *(lds_ptr8)(size_t)(unsigned)(fr[ks] + row0 * ACfg<D>::ROWB);
+  }
+  __device__ __forceinline__ bf16x8_t cols(int db, int t0) const {
+    typedef bf16x4_t __attribute__((address_space(3))) * lds_ptr;
+    const unsigned a0 = (unsigned)(tc[db] + t0 * ACfg<D>::ROWB);
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(size_t)(a0));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(size_t)(a0 + 16 * ACfg<D>::ROWB));
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  }
+};
 
 // two 16x16 accumulator tiles (rows 4g+r of frames [t0, t0+16) and [t0+16, t0+32), column on the lane) -> B fragment
 __device__ __forceinline__ bf16x8_t pack_acc(const f32x4& a, const f32x4& b) {
@@ -96,8 +123,12 @@ __device__ __forceinline__ void store4(bf16* p, const f32x4& v, float s) {
 // =============================================================================================
 // forward: O = softmax(scale Q K^T) V ; lse = log sum exp of the scaled scores
 // =============================================================================================
-template <int D>
-__global__ __launch_bounds__(256) void attn_tmfma_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+// 8 waves per workgroup, <= 128 VGPRs: two workgroups (72 KiB of LDS each) = 16 waves per CU, to cover the MFMA -> softmax -> MFMA
+// dependency chain of a strip with other strips' work
+// NTC: compile-time number of 16-frame tiles (16 for the 243-frame windows: every loop over tiles fully unrolled, LDS row offsets
+// become instruction immediates, the padding mask exists in the last tile only) or 0 (run-time count, rolled loops).
+template <int D, int NTC>
+__global__ __launch_bounds__(512, 4) void attn_tmfma_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                               float* __restrict__ lse, int T, int J, int C, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB;
@@ -107,11 +138,15 @@ __global__ __launch_bounds__(256) void attn_tmfma_fwd_kernel(const bf16* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const long rs3 = (long)J * 3 * C;
   const bf16* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;
-  stage_rows<D, 256>(Ks, qb + C, rs3, T, tid);
-  stage_rows<D, 256>(Vs, qb + 2 * C, rs3, T, tid);
+  stage_rows<D, 512>(Ks, qb + C, rs3, T, tid);
+  stage_rows<D, 512>(Vs, qb + 2 * C, rs3, T, tid);
   __syncthreads();
-  const int ntile = (T + 15) >> 4;
-  for (int qt = wave; qt < ntile; qt += 4) {
+  const int ntile = NTC ? NTC : (T + 15) >> 4;
+  ImgRd<D> Kr, Vr;
+  Kr.init(Ks, lane);
+  Vr.init(Vs, lane);
+  const float scale2 = scale * 1.4426950408889634f;    // softmax evaluated as 2^(x log2 e): one v_exp_f32 per score, no extra multiply
+  for (int qt = wave; qt < ntile; qt += 8) {
     const int tq = qt * 16 + l15;                      // this lane's query (column of every tile below)
     bf16x8_t bq[KS];
 #pragma unroll
@@ -120,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_tmfma_fwd_kernel(const bf16* __restr
       bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
       bq[ks] = (tq < T && d0 < D) ? *reinterpret_cast<const bf16x8_t*>(qb + (long)tq * rs3 + d0) : z;
     }
-    // scores^T strip: s[kt][r] = scale * K[kt*16 + 4g + r] . Q[tq]
+    // scores^T strip in the log2 domain: s[kt][r] = (scale log2 e) K[kt*16 + 4g + r] . Q[tq]; only the last key tile has padding
     f32x4 s[NTILE];
     float mx = -INFINITY;
 #pragma unroll
@@ -128,26 +163,34 @@ __global__ __launch_bounds__(256) void attn_tmfma_fwd_kernel(const bf16* __restr
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (kt < ntile) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<D>(Ks, kt * 16, ks, lane), bq[ks], acc, 0, 0, 0);
-      }
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kr.rows(ks, kt * 16), bq[ks], acc, 0, 0, 0);
+        acc *= scale2;
+        if (kt == ntile - 1) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = (kt * 16 + 4 * g + r < T) ? acc[r] * scale : -INFINITY;
-        acc[r] = v;
-        mx = fmaxf(mx, v);
+          for (int r = 0; r < 4; ++r)
+            if (kt * 16 + 4 * g + r >= T) acc[r] = -INFINITY;
+        }
+        mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+      } else {
+        acc = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       }
       s[kt] = acc;
     }
     mx = group_max(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < NTILE; ++kt)
+    for (int kt = 0; kt < NTILE; ++kt) {
+      if (kt < ntile) {
+        const f32x4 t = s[kt] - mx;
+        f32x4 e;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __expf(s[kt][r] - mx);
-        s[kt][r] = e;
-        sum += e;
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+        s[kt] = e;
+        sum += (e[0] + e[1]) + (e[2] + e[3]);
+      } else {
+        s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+    }
     sum = group_sum(sum);
     // O^T[d][tq] = sum_t V[t][d] P[tq][t]
     f32x4 o[DB];
@@ -158,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_tmfma_fwd_kernel(const bf16* __restr
       if (2 * kp < ntile) {
         const bf16x8_t bp = pack_acc(s[2 * kp], s[2 * kp + 1]);
 #pragma unroll
-        for (int db = 0; db < DB; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_perm<D>(Vs, kp * 32, db, lane), bp, o[db], 0, 0, 0);
+        for (int db = 0; db < DB; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vr.cols(db, kp * 32), bp, o[db], 0, 0, 0);
       }
     }
     if (tq < T) {
@@ -166,7 +209,7 @@ __global__ __launch_bounds__(256) void attn_tmfma_fwd_kernel(const bf16* __restr
       bf16* orow = out + ((long)(b * T + tq) * J + j) * C + h * D;
 #pragma unroll
       for (int db = 0; db < DB; ++db) store4(orow + 16 * db + 4 * g, o[db], inv);
-      if (g == 0) lse[(long)unit * T + tq] = mx + __logf(sum);
+      if (g == 0) lse[(long)unit * T + tq] = (mx + __log2f(sum)) * 0.6931471805599453f;      // natural-log units
     }
   }
 }
@@ -174,158 +217,153 @@ __global__ __launch_bounds__(256) void attn_tmfma_fwd_kernel(const bf16* __restr
 // =============================================================================================
 // backward: dQ, dK, dV from Q, K, V, O, dO and the saved log-sum-exp
 // =============================================================================================
-template <int D>
-__global__ __launch_bounds__(512) void attn_tmfma_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
-                                                              const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                              bf16* __restrict__ dqkv, int T, int J, int C, int H, float scale,
-                                                              int debug) {
+// One workgroup of 16 waves (<= 128 VGPRs) per (window, joint, head): Q, K, V, dO staged once (4 x 36 KiB + statistics = 146 KiB,
+// one workgroup per CU); wave w owns the 16-query strip w in pass A (dQ) and the 16-key strip w in pass B (dK, dV) and takes
+// its own strip's fragments from the LDS images like everyone else's.  16 waves (instead of 8 with two strips each) cover the
+// MFMA -> exp -> MFMA dependency chain of a strip with other strips' work.
+template <int D, int NTC>
+__global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                               const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                               bf16* __restrict__ dqkv, int T, int J, int C, int H, float scale,
+                                                               int debug) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
-  constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB;
+  constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB, NW = 16;
   char* Qs = sm;
   char* Ks = Qs + TP * ROWB;
   char* Vs = Ks + TP * ROWB;
   char* Gs = Vs + TP * ROWB;                           // dO
-  float* Ls = reinterpret_cast<float*>(Gs + TP * ROWB);  // log-sum-exp per query (+inf for padding -> p = 0)
-  float* Dl = Ls + TP;                                 // delta = sum_d dO * O per query
+  float* Ls = reinterpret_cast<float*>(Gs + TP * ROWB);  // MINUS the log2-domain log-sum-exp per query (-inf for padding -> p = 0)
+  float* Dl = Ls + TP;                                 // MINUS delta = -sum_d dO * O per query
   const int unit = blockIdx.x, h = unit % H, bj = unit / H, j = bj % J, b = bj / J;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const long rs3 = (long)J * 3 * C, rs1 = (long)J * C;
   const bf16* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;
   const bf16* ob = out + ((long)b * T * J + j) * C + h * D;
   const bf16* gb = dout + ((long)b * T * J + j) * C + h * D;
-  stage_rows<D, 512>(Qs, qb, rs3, T, tid);
-  stage_rows<D, 512>(Ks, qb + C, rs3, T, tid);
-  stage_rows<D, 512>(Vs, qb + 2 * C, rs3, T, tid);
-  stage_rows<D, 512>(Gs, gb, rs1, T, tid);
-  if (tid < TP) {
+  stage_rows<D, 1024>(Qs, qb, rs3, T, tid);
+  stage_rows<D, 1024>(Ks, qb + C, rs3, T, tid);
+  stage_rows<D, 1024>(Vs, qb + 2 * C, rs3, T, tid);
+  stage_rows<D, 1024>(Gs, gb, rs1, T, tid);
+  {   // delta and log-sum-exp: 4 threads per frame, each a quarter of the head dim
+    const int t = tid >> 2, part = tid & 3;
     float dl = 0.f;
-    if (tid < T) {
+    if (t < T) {
 #pragma unroll
-      for (int c = 0; c < D; c += 4) {
-        const float4 a = ld4(gb + (long)tid * rs1 + c), o4 = ld4(ob + (long)tid * rs1 + c);
+      for (int c = part * (D / 4); c < (part + 1) * (D / 4); c += 4) {
+        const float4 a = ld4(gb + (long)t * rs1 + c), o4 = ld4(ob + (long)t * rs1 + c);
         dl += (a.x * o4.x + a.y * o4.y) + (a.z * o4.z + a.w * o4.w);
       }
     }
-    Dl[tid] = dl;
-    Ls[tid] = (tid < T) ? lse[(long)unit * T + tid] : INFINITY;
+    dl += __shfl_xor(dl, 1, 64);
+    dl += __shfl_xor(dl, 2, 64);
+    if (part == 0) {
+      Dl[t] = -dl;                                        // stored negated: ds = p (dp + (-delta)) is a packed add + a packed multiply
+      Ls[t] = (t < T) ? lse[(long)unit * T + t] * -1.4426950408889634f : -INFINITY;    // MINUS lse in log2 units
+    }
   }
   __syncthreads();
-  const int ntile = (T + 15) >> 4;
+  const int ntile = NTC ? NTC : (T + 15) >> 4;
   bf16* dq_base = dqkv + ((long)b * T * J + j) * 3 * C + h * D;
   if (debug & 1) return;                                 // timing ablation: staging only
+  const float scale2 = scale * 1.4426950408889634f;    // p = 2^(s scale log2 e - lse log2 e)
+  ImgRd<D> Qr, Kr, Vr, Gr;
+  Qr.init(Qs, lane);
+  Kr.init(Ks, lane);
+  Vr.init(Vs, lane);
+  Gr.init(Gs, lane);
 
-  // ---- phase A: dQ.  Each wave iteration owns TWO 16-query strips so that every K / V fragment read from LDS feeds two
-  // MFMAs (scores in the [key][query] orientation: query on the lane, 4 keys per accumulator) ----
-  for (int qp0 = wave; 2 * qp0 < ntile; qp0 += 8) {
-    const int qtA = 2 * qp0, qtB = 2 * qp0 + 1;       // qtB may be an all-padding strip (Ls = +inf there)
-    const int tqA = qtA * 16 + l15, tqB = qtB * 16 + l15;
-    bf16x8_t bqA[KS], bgA[KS], bqB[KS], bgB[KS];
+  // ---- pass A: dQ (scores in the [key][query] orientation: query on the lane, 4 keys per accumulator) ----
+  for (int qt = wave; qt < ntile; qt += NW) {
+    const int tq = qt * 16 + l15;
+    bf16x8_t bq[KS], bg[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bqA[ks] = frag_rows<D>(Qs, qtA * 16, ks, lane); bgA[ks] = frag_rows<D>(Gs, qtA * 16, ks, lane);
-      bqB[ks] = frag_rows<D>(Qs, qtB * 16, ks, lane); bgB[ks] = frag_rows<D>(Gs, qtB * 16, ks, lane);
+      bq[ks] = Qr.rows(ks, qt * 16);
+      bg[ks] = Gr.rows(ks, qt * 16);
     }
-    const float LA = Ls[tqA], dlA = Dl[tqA], LB = Ls[tqB], dlB = Dl[tqB];
-    f32x4 dqA[DB], dqB[DB];
+    const float nL = Ls[tq], ndl = Dl[tq];
+    f32x4 dq[DB];
 #pragma unroll
-    for (int db = 0; db < DB; ++db) { dqA[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dqB[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int db = 0; db < DB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll(NTC ? NTC / 2 : 1)
     for (int kp = 0; 2 * kp < ntile; ++kp) {
-      f32x4 dsA[2], dsB[2];
+      f32x4 ds[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int kt = 2 * kp + hf;
-        f32x4 sA = {0.f, 0.f, 0.f, 0.f}, pA = {0.f, 0.f, 0.f, 0.f}, sB = {0.f, 0.f, 0.f, 0.f}, pB = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8_t kf = frag_rows<D>(Ks, kt * 16, ks, lane), vf = frag_rows<D>(Vs, kt * 16, ks, lane);
-          sA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bqA[ks], sA, 0, 0, 0);
-          sB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bqB[ks], sB, 0, 0, 0);
-          pA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, bgA[ks], pA, 0, 0, 0);
-          pB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, bgB[ks], pB, 0, 0, 0);
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kr.rows(ks, kt * 16), bq[ks], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vr.rows(ks, kt * 16), bg[ks], dp, 0, 0, 0);
         }
+        const f32x4 t = sc * scale2 + nL;
+        f32x4 e;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool kok = kt * 16 + 4 * g + r < T;
-          const float eA = kok ? __expf(sA[r] * scale - LA) : 0.f, eB = kok ? __expf(sB[r] * scale - LB) : 0.f;
-          dsA[hf][r] = eA * (pA[r] - dlA);
-          dsB[hf][r] = eB * (pB[r] - dlB);
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+        if (kt >= ntile - 1) {                         // key padding exists in the last tile only (and in the tile past an odd count)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kt * 16 + 4 * g + r >= T) e[r] = 0.f;
         }
+        ds[hf] = e * (dp + ndl);
       }
-      const bf16x8_t bA = pack_acc(dsA[0], dsA[1]), bB = pack_acc(dsB[0], dsB[1]);
+      const bf16x8_t bd = pack_acc(ds[0], ds[1]);
 #pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        const bf16x8_t kT = frag_cols_perm<D>(Ks, kp * 32, db, lane);
-        dqA[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, bA, dqA[db], 0, 0, 0);
-        dqB[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, bB, dqB[db], 0, 0, 0);
-      }
+      for (int db = 0; db < DB; ++db) dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kr.cols(db, kp * 32), bd, dq[db], 0, 0, 0);
     }
+    if (tq < T) {
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      if (tqA < T) store4(dq_base + (long)tqA * rs3 + 16 * db + 4 * g, dqA[db], scale);
-      if (tqB < T) store4(dq_base + (long)tqB * rs3 + 16 * db + 4 * g, dqB[db], scale);
+      for (int db = 0; db < DB; ++db) store4(dq_base + (long)tq * rs3 + 16 * db + 4 * g, dq[db], scale);
     }
   }
-
   if (debug & 2) return;                                 // timing ablation: no dK/dV pass
-  // ---- phase B: dK, dV, two 16-key strips per wave iteration (scores in the [query][key] orientation) ----
-  for (int kp0 = wave; 2 * kp0 < ntile; kp0 += 8) {
-    const int ktA = 2 * kp0, ktB = 2 * kp0 + 1;
-    const int tkA = ktA * 16 + l15, tkB = ktB * 16 + l15;
-    bf16x8_t bkA[KS], bvA[KS], bkB[KS], bvB[KS];
+
+  // ---- pass B: dK, dV (scores in the [query][key] orientation) ----
+  for (int kt = wave; kt < ntile; kt += NW) {
+    const int tk = kt * 16 + l15;
+    bf16x8_t bk[KS], bv[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bkA[ks] = frag_rows<D>(Ks, ktA * 16, ks, lane); bvA[ks] = frag_rows<D>(Vs, ktA * 16, ks, lane);
-      bkB[ks] = frag_rows<D>(Ks, ktB * 16, ks, lane); bvB[ks] = frag_rows<D>(Vs, ktB * 16, ks, lane);
+      bk[ks] = Kr.rows(ks, kt * 16);
+      bv[ks] = Vr.rows(ks, kt * 16);
     }
-    f32x4 dkA[DB], dvA[DB], dkB[DB], dvB[DB];
+    f32x4 dk[DB], dv[DB];
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      dkA[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvA[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dkB[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvB[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int db = 0; db < DB; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll(NTC ? NTC / 2 : 1)
     for (int qp = 0; 2 * qp < ntile; ++qp) {
-      f32x4 pA2[2], dA2[2], pB2[2], dB2[2];
+      f32x4 p2[2], d2[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int qt = 2 * qp + hf;
-        f32x4 sA = {0.f, 0.f, 0.f, 0.f}, gA = {0.f, 0.f, 0.f, 0.f}, sB = {0.f, 0.f, 0.f, 0.f}, gB = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8_t qf = frag_rows<D>(Qs, qt * 16, ks, lane), gf = frag_rows<D>(Gs, qt * 16, ks, lane);
-          sA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, bkA[ks], sA, 0, 0, 0);
-          sB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, bkB[ks], sB, 0, 0, 0);
-          gA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, bvA[ks], gA, 0, 0, 0);
-          gB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, bvB[ks], gB, 0, 0, 0);
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qr.rows(ks, qt * 16), bk[ks], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Gr.rows(ks, qt * 16), bv[ks], dp, 0, 0, 0);
         }
+        // rows of this orientation are queries (4 consecutive per lane group); -lse = -inf on padding -> p = 0
+        const f32x4 nL = *reinterpret_cast<const f32x4*>(Ls + qt * 16 + 4 * g), ndl = *reinterpret_cast<const f32x4*>(Dl + qt * 16 + 4 * g);
+        const f32x4 t = sc * scale2 + nL;
+        f32x4 e;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int tq = qt * 16 + 4 * g + r;            // rows of this orientation are queries; Ls = +inf on padding -> 0
-          const float L = Ls[tq], dl = Dl[tq];
-          const float eA = __expf(sA[r] * scale - L), eB = __expf(sB[r] * scale - L);
-          pA2[hf][r] = eA; dA2[hf][r] = eA * (gA[r] - dl);
-          pB2[hf][r] = eB; dB2[hf][r] = eB * (gB[r] - dl);
-        }
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+        p2[hf] = e;
+        d2[hf] = e * (dp + ndl);
       }
-      const bf16x8_t bpA = pack_acc(pA2[0], pA2[1]), bdA = pack_acc(dA2[0], dA2[1]);
-      const bf16x8_t bpB = pack_acc(pB2[0], pB2[1]), bdB = pack_acc(dB2[0], dB2[1]);
+      const bf16x8_t bp = pack_acc(p2[0], p2[1]), bd = pack_acc(d2[0], d2[1]);
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        const bf16x8_t gT = frag_cols_perm<D>(Gs, qp * 32, db, lane), qT = frag_cols_perm<D>(Qs, qp * 32, db, lane);
-        dvA[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT, bpA, dvA[db], 0, 0, 0);
-        dvB[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gT, bpB, dvB[db], 0, 0, 0);
-        dkA[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, bdA, dkA[db], 0, 0, 0);
-        dkB[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, bdB, dkB[db], 0, 0, 0);
+        dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Gr.cols(db, qp * 32), bp, dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qr.cols(db, qp * 32), bd, dk[db], 0, 0, 0);
       }
     }
+    if (tk < T) {
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      if (tkA < T) {
-        store4(dq_base + C + (long)tkA * rs3 + 16 * db + 4 * g, dkA[db], scale);
-        store4(dq_base + 2 * C + (long)tkA * rs3 + 16 * db + 4 * g, dvA[db], 1.0f);
-      }
-      if (tkB < T) {
-        store4(dq_base + C + (long)tkB * rs3 + 16 * db + 4 * g, dkB[db], scale);
-        store4(dq_base + 2 * C + (long)tkB * rs3 + 16 * db + 4 * g, dvB[db], 1.0f);
+      for (int db = 0; db < DB; ++db) {
+        store4(dq_base + C + (long)tk * rs3 + 16 * db + 4 * g, dk[db], scale);
+        store4(dq_base + 2 * C + (long)tk * rs3 + 16 * db + 4 * g, dv[db], 1.0f);
       }
     }
   }
@@ -593,27 +631,41 @@ int attn_smfma_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, int B, int T, 
 
 bool attn_tmfma_supported(int T, int D) { return T <= TP && (D == 64 || D == 16); }
 
+template <int D, int NTC>
+static int launch_tmfma_fwd(const bf16* qkv, bf16* out, float* lse, int units, int T, int J, int C, int H, float scale, hipStream_t st) {
+  const size_t lds = 2 * TP * ACfg<D>::ROWB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_kernel<D, NTC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_tmfma_fwd_kernel<D, NTC>), dim3(units), dim3(512), lds, st, qkv, out, lse, T, J, C, H, scale);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
 int attn_tmfma_fwd(const bf16* qkv, bf16* out, float* lse, int B, int T, int J, int C, int H, hipStream_t st) {
   const int D = C / H;
   MP_CHECK(attn_tmfma_supported(T, D) && C % 8 == 0, MP_ERR_ARG, "attn_tmfma_fwd: T=%d D=%d unsupported", T, D);
   const float scale = 1.0f / sqrtf((float)D);
   const int units = B * J * H;
-  if (D == 64) {
-    const size_t lds = 2 * TP * ACfg<64>::ROWB;
-    static bool attr_set = false;
-    if (!attr_set) {
-      MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(attn_tmfma_fwd_kernel<64>, dim3(units), dim3(256), lds, st, qkv, out, lse, T, J, C, H, scale);
-  } else {
-    const size_t lds = 2 * TP * ACfg<16>::ROWB;
-    hipLaunchKernelGGL(attn_tmfma_fwd_kernel<16>, dim3(units), dim3(256), lds, st, qkv, out, lse, T, J, C, H, scale);
+  // (run-time tile count only: with a compile-time count the scheduler hoists across the whole score strip and spills)
+  if (D == 64) return launch_tmfma_fwd<64, 0>(qkv, out, lse, units, T, J, C, H, scale, st);
+  return launch_tmfma_fwd<16, 0>(qkv, out, lse, units, T, J, C, H, scale, st);
+}
+
+template <int D, int NTC>
+static int launch_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, const float* lse, bf16* dqkv, int units, int T, int J, int C,
+                            int H, float scale, int dbg, hipStream_t st) {
+  const size_t lds = 4 * TP * ACfg<D>::ROWB + 2 * TP * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_bwd_kernel<D, NTC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
   }
+  hipLaunchKernelGGL((attn_tmfma_bwd_kernel<D, NTC>), dim3(units), dim3(1024), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
-
 int attn_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, const float* lse, bf16* dqkv, int B, int T, int J, int C, int H,
                    hipStream_t st) {
   const int D = C / H;
@@ -622,20 +674,11 @@ int attn_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, const flo
   const int units = B * J * H;
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("MANIPOSE_ATTN_DEBUG"); dbg = e ? atoi(e) : 0; }
-  if (D == 64) {
-    const size_t lds = 4 * TP * ACfg<64>::ROWB + 2 * TP * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(attn_tmfma_bwd_kernel<64>, dim3(units), dim3(512), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg);
-  } else {
-    const size_t lds = 4 * TP * ACfg<16>::ROWB + 2 * TP * sizeof(float);
-    hipLaunchKernelGGL(attn_tmfma_bwd_kernel<16>, dim3(units), dim3(512), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg);
-  }
-  MP_LAUNCH_CHECK();
-  return MP_OK;
+  const bool full = T > 240;
+  if (D == 64) return full ? launch_tmfma_bwd<64, 16>(qkv, out, dout, lse, dqkv, units, T, J, C, H, scale, dbg, st)
+                           : launch_tmfma_bwd<64, 0>(qkv, out, dout, lse, dqkv, units, T, J, C, H, scale, dbg, st);
+  return full ? launch_tmfma_bwd<16, 16>(qkv, out, dout, lse, dqkv, units, T, J, C, H, scale, dbg, st)
+              : launch_tmfma_bwd<16, 0>(qkv, out, dout, lse, dqkv, units, T, J, C, H, scale, dbg, st);
 }
 
 }  // namespace mp

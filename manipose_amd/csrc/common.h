@@ -51,9 +51,14 @@ __device__ __forceinline__ float4 ld4(const bf16* p) {
   v.w = __uint_as_float(r.y & 0xffff0000u);
   return v;
 }
+// two fp32 -> one dword of two bf16 (round to nearest even): a single v_cvt_pk_bf16_f32 (the scalar __float2bfloat16 route costs
+// two conversions, a shift and an or per pair)
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  bf16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
-  return (unsigned)(*reinterpret_cast<unsigned short*>(&a)) | ((unsigned)(*reinterpret_cast<unsigned short*>(&b)) << 16);
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  return *reinterpret_cast<const unsigned*>(&r);
 }
 __device__ __forceinline__ void st4(bf16* p, float4 v) {
   uint2 r;
