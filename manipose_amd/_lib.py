@@ -10,7 +10,8 @@ import re
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmanipose_hip.so")
+# MANIPOSE_HIP_LIB: another build of the same library (A/B timing of two builds on one box)
+LIB_PATH = os.environ.get("MANIPOSE_HIP_LIB") or os.path.join(_HERE, "libmanipose_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "manipose_hip.h")
 
 _lib: Optional[C.CDLL] = None

@@ -98,6 +98,36 @@ __device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& pdf)
   cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
   pdf = 0.39894228040143267794f * e;
 }
+// Two elements at a time on the packed-fp32 VALU (v_pk_mul_f32 / v_pk_fma_f32): the GELU epilogue of the fc1 GEMM is bound by
+// VALU issue (about 20 instructions per element in the scalar form), not by HBM.  Same formula as gelu_parts_fast; the
+// reciprocal is the 1-ulp hardware v_rcp_f32.  Returns f = x cdf and f' = cdf + x pdf.
+typedef float mp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_pair_fast(float x0, float x1, float& f0, float& f1, float& d0, float& d1) {
+  const mp_f32x2 x = {x0, x1};
+  const mp_f32x2 ax = {fabsf(x0), fabsf(x1)};
+  const mp_f32x2 den = ax * (0.3275911f * 0.70710678118654752440f) + 1.0f;
+  const mp_f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  const mp_f32x2 arg = (x * -0.72134752044448170368f) * x;                 // -(x^2 / 2) log2 e
+  const mp_f32x2 e = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+  mp_f32x2 poly = t * 1.061405429f + -1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t + -0.284496736f;
+  poly = poly * t + 0.254829592f;
+  poly = poly * t;
+  const mp_f32x2 erf_abs = 1.0f - poly * e;
+  const mp_f32x2 erf_s = {copysignf(erf_abs[0], x0), copysignf(erf_abs[1], x1)};
+  const mp_f32x2 cdf = erf_s * 0.5f + 0.5f;
+  const mp_f32x2 pdf = e * 0.39894228040143267794f;
+  const mp_f32x2 f = x * cdf, d = x * pdf + cdf;
+  f0 = f[0]; f1 = f[1]; d0 = d[0]; d1 = d[1];
+}
+// float4 form used by the GEMM epilogues: v <- gelu(v), returns gelu'(v)
+__device__ __forceinline__ float4 gelu_fwd4_fast(float4& v) {
+  float4 d;
+  gelu_pair_fast(v.x, v.y, v.x, v.y, d.x, d.y);
+  gelu_pair_fast(v.z, v.w, v.z, v.w, d.z, d.w);
+  return d;
+}
 __device__ __forceinline__ float gelu_fast(float x) {
   float c, p;
   gelu_parts_fast(x, c, p);
@@ -117,5 +147,32 @@ __device__ __forceinline__ float droppath_scale(const float* mask, int mode, int
   const int b = m / (T * J);
   return mask[b * J + (m % J)];
 }
+
+// The same map for the rows of one GEMM tile, without a per-row integer division (~30 VALU instructions each, which dominated
+// the residual epilogues): m = b0 TJ + r with b0, r0 divided out ONCE from the wave-uniform first row; per row only the small
+// r = r0 + (m - row0) remains, whose quotients by J and TJ are exact in fp32 ((r + 0.5) / d is at least 0.5 / d away from an
+// integer and r < 2^20).  TJ is a multiple of J, so m / J = b0 T + r / J and m % J = r % J.
+struct DropPathRows {
+  const float* mk;
+  int mode, T, J, TJ, b0, r0, row0;
+  float invJ, invTJ;
+  __device__ __forceinline__ void init(const float* mask, int mask_mode, int T_, int J_, int row0_uniform) {
+    mk = (mask != nullptr && mask_mode != 0) ? mask : nullptr;
+    mode = mask_mode; T = T_; J = J_; TJ = T_ * J_;
+    row0 = __builtin_amdgcn_readfirstlane(row0_uniform);
+    b0 = mk != nullptr ? row0 / TJ : 0;
+    r0 = mk != nullptr ? row0 - b0 * TJ : 0;
+    invJ = 1.0f / (float)J;
+    invTJ = 1.0f / (float)TJ;
+  }
+  __device__ __forceinline__ float scale(int m) const {      // m >= row0, m - row0 < 2^19
+    if (mk == nullptr) return 1.0f;
+    const int r = r0 + (m - row0);
+    const int q = (int)(((float)r + 0.5f) * invJ);
+    if (mode == 1) return mk[b0 * T + q];
+    const int qb = (int)(((float)r + 0.5f) * invTJ);
+    return mk[(b0 + qb) * J + (r - q * J)];
+  }
+};
 
 }  // namespace mp

@@ -188,10 +188,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmB16Args g) {
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
       }
       if (EPI == EPI_BIAS_GELU) {
-        float4 c, d;     // cdf / pdf parts: f = x cdf, f' = cdf + x pdf; Z keeps f' (all the backward needs from z)
-        gelu_parts_fast(v.x, c.x, d.x); gelu_parts_fast(v.y, c.y, d.y); gelu_parts_fast(v.z, c.z, d.z); gelu_parts_fast(v.w, c.w, d.w);
-        st4(Z + o, make_float4(c.x + v.x * d.x, c.y + v.y * d.y, c.z + v.z * d.z, c.w + v.w * d.w));
-        v = make_float4(v.x * c.x, v.y * c.y, v.z * c.z, v.w * c.w);
+        const float4 d = gelu_fwd4_fast(v);     // v <- gelu(v); Z keeps gelu' (all the backward needs from the pre-activation)
+        st4(Z + o, d);
       } else if (EPI == EPI_BIAS_RESID) {
         const float4 r = ld4(g.R + o);
         v = make_float4(r.x + dscale * v.x, r.y + dscale * v.y, r.z + dscale * v.z, r.w + dscale * v.w);
@@ -401,6 +399,8 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   const int col = n0 + wc * 64 + 4 * l15;            // read-back mapping: 16 lanes cover the 64 columns of a row
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (EPI != EPI_SLAB && EPI != EPI_DGELU && g.bias != nullptr && col < g.N) bias4 = ld4(g.bias + col);
+  DropPathRows dp;
+  dp.init(EPI == EPI_BIAS_RESID ? g.mask : nullptr, g.mask_mode, g.T, g.J, m0 + wr * (BT / 2));
 #pragma unroll
   for (int hp = 0; hp < MI / 4; ++hp) {              // 64 rows of the wave tile per pass
 #pragma unroll
@@ -421,12 +421,10 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
       const long o = (long)row * g.ldc + col;
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
       if (EPI == EPI_BIAS_GELU) {
-        float4 c, d;     // cdf / pdf parts: f = x cdf, f' = cdf + x pdf; Z keeps f' (all the backward needs from z)
-        gelu_parts_fast(v.x, c.x, d.x); gelu_parts_fast(v.y, c.y, d.y); gelu_parts_fast(v.z, c.z, d.z); gelu_parts_fast(v.w, c.w, d.w);
-        st4(Z + o, make_float4(c.x + v.x * d.x, c.y + v.y * d.y, c.z + v.z * d.z, c.w + v.w * d.w));
-        v = make_float4(v.x * c.x, v.y * c.y, v.z * c.z, v.w * c.w);
+        const float4 d = gelu_fwd4_fast(v);     // v <- gelu(v); Z keeps gelu' (all the backward needs from the pre-activation)
+        st4(Z + o, d);
       } else if (EPI == EPI_BIAS_RESID) {
-        const float dscale = droppath_scale(g.mask, g.mask_mode, row, g.T, g.J);
+        const float dscale = dp.scale(row);
         const float4 r = ld4(g.R + o);
         v = make_float4(r.x + dscale * v.x, r.y + dscale * v.y, r.z + dscale * v.z, r.w + dscale * v.w);
       } else if (EPI == EPI_DGELU) {
@@ -480,11 +478,12 @@ template <typename TC, int EPI, bool FULL>
 __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32x4 (&acc)[8][4], float* __restrict__ img, int row0, int col,
                                                  const float4& bias4, TC* __restrict__ C, TC* __restrict__ Z, int l15, int gq) {
   constexpr bool LOADS = (EPI == EPI_BIAS_RESID || EPI == EPI_DGELU);
-  const float* const mk = (EPI == EPI_BIAS_RESID && g.mask != nullptr && g.mask_mode != 0) ? g.mask : nullptr;
   float4 in_nxt[4];
   float ds_nxt[4];
   // the residual / gelu' rows (and DropPath scales) of pass i+1 are requested BEFORE the stores of pass i are issued: memory
   // operations retire in order, so a pass never waits for the previous pass's stores.
+  DropPathRows dp;
+  dp.init(EPI == EPI_BIAS_RESID ? g.mask : nullptr, g.mask_mode, g.T, g.J, row0);
   auto request = [&](int i) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -493,8 +492,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
       const long o = (long)rc * g.ldc + col;
       if (LOADS) in_nxt[it] = (EPI == EPI_DGELU) ? ld4(Z + o) : ld4(g.R + o);
       ds_nxt[it] = 1.0f;
-      if (EPI == EPI_BIAS_RESID && mk != nullptr)
-        ds_nxt[it] = mk[g.mask_mode == 1 ? rc / g.J : (rc / (g.T * g.J)) * g.J + rc % g.J];     // == droppath_scale
+      if (EPI == EPI_BIAS_RESID) ds_nxt[it] = dp.scale(rc);
     }
   };
   if (LOADS) request(0);
@@ -515,10 +513,8 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
       const long o = (long)row * g.ldc + col;
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
       if (EPI == EPI_BIAS_GELU) {
-        float4 c, d;     // cdf / pdf parts: f = x cdf, f' = cdf + x pdf; Z keeps f' (all the backward needs from z)
-        gelu_parts_fast(v.x, c.x, d.x); gelu_parts_fast(v.y, c.y, d.y); gelu_parts_fast(v.z, c.z, d.z); gelu_parts_fast(v.w, c.w, d.w);
-        if (FULL || row < g.M) st4(Z + o, make_float4(c.x + v.x * d.x, c.y + v.y * d.y, c.z + v.z * d.z, c.w + v.w * d.w));
-        v = make_float4(v.x * c.x, v.y * c.y, v.z * c.z, v.w * c.w);
+        const float4 d = gelu_fwd4_fast(v);     // v <- gelu(v); Z keeps gelu' (all the backward needs from the pre-activation)
+        if (FULL || row < g.M) st4(Z + o, d);
       } else if (EPI == EPI_BIAS_RESID) {
         v = make_float4(in[it].x + ds[it] * v.x, in[it].y + ds[it] * v.y, in[it].z + ds[it] * v.z, in[it].w + ds[it] * v.w);
       } else if (EPI == EPI_DGELU) {
