@@ -238,28 +238,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 
 // out segment j (<=4): dst[j][i] += sum_p partial[p][off_j + i]
 struct ReduceDst { float* dst[4]; int off[5]; int stride[4]; };
-// block = 32 outputs x 8 row groups: each thread sums P/8 partial rows (4 independent chains), LDS-combines the 8 groups
+// block = RP_OUT outputs x RP_GRP row groups: each thread sums P / RP_GRP partial rows (4 independent chains), LDS-combines the groups.
+// 16 x 16 (instead of 32 x 8) doubles the workgroups (the partials are L2-resident; the kernel is latency-, not bandwidth-bound).
+constexpr int RP_OUT = 16, RP_GRP = 16;
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int P, int n, ReduceDst d) {
-  __shared__ float red[8][33];
-  const int oi = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + oi;
+  __shared__ float red[RP_GRP][RP_OUT + 1];
+  const int oi = threadIdx.x % RP_OUT, grp = threadIdx.x / RP_OUT;
+  const int i = blockIdx.x * RP_OUT + oi;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n) {
     int p = grp;
-    for (; p + 24 < P; p += 32) {
+    for (; p + 3 * RP_GRP < P; p += 4 * RP_GRP) {
       s0 += partial[(long)p * n + i];
-      s1 += partial[(long)(p + 8) * n + i];
-      s2 += partial[(long)(p + 16) * n + i];
-      s3 += partial[(long)(p + 24) * n + i];
+      s1 += partial[(long)(p + RP_GRP) * n + i];
+      s2 += partial[(long)(p + 2 * RP_GRP) * n + i];
+      s3 += partial[(long)(p + 3 * RP_GRP) * n + i];
     }
-    for (; p < P; p += 8) s0 += partial[(long)p * n + i];
+    for (; p < P; p += RP_GRP) s0 += partial[(long)p * n + i];
   }
   red[grp][oi] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (grp == 0 && i < n) {
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += red[k][oi];
+    for (int k = 0; k < RP_GRP; ++k) s += red[k][oi];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (i >= d.off[j] && i < d.off[j + 1] && d.dst[j] != nullptr) d.dst[j][(long)(i - d.off[j]) * d.stride[j]] += s;
@@ -280,7 +282,7 @@ int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, cons
 #undef MP_LN_BWD
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dgamma, dbeta, nullptr, nullptr}, {0, C, 2 * C, 2 * C, 2 * C}, {1, 1, 1, 1}};
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, scratch, grid, 2 * C, d);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, RP_OUT)), dim3(256), 0, st, scratch, grid, 2 * C, d);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -409,7 +411,7 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
                        dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C);
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dgamma1, dbeta1, dgamma0, dbeta0}, {0, C, 2 * C, 3 * C, 4 * C}, {1, 1, 1, 1}};
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(4 * C, 32)), dim3(256), 0, st, scratch, grid, 4 * C, d);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(4 * C, RP_OUT)), dim3(256), 0, st, scratch, grid, 4 * C, d);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -484,7 +486,7 @@ int embed_bwd(const float* g, const float* xin, float* dW, float* db, float* dsp
                      M, C, J);
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dW, db, dspos, nullptr}, {0, 2 * C, 3 * C, n, n}, {1, 1, 1, 1}};
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 32)), dim3(256), 0, st, scratch, chunks, n, d);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, RP_OUT)), dim3(256), 0, st, scratch, chunks, n, d);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -492,7 +494,7 @@ int embed_bwd(const float* g, const float* xin, float* dW, float* db, float* dsp
 // ---------------------------------------------------------------------------------------------
 // bones net input: Linear(J*2 = IN, S*Cs = O) + Spatial_pos_embed flattened (manifold_mix_ste.py:133-150)
 // ---------------------------------------------------------------------------------------------
-constexpr int BE_FRAMES = 8, BE_IN = 34;
+constexpr int BE_FRAMES = 32, BE_IN = 34;      // frames per workgroup: every weight element is loaded once per 32 frames
 __global__ __launch_bounds__(256) void bones_embed_fwd_kernel(const float* __restrict__ xin, const float* __restrict__ W,
                                                                const float* __restrict__ b, const float* __restrict__ spos,
                                                                float* __restrict__ out, int BT, int O) {
@@ -566,10 +568,10 @@ int bones_embed_bwd(const float* g, const float* xin, float* dW, float* db, floa
   MP_LAUNCH_CHECK();
   // the positional table is added exactly like the bias (index o = s*Cs + c), so dspos == db contribution
   ReduceDst d = {{dW, db, nullptr, nullptr}, {0, O * BE_IN, n, n, n}, {1, 1, 1, 1}};
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 32)), dim3(256), 0, st, scratch, chunks, n, d);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, RP_OUT)), dim3(256), 0, st, scratch, chunks, n, d);
   MP_LAUNCH_CHECK();
   ReduceDst d2 = {{nullptr, dspos, nullptr, nullptr}, {0, O * BE_IN, n, n, n}, {1, 1, 1, 1}};
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 32)), dim3(256), 0, st, scratch, chunks, n, d2);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, RP_OUT)), dim3(256), 0, st, scratch, chunks, n, d2);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

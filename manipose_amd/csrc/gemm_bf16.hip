@@ -677,12 +677,36 @@ static int launch_glds(const GemmB16Args& g, int splits, hipStream_t st) {
   return use_big_tile(g) ? launch_glds_bt<TRA, TRB, TC, EPI, 256>(g, splits, st) : launch_glds_bt<TRA, TRB, TC, EPI, 128>(g, splits, st);
 }
 
-__global__ void reduce_slabs_b16_kernel(const float* __restrict__ slab, float* __restrict__ out, long n, int S) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < S; ++k) s += slab[(long)k * n + i];
-  out[i] += s;
+// dW += sum of the split-K slabs, db += sum of the bias slabs, ONE launch: a float4 of outputs per thread, the slabs summed in their
+// fixed order (deterministic) with four independent loads in flight.
+__global__ __launch_bounds__(256) void reduce_slabs_b16_kernel(const float* __restrict__ slabW, float* __restrict__ dW, long nW4,
+                                                               const float* __restrict__ slabB, float* __restrict__ db, long nB4, int S) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const float* slab = slabW;
+  float* out = dW;
+  long n4 = nW4;
+  if (i >= nW4) {
+    i -= nW4;
+    if (i >= nB4) return;
+    slab = slabB; out = db; n4 = nB4;
+  }
+  const float4* p = reinterpret_cast<const float4*>(slab) + i;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k = 0;
+  for (; k + 4 <= S; k += 4) {
+    const float4 a = p[(long)k * n4], b = p[(long)(k + 1) * n4], c = p[(long)(k + 2) * n4], d = p[(long)(k + 3) * n4];
+    s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+    s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+  }
+  for (; k < S; ++k) {
+    const float4 a = p[(long)k * n4];
+    s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+  }
+  float4 o = reinterpret_cast<float4*>(out)[i];
+  o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+  reinterpret_cast<float4*>(out)[i] = o;
 }
 
 template <typename TA, int TRA, typename TB, int TRB, typename TC, int EPI>
@@ -742,13 +766,9 @@ int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, i
   int rc = dy_f32 ? launch_b16<float, 1, bf16, 1, float, EPI_SLAB>(g, splits, st)
                   : launch_glds<1, 1, float, EPI_SLAB>(g, splits, st);
   if (rc) return rc;
-  const long n = (long)Nout * Kin;
-  hipLaunchKernelGGL(reduce_slabs_b16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, slab, dW, n, splits);
+  const long nW4 = (long)Nout * Kin / 4, nB4 = db != nullptr ? Nout / 4 : 0;        // Nout, Kin are multiples of 8
+  hipLaunchKernelGGL(reduce_slabs_b16_kernel, dim3(cdiv(nW4 + nB4, 256)), dim3(256), 0, st, slab, dW, nW4, g.bias_slab, db, nB4, splits);
   MP_LAUNCH_CHECK();
-  if (db != nullptr) {
-    hipLaunchKernelGGL(reduce_slabs_b16_kernel, dim3(cdiv(Nout, 256)), dim3(256), 0, st, g.bias_slab, db, (long)Nout, splits);
-    MP_LAUNCH_CHECK();
-  }
   return MP_OK;
 }
 
