@@ -161,10 +161,12 @@ int mp_model_peek(const mp_model* m, int which, const float** ptr, int64_t* nume
 /* copy `numel` floats of intermediate `which` into dst (device) on `stream` */
 int mp_model_peek_copy(const mp_model* m, int which, float* dst, int64_t numel, void* stream);
 
-/* per-kernel-class device timing (HIP events on `stream`): classes 0 gemm_fwd, 1 gemm_dgrad, 2 gemm_wgrad,
- * 3 attention, 4 layernorm, 5 other.  collect() synchronises the events, adds up elapsed ms / launch counts /
+/* per-kernel-class device timing (HIP events on the stream each kernel is launched on): classes 0 gemm_fwd, 1 gemm_dgrad,
+ * 2 gemm_wgrad, 3 attention, 4 layernorm, 5 other partition the launches; class 6 gemm_persist is the SUBSET of classes 0/1 that
+ * ran gemm_bf16_persist_kernel (the kernel with the largest share of a training step: its average launch time is what
+ * rocprofv3 reports for that kernel name).  collect() synchronises the events, adds up elapsed ms / launch counts /
  * algorithmic FLOPs per class since the last reset and resets. */
-#define MP_PROF_CLASSES 6
+#define MP_PROF_CLASSES 7
 int mp_prof_enable(mp_model* m, int on);
 int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops);
 

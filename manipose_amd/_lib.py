@@ -70,7 +70,7 @@ _SIGNATURES = {
     "mp_prof_enable": (i32, [vp, i32]),
     "mp_prof_collect": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
 }
-PROF_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "attention", "layernorm", "other")
+PROF_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "attention", "layernorm", "other", "gemm_persist")   # last: subset of the first two
 
 
 def declared_symbols(header: str = HEADER_PATH):

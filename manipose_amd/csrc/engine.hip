@@ -71,6 +71,7 @@ struct mp_model {
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_cls;
   std::vector<double> ev_flops;
+  std::vector<char> ev_tag;              // 1: the launch ran gemm_bf16_persist_kernel
   size_t ev_used = 0;
 };
 
@@ -230,6 +231,7 @@ struct ProfScope {
       on = true;
       m->ev_cls.push_back(cls);
       m->ev_flops.push_back(flops);
+      (void)gemm_bf16_take_last_persist();
       (void)hipEventRecord(m->ev[m->ev_used], st);
     }
   }
@@ -237,6 +239,7 @@ struct ProfScope {
     if (on) {
       (void)hipEventRecord(m->ev[m->ev_used + 1], st);
       m->ev_used += 2;
+      m->ev_tag.push_back((char)gemm_bf16_take_last_persist());
     }
   }
 };
@@ -778,6 +781,7 @@ int mp_prof_enable(mp_model* m, int on) {
   m->ev_used = 0;
   m->ev_cls.clear();
   m->ev_flops.clear();
+  m->ev_tag.clear();
   return MP_OK;
 }
 
@@ -792,10 +796,16 @@ int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops) {
     ms[c] += t;
     launches[c] += 1;
     flops[c] += m->ev_flops[i];
+    if (i < m->ev_tag.size() && m->ev_tag[i]) {         // class 6: the launches of classes 0/1 that ran gemm_bf16_persist_kernel
+      ms[6] += t;
+      launches[6] += 1;
+      flops[6] += m->ev_flops[i];
+    }
   }
   m->ev_used = 0;
   m->ev_cls.clear();
   m->ev_flops.clear();
+  m->ev_tag.clear();
   return MP_OK;
 }
 

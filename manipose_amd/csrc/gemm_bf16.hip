@@ -329,16 +329,22 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
-  int tm, tn;
+  // XCD-aware bijective remap over the WHOLE grid, split index slowest: every XCD gets a contiguous chunk of (split, tile) pairs,
+  // so the tiles of one k-split - which all read the same token range of both operands - share that XCD's L2 (split-K wgrad:
+  // the per-launch fabric traffic was 2.4x the algorithmic bytes when the splits were dealt round-robin over the XCDs).
+  int tm, tn, tz;
   {
-    const int nwg = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int tiles = gridDim.x * gridDim.y, nwg = tiles * gridDim.z;
+    const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const int xcd = id & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-    tm = wg / gridDim.x;
-    tn = wg - tm * gridDim.x;
+    tz = wg / tiles;
+    const int t = wg - tz * tiles;
+    tm = t / gridDim.x;
+    tn = t - tm * gridDim.x;
   }
   const int m0 = tm * BT, n0 = tn * BT;
-  const int kbeg = blockIdx.z * g.k_per_split;
+  const int kbeg = tz * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   if (BT == 256 && g.stagger > 0) {
     // All tiles cost the same, so with one workgroup per CU every CU would reach its (HBM-write-bound) epilogue at the same
@@ -388,9 +394,9 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   // so bias / residual / pre-activation loads and the output stores are full 128/256-byte lines, 16 lanes per row. ----
   TC* C = reinterpret_cast<TC*>(g.C);
   if (EPI == EPI_SLAB) {
-    C += (long)blockIdx.z * g.M * g.ldc;
+    C += (long)tz * g.M * g.ldc;
     if (TRA == 1 && tn == 0 && tid < BT && m0 + tid < g.M && g.bias_slab != nullptr)
-      g.bias_slab[(long)blockIdx.z * g.M + m0 + tid] = bsum;
+      g.bias_slab[(long)tz * g.M + m0 + tid] = bsum;
   }
   TC* Z = reinterpret_cast<TC*>(g.Z);
   __syncthreads();                                   // every wave is done with the operand stages: reuse them
@@ -628,8 +634,13 @@ static int persist_workgroups() {
   return g_persist_mode == 0 ? 0 : n;
 }
 
+// profiling tag: 1 if the last gemm_bf16() of this thread went to the persistent kernel (the engine's per-kernel timing)
+static thread_local int g_last_persist = 0;
+int gemm_bf16_take_last_persist() { const int v = g_last_persist; g_last_persist = 0; return v; }
+
 template <int TRB, typename TC, int EPI>
 static int launch_persist(const GemmB16Args& g, int wgs, hipStream_t st) {
+  g_last_persist = 1;
   constexpr size_t lds = 2 * 2 * 256 * 128 + 8 * 4096;     // two operand stages + the epilogue images = 160 KiB
   static bool attr_set = false;
   if (!attr_set) {
