@@ -4,8 +4,8 @@
 One "step" = forward + WTA multi-hypothesis loss + backward + gradient all-reduce + Adam on a synthetic batch of
 B windows per GPU of H36M shape (T=243, J=17, K=5, C=512, depth 8), inputs resident in HBM.
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank/GPU)
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the forward GEMM kernel; HIP events inside the
-engine on the compute stream) and `cpu_baseline` (oracle/manipose_ref.py timed on the host cores, rank 0, N=1 only).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = gemm_bf16_persist_kernel, the forward + dgrad Linear
+GEMMs; HIP events inside the engine on the stream each launch goes to) and `cpu_baseline` (oracle/manipose_ref.py timed on the host cores, rank 0, N=1 only).
 """
 import argparse
 import json
@@ -20,7 +20,7 @@ TRAIN_GFLOP_PER_POSE = {243: 3.705, 81: 3.562, 27: 3.513}      # SURVEY.md 8d (3
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}                  # MI355X_MICROARCH.md: dense matrix peaks
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction of
 # MI355X_MICROARCH.md section HBM, + WRITE_SIZE), see profiles/README.md; keyed by (precision, windows per GPU).
-PMC_TRAFFIC_PER_LAUNCH = {("bf16", 32): 620.4e6, ("bf16", 64): 1245.4e6}   # profiles/r01_bf16_B{32,64}_pmc_hbm_traffic.csv (forward-GEMM class average)
+PMC_TRAFFIC_PER_LAUNCH = {("bf16", 64): 1210.2e6}   # profiles/r01_final_bf16_B64_pmc_hbm_traffic.csv, last row: gemm_bf16_persist_kernel, all instantiations
 
 
 def host_cores():
