@@ -68,15 +68,31 @@ __device__ __forceinline__ void st4(bf16* p, float4 v) {
 }
 
 // ---- wave (64-lane) reductions ----------------------------------------------------------------
+// DPP cross-lane operands (no LDS crossbar: a __shfl_xor butterfly is six dependent ds_bpermute_b32, ~100 clocks each):
+// quad_perm [1,0,3,2] and [2,3,0,1], row_half_mirror, row_mirror leave every lane with the result over its row of 16;
+// row_bcast:15 / row_bcast:31 carry it into lane 63, which is read back as a wave-uniform scalar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f<0xB1, 0xf>(0.f, v);
+  v += dpp_f<0x4E, 0xf>(0.f, v);
+  v += dpp_f<0x141, 0xf>(0.f, v);
+  v += dpp_f<0x140, 0xf>(0.f, v);
+  v += dpp_f<0x142, 0xa>(0.f, v);       // rows 1, 3 += last lane of rows 0, 2
+  v += dpp_f<0x143, 0xc>(0.f, v);       // rows 2, 3 += lane 31
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  const float ninf = -__builtin_inff();
+  v = fmaxf(v, dpp_f<0xB1, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<0x4E, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<0x141, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<0x140, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<0x142, 0xa>(ninf, v));
+  v = fmaxf(v, dpp_f<0x143, 0xc>(ninf, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // exact (erf) GELU and its derivative, as torch.nn.GELU() (mix_ste.py:297 act_layer=nn.GELU)
