@@ -25,15 +25,16 @@ const char* last_error() { return g_err; }
 // ---------------------------------------------------------------------------------------------
 constexpr int LN_MAXV = 4;  // float4 per lane -> C <= 1024
 
-__device__ __forceinline__ void row_stats(const float4 (&v)[LN_MAXV], int lane, int C, float eps, float& mean, float& rstd) {
+template <int V>
+__device__ __forceinline__ void row_stats(const float4 (&v)[V], int lane, int C, float eps, float& mean, float& rstd) {
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i)
+  for (int i = 0; i < V; ++i)
     if (lane * 4 + 256 * i < C) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   mean = wave_sum(s) / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i)
+  for (int i = 0; i < V; ++i)
     if (lane * 4 + 256 * i < C) {
       const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
       q += (a * a + b * b) + (c * c + d * d);
@@ -41,35 +42,45 @@ __device__ __forceinline__ void row_stats(const float4 (&v)[LN_MAXV], int lane, 
   rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
 }
 
-template <typename T>
+// V float4 per lane (C <= 256 V); gamma / beta of both stages live in registers for the whole kernel
+template <typename T, int V>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int C = a.C;
-  auto load_row = [&](int m, float4 (&v)[LN_MAXV]) {
+  float4 g1[V], b1[V], g2[V], b2[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = lane * 4 + 256 * i;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    g1[i] = (a.g1 != nullptr && c < C) ? ld4(a.g1 + c) : z;
+    b1[i] = (a.g1 != nullptr && c < C) ? ld4(a.b1 + c) : z;
+    g2[i] = (a.g2 != nullptr && c < C) ? ld4(a.g2 + c) : z;
+    b2[i] = (a.g2 != nullptr && c < C) ? ld4(a.b2 + c) : z;
+  }
+  auto load_row = [&](int m, float4 (&v)[V]) {
     const float* xr = a.x + (long)m * C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < V; ++i) {
       const int c = lane * 4 + 256 * i;
       if (c < C) v[i] = ld4(xr + c);
     }
   };
-  auto finish_row = [&](int m, float4 (&v)[LN_MAXV]) {
+  auto finish_row = [&](int m, float4 (&v)[V]) {
     if (a.g1 != nullptr) {
       float mean, rstd;
-      row_stats(v, lane, C, a.eps1, mean, rstd);
+      row_stats<V>(v, lane, C, a.eps1, mean, rstd);
       const float* pr = (a.pos != nullptr) ? a.pos + (long)((m / a.J) % a.T) * C : nullptr;
 #pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
+      for (int i = 0; i < V; ++i) {
         const int c = lane * 4 + 256 * i;
         if (c < C) {
-          const float4 g = ld4(a.g1 + c), b = ld4(a.b1 + c);
           float4 o;
-          o.x = (v[i].x - mean) * rstd * g.x + b.x;
-          o.y = (v[i].y - mean) * rstd * g.y + b.y;
-          o.z = (v[i].z - mean) * rstd * g.z + b.z;
-          o.w = (v[i].w - mean) * rstd * g.w + b.w;
+          o.x = (v[i].x - mean) * rstd * g1[i].x + b1[i].x;
+          o.y = (v[i].y - mean) * rstd * g1[i].y + b1[i].y;
+          o.z = (v[i].z - mean) * rstd * g1[i].z + b1[i].z;
+          o.w = (v[i].w - mean) * rstd * g1[i].w + b1[i].w;
           if (pr != nullptr) {
             const float4 p = ld4(pr + c);
             o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
@@ -85,18 +96,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
     }
     if (a.g2 != nullptr) {
       float mean, rstd;
-      row_stats(v, lane, C, a.eps2, mean, rstd);
+      row_stats<V>(v, lane, C, a.eps2, mean, rstd);
       T* yr = reinterpret_cast<T*>(a.y2) + (long)m * C;
 #pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
+      for (int i = 0; i < V; ++i) {
         const int c = lane * 4 + 256 * i;
         if (c < C) {
-          const float4 g = ld4(a.g2 + c), b = ld4(a.b2 + c);
           float4 o;
-          o.x = (v[i].x - mean) * rstd * g.x + b.x;
-          o.y = (v[i].y - mean) * rstd * g.y + b.y;
-          o.z = (v[i].z - mean) * rstd * g.z + b.z;
-          o.w = (v[i].w - mean) * rstd * g.w + b.w;
+          o.x = (v[i].x - mean) * rstd * g2[i].x + b2[i].x;
+          o.y = (v[i].y - mean) * rstd * g2[i].y + b2[i].y;
+          o.z = (v[i].z - mean) * rstd * g2[i].z + b2[i].z;
+          o.w = (v[i].w - mean) * rstd * g2[i].w + b2[i].w;
           st4(yr + c, o);
         }
       }
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
   };
   // two rows in flight per wave: the second row's loads are outstanding while the first row is reduced and stored
   for (int m = wave; m < a.M; m += 2 * nwaves) {
-    float4 va[LN_MAXV], vb[LN_MAXV];
+    float4 va[V], vb[V];
     const int mb = m + nwaves;
     load_row(m, va);
     if (mb < a.M) load_row(mb, vb);
@@ -122,10 +132,11 @@ static int row_grid(int M) { return max(1, min(cdiv(M, 4), 256 * 8)); }
 int ln_fwd(const LnFwdArgs& a, int out_bf16, hipStream_t st) {
   MP_CHECK(a.C % 4 == 0 && a.C <= 256 * LN_MAXV, MP_ERR_ARG, "ln_fwd: C=%d must be a multiple of 4 and <= 1024", a.C);
   MP_CHECK(a.g1 != nullptr || a.g2 != nullptr, MP_ERR_ARG, "ln_fwd: no stage requested");
-  if (out_bf16)
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16>, dim3(row_grid(a.M)), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(row_grid(a.M)), dim3(256), 0, st, a);
+#define MP_LN_FWD(TT, V) hipLaunchKernelGGL((ln_fwd_kernel<TT, V>), dim3(row_grid(a.M)), dim3(256), 0, st, a)
+  if (a.C <= 256)      { if (out_bf16) MP_LN_FWD(bf16, 1); else MP_LN_FWD(float, 1); }
+  else if (a.C <= 512) { if (out_bf16) MP_LN_FWD(bf16, 2); else MP_LN_FWD(float, 2); }
+  else                 { if (out_bf16) MP_LN_FWD(bf16, 4); else MP_LN_FWD(float, 4); }
+#undef MP_LN_FWD
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
