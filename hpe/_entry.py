@@ -73,13 +73,17 @@ def synthetic_windows(n, T, device, seed):
 
 
 @torch.no_grad()
-def evaluate(model, X, y, batch, tta=True):
+def evaluate(model, X, y, batch, tta=True, analytics=False):
     """MPJPE (mm) of the aggregated / best-score / oracle hypotheses, with the reference's flip test-time augmentation
     (hpe/eval_utils.py:16-223).  The flipped copy is batched with the original into ONE forward of 2B windows
-    instead of a second pass."""
+    instead of a second pass.  ``analytics=True`` adds the reference's evaluation table (main_h36m_lifting.py:933-990,
+    main_3dhp.py:860-910: MPSSE, MPSCE, segment-length error, MSE / error variance, 3DPCK, AUC, per-joint errors) of the
+    aggregated prediction in millimetres, from the one-pass HIP analytics kernel."""
     from manipose_amd import RMCLManifoldMixSTE
     from manipose_amd.augmentations import pose_flip
     from manipose_amd.metrics import mpjpe_error
+    from manipose_amd.metrics.analytics import AnalyticsAccumulator, pose_analytics
+    acc = AnalyticsAccumulator() if analytics else None
     model.eval()
     sk = model.decoder.skeleton
     rmcl = isinstance(model, RMCLManifoldMixSTE)
@@ -112,7 +116,12 @@ def evaluate(model, X, y, batch, tta=True):
                 pred = (pred + pose_flip((out[nb:].clone(),), sk)[0]) / 2
             sums["mpjpe"] += mpjpe_error(pred, yb, "sum").item()
         n += yb.numel() // 3
-    return {k: 1000.0 * v / n for k, v in sums.items() if v > 0}
+        if acc is not None:
+            acc.add(pose_analytics(pred.detach().contiguous(), yb.contiguous(), pred_scale=1000.0, gt_scale=1000.0))
+    out = {k: 1000.0 * v / n for k, v in sums.items() if v > 0}
+    if acc is not None:
+        out["analytics"] = acc.report()
+    return out
 
 
 def save_state(model, trainer, scheduler_state, epoch, folder, tag=None):
@@ -187,5 +196,8 @@ def run(argv, extra_defaults=None):
         if rank == 0:
             save_state(model, trainer, {"best": best_val, "bad_epochs": bad_epochs}, cfg.train.epochs, out_dir, "end")
     if cfg.run.test and rank == 0:
-        print("test:", {k: round(v, 3) for k, v in evaluate(model, Xv, yv, cfg.train.batch_size_test, tta=cfg.train.tta).items()}, flush=True)
+        res = evaluate(model, Xv, yv, cfg.train.batch_size_test, tta=cfg.train.tta, analytics=True)
+        table = res.pop("analytics")
+        print("test:", {k: round(v, 3) for k, v in res.items()}, flush=True)
+        print("test analytics (mm):", {k: round(v, 4) for k, v in table.items() if not isinstance(v, list)}, flush=True)
     return best_val

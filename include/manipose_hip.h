@@ -170,6 +170,24 @@ int mp_model_peek_copy(const mp_model* m, int which, float* dst, int64_t numel, 
 int mp_prof_enable(mp_model* m, int on);
 int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops);
 
+/* Evaluation analytics of pose sequences in one pass over the frames (17-joint H36M / 3DHP tree compiled in): the running sums
+ * behind mpjpe_error / mse_error / jointwise_error / segments_len_err (hpe/mh_so3_hpe/metrics/mean_joint_errors.py:31-130),
+ * sagittal_symmetry(_per_bone) and segments_time_consistency(_per_bone) (metrics/regularizations.py:8-157), the evaluation form of
+ * mean_velocity_error (metrics/losses.py:75-101) and keypoint_3d_pck / keypoint_3d_auc (metrics/pck.py:92-199; alignment 'none',
+ * or 'scale' with scale_align = 1).  pred / gt are addressed through ELEMENT strides of (b, t, j, c), so the reference's
+ * (B,3,J,L) permutations need no copy; gt (and its strides) may be null for the prediction-only metrics; mask: (B,L,J) bytes or null.
+ * out: (B, mp_pose_metrics_row_floats()) sums per batch item, laid out as
+ *   [0] sum ||e||  [1] sum ||e||^2  [2] sum_pairs |l-r|  [3] sum_pairs (l-r)^2  [4] sum_bones |gt-pred|  [5] sum_bones (gt-pred)
+ *   [6] #(||e|| < pck_threshold)  [7] sum_j #(AUC thresholds i*auc_max/(auc_steps-1) above ||e||)  [8] #visible joints
+ *   [9] sum ||d_t pred - d_t gt||  [10] the same squared  [11] frames;
+ *   then per bone k (16): sum (len-len0), sum (len-len0)^2, sum |gt-pred|, sum (gt-pred);  per left/right pair (6): sum |l-r|,
+ *   sum (l-r)^2;  per joint (17): sum ||e||, sum ||e||^2.   len0: (B,16) bone lengths of frame 0 (the shift of the variance sums).
+ * scratch: >= B * ceil(L/256) * row_floats floats. */
+int mp_pose_metrics_row_floats(void);
+int mp_pose_metrics(const float* pred, const int64_t* pred_strides, const float* gt, const int64_t* gt_strides, const uint8_t* mask, int B,
+                    int L, int J, float pred_scale, float gt_scale, float pck_threshold, float auc_max, int auc_steps, int scale_align,
+                    float* out, float* len0, float* scratch, int64_t scratch_floats, void* stream);
+
 /* test / tuning hooks (no reference counterpart): "gemm_small_tile" (1 = 128x128 GEMM tiles everywhere),
  * "gemm_persist_min_tiles" (output-tile count from which the persistent GEMM kernels are used; 0 = default),
  * "gemm_persist_mode" (0 tiled kernels only, 1 = default: persistent kernel where it applies). */

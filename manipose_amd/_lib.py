@@ -66,6 +66,8 @@ _SIGNATURES = {
     "mp_model_backward": (i32, [vp, vp, vp, vp, vp, vp]),
     "mp_model_peek": (i32, [vp, i32, C.POINTER(vp), C.POINTER(i64)]),
     "mp_model_peek_copy": (i32, [vp, i32, vp, i64, vp]),
+    "mp_pose_metrics_row_floats": (i32, []),
+    "mp_pose_metrics": (i32, [vp, C.POINTER(i64), vp, C.POINTER(i64), vp, i32, i32, i32, f32, f32, f32, f32, i32, i32, vp, vp, vp, i64, vp]),
     "mp_set_option": (i32, [C.c_char_p, i32]),
     "mp_prof_enable": (i32, [vp, i32]),
     "mp_prof_collect": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
                                                                bf16* __restrict__ dqkv, int T, int J, int C, int H, float scale,
                                                                int debug) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
-  constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB, NW = 16;
+  constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB, NW = 16, UNR = NTC ? NTC / 2 : 1;
   char* Qs = sm;
   char* Ks = Qs + TP * ROWB;
   char* Vs = Ks + TP * ROWB;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
     f32x4 dq[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll(NTC ? NTC / 2 : 1)
+#pragma unroll UNR
     for (int kp = 0; 2 * kp < ntile; ++kp) {
       f32x4 ds[2];
 #pragma unroll
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
     f32x4 dk[DB], dv[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll(NTC ? NTC / 2 : 1)
+#pragma unroll UNR
     for (int qp = 0; 2 * qp < ntile; ++qp) {
       f32x4 p2[2], d2[2];
 #pragma unroll

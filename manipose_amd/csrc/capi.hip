@@ -141,6 +141,17 @@ int mp_attention_bwd_bf16(const void* qkv, const void* out, const void* d_out, c
                   : attn_spatial_bwd(qkv, d_out, d_qkv, 1, B, T, J, C, H, (hipStream_t)stream);
 }
 
+int mp_pose_metrics_row_floats(void) { return pose_metrics_row_floats(); }
+int mp_pose_metrics(const float* pred, const int64_t* pred_strides, const float* gt, const int64_t* gt_strides, const uint8_t* mask, int B,
+                    int L, int J, float pred_scale, float gt_scale, float pck_threshold, float auc_max, int auc_steps, int scale_align,
+                    float* out, float* len0, float* scratch, int64_t scratch_floats, void* stream) {
+  MP_CHECK(pred && pred_strides && out && len0 && scratch, MP_ERR_ARG, "mp_pose_metrics: null pointer");
+  long ps[4], gs[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) { ps[i] = (long)pred_strides[i]; if (gt_strides) gs[i] = (long)gt_strides[i]; }
+  return pose_metrics(pred, ps, gt, gt_strides ? gs : nullptr, mask, B, L, J, pred_scale, gt_scale, pck_threshold, auc_max, auc_steps,
+                      scale_align, out, len0, scratch, (long)scratch_floats, (hipStream_t)stream);
+}
+
 /* test / tuning hooks: "gemm_small_tile" (1 = 128x128 tiles everywhere), "gemm_persist_min_tiles" (tile count from which the
  * persistent GEMM kernels run; 0 = default), "gemm_persist_mode" (0 tiled kernels only, 1 persistent kernel where it applies) */
 int mp_set_option(const char* name, int value) {

@@ -133,4 +133,10 @@ int aggregate_poses(const float* poses, const float* scores, const float* y, int
 int mpjpe_sum(const float* pred, const float* gt, long njoints, float* out_sum, float* scratch, long scratch_floats,
               hipStream_t st);
 
+// ---------------------------------------------------------------- pose_metrics.hip
+int pose_metrics_row_floats();
+int pose_metrics(const float* pred, const long* ps, const float* gt, const long* gs, const unsigned char* mask, int B, int L, int J,
+                 float pred_scale, float gt_scale, float pck_thr, float auc_max, int auc_n, int scale_align, float* out, float* len0,
+                 float* scratch, long scratch_floats, hipStream_t st);
+
 }  // namespace mp

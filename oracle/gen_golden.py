@@ -210,9 +210,70 @@ def gen_loss_fixture(ref):
     print("loss: ok")
 
 
+def gen_metrics_fixture(ref):
+    """Evaluation analytics: outputs of the reference's own metric functions on seeded pose sequences in
+    millimetres: a 'free' prediction (noisy bones) and a 'rigid' one (constant bone lengths, the manifold case where a naive
+    variance cancels)."""
+    import mh_so3_hpe.metrics.regularizations as R
+    import mh_so3_hpe.metrics.mean_joint_errors as E
+    import mh_so3_hpe.metrics.pck as P
+    from mh_so3_hpe.metrics.losses import mean_velocity_error
+    sk = ref["sk"]
+    g = torch.Generator().manual_seed(77)
+    B, L, J = 3, 301, 17
+    gt = 400.0 * torch.randn(B, L, J, 3, generator=g)
+    gt[:, :, 0] = 0
+    pred = gt + 60.0 * torch.randn(B, L, J, 3, generator=g)
+    # rigid sequence: fixed bone lengths, random directions (walk down the tree)
+    lens = 200.0 + 100.0 * torch.rand(B, 16, generator=g)
+    rigid = torch.zeros(B, L, J, 3)
+    for j in range(1, J):
+        d = torch.randn(B, L, 3, generator=g)
+        d = d / d.norm(dim=-1, keepdim=True)
+        rigid[:, :, j] = rigid[:, :, orc.H36M_PARENTS[j]] + lens[:, j - 1, None, None] * d
+    out = dict(pred=pred.numpy(), gt=gt.numpy(), rigid=rigid.numpy(), rigid_lens=lens.numpy())
+    for nm, x in (("pred", pred), ("rigid", rigid)):
+        jc = x.permute(0, 3, 2, 1)                            # (B, 3, J, L), the layout the reference passes
+        for mode in ("average", "sum", "std", "min", "max"):
+            out[f"{nm}.stc.{mode}"] = R.segments_time_consistency(jc, sk, mode).numpy()
+        for mode in ("average", "sum", "std"):
+            out[f"{nm}.stc_per_bone.{mode}"] = R.segments_time_consistency_per_bone(jc, sk, mode).numpy()
+        # the evaluation call flattens the batch into the time axis (main_h36m_lifting.py:950-959)
+        out[f"{nm}.stc_flat.std"] = R.segments_time_consistency(jc.permute(1, 2, 0, 3).reshape(1, 3, J, -1), sk, "std").numpy()
+        for sq in (False, True):
+            for mode in ("average", "sum"):
+                out[f"{nm}.sym.{mode}.{int(sq)}"] = R.sagittal_symmetry(jc, sk, mode, squared=sq).numpy()
+                out[f"{nm}.sym_per_bone.{mode}.{int(sq)}"] = R.sagittal_symmetry_per_bone(jc, sk, mode, squared=sq).numpy()
+        gj = gt.permute(0, 3, 2, 1)
+        for signed in (False, True):
+            for mode in ("average", "sum"):
+                out[f"{nm}.len_err.{mode}.{int(signed)}"] = E.segments_len_err(jc, gj, sk, mode, signed=signed).numpy()
+        for mode in ("average", "sum"):
+            out[f"{nm}.mpjpe.{mode}"] = E.mpjpe_error(x, gt, mode).numpy()
+            out[f"{nm}.mse.{mode}"] = E.mse_error(x, gt, mode).numpy()
+            out[f"{nm}.jw_err.{mode}"] = E.jointwise_error(x, gt, mode).numpy()
+            out[f"{nm}.jw_mse.{mode}"] = E.jointwise_mse(x, gt, mode).numpy()
+        out[f"{nm}.vel"] = mean_velocity_error(predicted=x, target=gt, squared=False, axis=1).numpy()
+        out[f"{nm}.vel_sq"] = mean_velocity_error(predicted=x, target=gt, squared=True, axis=1).numpy()
+        xf, gf = x.reshape(-1, J, 3).numpy(), gt.reshape(-1, J, 3).numpy()
+        mask = (torch.rand(B * L, J, generator=torch.Generator().manual_seed(5)) > 0.2).numpy()
+        out["mask"] = mask
+        for al in ("none", "scale"):
+            out[f"{nm}.pck.{al}"] = np.float64(P.keypoint_3d_pck(xf, gf, mask=None, alignment=al, threshold=150))
+            out[f"{nm}.auc.{al}"] = np.float64(P.keypoint_3d_auc(xf, gf, mask=None, alignment=al))
+        out[f"{nm}.pck.masked"] = np.float64(P.keypoint_3d_pck(xf, gf, mask=mask, alignment="none", threshold=150))
+        out[f"{nm}.auc.masked"] = np.float64(P.keypoint_3d_auc(xf, gf, mask=mask, alignment="none"))
+        out[f"{nm}.pck.thr80"] = np.float64(P.keypoint_3d_pck(xf, gf, mask=None, alignment="none", threshold=80))
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
+    print("metrics: ok", len(out), "arrays")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":       # regenerate the analytics fixture only
+        gen_metrics_fixture(ref)
+        return
     tiny = dict(T=9, J=17, num_bones=16, C_rot=32, depth_rot=2, heads_rot=4, C_seg=16, depth_seg=1, heads_seg=4, n_hyp=3)
     small = dict(T=27, J=17, num_bones=16, C_rot=64, depth_rot=2, heads_rot=8, C_seg=32, depth_seg=2, heads_seg=8, n_hyp=5)
     k1 = dict(T=27, J=17, num_bones=16, C_rot=64, depth_rot=2, heads_rot=8, C_seg=32, depth_seg=1, heads_seg=8, n_hyp=0)
@@ -222,6 +283,7 @@ def main():
     gen_model_fixture(ref, "rmcl_tiny_droppath", tiny, B=3, seed=14, drop_path_rate=0.5, train=True)
     gen_decoder_fixture(ref)
     gen_loss_fixture(ref)
+    gen_metrics_fixture(ref)
     # default initialisation under seed 42 (the product's constructors must consume the RNG identically)
     torch.manual_seed(42)
     m0 = build_ref_model(ref, small, 0.1)

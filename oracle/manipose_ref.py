@@ -390,6 +390,100 @@ def aggregate(hyp, scores=None, mode="weighted_ave", ground_truth=None):
 
 
 # ---------------------------------------------------------------------------
+# Evaluation analytics: skeleton-consistency metrics (metrics/regularizations.py:8-157,
+# metrics/utils.py:4-20), the remaining error metrics (metrics/mean_joint_errors.py:39-130), evaluation velocity
+# error (metrics/losses.py:75-101) and 3DPCK / AUC (metrics/pck.py:92-199).  joints_coords is (B, 3, J, L).
+# ---------------------------------------------------------------------------
+H36M_BONES = tuple((j, p) for j, p in enumerate(H36M_PARENTS) if p >= 0)          # data/skeleton.py:101-103
+H36M_BONES_LEFT = tuple(j - 1 for j in H36M_JOINTS_LEFT)                          # data/skeleton.py:110-120 (bone k <-> joint k+1)
+H36M_BONES_RIGHT = tuple(j - 1 for j in H36M_JOINTS_RIGHT)
+
+
+def measure_bones_length(joints_coords: Tensor, bones=H36M_BONES) -> Tensor:
+    """metrics/utils.py:4-20 -> (B, num_bones, L)."""
+    return torch.stack([(joints_coords[:, :, j, :] - joints_coords[:, :, p, :]).pow(2).sum(1).sqrt() for j, p in bones], dim=1)
+
+
+def segments_time_stat(joints_coords: Tensor, mode: str) -> Tensor:
+    """regularizations.py:8-35: unbiased variance (std for mode 'std') over time of every bone length -> (B, num_bones)."""
+    bl = measure_bones_length(joints_coords)
+    return torch.std(bl, dim=2) if mode == "std" else torch.var(bl, dim=2)
+
+
+def segments_time_consistency(joints_coords: Tensor, mode: str) -> Tensor:
+    """regularizations.py:38-50."""
+    agg = {"average": torch.mean, "sum": torch.sum, "std": torch.mean, "min": torch.min, "max": torch.max}[mode]
+    return agg(segments_time_stat(joints_coords, mode))
+
+
+def segments_time_consistency_per_bone(joints_coords: Tensor, mode: str) -> Tensor:
+    """regularizations.py:53-64 (modes with a tensor result)."""
+    agg = {"average": torch.mean, "sum": torch.sum, "std": torch.mean}[mode]
+    return agg(segments_time_stat(joints_coords, mode), dim=0)
+
+
+def sagittal_diff(joints_coords: Tensor, squared: bool) -> Tensor:
+    """regularizations.py:96-122 -> (B, num_pairs, L)."""
+    bl = measure_bones_length(joints_coords)
+    d = (bl[:, list(H36M_BONES_LEFT), :] - bl[:, list(H36M_BONES_RIGHT), :]).abs()
+    return d ** 2.0 if squared else d
+
+
+def sagittal_symmetry(joints_coords: Tensor, mode: str, squared: bool = True) -> Tensor:
+    """regularizations.py:125-138."""
+    d = sagittal_diff(joints_coords, squared)
+    return d.mean() if mode == "average" else d.sum()
+
+
+def sagittal_symmetry_per_bone(joints_coords: Tensor, mode: str, squared: bool = True) -> Tensor:
+    """regularizations.py:141-157."""
+    d = sagittal_diff(joints_coords, squared).permute(0, 2, 1).reshape(-1, len(H36M_BONES_LEFT))
+    return d.mean(0) if mode == "average" else d.sum(0)
+
+
+def segments_len_err(batch_imp: Tensor, batch_gt: Tensor, mode: str, signed: bool = True) -> Tensor:
+    """mean_joint_errors.py:83-130: gt - predicted bone lengths over (frame, bone)."""
+    diff = measure_bones_length(batch_gt) - measure_bones_length(batch_imp)
+    if not signed:
+        diff = diff.abs()
+    return diff.mean() if mode == "average" else diff.sum()
+
+
+def mse_error(pred: Tensor, gt: Tensor, mode: str = "average") -> Tensor:
+    """mean_joint_errors.py:39-44."""
+    d = (gt.reshape(-1, 3) - pred.reshape(-1, 3)).pow(2).sum(1)
+    return d.mean() if mode == "average" else d.sum()
+
+
+def jointwise_error(pred: Tensor, gt: Tensor, mode: str = "average", squared: bool = False) -> Tensor:
+    """mean_joint_errors.py:47-80 (jointwise_error / jointwise_mse) -> (J,)."""
+    J = gt.shape[-2]
+    d = gt.reshape(-1, J, 3) - pred.reshape(-1, J, 3)
+    e = d.pow(2).sum(2) if squared else torch.norm(d, 2, 2)
+    return e.mean(0) if mode == "average" else e.sum(0)
+
+
+def eval_velocity_error(pred: Tensor, target: Tensor, axis: int = 1, squared: bool = False) -> Tensor:
+    """metrics/losses.py:75-101 for equal shapes (the evaluation call, main_h36m_lifting.py:968-973)."""
+    dv = torch.diff(pred, dim=axis) - torch.diff(target, dim=axis)
+    return (dv ** 2).mean() if squared else torch.norm(dv, dim=pred.dim() - 1).mean()
+
+
+def keypoint_3d_pck_auc(pred: Tensor, gt: Tensor, mask: Optional[Tensor] = None, alignment: str = "none", threshold: float = 150.0):
+    """metrics/pck.py:92-199: (pck, auc) in percent; pred / gt (N, K, 3); alignment 'none' or 'scale'."""
+    pred, gt = pred.double(), gt.double()
+    if alignment == "scale":
+        f = (pred * gt).sum((1, 2)) / (pred * pred).sum((1, 2))
+        pred = pred * f[:, None, None]
+    err = torch.norm(pred - gt, dim=-1)
+    m = torch.ones_like(err, dtype=torch.bool) if mask is None else mask.bool()
+    pck = (err < threshold)[m].double().mean() * 100
+    ths = torch.linspace(0.0, 150.0, 31, dtype=torch.float64)
+    auc = torch.stack([(err < t)[m].double().mean() for t in ths]).mean() * 100
+    return pck, auc
+
+
+# ---------------------------------------------------------------------------
 # Optimizer (torch.optim.Adam with L2 weight decay, main_h36m_lifting.py:234-238)
 # ---------------------------------------------------------------------------
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr=4e-5, beta1=0.9,

@@ -605,3 +605,115 @@ def test_bf16_persistent_gemm_path_matches_tiled_path(lib):
         close(outs[0][1], o[1], rtol=1e-5, atol=1e-5)
         assert _cos(outs[0][2], o[2]) > 0.99999
         assert (outs[0][2] - o[2]).abs().max() <= 1e-4 * outs[0][2].abs().max()
+
+
+# --------------------------------------------------------------------------------- evaluation analytics
+def _close_rel(got, want, rtol=2e-4, atol=0.0):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, dtype=np.float64)
+    np.testing.assert_allclose(got, np.asarray(want, dtype=np.float64), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("nm", ["pred", "rigid"])
+def test_consistency_metrics_match_reference_fixture(lib, nm):
+    """segments_time_consistency / sagittal_symmetry / segments_len_err (+ per-bone forms) from the one-pass HIP kernel against
+    the outputs of the reference's own functions; 'rigid' has constant bone lengths (time variance ~ rounding noise)."""
+    from manipose_amd import h36m_skeleton
+    from manipose_amd.metrics import (sagittal_symmetry, sagittal_symmetry_per_bone, segments_len_err, segments_time_consistency,
+                                      segments_time_consistency_per_bone)
+    fx, sk = load_fixture("metrics"), h36m_skeleton()
+    jc = dev(fx[nm]).permute(0, 3, 2, 1)                  # (B, 3, J, L) view, read through its strides (no copy)
+    gj = dev(fx["gt"]).permute(0, 3, 2, 1)
+    # variance of lengths ~250 mm known to ~2e-5 mm: absolute floor for the rigid case
+    vat, sat = (1e-6, 1e-3) if nm == "rigid" else (0.0, 0.0)
+    for mode in ("average", "sum", "min", "max"):
+        _close_rel(segments_time_consistency(jc, sk, mode), fx[f"{nm}.stc.{mode}"], atol=vat * (48 if mode == "sum" else 1))
+    _close_rel(segments_time_consistency(jc, sk, "std"), fx[f"{nm}.stc.std"], atol=sat)
+    for mode in ("average", "sum"):
+        _close_rel(segments_time_consistency_per_bone(jc, sk, mode), fx[f"{nm}.stc_per_bone.{mode}"], atol=vat * 3)
+    _close_rel(segments_time_consistency_per_bone(jc, sk, "std"), fx[f"{nm}.stc_per_bone.std"], atol=sat)
+    flat = jc.permute(1, 2, 0, 3).reshape(1, 3, 17, -1)   # the evaluation call: batch flattened into time (903 frames, 4 chunks)
+    _close_rel(segments_time_consistency(flat, sk, "std"), fx[f"{nm}.stc_flat.std"], atol=sat)
+    for sq in (False, True):
+        for mode in ("average", "sum"):
+            _close_rel(sagittal_symmetry(jc, sk, mode, squared=sq), fx[f"{nm}.sym.{mode}.{int(sq)}"])
+            _close_rel(sagittal_symmetry_per_bone(jc, sk, mode, squared=sq), fx[f"{nm}.sym_per_bone.{mode}.{int(sq)}"])
+    for signed in (False, True):
+        for mode in ("average", "sum"):
+            want = fx[f"{nm}.len_err.{mode}.{int(signed)}"]
+            # the signed sum cancels: bound it by the unsigned scale
+            _close_rel(segments_len_err(jc, gj, sk, mode, signed=signed), want,
+                       atol=2e-4 * abs(float(fx[f"{nm}.len_err.{mode}.0"])))
+    with pytest.raises(ValueError):
+        segments_time_consistency(jc, sk, "median")
+    with pytest.raises(ValueError):
+        sagittal_symmetry(jc, sk, "max")
+
+
+@pytest.mark.parametrize("nm", ["pred", "rigid"])
+def test_error_metrics_and_pck_auc_match_reference_fixture(lib, nm):
+    from manipose_amd.metrics import (jointwise_error, jointwise_mse, keypoint_3d_auc, keypoint_3d_pck, mpjpe_error, mse_error,
+                                      pose_analytics)
+    fx = load_fixture("metrics")
+    x, gt = dev(fx[nm]), dev(fx["gt"])
+    for mode in ("average", "sum"):
+        _close_rel(mpjpe_error(x, gt, mode), fx[f"{nm}.mpjpe.{mode}"])
+        _close_rel(mse_error(x, gt, mode), fx[f"{nm}.mse.{mode}"])
+        _close_rel(jointwise_error(x, gt, mode), fx[f"{nm}.jw_err.{mode}"])
+        _close_rel(jointwise_mse(x, gt, mode), fx[f"{nm}.jw_mse.{mode}"])
+    r = pose_analytics(x, gt)                               # velocity error sums: one pass, both forms
+    n = x.shape[0] * (x.shape[1] - 1) * 17
+    _close_rel(r.scalar(9) / n, fx[f"{nm}.vel"])
+    _close_rel(r.scalar(10) / (3 * n), fx[f"{nm}.vel_sq"])
+    xf, gf = x.reshape(-1, 17, 3), gt.reshape(-1, 17, 3)
+    tol = 100.0 * 3 / (xf.shape[0] * 17)                   # at most a few joints within rounding of a threshold
+    for al in ("none", "scale"):
+        assert abs(keypoint_3d_pck(xf, gf, None, al, 150) - float(fx[f"{nm}.pck.{al}"])) <= tol
+        assert abs(keypoint_3d_auc(xf, gf, None, al) - float(fx[f"{nm}.auc.{al}"])) <= tol
+    assert abs(keypoint_3d_pck(xf.cpu().numpy(), gf.cpu().numpy(), fx["mask"], "none", 150) - float(fx[f"{nm}.pck.masked"])) <= 2 * tol
+    assert abs(keypoint_3d_auc(xf, gf, fx["mask"], "none") - float(fx[f"{nm}.auc.masked"])) <= 2 * tol
+    assert abs(keypoint_3d_pck(xf, gf, None, "none", 80) - float(fx[f"{nm}.pck.thr80"])) <= tol
+    with pytest.raises(NotImplementedError):
+        keypoint_3d_pck(xf, gf, None, "procrustes")
+    with pytest.raises(ValueError):
+        keypoint_3d_auc(xf, gf, None, "affine")
+
+
+def test_pose_analytics_refuses_cpu_tensors_and_foreign_skeletons(lib):
+    from manipose_amd.data.skeleton import Skeleton, T_POSE_OPERATORS
+    from manipose_amd.metrics import pose_analytics, sagittal_symmetry
+    x = torch.zeros(1, 4, 17, 3)
+    with pytest.raises(RuntimeError):
+        pose_analytics(x)
+    other = Skeleton([-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 8, 11, 12, 8, 14, 14], [4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16], T_POSE_OPERATORS)
+    with pytest.raises(AssertionError):
+        sagittal_symmetry(x.cuda().permute(0, 3, 2, 1), other, "average")
+
+
+def test_evaluate_analytics_table_matches_oracle_on_the_flattened_sequence(lib):
+    """hpe entry evaluate(analytics=True): the accumulated table (batches merged into ONE sequence like the reference's
+    (1,3,J,B*L) reshape, shifted variance sums re-centred across batches) against the oracle restatement applied to the
+    concatenated aggregated predictions."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hpe"))
+    from _entry import evaluate
+    fx = load_fixture("rmcl_small")
+    model = _build(fx).eval()
+    g = torch.Generator().manual_seed(21)
+    X = torch.cat([torch.from_numpy(fx["X"]), 0.3 * torch.randn(3, 27, 17, 2, generator=g)]).cuda()
+    y = torch.cat([torch.from_numpy(fx["y"]), 0.3 * torch.randn(3, 27, 17, 3, generator=g)]).cuda()
+    y[:, :, 0] = 0
+    got = evaluate(model, X, y, batch=2, tta=False, analytics=True)["analytics"]
+    with torch.no_grad():
+        poses, scores = model(X)
+        pred = (model.aggregate(poses, scores, "weighted_ave") * 1000.0).cpu()
+    gt = (y * 1000.0).cpu()
+    jc, gj = pred.permute(0, 3, 2, 1), gt.permute(0, 3, 2, 1)
+    flat = jc.permute(1, 2, 0, 3).reshape(1, 3, 17, -1)
+    want = {"mpjpe": orc.mpjpe_error(pred, gt).item(), "mse": orc.mse_error(pred, gt).item(),
+            "mpsse": orc.sagittal_symmetry(jc, "average", False).item(), "mpsce": orc.segments_time_consistency(flat, "std").item(),
+            "seg_len_err": orc.segments_len_err(jc, gj, "average", False).item()}
+    pck, auc = orc.keypoint_3d_pck_auc(pred.reshape(-1, 17, 3), gt.reshape(-1, 17, 3))
+    for k, v in want.items():
+        assert abs(got[k] - v) <= 2e-4 * abs(v) + 1e-3, (k, got[k], v)
+    assert abs(got["pck"] - pck.item()) <= 0.2 and abs(got["auc"] - auc.item()) <= 0.2
+    assert abs(got["err_var"] - (want["mse"] - want["mpjpe"] ** 2)) <= 1e-3 * want["mse"]

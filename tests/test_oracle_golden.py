@@ -146,3 +146,54 @@ def test_param_counts_and_key_layout(golden_dir):
     want = open(golden_dir + "/state_dict_keys_T243_K5.txt").read().split()
     got = sorted(f"{k}|{'x'.join(map(str, v.shape))}" for k, v in st.items())
     assert got == want
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# evaluation analytics: oracle restatement vs the reference's own metric functions (metrics.npz)
+# ---------------------------------------------------------------------------------------------------------------------
+def _metric_cases(fx):
+    for nm in ("pred", "rigid"):
+        x, gt = torch.from_numpy(fx[nm]), torch.from_numpy(fx["gt"])
+        yield nm, x, gt, x.permute(0, 3, 2, 1), gt.permute(0, 3, 2, 1)
+
+
+def test_oracle_consistency_metrics_match_reference():
+    fx = load_fixture("metrics")
+    for nm, x, gt, jc, gj in _metric_cases(fx):
+        for mode in ("average", "sum", "std", "min", "max"):
+            np.testing.assert_allclose(orc.segments_time_consistency(jc, mode).numpy(), fx[f"{nm}.stc.{mode}"], rtol=1e-6, atol=0)
+        for mode in ("average", "sum", "std"):
+            np.testing.assert_allclose(orc.segments_time_consistency_per_bone(jc, mode).numpy(), fx[f"{nm}.stc_per_bone.{mode}"],
+                                       rtol=1e-6)
+        flat = jc.permute(1, 2, 0, 3).reshape(1, 3, 17, -1)
+        np.testing.assert_allclose(orc.segments_time_consistency(flat, "std").numpy(), fx[f"{nm}.stc_flat.std"], rtol=1e-6)
+        for sq in (False, True):
+            for mode in ("average", "sum"):
+                np.testing.assert_allclose(orc.sagittal_symmetry(jc, mode, sq).numpy(), fx[f"{nm}.sym.{mode}.{int(sq)}"], rtol=1e-6)
+                np.testing.assert_allclose(orc.sagittal_symmetry_per_bone(jc, mode, sq).numpy(),
+                                           fx[f"{nm}.sym_per_bone.{mode}.{int(sq)}"], rtol=1e-6)
+        for signed in (False, True):
+            for mode in ("average", "sum"):
+                np.testing.assert_allclose(orc.segments_len_err(jc, gj, mode, signed).numpy(),
+                                           fx[f"{nm}.len_err.{mode}.{int(signed)}"], rtol=1e-6, atol=1e-9)
+
+
+def test_oracle_error_metrics_and_pck_match_reference():
+    fx = load_fixture("metrics")
+    mask = torch.from_numpy(fx["mask"])
+    for nm, x, gt, jc, gj in _metric_cases(fx):
+        for mode in ("average", "sum"):
+            np.testing.assert_allclose(orc.mpjpe_error(x, gt, mode).numpy(), fx[f"{nm}.mpjpe.{mode}"], rtol=1e-6)
+            np.testing.assert_allclose(orc.mse_error(x, gt, mode).numpy(), fx[f"{nm}.mse.{mode}"], rtol=1e-6)
+            np.testing.assert_allclose(orc.jointwise_error(x, gt, mode).numpy(), fx[f"{nm}.jw_err.{mode}"], rtol=1e-6)
+            np.testing.assert_allclose(orc.jointwise_error(x, gt, mode, squared=True).numpy(), fx[f"{nm}.jw_mse.{mode}"], rtol=1e-6)
+        np.testing.assert_allclose(orc.eval_velocity_error(x, gt, 1, False).numpy(), fx[f"{nm}.vel"], rtol=1e-6)
+        np.testing.assert_allclose(orc.eval_velocity_error(x, gt, 1, True).numpy(), fx[f"{nm}.vel_sq"], rtol=1e-6)
+        xf, gf = x.reshape(-1, 17, 3), gt.reshape(-1, 17, 3)
+        for al in ("none", "scale"):
+            pck, auc = orc.keypoint_3d_pck_auc(xf, gf, None, al)
+            assert abs(pck.item() - float(fx[f"{nm}.pck.{al}"])) < 1e-4 and abs(auc.item() - float(fx[f"{nm}.auc.{al}"])) < 1e-4
+        pck, auc = orc.keypoint_3d_pck_auc(xf, gf, mask, "none")
+        assert abs(pck.item() - float(fx[f"{nm}.pck.masked"])) < 1e-4 and abs(auc.item() - float(fx[f"{nm}.auc.masked"])) < 1e-4
+        pck, _ = orc.keypoint_3d_pck_auc(xf, gf, None, "none", threshold=80.0)
+        assert abs(pck.item() - float(fx[f"{nm}.pck.thr80"])) < 1e-4
