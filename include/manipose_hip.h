@@ -182,7 +182,7 @@ int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops);
  *   [9] sum ||d_t pred - d_t gt||  [10] the same squared  [11] frames;
  *   then per bone k (16): sum (len-len0), sum (len-len0)^2, sum |gt-pred|, sum (gt-pred);  per left/right pair (6): sum |l-r|,
  *   sum (l-r)^2;  per joint (17): sum ||e||, sum ||e||^2.   len0: (B,16) bone lengths of frame 0 (the shift of the variance sums).
- * scratch: >= B * ceil(L/256) * row_floats floats. */
+ * scratch: >= B * ceil(L/128) * row_floats floats. */
 int mp_pose_metrics_row_floats(void);
 int mp_pose_metrics(const float* pred, const int64_t* pred_strides, const float* gt, const int64_t* gt_strides, const uint8_t* mask, int B,
                     int L, int J, float pred_scale, float gt_scale, float pck_threshold, float auc_max, int auc_steps, int scale_align,

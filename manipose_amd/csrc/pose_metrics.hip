@@ -49,13 +49,39 @@ __device__ __forceinline__ void pm_load(const float* p, const long (&s)[4], int 
   }
 }
 
-__global__ __launch_bounds__(256) void pose_metrics_kernel(PmArgs a, float* __restrict__ partial, float* __restrict__ len0_out) {
-  extern __shared__ float red[];           // [4 waves][NV] + len0[NB]
-  float* len0 = red + 4 * a.NV;
+// frame from an LDS image of consecutive (J x 3)-float frames (row pitch 51 dwords: odd, so a wave's 64 rows hit 64 banks)
+__device__ __forceinline__ void pm_load_lds(const float* img, int row, float sc, float (&x)[PM_J][3]) {
+#pragma unroll
+  for (int j = 0; j < PM_J; ++j) {
+    x[j][0] = sc * img[row * (3 * PM_J) + 3 * j];
+    x[j][1] = sc * img[row * (3 * PM_J) + 3 * j + 1];
+    x[j][2] = sc * img[row * (3 * PM_J) + 3 * j + 2];
+  }
+}
+
+// FR frames (= threads) per block.  STAGED: both tensors are plain contiguous (B, L, J, 3): the block's FR frames plus the one
+// before them (for the velocity terms) are copied into LDS with coalesced loads - every byte of the inputs is read from HBM
+// exactly once - and each thread then takes its frame from there; otherwise every thread gathers its frame through the strides.
+template <bool STAGED, int FR>
+__global__ __launch_bounds__(FR) void pose_metrics_kernel(PmArgs a, float* __restrict__ partial, float* __restrict__ len0_out) {
+  extern __shared__ float red[];           // [FR/64 waves][NV] + len0[NB] (+ the two frame images when STAGED)
+  constexpr int NWV = FR / 64, ROW = 3 * PM_J;
+  float* len0 = red + NWV * a.NV;
+  float* img_p = len0 + PM_NB;
+  float* img_g = img_p + (FR + 1) * ROW;
   constexpr int J = PM_J, NB = PM_NB, NP = PM_NP;
-  const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y, t0 = blockIdx.x * FR, t = t0 + threadIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool live = t < a.L;
+  if (STAGED) {
+    const int first = max(t0 - 1, 0), last = min(t0 + FR, a.L);          // frames [first, last) -> image rows from (first - (t0 - 1))
+    const long src = ((long)b * a.L + first) * ROW;
+    const int dst = (first - (t0 - 1)) * ROW, count = (last - first) * ROW;
+    for (int i = threadIdx.x; i < count; i += FR) {
+      img_p[dst + i] = a.pred[src + i];
+      img_g[dst + i] = a.gt[src + i];
+    }
+  }
   if (threadIdx.x < NB) {                  // reference length of every bone of this batch item: frame 0
     const float* base = a.pred + b * a.ps[0];
     const int j = threadIdx.x + 1, p = PM_PARENT[j];
@@ -67,14 +93,19 @@ __global__ __launch_bounds__(256) void pose_metrics_kernel(PmArgs a, float* __re
     len0[threadIdx.x] = sqrtf(s);
     if (blockIdx.x == 0) len0_out[b * NB + threadIdx.x] = len0[threadIdx.x];
   }
-  __syncthreads();
+  __syncthreads();                         // len0 (and the staged frames) visible
 
   float x[J][3], y[J][3];
   float plen[NB], glen[NB];
   const bool has_gt = a.gt != nullptr;
   if (live) {
-    pm_load(a.pred, a.ps, b, t, a.pred_scale, x);
-    if (has_gt) pm_load(a.gt, a.gs, b, t, a.gt_scale, y);
+    if (STAGED) {
+      pm_load_lds(img_p, threadIdx.x + 1, a.pred_scale, x);
+      pm_load_lds(img_g, threadIdx.x + 1, a.gt_scale, y);
+    } else {
+      pm_load(a.pred, a.ps, b, t, a.pred_scale, x);
+      if (has_gt) pm_load(a.gt, a.gs, b, t, a.gt_scale, y);
+    }
     if (has_gt && a.scale_align) {
       float pp = 0.f, pg = 0.f;
 #pragma unroll
@@ -147,8 +178,13 @@ __global__ __launch_bounds__(256) void pose_metrics_kernel(PmArgs a, float* __re
   float s_v = 0.f, s_v2 = 0.f;
   if (live && has_gt && t >= 1) {          // velocity error against frame t-1 (mean_velocity_error, axis = time)
     float xp[J][3], yp[J][3];
-    pm_load(a.pred, a.ps, b, t - 1, a.pred_scale, xp);
-    pm_load(a.gt, a.gs, b, t - 1, a.gt_scale, yp);
+    if (STAGED) {
+      pm_load_lds(img_p, threadIdx.x, a.pred_scale, xp);
+      pm_load_lds(img_g, threadIdx.x, a.gt_scale, yp);
+    } else {
+      pm_load(a.pred, a.ps, b, t - 1, a.pred_scale, xp);
+      pm_load(a.gt, a.gs, b, t - 1, a.gt_scale, yp);
+    }
     if (a.scale_align) {                   // the aligned prediction of the previous frame
       float pp = 0.f, pg = 0.f;
 #pragma unroll
@@ -173,7 +209,12 @@ __global__ __launch_bounds__(256) void pose_metrics_kernel(PmArgs a, float* __re
   emit(6, s_pck); emit(7, s_auc); emit(8, s_vis); emit(9, s_v); emit(10, s_v2); emit(11, 1.f);
   __syncthreads();
   float* prow = partial + ((long)b * gridDim.x + blockIdx.x) * a.NV;
-  for (int v = threadIdx.x; v < a.NV; v += 256) prow[v] = (red[v] + red[a.NV + v]) + (red[2 * a.NV + v] + red[3 * a.NV + v]);
+  for (int v = threadIdx.x; v < a.NV; v += FR) {
+    float sacc = red[v];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) sacc += red[w * a.NV + v];
+    prow[v] = sacc;
+  }
 }
 
 __global__ void pose_metrics_finalize_kernel(const float* __restrict__ partial, int chunks, int NV, float* __restrict__ out) {
@@ -202,11 +243,19 @@ int pose_metrics(const float* pred, const long* ps, const float* gt, const long*
   a.NV = pose_metrics_row_floats();
   a.pred_scale = pred_scale; a.gt_scale = gt_scale; a.pck_thr = pck_thr; a.auc_step = auc_max / (float)(auc_n - 1); a.auc_n = auc_n;
   a.scale_align = scale_align;
-  const int chunks = cdiv(L, 256);
+  const long row = 3 * PM_J;
+  const bool staged = gt != nullptr && ps[0] == (long)L * row && ps[1] == row && ps[2] == 3 && ps[3] == 1 && gs[0] == ps[0] &&
+                      gs[1] == ps[1] && gs[2] == ps[2] && gs[3] == ps[3];
+  const int fr = staged ? 128 : 256, chunks = cdiv(L, fr);
   MP_CHECK(scratch_floats >= (long)B * chunks * a.NV, MP_ERR_ARG, "pose_metrics: scratch too small (%ld < %ld)", scratch_floats,
            (long)B * chunks * a.NV);
-  const size_t lds = sizeof(float) * (4 * a.NV + PM_NB);
-  hipLaunchKernelGGL(pose_metrics_kernel, dim3(chunks, B), dim3(256), lds, st, a, scratch, len0);
+  if (staged) {
+    const size_t lds = sizeof(float) * (2 * a.NV + PM_NB + 2 * (128 + 1) * row);
+    hipLaunchKernelGGL((pose_metrics_kernel<true, 128>), dim3(chunks, B), dim3(128), lds, st, a, scratch, len0);
+  } else {
+    const size_t lds = sizeof(float) * (4 * a.NV + PM_NB);
+    hipLaunchKernelGGL((pose_metrics_kernel<false, 256>), dim3(chunks, B), dim3(256), lds, st, a, scratch, len0);
+  }
   MP_LAUNCH_CHECK();
   hipLaunchKernelGGL(pose_metrics_finalize_kernel, dim3(B), dim3(128), 0, st, scratch, chunks, a.NV, out);
   MP_LAUNCH_CHECK();

@@ -82,7 +82,7 @@ def pose_analytics(pred: torch.Tensor, gt: Optional[torch.Tensor] = None, layout
     nv = int(lib.mp_pose_metrics_row_floats())
     rows = torch.empty(B, nv, device=pred.device)
     len0 = torch.empty(B, NB, device=pred.device)
-    chunks = (L + 255) // 256
+    chunks = (L + 127) // 128
     scratch = torch.empty(B * chunks * nv, device=pred.device)
     m = None
     if mask is not None:
