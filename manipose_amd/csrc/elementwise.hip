@@ -590,17 +590,49 @@ int bones_embed_bwd(const float* g, const float* xin, float* dW, float* db, floa
 // ---------------------------------------------------------------------------------------------
 // dTemporal_pos_embed[t][c] += sum_{b,j} g[(b,t,j)][c]   (mix_ste.py:149)
 // ---------------------------------------------------------------------------------------------
-__global__ void tpos_grad_kernel(const float* __restrict__ g, float* __restrict__ dtpos, int B, int T, int J, int C) {
-  const int t = blockIdx.x, c = blockIdx.y * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int b = 0; b < B; ++b)
-    for (int j = 0; j < J; ++j) s += g[((long)(b * T + t) * J + j) * C + c];
-  dtpos[(long)t * C + c] += s;
+// block = (frame t, 256 channels): 64 float4 columns x 4 row groups; every thread sums its share of the B*J rows of that frame with
+// four independent accumulators (the loads of a serial chain were the whole cost), the groups are combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void tpos_grad_kernel(const float* __restrict__ g, float* __restrict__ dtpos, int B, int T, int J, int C) {
+  __shared__ float4 red[4][64];
+  const int t = blockIdx.x, c4 = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.y * 256 + c4 * 4;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  if (c < C) {
+    // rows (b, j) of this frame in steps of 4 per group, walked with a running (b, j) (J >= 4): no integer division
+    int b = 0, j = grp;
+    auto step = [&](float4& acc, bool& more) {              // token of the running (b, j), then advance by 4 rows
+      more = b < B;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (more) v = ld4(g + ((long)(b * T + t) * J + j) * C + c);
+      j += 4;
+      if (j >= J) { j -= J; ++b; }
+      return v;
+    };
+    bool more = true;
+    while (more) {                                           // four loads in flight, four independent sums (fixed order)
+      bool m0, m1, m2, m3;
+      const float4 v0 = step(a0, m0), v1 = step(a1, m1), v2 = step(a2, m2), v3 = step(a3, m3);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+      more = m3;
+    }
+  }
+  red[grp][c4] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                             (a0.w + a1.w) + (a2.w + a3.w));
+  __syncthreads();
+  if (grp == 0 && c < C) {
+    float4 o = ld4(dtpos + (long)t * C + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o.x += red[k][c4].x; o.y += red[k][c4].y; o.z += red[k][c4].z; o.w += red[k][c4].w; }
+    st4(dtpos + (long)t * C + c, o);
+  }
 }
 
 int tpos_grad(const float* g, float* dtpos, int B, int T, int J, int C, hipStream_t st) {
-  hipLaunchKernelGGL(tpos_grad_kernel, dim3(T, cdiv(C, 128)), dim3(128), 0, st, g, dtpos, B, T, J, C);
+  MP_CHECK(C % 4 == 0, MP_ERR_ARG, "tpos_grad: C %% 4");
+  hipLaunchKernelGGL(tpos_grad_kernel, dim3(T, cdiv(C, 256)), dim3(256), 0, st, g, dtpos, B, T, J, C);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

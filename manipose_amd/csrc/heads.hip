@@ -380,8 +380,16 @@ __global__ __launch_bounds__(256) void bones_mean_bwd_kernel(const float* __rest
   __shared__ float tot[32];
   const int b = blockIdx.x, s = threadIdx.x % S, sub = threadIdx.x / S, nsub = 256 / S;
   float a = 0.f;
-  if (sub < nsub)
-    for (int i = sub; i < KT; i += nsub) a += dlen_pose[((long)b * KT + i) * S + s];
+  if (sub < nsub) {
+    const float* p = dlen_pose + (long)b * KT * S + s;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;          // four loads in flight instead of one serial chain
+    int i = sub;
+    for (; i + 3 * nsub < KT; i += 4 * nsub) {
+      a0 += p[(long)i * S]; a1 += p[(long)(i + nsub) * S]; a2 += p[(long)(i + 2 * nsub) * S]; a3 += p[(long)(i + 3 * nsub) * S];
+    }
+    for (; i < KT; i += nsub) a0 += p[(long)i * S];
+    a = (a0 + a1) + (a2 + a3);
+  }
   red[threadIdx.x] = (sub < nsub) ? a : 0.f;
   __syncthreads();
   if (threadIdx.x < S) {
