@@ -13,6 +13,7 @@ import copy
 import os
 import sys
 
+import numpy as np
 import torch
 import yaml
 
@@ -70,6 +71,30 @@ def synthetic_windows(n, T, device, seed):
     y = 0.3 * torch.randn(n, T, 17, 3, device=device, generator=g)
     y[:, :, 0] = 0
     return X, y
+
+
+def synthetic_generator(cfg, device, seed, rank, world):
+    """The training data path of the reference (fetch -> PoseSequenceGenerator(random_start=True, PoseFlip(0.5)) -> DataLoader,
+    main_h36m_lifting.py:560-610) with the sequences resident in HBM: synthetic H36M-shaped action sequences (no dataset ships here),
+    every rank keeps its own shard of them."""
+    from manipose_amd import h36m_skeleton
+    from manipose_amd.augmentations import PoseFlip
+    from manipose_amd.data import PoseSequenceGenerator
+    from manipose_amd.distributed import shard_windows
+    rng = np.random.default_rng(seed)
+    n_seq = max(world, int(cfg.data.get("synthetic_sequences", 16)))
+    lens = [int(cfg.data.seq_len) * 4 + 37 * (i % 5) + 11 for i in range(n_seq)]
+    mine = list(shard_windows(n_seq, rank, world))
+    p3, p2 = [], []
+    for i in range(n_seq):
+        a = (0.3 * rng.standard_normal((lens[i], 17, 3))).astype(np.float32)
+        b = np.clip(0.3 * rng.standard_normal((lens[i], 17, 2)), -1, 1).astype(np.float32)
+        a[:, 0] = 0
+        if i in mine:
+            p3.append(a); p2.append(b)
+    tf = PoseFlip(h36m_skeleton(), 0.5) if cfg.train.flip_aug else None
+    return PoseSequenceGenerator(p3, p2, None, seq_len=int(cfg.data.seq_len), random_start=True, drop_last=True, miss_type="no_miss",
+                                 transform=tf, device=device)
 
 
 @torch.no_grad()
@@ -165,11 +190,14 @@ def run(argv, extra_defaults=None):
     Xv, yv = synthetic_windows(4 * cfg.train.batch_size_test, T, dev, seed=10_000)
     best_val, bad_epochs, lr = 1e10, 0, cfg.train.lr
     if cfg.run.train:
+        gen = synthetic_generator(cfg, dev, cfg.run.seed, rank, world)      # sequences resident in HBM, one gather kernel per batch
+        torch.manual_seed(cfg.run.seed + 1000 * rank)                        # per-rank window / flip draws
         for epoch in range(start_epoch, cfg.train.epochs):
             model.train()
             acc = torch.zeros(4, device=dev)
             for it in range(cfg.train.steps_per_epoch):
-                X, y = synthetic_windows(B, T, dev, seed=cfg.run.seed + 7919 * (epoch * cfg.train.steps_per_epoch + it) + rank)
+                idx = torch.randint(0, len(gen), (B,)).tolist()              # shuffled sampling with replacement over this rank's windows
+                X, y = gen.batch(idx)
                 acc += trainer.train_step(X, y)                      # device-side accumulation: no per-step host sync
             terms = (acc / cfg.train.steps_per_epoch).tolist()
             if (epoch + 1) % cfg.train.valid_epoch_interval == 0:

@@ -31,7 +31,7 @@ class PoseFlip:
         self.skeleton, self.p = skeleton, p
 
     def __call__(self, pose_2d: torch.Tensor, pose_3d: torch.Tensor):
-        if float(torch.rand(())) < self.p:
+        if torch.rand(1).item() <= self.p:                    # transforms.py:22 (same draw, same comparison)
             pose_2d, pose_3d = pose_flip((pose_2d, pose_3d), self.skeleton)
         return pose_2d, pose_3d
 

@@ -141,6 +141,14 @@ int mp_attention_bwd_bf16(const void* qkv, const void* out, const void* d_out, c
                   : attn_spatial_bwd(qkv, d_out, d_qkv, 1, B, T, J, C, H, (hipStream_t)stream);
 }
 
+int mp_gather_windows(const float* poses_2d, const float* poses_3d, const int64_t* seq_offset, int S, const int32_t* win_seq,
+                      const int32_t* win_start, const uint8_t* win_flip, const int32_t* mirror, int B, int T, int J, float* X, float* y,
+                      void* stream) {
+  static_assert(sizeof(long) == sizeof(int64_t), "LP64");
+  return gather_windows(poses_2d, poses_3d, (const long*)seq_offset, S, win_seq, win_start, win_flip, mirror, B, T, J, X, y,
+                        (hipStream_t)stream);
+}
+
 int mp_pose_metrics_row_floats(void) { return pose_metrics_row_floats(); }
 int mp_pose_metrics(const float* pred, const int64_t* pred_strides, const float* gt, const int64_t* gt_strides, const uint8_t* mask, int B,
                     int L, int J, float pred_scale, float gt_scale, float pck_threshold, float auc_max, int auc_steps, int scale_align,

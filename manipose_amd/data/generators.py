@@ -1,0 +1,115 @@
+"""GPU-resident counterpart of the reference's ``PoseSequenceGenerator`` (hpe/mh_so3_hpe/data/generators.py:44-219) with its
+``PoseFlip`` transform (hpe/mh_so3_hpe/augmentations/transforms.py:7-28): the pose sequences are uploaded once, back to back, and
+every batch of windows is cut out of them by one HIP kernel (``mp_gather_windows``) - no CPU workers, no host copies per step.
+
+Same constructor arguments, the same index tables (``_map_index_to_pose`` / ``_map_index_to_frame``), the same consumption of the
+torch CPU RNG per item (random start: one ``torch.randint``; flip: one ``torch.rand``), so a seeded run draws the windows the
+reference's loader draws with ``num_workers=0``.  Only ``miss_type="no_miss"`` (the reference's default) is provided.
+
+Not replicated: the reference flips IN PLACE a view of its own float32 dataset array (``torch.from_numpy(...).float()`` does not copy
+float32 data), i.e. it mirrors its stored sequences a little more every epoch; here the stored sequences are never modified.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class PoseSequenceGenerator:
+    def __init__(self, poses_3d: Sequence, poses_2d: Sequence, cameras=None, seq_len: int = 8, random_start: bool = False,
+                 drop_last: bool = True, miss_type: str = "no_miss", miss_rate: float = 0.2, noise_sigma: float = 5,
+                 transform=None, device: Optional[torch.device] = None):
+        assert poses_3d is not None
+        assert len(poses_3d) == len(poses_2d)
+        if miss_type != "no_miss":
+            raise NotImplementedError(f"manipose_amd: miss_type={miss_type!r}; the GPU-resident generator provides the reference's "
+                                      "default 'no_miss' only")
+        if transform is not None and not hasattr(transform, "p") and not hasattr(transform, "probability"):
+            raise NotImplementedError("manipose_amd: the only transform fused into the window kernel is PoseFlip")
+        self._seq_len, self._random_start, self.drop_last = int(seq_len), bool(random_start), bool(drop_last)
+        self.miss_type, self.miss_rate, self.noise_sigma, self.transform = miss_type, miss_rate, noise_sigma, transform
+        self._cameras = cameras
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise RuntimeError("manipose_amd: the window generator keeps the sequences in HBM and runs a HIP kernel; no CPU fallback")
+        lens = [int(p.shape[0]) for p in poses_3d]
+        for a, b in zip(poses_3d, poses_2d):
+            assert a.shape[0] == b.shape[0] and a.shape[1] == b.shape[1] and a.shape[2] == 3 and b.shape[2] == 2
+        self._lens = lens
+        self._J = int(poses_3d[0].shape[1])
+        # index tables exactly as generators.py:87-104
+        self._map_index_to_pose, self._map_index_to_frame = [], []
+        for i, n in enumerate(lens):
+            size = n // self._seq_len
+            if not drop_last and n % self._seq_len > 0:
+                size += 1
+            self._map_index_to_pose += [i] * size
+            self._map_index_to_frame += [k * self._seq_len for k in range(size)]
+        self._ds_len = len(self._map_index_to_pose)
+        off = np.zeros(len(lens) + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lens)
+        to32 = lambda seqs: torch.from_numpy(np.concatenate([np.asarray(s, dtype=np.float32) for s in seqs], axis=0))
+        self._p3 = to32(poses_3d).to(self.device).contiguous()
+        self._p2 = to32(poses_2d).to(self.device).contiguous()
+        self._off = torch.from_numpy(off).to(self.device)
+        sk = getattr(transform, "skeleton", None)
+        mirror = list(range(self._J))
+        if sk is not None:
+            for l, r in zip(sk.joints_left, sk.joints_right):
+                mirror[l], mirror[r] = r, l
+        self._mirror = (C.c_int32 * self._J)(*mirror)
+        self._p_flip = float(getattr(transform, "p", getattr(transform, "probability", 0.0))) if transform is not None else 0.0
+
+    def __len__(self) -> int:
+        return self._ds_len
+
+    def draw(self, indices: Sequence[int]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Host part of ``__getitem__`` for a batch: (sequence, start, flip) per index, consuming the torch CPU RNG item by item in the
+        reference's order (generators.py:121-131 then transforms.py:22)."""
+        seq = np.empty(len(indices), dtype=np.int32)
+        start = np.empty(len(indices), dtype=np.int32)
+        flip = np.zeros(len(indices), dtype=np.uint8)
+        for n, index in enumerate(indices):
+            s = self._map_index_to_pose[index]
+            seq[n] = s
+            if self._random_start:
+                start[n] = torch.randint(low=0, high=self._lens[s] - self._seq_len, size=(1,)).item()
+            else:
+                start[n] = self._map_index_to_frame[index]
+            if self.drop_last and start[n] + self._seq_len > self._lens[s]:
+                raise IndexError("window past the end of its sequence (drop_last=True)")
+            if self.transform is not None and torch.rand(1).item() <= self._p_flip:
+                flip[n] = 1
+        return torch.from_numpy(seq), torch.from_numpy(start), torch.from_numpy(flip)
+
+    def gather(self, seq: torch.Tensor, start: torch.Tensor, flip: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(X (B,T,J,2), y (B,T,J,3)) on the device for explicit (sequence, start, flip) triples: one kernel launch."""
+        B, T, J = int(seq.numel()), self._seq_len, self._J
+        seq_d = seq.to(self.device, torch.int32).contiguous()
+        start_d = start.to(self.device, torch.int32).contiguous()
+        flip_d = flip.to(self.device, torch.uint8).contiguous() if flip is not None else None
+        X = torch.empty(B, T, J, 2, device=self.device)
+        y = torch.empty(B, T, J, 3, device=self.device)
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.mp_gather_windows(_lib.ptr(self._p2), _lib.ptr(self._p3), C.c_void_p(self._off.data_ptr()), len(self._lens),
+                                             C.c_void_p(seq_d.data_ptr()), C.c_void_p(start_d.data_ptr()),
+                                             C.c_void_p(flip_d.data_ptr()) if flip_d is not None else None, self._mirror, B, T, J,
+                                             _lib.ptr(X), _lib.ptr(y), _lib.stream_ptr()), "mp_gather_windows")
+        return X, y
+
+    def batch(self, indices: Sequence[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The windows the reference's ``__getitem__`` returns for ``indices`` (stacked), as device tensors."""
+        return self.gather(*self.draw(indices))
+
+    def __getitem__(self, index: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        X, y = self.batch([index])
+        return X[0], y[0]
+
+
+__all__ = ["PoseSequenceGenerator"]

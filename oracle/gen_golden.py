@@ -268,9 +268,47 @@ def gen_metrics_fixture(ref):
     print("metrics: ok", len(out), "arrays")
 
 
+def gen_windows_fixture(ref):
+    """Input pipeline: windows produced by the reference's PoseSequenceGenerator (+ PoseFlip) on seeded sequences
+    of uneven lengths.  The source arrays are float64 so that the reference's in-place flip (which aliases float32 dataset arrays)
+    cannot modify them between items."""
+    from mh_so3_hpe.data.generators import PoseSequenceGenerator
+    from mh_so3_hpe.augmentations.transforms import PoseFlip
+    g = np.random.default_rng(123)
+    lens = [61, 28, 100, 35, 54]      # every sequence longer than the window (the reference's random start needs len > seq_len)
+    p3 = [g.normal(size=(n, 17, 3)) for n in lens]
+    p2 = [g.normal(size=(n, 17, 2)) for n in lens]
+    out = {"lens": np.array(lens)}
+    for i, (a, b) in enumerate(zip(p3, p2)):
+        out[f"p3.{i}"], out[f"p2.{i}"] = a.astype(np.float32), b.astype(np.float32)
+    p3 = [out[f"p3.{i}"].astype(np.float64) for i in range(len(lens))]      # exactly representable float32 values
+    p2 = [out[f"p2.{i}"].astype(np.float64) for i in range(len(lens))]
+    import contextlib, io
+    cases = {"strided_drop": dict(random_start=False, drop_last=True, flip=False),
+             "strided_pad": dict(random_start=False, drop_last=False, flip=False),
+             "random_flip": dict(random_start=True, drop_last=True, flip=True),
+             "strided_pad_flip": dict(random_start=False, drop_last=False, flip=True)}
+    for nm, c in cases.items():
+        with contextlib.redirect_stdout(io.StringIO()):
+            gen = PoseSequenceGenerator(p3, p2, None, seq_len=27, random_start=c["random_start"], drop_last=c["drop_last"],
+                                        miss_type="no_miss", transform=PoseFlip(ref["sk"], 0.5) if c["flip"] else None)
+        torch.manual_seed(2024)
+        xs, ys = [], []
+        for i in range(len(gen)):
+            x, y = gen[i]
+            xs.append(x.clone().numpy()); ys.append(y.clone().numpy())
+        out[f"{nm}.X"], out[f"{nm}.y"] = np.stack(xs), np.stack(ys)
+        out[f"{nm}.len"] = np.int64(len(gen))
+    np.savez_compressed(os.path.join(OUT, "windows.npz"), **out)
+    print("windows: ok", {k: v.shape for k, v in out.items() if k.endswith(".X")})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "windows":       # regenerate the input-pipeline fixture only
+        gen_windows_fixture(ref)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":       # regenerate the analytics fixture only
         gen_metrics_fixture(ref)
         return
@@ -284,6 +322,7 @@ def main():
     gen_decoder_fixture(ref)
     gen_loss_fixture(ref)
     gen_metrics_fixture(ref)
+    gen_windows_fixture(ref)
     # default initialisation under seed 42 (the product's constructors must consume the RNG identically)
     torch.manual_seed(42)
     m0 = build_ref_model(ref, small, 0.1)

@@ -390,6 +390,48 @@ def aggregate(hyp, scores=None, mode="weighted_ave", ground_truth=None):
 
 
 # ---------------------------------------------------------------------------
+# Input pipeline: PoseSequenceGenerator with miss_type "no_miss" (data/generators.py:44-219) and the
+# PoseFlip transform (augmentations/transforms.py:7-28, functional.py:7-31).  Draws from the torch CPU RNG exactly like the
+# reference: per item one torch.randint (random start), then one torch.rand (flip decision).
+# ---------------------------------------------------------------------------
+def window_tables(lengths, seq_len: int, drop_last: bool):
+    """generators.py:87-104 -> (_map_index_to_pose, _map_index_to_frame)."""
+    to_pose, to_frame = [], []
+    for i, n in enumerate(lengths):
+        size = n // seq_len
+        if not drop_last and n % seq_len > 0:
+            size += 1
+        to_pose += [i] * size
+        to_frame += [k * seq_len for k in range(size)]
+    return to_pose, to_frame
+
+
+def flip_pose(pose: Tensor, joints_left=H36M_JOINTS_LEFT, joints_right=H36M_JOINTS_RIGHT) -> Tensor:
+    """functional.py:7-31 (out of place): horizontal coordinate negated, left and right joints swapped."""
+    out = pose.clone()
+    out[..., 0] *= -1
+    l, r = list(joints_left), list(joints_right)
+    out[..., l + r, :] = out[..., r + l, :].clone()
+    return out
+
+
+def sequence_window(poses_3d, poses_2d, index: int, seq_len: int, random_start: bool, drop_last: bool, flip_probability=None):
+    """generators.py:106-219 for miss_type 'no_miss': (pose_2d (L,J,2), pose_3d (L,J,3)) of dataset item `index`."""
+    to_pose, to_frame = window_tables([p.shape[0] for p in poses_3d], seq_len, drop_last)
+    p3 = torch.as_tensor(poses_3d[to_pose[index]]).float()
+    p2 = torch.as_tensor(poses_2d[to_pose[index]]).float()
+    if random_start:
+        start = torch.randint(low=0, high=p3.shape[0] - seq_len, size=(1,)).item()
+    else:
+        start = to_frame[index]
+    idx = torch.clamp(torch.arange(start, start + seq_len), max=p3.shape[0] - 1)       # replicate padding of a short last window
+    w2, w3 = p2[idx], p3[idx]
+    if flip_probability is not None and torch.rand(1).item() <= flip_probability:
+        w2, w3 = flip_pose(w2), flip_pose(w3)
+    return w2, w3
+
+
+# ---------------------------------------------------------------------------
 # Evaluation analytics (SURVEY section 8f rows 1-2): skeleton-consistency metrics (metrics/regularizations.py:8-157,
 # metrics/utils.py:4-20), the remaining error metrics (metrics/mean_joint_errors.py:39-130), evaluation velocity
 # error (metrics/losses.py:75-101) and 3DPCK / AUC (metrics/pck.py:92-199).  joints_coords is (B, 3, J, L).

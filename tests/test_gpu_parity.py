@@ -717,3 +717,72 @@ def test_evaluate_analytics_table_matches_oracle_on_the_flattened_sequence(lib):
         assert abs(got[k] - v) <= 2e-4 * abs(v) + 1e-3, (k, got[k], v)
     assert abs(got["pck"] - pck.item()) <= 0.2 and abs(got["auc"] - auc.item()) <= 0.2
     assert abs(got["err_var"] - (want["mse"] - want["mpjpe"] ** 2)) <= 1e-3 * want["mse"]
+
+
+# ------------------------------------------------------------------------------------ GPU-resident input pipeline
+WINDOW_CASES = {"strided_drop": (False, True, False), "strided_pad": (False, False, False), "random_flip": (True, True, True),
+                "strided_pad_flip": (False, False, True)}
+
+
+@pytest.mark.parametrize("case", sorted(WINDOW_CASES))
+def test_window_generator_is_bit_exact_with_the_reference_generator(lib, case):
+    """PoseSequenceGenerator + PoseFlip on the device (one gather kernel per batch) against the windows the reference's generator
+    produced item by item under the same torch seed: index tables, random starts, replicate padding, flip decisions, mirroring."""
+    from manipose_amd import h36m_skeleton
+    from manipose_amd.augmentations import PoseFlip
+    from manipose_amd.data import PoseSequenceGenerator
+    fx = load_fixture("windows")
+    n = len(fx["lens"])
+    p3, p2 = [fx[f"p3.{i}"] for i in range(n)], [fx[f"p2.{i}"] for i in range(n)]
+    random_start, drop_last, flip = WINDOW_CASES[case]
+    gen = PoseSequenceGenerator(p3, p2, None, seq_len=27, random_start=random_start, drop_last=drop_last,
+                                transform=PoseFlip(h36m_skeleton(), 0.5) if flip else None)
+    assert len(gen) == int(fx[f"{case}.len"])
+    torch.manual_seed(2024)
+    X, y = gen.batch(range(len(gen)))                      # one launch for the whole epoch
+    assert torch.equal(X.cpu(), torch.from_numpy(fx[f"{case}.X"])) and torch.equal(y.cpu(), torch.from_numpy(fx[f"{case}.y"]))
+    torch.manual_seed(2024)
+    x0, y0 = gen[0]                                          # the reference's per-item interface
+    assert torch.equal(x0.cpu(), torch.from_numpy(fx[f"{case}.X"][0])) and torch.equal(y0.cpu(), torch.from_numpy(fx[f"{case}.y"][0]))
+
+
+def test_window_generator_properties_at_training_size(lib):
+    """T = 243 windows out of long sequences: mirroring twice is the identity, un-flipped windows are verbatim slices, frames past the
+    end of a sequence repeat its last frame; unsupported options fail loudly."""
+    from manipose_amd import h36m_skeleton
+    from manipose_amd.augmentations import PoseFlip, pose_flip
+    from manipose_amd.data import PoseSequenceGenerator
+    g = np.random.default_rng(5)
+    lens = [3000, 1700, 2431]
+    p3 = [g.normal(size=(n, 17, 3)).astype(np.float32) for n in lens]
+    p2 = [g.normal(size=(n, 17, 2)).astype(np.float32) for n in lens]
+    sk = h36m_skeleton()
+    gen = PoseSequenceGenerator(p3, p2, None, seq_len=243, random_start=False, drop_last=False, transform=PoseFlip(sk, 0.5))
+    assert len(gen) == sum(-(-n // 243) for n in lens)
+    seq = torch.tensor([0, 0, 1, 2, 2], dtype=torch.int32)
+    start = torch.tensor([0, 2916, 1500, 243, 2430], dtype=torch.int32)
+    X, y = gen.gather(seq, start, torch.zeros(5, dtype=torch.uint8))
+    Xf, yf = gen.gather(seq, start, torch.ones(5, dtype=torch.uint8))
+    assert torch.equal(X[0].cpu(), torch.from_numpy(p2[0][:243])) and torch.equal(y[2, :200].cpu(), torch.from_numpy(p3[1][1500:1700]))
+    assert torch.equal(y[1, :84].cpu(), torch.from_numpy(p3[0][2916:3000])) and bool((y[1, 84:] == y[1, 83]).all())     # replicate padding
+    assert bool((y[4, 1:] == y[4, 0]).all())
+    Xb, yb = pose_flip((Xf.clone(), yf.clone()), sk)       # mirroring the mirrored windows on the host side gives the originals back
+    assert torch.equal(Xb, X) and torch.equal(yb, y)
+    with pytest.raises(NotImplementedError):
+        PoseSequenceGenerator(p3, p2, None, seq_len=243, miss_type="random")
+    with pytest.raises(RuntimeError):
+        PoseSequenceGenerator(p3, p2, None, seq_len=243, device="cpu")
+
+
+def test_training_entry_runs_on_resident_sequences(lib, tmp_path, monkeypatch):
+    """hpe/main_h36m_lifting.py (the reference's entry point and override grammar) end to end on a small model: windows drawn by the
+    GPU-resident generator with flip augmentation, two training steps, validation, checkpoint, analytics table."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hpe"))
+    from _entry import run
+    monkeypatch.chdir(tmp_path)
+    best = run(["train.epochs=1", "train.steps_per_epoch=2", "train.batch_size=4", "train.batch_size_test=2", "data.seq_len=27",
+                "model.channels=64", "model.layers=2", "model.nheads=4", "model.channels_seg=32", "model.layers_seg=1",
+                "model.nheads_seg=4", "multi_hyp.n_hyp=3", "data.synthetic_sequences=6", "run.test=true"])
+    assert np.isfinite(best) and best < 1e9
+    assert any(f.endswith(".pth") for _, _, fs in os.walk(tmp_path) for f in fs)

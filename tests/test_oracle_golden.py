@@ -197,3 +197,29 @@ def test_oracle_error_metrics_and_pck_match_reference():
         assert abs(pck.item() - float(fx[f"{nm}.pck.masked"])) < 1e-4 and abs(auc.item() - float(fx[f"{nm}.auc.masked"])) < 1e-4
         pck, _ = orc.keypoint_3d_pck_auc(xf, gf, None, "none", threshold=80.0)
         assert abs(pck.item() - float(fx[f"{nm}.pck.thr80"])) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# input pipeline: oracle restatement of PoseSequenceGenerator + PoseFlip vs windows produced by the reference
+# ---------------------------------------------------------------------------------------------------------------------
+WINDOW_CASES = {"strided_drop": (False, True, False), "strided_pad": (False, False, False), "random_flip": (True, True, True),
+                "strided_pad_flip": (False, False, True)}
+
+
+def _window_sequences(fx):
+    n = len(fx["lens"])
+    return [fx[f"p3.{i}"] for i in range(n)], [fx[f"p2.{i}"] for i in range(n)]
+
+
+@pytest.mark.parametrize("case", sorted(WINDOW_CASES))
+def test_oracle_sequence_windows_match_reference_generator(case):
+    fx = load_fixture("windows")
+    p3, p2 = _window_sequences(fx)
+    random_start, drop_last, flip = WINDOW_CASES[case]
+    n = len(orc.window_tables([p.shape[0] for p in p3], 27, drop_last)[0])
+    assert n == int(fx[f"{case}.len"])
+    torch.manual_seed(2024)                                  # the same RNG stream the reference consumed item by item
+    for i in range(n):
+        x, y = orc.sequence_window(p3, p2, i, 27, random_start, drop_last, 0.5 if flip else None)
+        np.testing.assert_array_equal(x.numpy(), fx[f"{case}.X"][i])
+        np.testing.assert_array_equal(y.numpy(), fx[f"{case}.y"][i])
