@@ -107,7 +107,7 @@ def evaluate(model, X, y, batch, tta=True, analytics=False):
     from manipose_amd import RMCLManifoldMixSTE
     from manipose_amd.augmentations import pose_flip
     from manipose_amd.metrics import mpjpe_error
-    from manipose_amd.metrics.analytics import AnalyticsAccumulator, pose_analytics
+    from manipose_amd.metrics.analytics import AnalyticsAccumulator, pose_analytics, procrustes_sums
     acc = AnalyticsAccumulator() if analytics else None
     model.eval()
     sk = model.decoder.skeleton
@@ -143,6 +143,7 @@ def evaluate(model, X, y, batch, tta=True, analytics=False):
         n += yb.numel() // 3
         if acc is not None:
             acc.add(pose_analytics(pred.detach().contiguous(), yb.contiguous(), pred_scale=1000.0, gt_scale=1000.0))
+            acc.add_procrustes(procrustes_sums(pred.detach(), yb, pred_scale=1000.0, gt_scale=1000.0))
     out = {k: 1000.0 * v / n for k, v in sums.items() if v > 0}
     if acc is not None:
         out["analytics"] = acc.report()

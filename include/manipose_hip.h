@@ -199,6 +199,15 @@ int mp_pose_metrics(const float* pred, const int64_t* pred_strides, const float*
                     int L, int J, float pred_scale, float gt_scale, float pck_threshold, float auc_max, int auc_steps, int scale_align,
                     float* out, float* len0, float* scratch, int64_t scratch_floats, void* stream);
 
+/* Procrustes-aligned errors: per frame the similarity transform (scale, proper rotation, translation) taking the predicted joints onto
+ * the target ones in the least-squares sense - p_mpjpe (hpe/mh_so3_hpe/metrics/mean_joint_errors.py:148-189, batched numpy SVD on the
+ * host in the reference) and the 'procrustes' alignment of keypoint_3d_pck / keypoint_3d_auc (metrics/pck.py:5-60,127-131) - solved on
+ * the device with Horn's quaternion closed form (thread per frame, 4x4 Jacobi).  pred, gt: (N,17,3) contiguous; mask (N,17) bytes or
+ * null.  out[5]: sum of aligned per-joint errors, #(error < pck_threshold), sum of AUC threshold counts, #visible joints, frames.
+ * scratch: >= 5 * ceil(N/256) floats. */
+int mp_procrustes_errors(const float* pred, const float* gt, const uint8_t* mask, int64_t N, int J, float pred_scale, float gt_scale,
+                         float pck_threshold, float auc_max, int auc_steps, float* out, float* scratch, int64_t scratch_floats, void* stream);
+
 /* test / tuning hooks (no reference counterpart): "gemm_small_tile" (1 = 128x128 GEMM tiles everywhere),
  * "gemm_persist_min_tiles" (output-tile count from which the persistent GEMM kernels are used; 0 = default),
  * "gemm_persist_mode" (0 tiled kernels only, 1 = default: persistent kernel where it applies). */

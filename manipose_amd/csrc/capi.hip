@@ -149,6 +149,12 @@ int mp_gather_windows(const float* poses_2d, const float* poses_3d, const int64_
                         (hipStream_t)stream);
 }
 
+int mp_procrustes_errors(const float* pred, const float* gt, const uint8_t* mask, int64_t N, int J, float pred_scale, float gt_scale,
+                         float pck_threshold, float auc_max, int auc_steps, float* out, float* scratch, int64_t scratch_floats, void* stream) {
+  return procrustes_errors(pred, gt, mask, (long)N, J, pred_scale, gt_scale, pck_threshold, auc_max, auc_steps, 1, out, scratch,
+                           (long)scratch_floats, (hipStream_t)stream);
+}
+
 int mp_pose_metrics_row_floats(void) { return pose_metrics_row_floats(); }
 int mp_pose_metrics(const float* pred, const int64_t* pred_strides, const float* gt, const int64_t* gt_strides, const uint8_t* mask, int B,
                     int L, int J, float pred_scale, float gt_scale, float pck_threshold, float auc_max, int auc_steps, int scale_align,

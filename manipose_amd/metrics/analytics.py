@@ -111,6 +111,7 @@ class AnalyticsAccumulator:
         self.ref = None             # (16,) common shift of the variance sums
         self.s1 = None              # (16,) sum (len - ref)
         self.s2 = None              # (16,) sum (len - ref)^2
+        self.proc = None            # (5,) Procrustes sums (procrustes_sums)
 
     def add(self, a: PoseAnalytics) -> None:
         rows = a.rows.double()
@@ -131,6 +132,9 @@ class AnalyticsAccumulator:
         self.s2 += (pb[..., 1] + 2.0 * d * pb[..., 0] + n * d * d).sum(0)
         self.n += n * a.B
 
+    def add_procrustes(self, sums: torch.Tensor) -> None:
+        self.proc = sums.clone() if self.proc is None else self.proc + sums
+
     def report(self) -> dict:
         s, n = self.scal, self.n
         nj = n * NJ
@@ -145,4 +149,32 @@ class AnalyticsAccumulator:
                "auc": (100.0 * s[7] / (31.0 * s[8])).item() if s[8] > 0 else float("nan"),
                "jointwise_err": (self.joints[:, 0] / n).tolist(),
                "mpsce_per_bone": var.sqrt().tolist(), "mpsse_per_pair": (self.pairs[:, 0] / n).tolist()}
+        if self.proc is not None:                # Protocol #2 and the Procrustes-aligned 3DPCK / AUC
+            out["p_mpjpe"] = (self.proc[0] / (self.proc[4] * NJ)).item()
+            out["pck_procrustes"] = (100.0 * self.proc[1] / self.proc[3]).item()
+            out["auc_procrustes"] = (100.0 * self.proc[2] / (31.0 * self.proc[3])).item()
         return out
+
+
+def procrustes_sums(pred: torch.Tensor, gt: torch.Tensor, mask: Optional[torch.Tensor] = None, pred_scale: float = 1.0,
+                    gt_scale: float = 1.0, pck_threshold: float = 150.0, auc_max: float = 150.0, auc_steps: int = 31) -> torch.Tensor:
+    """(5,) float64: sum of Procrustes-aligned per-joint errors, PCK count, AUC count sum, visible joints, frames (mp_procrustes_errors).
+    pred / gt: (..., 17, 3) on the device."""
+    if pred.device.type != "cuda":
+        raise RuntimeError("manipose_amd: Procrustes errors run on the ROCm device only (HIP kernel, no CPU fallback)")
+    assert pred.shape == gt.shape and pred.shape[-1] == 3 and pred.shape[-2] == NJ
+    p = pred.detach().float().reshape(-1, NJ, 3).contiguous()
+    g = gt.detach().to(p.device).float().reshape(-1, NJ, 3).contiguous()
+    n = p.shape[0]
+    m = None
+    if mask is not None:
+        m = mask.to(device=p.device, dtype=torch.uint8).contiguous()
+        assert m.numel() == n * NJ
+    lib = _lib.load()
+    out = torch.empty(5, device=p.device)
+    scratch = torch.empty(5 * ((n + 255) // 256), device=p.device)
+    with torch.cuda.device(p.device):
+        _lib.check(lib.mp_procrustes_errors(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), n, NJ, float(pred_scale), float(gt_scale),
+                                            float(pck_threshold), float(auc_max), int(auc_steps), _lib.ptr(out), _lib.ptr(scratch),
+                                            scratch.numel(), _lib.stream_ptr()), "mp_procrustes_errors")
+    return out.double()

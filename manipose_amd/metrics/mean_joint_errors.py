@@ -78,3 +78,13 @@ def segments_len_err(batch_imp: torch.Tensor, batch_gt: torch.Tensor, skeleton, 
     r = pose_analytics(batch_imp.detach().float(), batch_gt.detach().float(), layout="BCJL", skeleton=skeleton)
     tot = r.scalar(5 if signed else 4)
     return (tot / (r.B * r.L * 16) if mode == "average" else tot).float()
+
+
+def p_mpjpe(predicted: torch.Tensor, target: torch.Tensor) -> float:
+    """mean_joint_errors.py:148-189: MPJPE after per-frame rigid alignment with scale ("Protocol #2"); solved on the device
+    (Horn's closed form) instead of a batched numpy SVD on the host.  predicted / target: (B, L, J, 3)."""
+    from .analytics import procrustes_sums
+    assert predicted.shape == target.shape
+    assert predicted.shape[-1] == target.shape[-1] == 3
+    r = procrustes_sums(predicted, target)
+    return float((r[0] / (r[4] * predicted.shape[-2])).item())

@@ -258,9 +258,11 @@ def gen_metrics_fixture(ref):
         xf, gf = x.reshape(-1, J, 3).numpy(), gt.reshape(-1, J, 3).numpy()
         mask = (torch.rand(B * L, J, generator=torch.Generator().manual_seed(5)) > 0.2).numpy()
         out["mask"] = mask
-        for al in ("none", "scale"):
+        for al in ("none", "scale", "procrustes"):
             out[f"{nm}.pck.{al}"] = np.float64(P.keypoint_3d_pck(xf, gf, mask=None, alignment=al, threshold=150))
             out[f"{nm}.auc.{al}"] = np.float64(P.keypoint_3d_auc(xf, gf, mask=None, alignment=al))
+        out[f"{nm}.pck.procrustes.masked"] = np.float64(P.keypoint_3d_pck(xf, gf, mask=mask, alignment="procrustes", threshold=150))
+        out[f"{nm}.p_mpjpe"] = np.float64(E.p_mpjpe(x.clone(), gt.clone()))
         out[f"{nm}.pck.masked"] = np.float64(P.keypoint_3d_pck(xf, gf, mask=mask, alignment="none", threshold=150))
         out[f"{nm}.auc.masked"] = np.float64(P.keypoint_3d_auc(xf, gf, mask=mask, alignment="none"))
         out[f"{nm}.pck.thr80"] = np.float64(P.keypoint_3d_pck(xf, gf, mask=None, alignment="none", threshold=80))

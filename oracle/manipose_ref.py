@@ -511,9 +511,40 @@ def eval_velocity_error(pred: Tensor, target: Tensor, axis: int = 1, squared: bo
     return (dv ** 2).mean() if squared else torch.norm(dv, dim=pred.dim() - 1).mean()
 
 
+def procrustes_align(pred: Tensor, gt: Tensor) -> Tensor:
+    """Similarity transform of p_mpjpe (mean_joint_errors.py:148-189) == compute_similarity_transform (pck.py:5-60), batched SVD in
+    float64: pred, gt (N, J, 3) -> pred aligned onto gt."""
+    X, Y = gt.double(), pred.double()
+    muX, muY = X.mean(1, keepdim=True), Y.mean(1, keepdim=True)
+    X0, Y0 = X - muX, Y - muY
+    nX, nY = X0.pow(2).sum((1, 2), keepdim=True).sqrt(), Y0.pow(2).sum((1, 2), keepdim=True).sqrt()
+    X0, Y0 = X0 / nX, Y0 / nY
+    H = X0.transpose(1, 2) @ Y0
+    U, s, Vt = torch.linalg.svd(H)
+    V = Vt.transpose(1, 2)
+    R = V @ U.transpose(1, 2)
+    sign = torch.sign(torch.linalg.det(R))
+    V = V.clone(); s = s.clone()
+    V[:, :, -1] *= sign[:, None]
+    s[:, -1] *= sign
+    R = V @ U.transpose(1, 2)
+    a = s.sum(1)[:, None, None] * nX / nY
+    t = muX - a * (muY @ R)
+    return a * (Y @ R) + t
+
+
+def p_mpjpe(pred: Tensor, gt: Tensor) -> Tensor:
+    """mean_joint_errors.py:148-189."""
+    J = gt.shape[-2]
+    al = procrustes_align(pred.reshape(-1, J, 3), gt.reshape(-1, J, 3))
+    return torch.norm(al - gt.reshape(-1, J, 3).double(), dim=-1).mean()
+
+
 def keypoint_3d_pck_auc(pred: Tensor, gt: Tensor, mask: Optional[Tensor] = None, alignment: str = "none", threshold: float = 150.0):
-    """metrics/pck.py:92-199: (pck, auc) in percent; pred / gt (N, K, 3); alignment 'none' or 'scale'."""
+    """metrics/pck.py:92-199: (pck, auc) in percent; pred / gt (N, K, 3); alignment 'none', 'scale' or 'procrustes'."""
     pred, gt = pred.double(), gt.double()
+    if alignment == "procrustes":
+        pred = procrustes_align(pred, gt)
     if alignment == "scale":
         f = (pred * gt).sum((1, 2)) / (pred * pred).sum((1, 2))
         pred = pred * f[:, None, None]

@@ -672,8 +672,16 @@ def test_error_metrics_and_pck_auc_match_reference_fixture(lib, nm):
     assert abs(keypoint_3d_pck(xf.cpu().numpy(), gf.cpu().numpy(), fx["mask"], "none", 150) - float(fx[f"{nm}.pck.masked"])) <= 2 * tol
     assert abs(keypoint_3d_auc(xf, gf, fx["mask"], "none") - float(fx[f"{nm}.auc.masked"])) <= 2 * tol
     assert abs(keypoint_3d_pck(xf, gf, None, "none", 80) - float(fx[f"{nm}.pck.thr80"])) <= tol
-    with pytest.raises(NotImplementedError):
-        keypoint_3d_pck(xf, gf, None, "procrustes")
+    # Procrustes-aligned metrics: Horn's closed form on the device against the reference's numpy SVD
+    from manipose_amd.metrics import p_mpjpe
+    assert abs(p_mpjpe(x, gt) - float(fx[f"{nm}.p_mpjpe"])) <= 2e-4 * float(fx[f"{nm}.p_mpjpe"])
+    assert abs(keypoint_3d_pck(xf, gf, None, "procrustes", 150) - float(fx[f"{nm}.pck.procrustes"])) <= tol
+    assert abs(keypoint_3d_auc(xf, gf, None, "procrustes") - float(fx[f"{nm}.auc.procrustes"])) <= tol
+    assert abs(keypoint_3d_pck(xf, gf, fx["mask"], "procrustes", 150) - float(fx[f"{nm}.pck.procrustes.masked"])) <= 2 * tol
+    rot = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(1)))[0].cuda()      # an exactly similar copy aligns to 0
+    if torch.linalg.det(rot) < 0:
+        rot[:, 0] *= -1
+    assert p_mpjpe((0.37 * gt @ rot + 5.0), gt) <= 1e-3
     with pytest.raises(ValueError):
         keypoint_3d_auc(xf, gf, None, "affine")
 
@@ -717,6 +725,7 @@ def test_evaluate_analytics_table_matches_oracle_on_the_flattened_sequence(lib):
         assert abs(got[k] - v) <= 2e-4 * abs(v) + 1e-3, (k, got[k], v)
     assert abs(got["pck"] - pck.item()) <= 0.2 and abs(got["auc"] - auc.item()) <= 0.2
     assert abs(got["err_var"] - (want["mse"] - want["mpjpe"] ** 2)) <= 1e-3 * want["mse"]
+    assert abs(got["p_mpjpe"] - orc.p_mpjpe(pred, gt).item()) <= 2e-4 * got["p_mpjpe"] + 1e-3
 
 
 # ------------------------------------------------------------------------------------ GPU-resident input pipeline

@@ -190,9 +190,12 @@ def test_oracle_error_metrics_and_pck_match_reference():
         np.testing.assert_allclose(orc.eval_velocity_error(x, gt, 1, False).numpy(), fx[f"{nm}.vel"], rtol=1e-6)
         np.testing.assert_allclose(orc.eval_velocity_error(x, gt, 1, True).numpy(), fx[f"{nm}.vel_sq"], rtol=1e-6)
         xf, gf = x.reshape(-1, 17, 3), gt.reshape(-1, 17, 3)
-        for al in ("none", "scale"):
+        for al in ("none", "scale", "procrustes"):
             pck, auc = orc.keypoint_3d_pck_auc(xf, gf, None, al)
             assert abs(pck.item() - float(fx[f"{nm}.pck.{al}"])) < 1e-4 and abs(auc.item() - float(fx[f"{nm}.auc.{al}"])) < 1e-4
+        pck, _ = orc.keypoint_3d_pck_auc(xf, gf, mask, "procrustes")
+        assert abs(pck.item() - float(fx[f"{nm}.pck.procrustes.masked"])) < 1e-4
+        np.testing.assert_allclose(orc.p_mpjpe(x, gt).item(), float(fx[f"{nm}.p_mpjpe"]), rtol=1e-6)
         pck, auc = orc.keypoint_3d_pck_auc(xf, gf, mask, "none")
         assert abs(pck.item() - float(fx[f"{nm}.pck.masked"])) < 1e-4 and abs(auc.item() - float(fx[f"{nm}.auc.masked"])) < 1e-4
         pck, _ = orc.keypoint_3d_pck_auc(xf, gf, None, "none", threshold=80.0)
