@@ -93,7 +93,8 @@ def synthetic_generator(cfg, device, seed, rank, world):
         if i in mine:
             p3.append(a); p2.append(b)
     tf = PoseFlip(h36m_skeleton(), 0.5) if cfg.train.flip_aug else None
-    return PoseSequenceGenerator(p3, p2, None, seq_len=int(cfg.data.seq_len), random_start=True, drop_last=True, miss_type="no_miss",
+    return PoseSequenceGenerator(p3, p2, None, seq_len=int(cfg.data.seq_len), random_start=True, drop_last=True,
+                                 miss_type=cfg.data.get("miss_type", "no_miss"), miss_rate=cfg.data.get("miss_rate", 0.2),
                                  transform=tf, device=device)
 
 

@@ -170,16 +170,18 @@ int mp_model_peek_copy(const mp_model* m, int which, float* dst, int64_t numel, 
 int mp_prof_enable(mp_model* m, int on);
 int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops);
 
-/* GPU-resident PoseSequenceGenerator (hpe/mh_so3_hpe/data/generators.py:44-219, miss_type "no_miss") + PoseFlip
+/* GPU-resident PoseSequenceGenerator (hpe/mh_so3_hpe/data/generators.py:44-219) + PoseFlip
  * (hpe/mh_so3_hpe/augmentations/transforms.py:7-28, functional.py:7-31): cuts B windows of T frames out of pose sequences stored
  * back to back in device memory.  poses_2d (Ntot,J,2), poses_3d (Ntot,J,3); seq_offset (S+1) device int64: first frame of each
  * sequence; win_seq / win_start (B) device int32: sequence and first frame (within it) of every window - the reference's
  * _map_index_to_pose / _map_index_to_frame entries or its random start; frames past the end of the sequence replicate its last
  * frame (the drop_last=False padding); win_flip (B) device bytes or null: windows to mirror (u / x negated, joint j read from
- * mirror[j]); mirror (J) HOST int32.  Outputs X (B,T,J,2), y (B,T,J,3). */
+ * mirror[j]); mirror (J) HOST int32.  mask2d (B,T,J) device floats or null: multipliers of the 2-D input (the occlusion patterns
+ * of generators.py:171-216); noise2d (B,T,J,2) or null: noise added to the 2-D input before the mask (miss_type "noisy").
+ * Outputs X (B,T,J,2), y (B,T,J,3). */
 int mp_gather_windows(const float* poses_2d, const float* poses_3d, const int64_t* seq_offset, int S, const int32_t* win_seq,
-                      const int32_t* win_start, const uint8_t* win_flip, const int32_t* mirror, int B, int T, int J, float* X, float* y,
-                      void* stream);
+                      const int32_t* win_start, const uint8_t* win_flip, const int32_t* mirror, const float* mask2d, const float* noise2d,
+                      int B, int T, int J, float* X, float* y, void* stream);
 
 /* Evaluation analytics of pose sequences in one pass over the frames (17-joint H36M / 3DHP tree compiled in): the running sums
  * behind mpjpe_error / mse_error / jointwise_error / segments_len_err (hpe/mh_so3_hpe/metrics/mean_joint_errors.py:31-130),

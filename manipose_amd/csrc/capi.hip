@@ -142,11 +142,11 @@ int mp_attention_bwd_bf16(const void* qkv, const void* out, const void* d_out, c
 }
 
 int mp_gather_windows(const float* poses_2d, const float* poses_3d, const int64_t* seq_offset, int S, const int32_t* win_seq,
-                      const int32_t* win_start, const uint8_t* win_flip, const int32_t* mirror, int B, int T, int J, float* X, float* y,
-                      void* stream) {
+                      const int32_t* win_start, const uint8_t* win_flip, const int32_t* mirror, const float* mask2d, const float* noise2d,
+                      int B, int T, int J, float* X, float* y, void* stream) {
   static_assert(sizeof(long) == sizeof(int64_t), "LP64");
-  return gather_windows(poses_2d, poses_3d, (const long*)seq_offset, S, win_seq, win_start, win_flip, mirror, B, T, J, X, y,
-                        (hipStream_t)stream);
+  return gather_windows(poses_2d, poses_3d, (const long*)seq_offset, S, win_seq, win_start, win_flip, mirror, mask2d, noise2d, B, T, J,
+                        X, y, (hipStream_t)stream);
 }
 
 int mp_procrustes_errors(const float* pred, const float* gt, const uint8_t* mask, int64_t N, int J, float pred_scale, float gt_scale,

@@ -141,7 +141,8 @@ int pose_metrics(const float* pred, const long* ps, const float* gt, const long*
 
 // ---------------------------------------------------------------- windows.hip
 int gather_windows(const float* p2, const float* p3, const long* seq_offset, int S, const int* win_seq, const int* win_start,
-                   const unsigned char* win_flip, const int* mirror, int B, int T, int J, float* X, float* y, hipStream_t st);
+                   const unsigned char* win_flip, const int* mirror, const float* mask2d, const float* noise2d, int B, int T, int J,
+                   float* X, float* y, hipStream_t st);
 
 // ---------------------------------------------------------------- procrustes.hip
 int procrustes_errors(const float* pred, const float* gt, const unsigned char* mask, long N, int J, float pred_scale, float gt_scale,

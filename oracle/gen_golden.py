@@ -301,6 +301,18 @@ def gen_windows_fixture(ref):
             xs.append(x.clone().numpy()); ys.append(y.clone().numpy())
         out[f"{nm}.X"], out[f"{nm}.y"] = np.stack(xs), np.stack(ys)
         out[f"{nm}.len"] = np.int64(len(gen))
+    # occlusion patterns (generators.py:160-216): numpy's global RNG
+    for mt in ("random", "random_left_arm_right_leg", "structured_joint", "structured_frame", "noisy", "all"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            gen = PoseSequenceGenerator(p3, p2, None, seq_len=27, random_start=True, drop_last=True, miss_type=mt, miss_rate=0.3,
+                                        noise_sigma=0.05, transform=PoseFlip(ref["sk"], 0.5))
+        torch.manual_seed(77)
+        np.random.seed(99)
+        xs, ys = [], []
+        for i in range(len(gen)):
+            x, y = gen[i]
+            xs.append(x.clone().numpy()); ys.append(y.clone().numpy())
+        out[f"miss.{mt}.X"], out[f"miss.{mt}.y"] = np.stack(xs), np.stack(ys)
     np.savez_compressed(os.path.join(OUT, "windows.npz"), **out)
     print("windows: ok", {k: v.shape for k, v in out.items() if k.endswith(".X")})
 

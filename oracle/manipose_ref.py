@@ -415,8 +415,43 @@ def flip_pose(pose: Tensor, joints_left=H36M_JOINTS_LEFT, joints_right=H36M_JOIN
     return out
 
 
-def sequence_window(poses_3d, poses_2d, index: int, seq_len: int, random_start: bool, drop_last: bool, flip_probability=None):
-    """generators.py:106-219 for miss_type 'no_miss': (pose_2d (L,J,2), pose_3d (L,J,3)) of dataset item `index`."""
+MISS_RATES = {"no_miss": 0.2, "random": 0.2, "random_left_arm_right_leg": 0.4, "structured_joint": 0.4, "structured_frame": 0.2}
+
+
+def occlusion_tables(seq_len: int, J: int, miss_type: str, miss_rate: float = 0.2, noise_sigma: float = 5):
+    """generators.py:160-216: (mask (L,J), noise (L,J,2) or None) drawn from numpy's global RNG with the reference's calls."""
+    import math
+    import numpy as np
+    shape = (seq_len, J)
+    if miss_type == "all":
+        miss_type = np.random.choice(list(MISS_RATES.keys()))
+        miss_rate = MISS_RATES[miss_type]
+    mask, noise = np.ones(shape), None
+    if miss_type == "random":
+        mask = np.zeros(shape)
+        mask[np.random.uniform(0.0, 1.0, size=shape) > miss_rate] = 1.0
+    elif miss_type == "random_left_arm_right_leg":
+        rand = np.random.choice(seq_len, size=math.floor(miss_rate * seq_len), replace=False).tolist()
+        for i in [1, 2, 3, 11, 12, 13]:
+            mask[rand, i] = 0.0
+    elif miss_type == "structured_joint":
+        occl = int(seq_len * miss_rate)
+        r = np.random.choice(seq_len - occl, size=1, replace=False)
+        mask[r[0]: r[0] + occl, [1, 2, 3]] = 0.0
+    elif miss_type == "structured_frame":
+        occl = int(seq_len * miss_rate)
+        r = np.random.choice(seq_len - occl, size=1, replace=False)
+        mask[r[0]: r[0] + occl] = 0.0
+    elif miss_type == "noisy":
+        noise = np.random.normal(0, noise_sigma, size=(seq_len, J, 2))
+    elif miss_type != "no_miss":
+        raise ValueError(f"Unexpected miss_type: {miss_type}")
+    return mask, noise
+
+
+def sequence_window(poses_3d, poses_2d, index: int, seq_len: int, random_start: bool, drop_last: bool, flip_probability=None,
+                    miss_type: str = "no_miss", miss_rate: float = 0.2, noise_sigma: float = 5):
+    """generators.py:106-219: (pose_2d (L,J,2) after occlusion, pose_3d (L,J,3)) of dataset item `index`."""
     to_pose, to_frame = window_tables([p.shape[0] for p in poses_3d], seq_len, drop_last)
     p3 = torch.as_tensor(poses_3d[to_pose[index]]).float()
     p2 = torch.as_tensor(poses_2d[to_pose[index]]).float()
@@ -428,7 +463,10 @@ def sequence_window(poses_3d, poses_2d, index: int, seq_len: int, random_start: 
     w2, w3 = p2[idx], p3[idx]
     if flip_probability is not None and torch.rand(1).item() <= flip_probability:
         w2, w3 = flip_pose(w2), flip_pose(w3)
-    return w2, w3
+    mask, noise = occlusion_tables(seq_len, w2.shape[1], miss_type, miss_rate, noise_sigma)
+    if noise is not None:
+        w2 = w2.double() + torch.from_numpy(noise)         # `float32 tensor += float64 ndarray` yields a float64 tensor in the reference
+    return w2 * torch.from_numpy(mask[..., None]).float(), w3
 
 
 # ---------------------------------------------------------------------------

@@ -777,8 +777,6 @@ def test_window_generator_properties_at_training_size(lib):
     assert bool((y[4, 1:] == y[4, 0]).all())
     Xb, yb = pose_flip((Xf.clone(), yf.clone()), sk)       # mirroring the mirrored windows on the host side gives the originals back
     assert torch.equal(Xb, X) and torch.equal(yb, y)
-    with pytest.raises(NotImplementedError):
-        PoseSequenceGenerator(p3, p2, None, seq_len=243, miss_type="random")
     with pytest.raises(RuntimeError):
         PoseSequenceGenerator(p3, p2, None, seq_len=243, device="cpu")
 
@@ -795,3 +793,29 @@ def test_training_entry_runs_on_resident_sequences(lib, tmp_path, monkeypatch):
                 "model.nheads_seg=4", "multi_hyp.n_hyp=3", "data.synthetic_sequences=6", "run.test=true"])
     assert np.isfinite(best) and best < 1e9
     assert any(f.endswith(".pth") for _, _, fs in os.walk(tmp_path) for f in fs)
+
+
+@pytest.mark.parametrize("mt", ["random", "random_left_arm_right_leg", "structured_joint", "structured_frame", "noisy", "all"])
+def test_window_generator_occlusion_patterns_match_reference(lib, mt):
+    """The generator's occlusion patterns (host-side numpy draws in the reference's order, applied by the gather kernel) against the
+    reference's generator under the same torch / numpy seeds; bit-exact except 'noisy' (the reference's result is float64 there:
+    one float32 ulp)."""
+    from manipose_amd import h36m_skeleton
+    from manipose_amd.augmentations import PoseFlip
+    from manipose_amd.data import PoseSequenceGenerator
+    fx = load_fixture("windows")
+    n = len(fx["lens"])
+    p3, p2 = [fx[f"p3.{i}"] for i in range(n)], [fx[f"p2.{i}"] for i in range(n)]
+    gen = PoseSequenceGenerator(p3, p2, None, seq_len=27, random_start=True, drop_last=True, miss_type=mt, miss_rate=0.3,
+                                noise_sigma=0.05, transform=PoseFlip(h36m_skeleton(), 0.5))
+    torch.manual_seed(77)
+    np.random.seed(99)
+    X, y = gen.batch(range(len(gen)))
+    assert torch.equal(y.cpu(), torch.from_numpy(fx[f"miss.{mt}.y"]))
+    want = torch.from_numpy(fx[f"miss.{mt}.X"])
+    if mt == "noisy":
+        np.testing.assert_allclose(X.cpu().numpy(), want.numpy(), rtol=3e-7, atol=1e-7)
+    else:
+        assert torch.equal(X.cpu(), want.float())
+    with pytest.raises(ValueError):
+        PoseSequenceGenerator(p3, p2, None, seq_len=27, miss_type="checkerboard")

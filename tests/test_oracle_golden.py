@@ -226,3 +226,18 @@ def test_oracle_sequence_windows_match_reference_generator(case):
         x, y = orc.sequence_window(p3, p2, i, 27, random_start, drop_last, 0.5 if flip else None)
         np.testing.assert_array_equal(x.numpy(), fx[f"{case}.X"][i])
         np.testing.assert_array_equal(y.numpy(), fx[f"{case}.y"][i])
+
+
+MISS_TYPES = ("random", "random_left_arm_right_leg", "structured_joint", "structured_frame", "noisy", "all")
+
+
+@pytest.mark.parametrize("mt", MISS_TYPES)
+def test_oracle_occlusion_patterns_match_reference_generator(mt):
+    fx = load_fixture("windows")
+    p3, p2 = _window_sequences(fx)
+    torch.manual_seed(77)
+    np.random.seed(99)
+    for i in range(fx[f"miss.{mt}.X"].shape[0]):
+        x, y = orc.sequence_window(p3, p2, i, 27, True, True, 0.5, miss_type=mt, miss_rate=0.3, noise_sigma=0.05)
+        np.testing.assert_array_equal(x.numpy(), fx[f"miss.{mt}.X"][i])
+        np.testing.assert_array_equal(y.numpy(), fx[f"miss.{mt}.y"][i])
