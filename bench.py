@@ -18,6 +18,7 @@ sys.path.insert(0, ROOT)
 
 TRAIN_GFLOP_PER_POSE = {243: 3.705, 81: 3.562, 27: 3.513}      # SURVEY.md 8d (3 x forward GEMM+attention FLOPs)
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}                  # MI355X_MICROARCH.md: dense matrix peaks
+PEAK_HBM_GBPS = 8000.0                                         # HBM3E spec peak (measured copy peak on this pool: ~5.5-6.3 TB/s)
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction of
 # MI355X_MICROARCH.md section HBM, + WRITE_SIZE), see profiles/README.md; keyed by (precision, windows per GPU).
 PMC_TRAFFIC_PER_LAUNCH = {("bf16", 64): 1210.2e6}   # profiles/r01_final_bf16_B64_pmc_hbm_traffic.csv, last row: gemm_bf16_persist_kernel, all instantiations
@@ -173,13 +174,25 @@ def main():
                 k = prof["gemm_fwd"]
                 kname = ("gemm_bf16_glds_kernel (forward Linear GEMMs)" if args.precision == "bf16"
                          else "gemm_f32_kernel<AL=0,BL=0,*> (forward Linear GEMMs, v_mfma_f32_32x32x2_f32)")
-            ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
-            peak = PEAK_TFLOPS[args.precision]
-            out["roofline"] = {"bound": "mfma", "kernel": kname,
-                               "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            # Which roof?  Arithmetic intensity of the average launch (algorithmic FLOPs / algorithmic bytes: operands read once,
+            # outputs written once) against the ridge peak_flops / peak_bw of the dtype.  Below the ridge the launch is HBM-bound
+            # by the roofline model and `achieved` is algorithmic bytes / time; the MFMA view is reported next to it.
+            tflops = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+            gbps = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+            peak_tf, peak_bw = PEAK_TFLOPS[args.precision], PEAK_HBM_GBPS
+            intensity = k["flops"] / k["bytes"] if k["bytes"] > 0 else float("inf")
+            ridge = peak_tf * 1e12 / (peak_bw * 1e9)
+            hbm_bound = intensity < ridge
+            out["roofline"] = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
+                               "achieved": gbps if hbm_bound else tflops, "peak": peak_bw if hbm_bound else peak_tf,
+                               "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                               "frac": (gbps / peak_bw) if hbm_bound else (tflops / peak_tf),
                                "traffic": PMC_TRAFFIC_PER_LAUNCH.get((args.precision, B)),
                                "avg_launch_ms": k["ms"] / max(1, k["launches"]), "launches": k["launches"],
-                               "flops_per_launch": k["flops"] / max(1, k["launches"])}
+                               "flops_per_launch": k["flops"] / max(1, k["launches"]),
+                               "bytes_per_launch": k["bytes"] / max(1, k["launches"]),
+                               "intensity_flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
+                               "mfma_tflops": tflops, "mfma_frac": tflops / peak_tf, "hbm_gbps": gbps, "hbm_frac": gbps / peak_bw}
             tot = sum(v["ms"] for v in prof.values())
             out["kernel_classes"] = {n: {"ms_per_step": v["ms"] / args.steps, "share": v["ms"] / tot if tot else 0.0,
                                          "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}

@@ -165,10 +165,11 @@ int mp_model_peek_copy(const mp_model* m, int which, float* dst, int64_t numel, 
  * 2 gemm_wgrad, 3 attention, 4 layernorm, 5 other partition the launches; class 6 gemm_persist is the SUBSET of classes 0/1 that
  * ran gemm_bf16_persist_kernel (the kernel with the largest share of a training step: its average launch time is what
  * rocprofv3 reports for that kernel name).  collect() synchronises the events, adds up elapsed ms / launch counts /
- * algorithmic FLOPs per class since the last reset and resets. */
+ * algorithmic FLOPs (and, for the forward / dgrad GEMM classes, algorithmic bytes: every operand read once, every output written
+ * once) per class since the last reset and resets. */
 #define MP_PROF_CLASSES 7
 int mp_prof_enable(mp_model* m, int on);
-int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops);
+int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops, double* bytes /* nullable: algorithmic bytes, GEMM classes */);
 
 /* GPU-resident PoseSequenceGenerator (hpe/mh_so3_hpe/data/generators.py:44-219) + PoseFlip
  * (hpe/mh_so3_hpe/augmentations/transforms.py:7-28, functional.py:7-31): cuts B windows of T frames out of pose sequences stored

@@ -70,7 +70,7 @@ struct mp_model {
   bool prof = false;
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_cls;
-  std::vector<double> ev_flops;
+  std::vector<double> ev_flops, ev_bytes;
   std::vector<char> ev_tag;              // 1: the launch ran gemm_bf16_persist_kernel
   size_t ev_used = 0;
 };
@@ -226,11 +226,12 @@ struct ProfScope {
   mp_model* m;
   hipStream_t st;
   bool on;
-  ProfScope(mp_model* mm, hipStream_t s, int cls, double flops) : m(mm), st(s), on(false) {
+  ProfScope(mp_model* mm, hipStream_t s, int cls, double flops, double bytes = 0.0) : m(mm), st(s), on(false) {
     if (m->prof && m->ev_used + 2 <= m->ev.size()) {
       on = true;
       m->ev_cls.push_back(cls);
       m->ev_flops.push_back(flops);
+      m->ev_bytes.push_back(bytes);
       (void)gemm_bf16_take_last_persist();
       (void)hipEventRecord(m->ev[m->ev_used], st);
     }
@@ -249,6 +250,13 @@ struct ProfScope {
     int rc__ = (call);                         \
     if (rc__) return rc__;                     \
   } while (0)
+// the same with the launch's ALGORITHMIC bytes (operands read once + outputs written once): GEMM classes only
+#define RUNB(cls, flops, bytes, call)                  \
+  do {                                                 \
+    ProfScope ps__(m, st, (cls), (flops), (bytes));    \
+    int rc__ = (call);                                 \
+    if (rc__) return rc__;                             \
+  } while (0)
 enum { PC_GEMM_FWD = 0, PC_GEMM_DGRAD = 1, PC_GEMM_WGRAD = 2, PC_ATTN = 3, PC_LN = 4, PC_OTHER = 5 };
 
 static const float* P(const mp_model* m, const float* flat, int idx) { return flat + m->params[idx].offset; }
@@ -262,13 +270,16 @@ static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* 
     GemmF32Args g = {};
     g.A = (const float*)A; g.lda = K; g.B = P(m, fp, widx); g.ldb = K; g.C = (float*)Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
     g.bias = P(m, fp, bidx); g.Z = (float*)Z; g.R = R; g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
-    RUN(PC_GEMM_FWD, 2.0 * M * N * K, gemm_f32(0, 0, epi, g, st));
+    RUNB(PC_GEMM_FWD, 2.0 * M * N * K, 4.0 * (M * K + (double)N * K + M * N * (1 + (epi == EPI_BIAS_RESID) + (epi == EPI_BIAS_GELU))),
+         gemm_f32(0, 0, epi, g, st));
     return MP_OK;
   }
   GemmB16Args g = {};
   g.A = A; g.lda = K; g.B = m->wbf + m->params[widx].offset; g.ldb = K; g.C = Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
   g.bias = P(m, fp, bidx); g.Z = Z; g.R = R; g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
-  RUN(PC_GEMM_FWD, 2.0 * M * N * K, gemm_bf16(g, 0, 0, 0, epi == EPI_BIAS_RESID ? 1 : 0, epi, st));
+  // bf16 A and weights; output bf16 (+ a second bf16 output gelu') or, for the residual epilogue, fp32 in + fp32 out
+  const double obytes = epi == EPI_BIAS_RESID ? 8.0 * M * N : 2.0 * M * N * (epi == EPI_BIAS_GELU ? 2 : 1);
+  RUNB(PC_GEMM_FWD, 2.0 * M * N * K, 2.0 * (M * K + (double)N * K) + obytes, gemm_bf16(g, 0, 0, 0, epi == EPI_BIAS_RESID ? 1 : 0, epi, st));
   return MP_OK;
 }
 // dX[M,K] = dY[M,N] W[N,K]  (optionally * gelu'(Z)).  dy_f32 / dx_f32: storage of dY / dX in bf16 mode.
@@ -278,12 +289,13 @@ static int linear_dgrad(mp_model* m, hipStream_t st, const float* fp, const void
     GemmF32Args g = {};
     g.A = (const float*)dY; g.lda = N; g.B = P(m, fp, widx); g.ldb = K; g.C = (float*)dX; g.ldc = K; g.M = (int)M; g.N = K; g.K = N;
     g.Z = (float*)Z;
-    RUN(PC_GEMM_DGRAD, 2.0 * M * N * K, gemm_f32(0, 1, Z ? EPI_DGELU : EPI_BIAS, g, st));
+    RUNB(PC_GEMM_DGRAD, 2.0 * M * N * K, 4.0 * (M * N + (double)N * K + M * K * (Z ? 2 : 1)), gemm_f32(0, 1, Z ? EPI_DGELU : EPI_BIAS, g, st));
     return MP_OK;
   }
   GemmB16Args g = {};
   g.A = dY; g.lda = N; g.B = m->wbf + m->params[widx].offset; g.ldb = K; g.C = dX; g.ldc = K; g.M = (int)M; g.N = K; g.K = N; g.Z = Z;
-  RUN(PC_GEMM_DGRAD, 2.0 * M * N * K, gemm_bf16(g, dy_f32, 0, 1, dx_f32, Z ? EPI_DGELU : EPI_BIAS, st));
+  RUNB(PC_GEMM_DGRAD, 2.0 * M * N * K, (dy_f32 ? 4.0 : 2.0) * M * N + 2.0 * N * K + (dx_f32 ? 4.0 : 2.0) * M * K + (Z ? 2.0 * M * K : 0.0),
+       gemm_bf16(g, dy_f32, 0, 1, dx_f32, Z ? EPI_DGELU : EPI_BIAS, st));
   return MP_OK;
 }
 static int linear_wgrad(mp_model* m, hipStream_t st, const void* dY, int dy_f32, const void* X, float* dW, float* db, long M, int N,
@@ -781,13 +793,14 @@ int mp_prof_enable(mp_model* m, int on) {
   m->ev_used = 0;
   m->ev_cls.clear();
   m->ev_flops.clear();
+  m->ev_bytes.clear();
   m->ev_tag.clear();
   return MP_OK;
 }
 
-int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops) {
+int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops, double* bytes) {
   MP_CHECK(m && ms && launches && flops, MP_ERR_ARG, "mp_prof_collect: null argument");
-  for (int c = 0; c < MP_PROF_CLASSES; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; }
+  for (int c = 0; c < MP_PROF_CLASSES; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; if (bytes) bytes[c] = 0; }
   for (size_t i = 0; i < m->ev_cls.size() && 2 * i + 1 < m->ev_used; ++i) {
     MP_HIP(hipEventSynchronize(m->ev[2 * i + 1]));
     float t = 0.f;
@@ -796,15 +809,18 @@ int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops) {
     ms[c] += t;
     launches[c] += 1;
     flops[c] += m->ev_flops[i];
+    if (bytes) bytes[c] += m->ev_bytes[i];
     if (i < m->ev_tag.size() && m->ev_tag[i]) {         // class 6: the launches of classes 0/1 that ran gemm_bf16_persist_kernel
       ms[6] += t;
       launches[6] += 1;
       flops[6] += m->ev_flops[i];
+      if (bytes) bytes[6] += m->ev_bytes[i];
     }
   }
   m->ev_used = 0;
   m->ev_cls.clear();
   m->ev_flops.clear();
+  m->ev_bytes.clear();
   m->ev_tag.clear();
   return MP_OK;
 }
