@@ -346,18 +346,6 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   const int m0 = tm * BT, n0 = tn * BT;
   const int kbeg = tz * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
-  if (BT == 256 && g.stagger > 0) {
-    // All tiles cost the same, so with one workgroup per CU every CU would reach its (HBM-write-bound) epilogue at the same
-    // moment and idle its matrix cores while the whole chip's stores queue up.  Phase-shift the FIRST wave of workgroups
-    // (later ones inherit the shift, a CU starts its next tile when the previous one retires) so epilogues of some CUs
-    // overlap main loops of others.
-    const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (id < 256) {
-      const int ph = (id >> 3) & 7;
-      for (int i = 0; i < ph * g.stagger; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-  }
-
   f32x4 acc[MI][4];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -731,7 +719,6 @@ static int launch_b16(const GemmB16Args& g, int splits, hipStream_t st) {
 // C[M,N] = A(i,r) B(r,j): a_f32/c_f32 select fp32 instead of bf16 storage; a_tr/b_tr select the "T" layouts.
 int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, hipStream_t st) {
   { const char* e = getenv("MANIPOSE_GEMM_DEBUG"); g.debug = e ? atoi(e) : 0; }   // timing ablations only (1 no MFMA, 2 no DMA, 4 no epilogue)
-  { static int stg = -1; if (stg < 0) { const char* e = getenv("MANIPOSE_GEMM_STAGGER"); stg = e ? atoi(e) : 0; } g.stagger = stg; }
   MP_CHECK(g.M > 0 && g.N > 0 && g.K > 0, MP_ERR_ARG, "gemm_bf16: empty problem");
   MP_CHECK((a_tr ? g.M : g.K) % 8 == 0 && (b_tr ? g.N : g.K) % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.N % 4 == 0 &&
                g.ldc % 4 == 0, MP_ERR_ARG,
@@ -773,7 +760,6 @@ int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, i
   g.C = slab; g.ldc = Kin;
   g.bias_slab = (db != nullptr) ? slab + (long)splits * Nout * Kin : nullptr;
   g.k_per_split = kper;
-  g.stagger = 0;       // split-K wgrad: one workgroup per CU, nothing to desynchronise
   int rc = dy_f32 ? launch_b16<float, 1, bf16, 1, float, EPI_SLAB>(g, splits, st)
                   : launch_glds<1, 1, float, EPI_SLAB>(g, splits, st);
   if (rc) return rc;

@@ -40,7 +40,6 @@ struct GemmB16Args {
   float* bias_slab;
   int k_per_split;
   int debug;           // timing-ablation bits (MANIPOSE_GEMM_DEBUG), 0 in production
-  int stagger;         // start-phase stagger of the first wave of workgroups, in ~0.5 us units per phase (0 = off)
 };
 int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, hipStream_t st);
 int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
