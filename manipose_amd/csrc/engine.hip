@@ -461,8 +461,8 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
       BlockWS& wp = md.ws[l - 1];
       const bool pspatial = ((l - 1) % 2 == 0);
       const float* mkp = branch_mask(m, md, l - 1, 1, B, m->train);
-      RUN(PC_LN, 0, ln_bwd2(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, wp.x_out, wp.stp, P(m, fp, pspatial ? md.sn_w : md.tn_w), g,
-                            m->g_b16, mkp, pspatial ? 1 : 2, T, N, G(m, fg, q.n1w), G(m, fg, q.n1b),
+      RUN(PC_LN, 0, ln_bwd2(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, wp.x_out, wp.stp, P(m, fp, pspatial ? md.sn_w : md.tn_w),
+                            P(m, fp, pspatial ? md.sn_b : md.tn_b), g, m->g_b16, mkp, pspatial ? 1 : 2, T, N, G(m, fg, q.n1w), G(m, fg, q.n1b),
                             G(m, fg, pspatial ? md.sn_w : md.tn_w), G(m, fg, pspatial ? md.sn_b : md.tn_b), (int)M, C, m->small,
                             m->small_floats, st));
       post_done = true;
