@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
             o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
           }
           v[i] = o;
-          st4(a.x1 + (long)m * C + c, o);
+          if (a.x1 != nullptr) st4(a.x1 + (long)m * C + c, o);      // null: the consumer recomputes it from x and stats1
         }
       }
       if (lane == 0) {

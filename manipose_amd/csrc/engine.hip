@@ -154,8 +154,11 @@ static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int half
   const long C = md.C;
   auto act = [&](long n) -> void* { return bp.take(half ? (n + 1) / 2 : n); };   // bf16 activations take half the floats
   md.ws.resize(2 * md.depth);
-  for (auto& w : md.ws) {
-    w.x_in = bp.take(M * C);   w.st1 = bp.take(M * 2);     w.a1 = act(M * C);   w.qkv = act(M * 3 * C);
+  for (size_t l = 0; l < md.ws.size(); ++l) {
+    BlockWS& w = md.ws[l];
+    const bool lazy_in = half && l >= 2 && C <= 512;         // lazy_block_input(): recomputed where it is used, never stored
+    w.x_in = lazy_in ? nullptr : bp.take(M * C);
+    w.st1 = bp.take(M * 2);     w.a1 = act(M * C);   w.qkv = act(M * 3 * C);
     w.lse = bp.take((long)Bmax * md.N * md.H * T);
     w.ao = act(M * C);         w.x_mid = bp.take(M * C);   w.st2 = bp.take(M * 2);  w.a2 = act(M * C);
     w.z = act(M * 2 * C);      w.f = act(M * 2 * C);       w.x_out = bp.take(M * C); w.stp = bp.take(M * 2);
@@ -264,8 +267,10 @@ static float* G(const mp_model* m, float* flat, int idx) { return flat + m->para
 
 // Linear layers: precision 0 -> fp32 matrix cores on fp32 buffers; precision 1 -> bf16 matrix cores, bf16 activations /
 // shadow weights, fp32 residual stream and fp32 gradient stream (converted to bf16 while staging).
+// rstats / rgamma / rbeta (bf16 mode, residual epilogue): the residual is LayerNorm(R) recomputed in the epilogue (kernels.h)
 static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* A, int widx, int bidx, void* Cc, long M, int N, int K,
-                      int epi, void* Z, const float* R, const float* mask, int mask_mode, int T, int J) {
+                      int epi, void* Z, const float* R, const float* mask, int mask_mode, int T, int J, const float* rstats = nullptr,
+                      const float* rgamma = nullptr, const float* rbeta = nullptr) {
   if (m->cfg.precision == 0) {
     GemmF32Args g = {};
     g.A = (const float*)A; g.lda = K; g.B = P(m, fp, widx); g.ldb = K; g.C = (float*)Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
@@ -277,6 +282,7 @@ static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* 
   GemmB16Args g = {};
   g.A = A; g.lda = K; g.B = m->wbf + m->params[widx].offset; g.ldb = K; g.C = Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
   g.bias = P(m, fp, bidx); g.Z = Z; g.R = R; g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
+  g.rstats = rstats; g.rgamma = rgamma; g.rbeta = rbeta;
   // bf16 A and weights; output bf16 (+ a second bf16 output gelu') or, for the residual epilogue, fp32 in + fp32 out
   const double obytes = epi == EPI_BIAS_RESID ? 8.0 * M * N : 2.0 * M * N * (epi == EPI_BIAS_GELU ? 2 : 1);
   RUNB(PC_GEMM_FWD, 2.0 * M * N * K, 2.0 * (M * K + (double)N * K) + obytes, gemm_bf16(g, 0, 0, 0, epi == EPI_BIAS_RESID ? 1 : 0, epi, st));
@@ -323,6 +329,13 @@ static const float* branch_mask(const mp_model* m, const Module& md, int l, int 
   return nullptr;
 }
 
+// Is the input of block l (the shared post-norm of block l-1's output) recomputed where it is used instead of stored?  bf16 mode,
+// blocks >= 2 (no embedding / positional table behind them), C <= 512 (their backward then runs through ln_bwd2, which
+// recomputes it as well).
+static bool lazy_block_input(const mp_model* m, const Module& md, int l) {
+  return m->cfg.precision == 1 && l >= 2 && md.C <= 512;
+}
+
 static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStream_t st) {
   const int T = m->cfg.num_frame, N = md.N, C = md.C, H = md.H, L = 2 * md.depth;
   const int half = m->cfg.precision == 1;
@@ -343,8 +356,18 @@ static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStre
     if (rc) return rc;
     if (spatial) RUN(PC_ATTN, 4.0 * B * T * N * N * C, attn_spatial_fwd(w.qkv, w.ao, half, B, T, N, C, H, st));
     else RUN(PC_ATTN, 4.0 * B * N * (double)T * T * C, attn_temporal_fwd(w.qkv, w.ao, w.lse, half, B, T, N, C, H, st));
-    rc = linear_fwd(m, st, fp, w.ao, q.pw, q.pb, w.x_mid, M, C, C, EPI_BIAS_RESID, nullptr, w.x_in,
-                    branch_mask(m, md, l, 0, B, m->train), mode, T, N);
+    // block input: materialised (blocks 0 and 1: embedding / positional table involved), or - bf16 mode - recomputed in the
+    // residual epilogue as the shared post-norm of the previous block's output (ln_fwd below does not store it then)
+    const bool lazy_in = lazy_block_input(m, md, l);
+    if (lazy_in) {
+      const bool pspatial = ((l - 1) % 2 == 0);
+      rc = linear_fwd(m, st, fp, w.ao, q.pw, q.pb, w.x_mid, M, C, C, EPI_BIAS_RESID, nullptr, md.ws[l - 1].x_out,
+                      branch_mask(m, md, l, 0, B, m->train), mode, T, N, md.ws[l - 1].stp, P(m, fp, pspatial ? md.sn_w : md.tn_w),
+                      P(m, fp, pspatial ? md.sn_b : md.tn_b));
+    } else {
+      rc = linear_fwd(m, st, fp, w.ao, q.pw, q.pb, w.x_mid, M, C, C, EPI_BIAS_RESID, nullptr, w.x_in,
+                      branch_mask(m, md, l, 0, B, m->train), mode, T, N);
+    }
     if (rc) return rc;
     {
       LnFwdArgs a = {};
@@ -363,7 +386,7 @@ static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStre
     a.x = w.x_out; a.M = (int)M; a.C = C;
     a.g1 = P(m, fp, spatial ? md.sn_w : md.tn_w); a.b1 = P(m, fp, spatial ? md.sn_b : md.tn_b); a.eps1 = 1e-6f;
     a.pos = (l == 0) ? P(m, fp, md.tpos) : nullptr; a.T = T; a.J = N;
-    a.x1 = (l + 1 < L) ? md.ws[l + 1].x_in : md.x_final;
+    a.x1 = (l + 1 < L) ? (lazy_block_input(m, md, l + 1) ? nullptr : md.ws[l + 1].x_in) : md.x_final;
     a.stats1 = w.stp;
     if (l + 1 < L) {
       a.g2 = P(m, fp, md.bp[l + 1].n1w); a.b2 = P(m, fp, md.bp[l + 1].n1b); a.eps2 = 1e-6f;

@@ -395,6 +395,8 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   if (EPI != EPI_SLAB && EPI != EPI_DGELU && g.bias != nullptr && col < g.N) bias4 = ld4(g.bias + col);
   DropPathRows dp;
   dp.init(EPI == EPI_BIAS_RESID ? g.mask : nullptr, g.mask_mode, g.T, g.J, m0 + wr * (BT / 2));
+  float4 rg4 = make_float4(0.f, 0.f, 0.f, 0.f), rb4 = rg4;
+  if (EPI == EPI_BIAS_RESID && g.rstats != nullptr && col < g.N) { rg4 = ld4(g.rgamma + col); rb4 = ld4(g.rbeta + col); }
 #pragma unroll
   for (int hp = 0; hp < MI / 4; ++hp) {              // 64 rows of the wave tile per pass
 #pragma unroll
@@ -419,7 +421,12 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
         st4(Z + o, d);
       } else if (EPI == EPI_BIAS_RESID) {
         const float dscale = dp.scale(row);
-        const float4 r = ld4(g.R + o);
+        float4 r = ld4(g.R + o);
+        if (g.rstats != nullptr) {               // the residual is LayerNorm(R), recomputed (ln_fwd stage-1 expression)
+          const float mean = g.rstats[2 * (long)row], rstd = g.rstats[2 * (long)row + 1];
+          r = make_float4((r.x - mean) * rstd * rg4.x + rb4.x, (r.y - mean) * rstd * rg4.y + rb4.y, (r.z - mean) * rstd * rg4.z + rb4.z,
+                          (r.w - mean) * rstd * rg4.w + rb4.w);
+        }
         v = make_float4(r.x + dscale * v.x, r.y + dscale * v.y, r.z + dscale * v.z, r.w + dscale * v.w);
       } else if (EPI == EPI_DGELU) {
         const float4 z = ld4(Z + o);
@@ -474,6 +481,11 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
   constexpr bool LOADS = (EPI == EPI_BIAS_RESID || EPI == EPI_DGELU);
   float4 in_nxt[4];
   float ds_nxt[4];
+  // residual = LayerNorm(R) recomputed from R and its row statistics (GemmB16Args::rstats): per-lane gamma / beta of its 4 columns
+  const bool resid_ln = EPI == EPI_BIAS_RESID && g.rstats != nullptr;
+  float2 rs_nxt[4];
+  float4 rg4 = make_float4(0.f, 0.f, 0.f, 0.f), rb4 = rg4;
+  if (resid_ln) { rg4 = ld4(g.rgamma + (FULL ? col : min(col, g.N - 4))); rb4 = ld4(g.rbeta + (FULL ? col : min(col, g.N - 4))); }
   // the residual / gelu' rows (and DropPath scales) of pass i+1 are requested BEFORE the stores of pass i are issued: memory
   // operations retire in order, so a pass never waits for the previous pass's stores.
   DropPathRows dp;
@@ -487,6 +499,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
       if (LOADS) in_nxt[it] = (EPI == EPI_DGELU) ? ld4(Z + o) : ld4(g.R + o);
       ds_nxt[it] = 1.0f;
       if (EPI == EPI_BIAS_RESID) ds_nxt[it] = dp.scale(rc);
+      rs_nxt[it] = resid_ln ? *reinterpret_cast<const float2*>(g.rstats + 2 * (long)rc) : make_float2(0.f, 1.f);
     }
   };
   if (LOADS) request(0);
@@ -495,7 +508,14 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
     float4 in[4];
     float ds[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) { in[it] = in_nxt[it]; ds[it] = ds_nxt[it]; }
+    for (int it = 0; it < 4; ++it) {
+      in[it] = in_nxt[it]; ds[it] = ds_nxt[it];
+      if (EPI == EPI_BIAS_RESID && resid_ln) {     // ln_fwd stage-1 expression
+        const float mean = rs_nxt[it].x, rstd = rs_nxt[it].y;
+        in[it] = make_float4((in[it].x - mean) * rstd * rg4.x + rb4.x, (in[it].y - mean) * rstd * rg4.y + rb4.y,
+                             (in[it].z - mean) * rstd * rg4.z + rb4.z, (in[it].w - mean) * rstd * rg4.w + rb4.w);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(img + l15 * 64 + (((4 * j + gq) ^ l15) << 2)) = acc[i][j];
     if (LOADS && i + 1 < 8) request(i + 1);
@@ -723,6 +743,8 @@ int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, 
   MP_CHECK((a_tr ? g.M : g.K) % 8 == 0 && (b_tr ? g.N : g.K) % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.N % 4 == 0 &&
                g.ldc % 4 == 0, MP_ERR_ARG,
            "gemm_bf16: contiguous operand dimensions and leading dimensions must be multiples of 8 (M=%d N=%d K=%d)", g.M, g.N, g.K);
+  MP_CHECK(g.rstats == nullptr || (!a_f32 && epi == EPI_BIAS_RESID && g.rgamma && g.rbeta), MP_ERR_ARG,
+           "gemm_bf16: a recomputed residual needs the direct-to-LDS residual variant and gamma / beta");
   g.k_per_split = ((g.K + GBK - 1) / GBK) * GBK;
   if (!a_f32 && !a_tr && !b_tr && !c_f32 && epi == EPI_BIAS) return launch_glds<0, 0, bf16, EPI_BIAS>(g, 1, st);
   if (!a_f32 && !a_tr && !b_tr && c_f32 && epi == EPI_BIAS) return launch_glds<0, 0, float, EPI_BIAS>(g, 1, st);

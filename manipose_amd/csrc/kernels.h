@@ -35,6 +35,11 @@ struct GemmB16Args {
   const float* bias;
   void* Z;             // gelu'(pre-activation) kept for the backward, element type of C
   const float* R;      // fp32 residual stream
+  // residual epilogue with the residual recomputed instead of materialised: R holds the INPUT of a LayerNorm, the residual added is
+  // (R - mean) * rstd * rgamma + rbeta with (mean, rstd) = rstats[2 row .. 2 row + 1]; all three null: R is added as it is
+  const float* rstats;
+  const float* rgamma;
+  const float* rbeta;
   const float* mask;
   int mask_mode, T, J;
   float* bias_slab;
