@@ -96,10 +96,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hooks (a one-GPU box cannot host two RCCL ranks): MANIPOSE_BENCH_DEVICE pins every rank to one device and
+    # MANIPOSE_BENCH_BACKEND=gloo carries the collectives through the host; the driver's multi-GPU runs use neither
+    if os.environ.get("MANIPOSE_BENCH_DEVICE"):
+        local = int(os.environ["MANIPOSE_BENCH_DEVICE"])
+    backend = os.environ.get("MANIPOSE_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton

@@ -819,3 +819,20 @@ def test_window_generator_occlusion_patterns_match_reference(lib, mt):
         assert torch.equal(X.cpu(), want.float())
     with pytest.raises(ValueError):
         PoseSequenceGenerator(p3, p2, None, seq_len=27, miss_type="checkerboard")
+
+
+def test_bench_two_rank_path_rehearsal_on_one_gpu(lib):
+    """bench.py launched by torch.distributed.run with two ranks pinned to this GPU and gloo carrying the collectives (a one-GPU box
+    cannot host two RCCL ranks): init, barrier, gradient all-reduce, max-over-ranks timing, one JSON line from rank 0."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MANIPOSE_BENCH_DEVICE="0", MANIPOSE_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--frames", "27"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert "cpu_baseline" not in d and d["roofline"]["launches"] >= 0
