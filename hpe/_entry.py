@@ -3,8 +3,9 @@ hpe/main_h36m_lifting.py:711-1270 and hpe/main_3dhp.py:662-1063): same `group.ke
 keys (hpe/conf/config.yaml), same model construction (_instantiate_model :613-670), loss assembly (make_loss :101-178),
 optimizer / scheduler (:227-270), checkpoint names (save_state :75-98: model{tag}.pth / params{tag}.pth) and the MPJPE
 evaluation of evaluate() (hpe/eval_utils.py:16-223: weighted-average, best-score and oracle aggregation, millimetres).
-The dataset pipelines are out of scope: without `data.data_dir` the script trains / evaluates on
-synthetic H36M-shaped windows so that the whole MI355X path (engine, fused loss, RCCL data parallelism, fused Adam) runs.
+With `data.data_dir` the reference's files (data_3d_h36m.npz + data_2d_h36m_<keypoints>.npz, or data_{train,test}_3dhp.npz) are
+ingested on the device (manipose_amd/data/ingest.py) and stay resident in HBM; without it the script trains / evaluates on synthetic
+H36M-shaped sequences so that the whole MI355X path (window kernel, engine, fused loss, RCCL data parallelism, fused Adam) runs.
 Launch on N GPUs with `python -m torch.distributed.run --nproc-per-node N hpe/main_h36m_lifting.py ...`.
 """
 from __future__ import annotations
@@ -98,8 +99,72 @@ def synthetic_generator(cfg, device, seed, rank, world):
                                  transform=tf, device=device)
 
 
+def load_sequences(cfg, device):
+    """fetch_and_prepare_data + get_subjects_and_actions + the fetch() calls of create_dataloader (main_h36m_lifting.py:511-583,
+    main_3dhp.py:503-532): {"train" | "valid": (poses_3d, poses_2d, cameras), "test": {group: (...)}} as lists of device tensors.
+    The reference's pickle cache of the prepared dataset is not needed: the ingest is a few hundred kernel launches."""
+    from manipose_amd.data import Dataset3DHP, Human36mDataset, create_2d_data, fetch, read_3d_data
+    from manipose_amd.data.ingest import TEST_SUBJECTS, TRAIN_SUBJECTS
+    root = str(cfg.data.data_dir)
+    with torch.cuda.device(device):
+        if cfg.data.dataset == "3dhp":
+            out = {"test": {}}
+            if cfg.run.train:
+                tr = Dataset3DHP(cfg, root + "/", train=True, device=device)
+                out["train"] = (tr.poses, tr.poses_2d, None)
+            te = Dataset3DHP(cfg, root + "/", train=False, device=device)
+            out["valid"] = (te.poses, te.poses_2d, None)
+            out["test"]["all"] = out["valid"]
+            return out
+        ds = read_3d_data(Human36mDataset(os.path.join(root, f"data_3d_{cfg.data.dataset}.npz"), n_joints=cfg.data.joints, device=device))
+        kp = create_2d_data(os.path.join(root, f"data_2d_{cfg.data.dataset}_{cfg.data.keypoints}.npz"), ds)
+        if cfg.data.use_valid:
+            s_train, s_val = TRAIN_SUBJECTS[:-1], TRAIN_SUBJECTS[-1:]
+        else:
+            s_train, s_val = TRAIN_SUBJECTS, TEST_SUBJECTS
+        if cfg.data.data == "one":
+            s_train = [s_train[0]]
+        actions = None if cfg.data.actions == "*" else [ds.define_actions(a)[0] for a in str(cfg.data.actions).split(",")]
+        have = lambda subjects: [s for s in subjects if s in kp]
+        out = {"train": fetch(have(s_train), ds, kp, actions)[:2] + (None,), "valid": fetch(have(s_val), ds, kp, actions)[:2] + (None,), "test": {}}
+        for a in (actions or ds.define_actions()):                 # per-action test on S11, main_h36m_lifting.py:884-893
+            p3, p2, _, _ = fetch(have(["S11"]), ds, kp, [a])
+            if p3:
+                out["test"][a] = (p3, p2, None)
+        return out
+
+
+def window_generator(cfg, seqs, train, device):
+    """create_dataloader (main_h36m_lifting.py:569-610) minus the DataLoader: the generator itself serves whole batches."""
+    from manipose_amd import h36m_skeleton
+    from manipose_amd.augmentations import PoseFlip
+    from manipose_amd.data import PoseSequenceGenerator
+    tf = PoseFlip(h36m_skeleton(), 0.5) if cfg.train.flip_aug else None
+    return PoseSequenceGenerator(seqs[0], seqs[1], seqs[2], seq_len=int(cfg.data.seq_len), random_start=train, miss_type=cfg.data.miss_type,
+                                 miss_rate=cfg.data.miss_rate, noise_sigma=cfg.data.get("noise_sigma", 5), transform=tf, device=device)
+
+
+def epoch_batches(gen, batch, shuffle, rank=0, world=1, seed=None):
+    """DataLoader(shuffle, drop_last=False) over the generator's indices, dealt round-robin over the ranks (DistributedSampler-style:
+    every rank draws the same permutation from ``seed`` and keeps every world-th index)."""
+    n = len(gen)
+    if shuffle:
+        g = torch.Generator().manual_seed(seed) if seed is not None else None
+        order = torch.randperm(n, generator=g).tolist()
+    else:
+        order = list(range(n))
+    order = order[rank::world]
+    for i in range(0, len(order), batch):
+        yield gen.batch(order[i:i + batch])
+
+
+def tensor_batches(X, y, batch):
+    for i in range(0, X.shape[0], batch):
+        yield X[i:i + batch], y[i:i + batch]
+
+
 @torch.no_grad()
-def evaluate(model, X, y, batch, tta=True, analytics=False):
+def evaluate(model, X, y=None, batch=None, tta=True, analytics=False):
     """MPJPE (mm) of the aggregated / best-score / oracle hypotheses, with the reference's flip test-time augmentation
     (hpe/eval_utils.py:16-223).  The flipped copy is batched with the original into ONE forward of 2B windows
     instead of a second pass.  ``analytics=True`` adds the reference's evaluation table (main_h36m_lifting.py:933-990,
@@ -115,8 +180,7 @@ def evaluate(model, X, y, batch, tta=True, analytics=False):
     rmcl = isinstance(model, RMCLManifoldMixSTE)
     sums = {"mpjpe": 0.0, "ps_oracle_mpjpe": 0.0, "oracle_mpjpe": 0.0}
     n = 0
-    for i in range(0, X.shape[0], batch):
-        xb, yb = X[i:i + batch], y[i:i + batch]
+    for xb, yb in (tensor_batches(X, y, batch) if torch.is_tensor(X) else X):      # tensors, or any iterable of (X, y) batches
         nb = xb.shape[0]
         if tta:
             xin = torch.cat([xb, pose_flip((xb.clone(),), sk)[0]], dim=0)
@@ -182,30 +246,45 @@ def run(argv, extra_defaults=None):
         st = torch.load(cfg.run.checkpoint_params, map_location="cpu")
         trainer.opt.load_state_dict(st["optimizer"])
         start_epoch = st["epoch"]
-    if cfg.data.data_dir:
-        raise NotImplementedError("dataset loading (hpe/mh_so3_hpe/data of the reference) is outside this repository's scope; "
-                                  "leave data.data_dir empty to run on synthetic H36M-shaped windows")
-    T, B = cfg.data.seq_len, cfg.train.batch_size
+    T, B, Bt = cfg.data.seq_len, cfg.train.batch_size, cfg.train.batch_size_test
     out_dir = os.path.join(os.getcwd(), cfg.run.experiment)
     if rank == 0:
         os.makedirs(out_dir, exist_ok=True)
-    Xv, yv = synthetic_windows(4 * cfg.train.batch_size_test, T, dev, seed=10_000)
+    real = bool(cfg.data.data_dir)
+    if real:
+        seqs = load_sequences(cfg, dev)
+        gen_valid = window_generator(cfg, seqs["valid"], False, dev)
+        valid_batches = lambda: epoch_batches(gen_valid, Bt, shuffle=False)
+        if rank == 0:
+            print(f">>> Validation dataset length: {len(gen_valid)} windows of {T} frames", flush=True)
+    else:
+        Xv, yv = synthetic_windows(4 * Bt, T, dev, seed=10_000)
+        valid_batches = lambda: tensor_batches(Xv, yv, Bt)
     best_val, bad_epochs, lr = 1e10, 0, cfg.train.lr
     if cfg.run.train:
-        gen = synthetic_generator(cfg, dev, cfg.run.seed, rank, world)      # sequences resident in HBM, one gather kernel per batch
+        if real:
+            gen = window_generator(cfg, seqs["train"], True, dev)       # sequences resident in HBM, one gather kernel per batch
+            if rank == 0:
+                print(f">>> Training dataset length: {len(gen)} windows of {T} frames", flush=True)
+        else:
+            gen = synthetic_generator(cfg, dev, cfg.run.seed, rank, world)
         torch.manual_seed(cfg.run.seed + 1000 * rank)                        # per-rank window / flip draws
+        np.random.seed(cfg.run.seed + 1000 * rank)                           # per-rank occlusion draws
         for epoch in range(start_epoch, cfg.train.epochs):
             model.train()
             acc = torch.zeros(4, device=dev)
-            for it in range(cfg.train.steps_per_epoch):
-                idx = torch.randint(0, len(gen), (B,)).tolist()              # shuffled sampling with replacement over this rank's windows
-                X, y = gen.batch(idx)
+            if real:       # one pass over the windows, shuffled, dealt over the ranks (main_h36m_lifting.py:597-610)
+                batches = epoch_batches(gen, B, shuffle=True, rank=rank, world=world, seed=cfg.run.seed + epoch)
+            else:          # shuffled sampling with replacement over this rank's synthetic windows
+                batches = (gen.batch(torch.randint(0, len(gen), (B,)).tolist()) for _ in range(cfg.train.steps_per_epoch))
+            steps = 0
+            for X, y in batches:
                 acc += trainer.train_step(X, y)                      # device-side accumulation: no per-step host sync
-            terms = (acc / cfg.train.steps_per_epoch).tolist()
+                steps += 1
+            terms = (acc / max(steps, 1)).tolist()
             if (epoch + 1) % cfg.train.valid_epoch_interval == 0:
                 model.eval()
-                val = sum(trainer.eval_loss(Xv[i:i + cfg.train.batch_size_test], yv[i:i + cfg.train.batch_size_test]).sum().item()
-                          for i in range(0, Xv.shape[0], cfg.train.batch_size_test))
+                val = sum(trainer.eval_loss(xb, yb).sum().item() for xb, yb in valid_batches())
                 if val < best_val * (1 - cfg.train.lr_threshold):     # ReduceLROnPlateau(mode=min, rel threshold)
                     bad_epochs = 0
                 else:
@@ -222,12 +301,24 @@ def run(argv, extra_defaults=None):
                 print(f"epoch {epoch}: tr_loss {sum(terms):.5f} wloss {terms[0]:.5f} score_reg {terms[1]:.5f} vloss {terms[2]:.5f} "
                       f"sreg {terms[3]:.5f} | best val {best_val:.5f} lr {lr:.2e}", flush=True)
             if (epoch + 1) % cfg.train.mpjpe_epoch_interval == 0 and rank == 0:
-                print("   eval:", {k: round(v, 3) for k, v in evaluate(model, Xv, yv, cfg.train.batch_size_test, tta=cfg.train.tta).items()}, flush=True)
+                print("   eval:", {k: round(v, 3) for k, v in evaluate(model, valid_batches(), tta=cfg.train.tta).items()}, flush=True)
         if rank == 0:
             save_state(model, trainer, {"best": best_val, "bad_epochs": bad_epochs}, cfg.train.epochs, out_dir, "end")
     if cfg.run.test and rank == 0:
-        res = evaluate(model, Xv, yv, cfg.train.batch_size_test, tta=cfg.train.tta, analytics=True)
-        table = res.pop("analytics")
-        print("test:", {k: round(v, 3) for k, v in res.items()}, flush=True)
-        print("test analytics (mm):", {k: round(v, 4) for k, v in table.items() if not isinstance(v, list)}, flush=True)
+        groups = {"synthetic": valid_batches}
+        if real:        # per action (H36M: subject S11, main_h36m_lifting.py:884-990) or the whole 3DHP test set (main_3dhp.py:800-910)
+            groups = {}
+            for name, sq in seqs["test"].items():
+                g = window_generator(cfg, sq, False, dev)
+                groups[name] = (lambda g=g: epoch_batches(g, Bt, shuffle=False))
+        rows = {}
+        for name, make in groups.items():
+            res = evaluate(model, make(), tta=cfg.train.tta, analytics=True)
+            table = res.pop("analytics")
+            rows[name] = res
+            print(f"test [{name}]:", {k: round(v, 3) for k, v in res.items()}, flush=True)
+            print(f"test analytics [{name}] (mm):", {k: round(v, 4) for k, v in table.items() if not isinstance(v, list)}, flush=True)
+        if len(rows) > 1:
+            keys = sorted({k for r in rows.values() for k in r})
+            print("test [average over groups]:", {k: round(float(np.mean([r[k] for r in rows.values() if k in r])), 3) for k in keys}, flush=True)
     return best_val

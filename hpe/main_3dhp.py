@@ -6,4 +6,4 @@ import sys
 from _entry import run
 
 if __name__ == "__main__":
-    run(sys.argv[1:], extra_defaults={"data.dataset": "3dhp", "data.seq_len": 27})
+    run(sys.argv[1:], extra_defaults={"data.dataset": "3dhp", "data.seq_len": 27, "data.keypoints": "gt"})

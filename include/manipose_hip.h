@@ -184,6 +184,25 @@ int mp_gather_windows(const float* poses_2d, const float* poses_3d, const int64_
                       const int32_t* win_start, const uint8_t* win_flip, const int32_t* mirror, const float* mask2d, const float* noise2d,
                       int B, int T, int J, float* X, float* y, void* stream);
 
+/* Dataset ingest: the raw arrays of the reference's on-disk formats -> the resident sequences mp_gather_windows reads.
+ * mp_ingest_pose3d: raw (frames_raw, raw_joints, 3) device floats; frames (N) device int32 or null (null: the first N raw frames;
+ * otherwise the raw frame of every output frame - temporal stride, valid-frame selection); joint_map (J <= 32) HOST int32 or null:
+ * raw joint of every output joint.  out[n][j] = (T(raw[map[j]] - raw[root_raw]) - T(raw[map[root_out]])) / divisor, where a negative
+ * root index drops its term and T is the world-to-camera transform qrot(qinverse(orientation), . - translation) when
+ * orientation (4, w-first, HOST) / translation (3, HOST) are given, identity when both are null.
+ *   Human3.6M (hpe/mh_so3_hpe/data/h36m_lifting.py:620-660 joint selection; data/utils.py:29-58 read_3d_data;
+ *   data/camera.py:24-28; data/quaternion.py:6-31): map = the 17 kept joints, camera given, root_raw -1, root_out 0, divisor 1.
+ *   MPI-INF-3DHP (data/dataset_3dhp.py:153-176,185-203): map = MAP_H36M_TO_MPI_JOINTS, no camera, root_raw 14, root_out -1,
+ *   divisor 1000, frames = the valid test frames.
+ * mp_ingest_pose2d: raw (frames_raw, raw_joints, raw_channels >= 2) pixel keypoints -> out (N, J, 2) = X / w * 2 - [1, h / w]
+ * (data/camera.py:9-14 as called by data/utils.py:9-26 and dataset_3dhp.py:170-175,212-224; the subtraction runs in double as in
+ * the reference, where a float64 list is subtracted from the float32 array). */
+int mp_ingest_pose3d(const float* raw, int raw_joints, const int32_t* frames, int64_t N, const int32_t* joint_map, int J,
+                     const float* orientation, const float* translation, int root_raw, int root_out, float divisor, float* out,
+                     void* stream);
+int mp_ingest_pose2d(const float* raw, int raw_joints, int raw_channels, const int32_t* frames, int64_t N, const int32_t* joint_map,
+                     int J, float res_w, float res_h, float* out, void* stream);
+
 /* Evaluation analytics of pose sequences in one pass over the frames (17-joint H36M / 3DHP tree compiled in): the running sums
  * behind mpjpe_error / mse_error / jointwise_error / segments_len_err (hpe/mh_so3_hpe/metrics/mean_joint_errors.py:31-130),
  * sagittal_symmetry(_per_bone) and segments_time_consistency(_per_bone) (metrics/regularizations.py:8-157), the evaluation form of

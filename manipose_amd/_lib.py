@@ -67,6 +67,8 @@ _SIGNATURES = {
     "mp_model_peek": (i32, [vp, i32, C.POINTER(vp), C.POINTER(i64)]),
     "mp_model_peek_copy": (i32, [vp, i32, vp, i64, vp]),
     "mp_gather_windows": (i32, [vp, vp, vp, i32, vp, vp, vp, C.POINTER(i32), vp, vp, i32, i32, i32, vp, vp, vp]),
+    "mp_ingest_pose3d": (i32, [vp, i32, vp, i64, C.POINTER(i32), i32, C.POINTER(f32), C.POINTER(f32), i32, i32, f32, vp, vp]),
+    "mp_ingest_pose2d": (i32, [vp, i32, i32, vp, i64, C.POINTER(i32), i32, f32, f32, vp, vp]),
     "mp_procrustes_errors": (i32, [vp, vp, vp, i64, i32, f32, f32, f32, f32, i32, vp, vp, i64, vp]),
     "mp_pose_metrics_row_floats": (i32, []),
     "mp_pose_metrics": (i32, [vp, C.POINTER(i64), vp, C.POINTER(i64), vp, i32, i32, i32, f32, f32, f32, f32, i32, i32, vp, vp, vp, i64, vp]),

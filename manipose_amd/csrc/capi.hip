@@ -149,6 +149,18 @@ int mp_gather_windows(const float* poses_2d, const float* poses_3d, const int64_
                         X, y, (hipStream_t)stream);
 }
 
+int mp_ingest_pose3d(const float* raw, int raw_joints, const int32_t* frames, int64_t N, const int32_t* joint_map, int J,
+                     const float* orientation, const float* translation, int root_raw, int root_out, float divisor, float* out,
+                     void* stream) {
+  return ingest_pose3d(raw, raw_joints, frames, (long)N, joint_map, J, orientation, translation, root_raw, root_out, divisor, out,
+                       (hipStream_t)stream);
+}
+
+int mp_ingest_pose2d(const float* raw, int raw_joints, int raw_channels, const int32_t* frames, int64_t N, const int32_t* joint_map,
+                     int J, float res_w, float res_h, float* out, void* stream) {
+  return ingest_pose2d(raw, raw_joints, raw_channels, frames, (long)N, joint_map, J, res_w, res_h, out, (hipStream_t)stream);
+}
+
 int mp_procrustes_errors(const float* pred, const float* gt, const uint8_t* mask, int64_t N, int J, float pred_scale, float gt_scale,
                          float pck_threshold, float auc_max, int auc_steps, float* out, float* scratch, int64_t scratch_floats, void* stream) {
   return procrustes_errors(pred, gt, mask, (long)N, J, pred_scale, gt_scale, pck_threshold, auc_max, auc_steps, 1, out, scratch,

@@ -148,6 +148,12 @@ int gather_windows(const float* p2, const float* p3, const long* seq_offset, int
                    const unsigned char* win_flip, const int* mirror, const float* mask2d, const float* noise2d, int B, int T, int J,
                    float* X, float* y, hipStream_t st);
 
+// ---------------------------------------------------------------- ingest.hip
+int ingest_pose3d(const float* raw, int Jraw, const int* frames, long N, const int* joint_map, int J, const float* quat,
+                  const float* trans, int root_raw, int root_out, float div, float* out, hipStream_t st);
+int ingest_pose2d(const float* raw, int Jraw, int Craw, const int* frames, long N, const int* joint_map, int J, float w, float h,
+                  float* out, hipStream_t st);
+
 // ---------------------------------------------------------------- procrustes.hip
 int procrustes_errors(const float* pred, const float* gt, const unsigned char* mask, long N, int J, float pred_scale, float gt_scale,
                       float pck_thr, float auc_max, int auc_n, int scaled, float* out, float* scratch, long scratch_floats, hipStream_t st);

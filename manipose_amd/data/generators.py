@@ -57,9 +57,14 @@ class PoseSequenceGenerator:
         self._ds_len = len(self._map_index_to_pose)
         off = np.zeros(len(lens) + 1, dtype=np.int64)
         off[1:] = np.cumsum(lens)
-        to32 = lambda seqs: torch.from_numpy(np.concatenate([np.asarray(s, dtype=np.float32) for s in seqs], axis=0))
-        self._p3 = to32(poses_3d).to(self.device).contiguous()
-        self._p2 = to32(poses_2d).to(self.device).contiguous()
+
+        def resident(seqs):      # device tensors (the ingest kernels' outputs) are concatenated in HBM; host arrays are uploaded once
+            if all(isinstance(s, torch.Tensor) for s in seqs):
+                return torch.cat([s.to(self.device, torch.float32) for s in seqs], dim=0).contiguous()
+            host = [s.cpu().numpy() if isinstance(s, torch.Tensor) else np.asarray(s) for s in seqs]
+            return torch.from_numpy(np.concatenate([h.astype(np.float32, copy=False) for h in host], axis=0)).to(self.device).contiguous()
+        self._p3 = resident(poses_3d)
+        self._p2 = resident(poses_2d)
         self._off = torch.from_numpy(off).to(self.device)
         sk = getattr(transform, "skeleton", None)
         mirror = list(range(self._J))

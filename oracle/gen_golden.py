@@ -317,11 +317,93 @@ def gen_windows_fixture(ref):
     print("windows: ok", {k: v.shape for k, v in out.items() if k.endswith(".X")})
 
 
+def _write_raw_dataset_files(d, raw):
+    """The on-disk formats of the reference's loaders (h36m_lifting.py:620, utils.py:13-14, dataset_3dhp.py:153,185): npz files whose
+    single entry is a pickled dict."""
+    np.savez_compressed(os.path.join(d, "data_3d_h36m.npz"), positions_3d=raw["h36m3"])
+    np.savez_compressed(os.path.join(d, "data_2d_h36m_gt.npz"), positions_2d=raw["h36m2"], metadata={"num_joints": 17})
+    np.savez_compressed(os.path.join(d, "data_train_3dhp.npz"), data=raw["hp_train"])
+    np.savez_compressed(os.path.join(d, "data_test_3dhp.npz"), data=raw["hp_test"])
+
+
+def gen_datasets_fixture(ref):
+    """Dataset ingest (on-disk formats): tiny synthetic files in the reference's formats, read by the reference's own
+    Human36mDataset / read_3d_data / create_2d_data / fetch and Dataset3DHP; the raw arrays and what the reference made of them are the
+    fixture.  Also dumps the Human3.6M camera calibration (dataset facts: the public calibration every VideoPose3D-derived loader
+    carries) to manipose_amd/data/h36m_cameras.json."""
+    import contextlib, copy, io, json, tempfile
+    from types import SimpleNamespace as NS
+    import mh_so3_hpe.data.h36m_lifting as H
+    from mh_so3_hpe.data.utils import create_2d_data, read_3d_data, fetch
+    from mh_so3_hpe.data.dataset_3dhp import Dataset3DHP
+    g = np.random.default_rng(7)
+    acts = {"S1": {"Walking": 33, "Eating 1": 29}, "S9": {"Walking 1": 31, "Photo": 28}, "S11": {"Walking": 30, "SittingDown 2": 35}}
+    raw = {"h36m3": {s: {a: (0.5 * g.normal(size=(n, 32, 3)) + [0.2, -0.1, 1.0]).astype(np.float32) for a, n in d.items()}
+                     for s, d in acts.items()},
+           "h36m2": {s: {a: [g.uniform(0, 1000, size=(n, 17, 2)).astype(np.float32) for _ in range(4)] for a, n in d.items()}
+                     for s, d in acts.items()}}
+    hp_train, hp_test = {}, {}
+    for seq, n in (("S1 Seq1", 31), ("S2 Seq1", 29)):
+        hp_train[seq] = [{str(c): {"data_3d": (600 * g.normal(size=(n, 17, 3)) + [0, 0, 3500]).astype(np.float32),
+                                   "data_2d": g.uniform(0, 2048, size=(n, 17, 2)).astype(np.float32)} for c in (0, 2, 7)}]
+    for seq, n in (("TS1", 34), ("TS5", 30)):
+        valid = (g.uniform(size=n) > 0.2).astype(np.float32)
+        hp_test[seq] = {"data_3d": (600 * g.normal(size=(n, 17, 3)) + [0, 0, 3500]).astype(np.float32),
+                        "data_2d": g.uniform(0, 1920 if seq == "TS5" else 2048, size=(n, 17, 2)).astype(np.float32), "valid": valid}
+    raw["hp_train"], raw["hp_test"] = hp_train, hp_test
+    out = {}
+    for s, d in raw["h36m3"].items():
+        for a, v in d.items():
+            out[f"raw.h36m3|{s}|{a}"] = v
+            for c, k in enumerate(raw["h36m2"][s][a]):
+                out[f"raw.h36m2|{s}|{a}|{c}"] = k
+    for seq, lst in hp_train.items():
+        for c, dd in lst[0].items():
+            out[f"raw.hptrain|{seq}|{c}|3d"], out[f"raw.hptrain|{seq}|{c}|2d"] = dd["data_3d"], dd["data_2d"]
+    for seq, dd in hp_test.items():
+        out[f"raw.hptest|{seq}|3d"], out[f"raw.hptest|{seq}|2d"], out[f"raw.hptest|{seq}|valid"] = dd["data_3d"], dd["data_2d"], dd["valid"]
+    with tempfile.TemporaryDirectory() as d:
+        _write_raw_dataset_files(d, copy.deepcopy(raw))
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            ds = H.Human36mDataset(os.path.join(d, "data_3d_h36m.npz"), n_joints=17)
+            ds = read_3d_data(ds)
+            kp = create_2d_data(os.path.join(d, "data_2d_h36m_gt.npz"), ds)
+        sk = ds.skeleton
+        out["h36m.parents"] = np.array(sk.parents)
+        out["h36m.joints_left"], out["h36m.joints_right"] = np.array(sk.joints_left), np.array(sk.joints_right)
+        for nm, subjects, filt, stride in (("all", ["S1", "S9"], None, 1), ("walk_s2", ["S9", "S11"], ["walking"], 2),
+                                           ("s11_sit", ["S11"], ["sittingdown"], 1)):
+            p3, p2, actions, cams = fetch(subjects, ds, kp, filt, stride)
+            out[f"h36m.{nm}.n"] = np.int64(len(p3))
+            for i in range(len(p3)):
+                out[f"h36m.{nm}.p3.{i}"], out[f"h36m.{nm}.p2.{i}"] = np.asarray(p3[i]), np.asarray(p2[i])
+                out[f"h36m.{nm}.cam.{i}"] = np.asarray(cams[i][0])
+            out[f"h36m.{nm}.actions"] = np.array([a[0] for a in actions])
+        cfg = NS(data=NS(dataset="3dhp", keypoints="gt", actions="*", downsample=1, seq_len=27, pad=0, out_all=True),
+                 train=NS(flip_aug=True, batch_size=2, batch_size_test=2, tta=True))
+        for nm, tr in (("train", True), ("test", False)):
+            with contextlib.redirect_stdout(io.StringIO()):
+                hp = Dataset3DHP(config=cfg, root_path=d + "/", train=tr)
+            out[f"hp.{nm}.n"] = np.int64(len(hp.poses))
+            for i in range(len(hp.poses)):
+                out[f"hp.{nm}.p3.{i}"], out[f"hp.{nm}.p2.{i}"] = np.asarray(hp.poses[i]), np.asarray(hp.poses_2d[i])
+    np.savez_compressed(os.path.join(OUT, "datasets.npz"), **out)
+    calib = {"intrinsic": [{k: v for k, v in c.items() if k != "azimuth"} for c in H.h36m_cameras_intrinsic_params],
+             "extrinsic": {s: [dict(c) for c in cams] for s, cams in H.h36m_cameras_extrinsic_params.items()}}
+    with open(os.path.join(os.path.dirname(HERE), "manipose_amd", "data", "h36m_cameras.json"), "w") as f:
+        json.dump(calib, f, indent=0, separators=(",", ":"))
+    print("datasets: ok", {k: v.shape for k, v in out.items() if k.endswith(".p3.0")},
+          {k: (v.dtype, v.shape) for k, v in out.items() if k.endswith(".p2.0") or k.endswith(".cam.0")})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "windows":       # regenerate the input-pipeline fixture only
         gen_windows_fixture(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "datasets":      # regenerate the dataset-ingest fixture only
+        gen_datasets_fixture(ref)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":       # regenerate the analytics fixture only
         gen_metrics_fixture(ref)
@@ -337,6 +419,7 @@ def main():
     gen_loss_fixture(ref)
     gen_metrics_fixture(ref)
     gen_windows_fixture(ref)
+    gen_datasets_fixture(ref)
     # default initialisation under seed 42 (the product's constructors must consume the RNG identically)
     torch.manual_seed(42)
     m0 = build_ref_model(ref, small, 0.1)

@@ -470,6 +470,103 @@ def sequence_window(poses_3d, poses_2d, index: int, seq_len: int, random_start: 
 
 
 # ---------------------------------------------------------------------------
+# Dataset ingest (on-disk formats): what the reference's loaders make of the raw npz dictionaries before
+# PoseSequenceGenerator sees them.  numpy float32 like the reference; `calib` is the Human3.6M camera calibration as
+# {"intrinsic": [4 dicts], "extrinsic": {subject: [4 dicts]}} (data/h36m_lifting.py:122-584).
+# ---------------------------------------------------------------------------
+import numpy as np  # noqa: E402
+
+H36M_KEPT_JOINTS_17 = tuple(j for j in range(32) if j not in (4, 5, 9, 10, 11, 16, 20, 21, 22, 23, 24, 28, 29, 30, 31))  # h36m_lifting.py:651-653
+MAP_H36M_TO_MPI_JOINTS = (14, 8, 9, 10, 11, 12, 13, 15, 1, 16, 0, 5, 6, 7, 2, 3, 4)                                     # dataset_3dhp.py:55-73
+
+
+def normalize_screen_coordinates(X, w, h):
+    """camera.py:9-14 ([0, w] -> [-1, 1], aspect ratio kept).  The list operand makes the subtraction a float64 one."""
+    return X / w * 2 - [1, h / w]
+
+
+def world_to_camera(X, R, t):
+    """camera.py:24-28 with quaternion.py:6-31: rotate X - t by the conjugate of the unit quaternion R (w first)."""
+    q = np.asarray(R, dtype=np.float32)
+    w, qv = q[0], -q[1:]
+    v = (X - np.asarray(t, dtype=np.float32)).astype(np.float32)
+    uv = np.cross(np.broadcast_to(qv, v.shape), v).astype(np.float32)
+    uuv = np.cross(np.broadcast_to(qv, v.shape), uv).astype(np.float32)
+    return (v + 2 * (w * uv + uuv)).astype(np.float32)
+
+
+def h36m_cameras(calib):
+    """h36m_lifting.py:591-618: per subject, the four cameras with normalised centre / focal length, translation in metres and the
+    9-vector of intrinsics."""
+    out = {}
+    for subject, cams in calib["extrinsic"].items():
+        out[subject] = []
+        for i, ext in enumerate(cams):
+            intr = calib["intrinsic"][i]
+            cam = {"res_w": intr["res_w"], "res_h": intr["res_h"]}
+            center = normalize_screen_coordinates(np.array(intr["center"], dtype="float32"), w=intr["res_w"], h=intr["res_h"]).astype("float32")
+            focal = np.array(intr["focal_length"], dtype="float32") / intr["res_w"] * 2.0
+            cam["intrinsic"] = np.concatenate((focal, center, np.array(intr["radial_distortion"], dtype="float32"),
+                                               np.array(intr["tangential_distortion"], dtype="float32")))
+            if "orientation" in ext:
+                cam["orientation"] = np.array(ext["orientation"], dtype="float32")
+                cam["translation"] = np.array(ext["translation"], dtype="float32") / 1000
+            out[subject].append(cam)
+    return out
+
+
+def h36m_sequences(positions_3d, positions_2d, calib, subjects, action_filter=None, stride=1):
+    """Human36mDataset (h36m_lifting.py:587-660, 17 joints) -> read_3d_data (utils.py:29-58) -> create_2d_data (utils.py:9-26) ->
+    fetch (utils.py:61-127): one (3-D, 2-D, action, camera vector) entry per subject x action x camera."""
+    cams = h36m_cameras(calib)
+    p3, p2, actions, cam_out = [], [], [], []
+    for subject in subjects:
+        for action in positions_2d[subject].keys():
+            if action_filter is not None and not any(action.lower().split(" ")[0] == a for a in action_filter):
+                continue
+            world = np.asarray(positions_3d[subject][action])[:, list(H36M_KEPT_JOINTS_17)]
+            for i, kps in enumerate(positions_2d[subject][action]):
+                cam = cams[subject][i]
+                k = np.array(kps, dtype=np.float32, copy=True)
+                k[..., :2] = normalize_screen_coordinates(k[..., :2], w=cam["res_w"], h=cam["res_h"])
+                p2.append(k[::stride])
+                actions.append(action.split(" ")[0])
+                cam_out.append(np.concatenate([cam["intrinsic"], cam["orientation"], cam["translation"], np.array([i])]))
+            for cam in cams[subject]:
+                c = world_to_camera(world, cam["orientation"], cam["translation"])
+                c = c - c[:, :1]
+                p3.append(c[::stride])
+    return p3, p2, actions, cam_out
+
+
+def hp3d_sequences(data, train: bool):
+    """Dataset3DHP.prepare_data (dataset_3dhp.py:146-229): root-relative (joint 14), H36M joint order, metres; 2-D normalised to the
+    2048^2 (TS5 / TS6: 1920x1080) frame; test sequences keep their valid frames only."""
+    p3, p2 = [], []
+    m = list(MAP_H36M_TO_MPI_JOINTS)
+    if train:
+        for seq in data.keys():
+            for cam in data[seq][0].keys():
+                d3 = np.array(data[seq][0][cam]["data_3d"], copy=True)
+                d3 = d3 - d3[:, 14:15]
+                p3.append(d3[:, m] / 1000)
+                d2 = np.array(data[seq][0][cam]["data_2d"], copy=True)
+                d2[..., :2] = normalize_screen_coordinates(d2[..., :2], w=2048, h=2048)
+                p2.append(d2[:, m])
+        return p3, p2
+    for seq in data.keys():
+        valid = np.asarray(data[seq]["valid"]).astype(bool)
+        d3 = np.array(data[seq]["data_3d"], copy=True)
+        d3 = d3 - d3[:, 14:15]
+        p3.append(d3[valid][:, m] / 1000)
+        w, h = (1920, 1080) if seq in ("TS5", "TS6") else (2048, 2048)
+        d2 = np.array(data[seq]["data_2d"], copy=True)
+        d2[..., :2] = normalize_screen_coordinates(d2[..., :2], w=w, h=h)
+        p2.append(d2[valid][:, m])
+    return p3, p2
+
+
+# ---------------------------------------------------------------------------
 # Evaluation analytics (SURVEY section 8f rows 1-2): skeleton-consistency metrics (metrics/regularizations.py:8-157,
 # metrics/utils.py:4-20), the remaining error metrics (metrics/mean_joint_errors.py:39-130), evaluation velocity
 # error (metrics/losses.py:75-101) and 3DPCK / AUC (metrics/pck.py:92-199).  joints_coords is (B, 3, J, L).

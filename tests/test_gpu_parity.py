@@ -836,3 +836,103 @@ def test_bench_two_rank_path_rehearsal_on_one_gpu(lib):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     assert "cpu_baseline" not in d and d["roofline"]["launches"] >= 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# dataset ingest (the on-disk formats either side of the window generator): HIP kernels vs what the reference's loaders made of the
+# same files (tests/golden/datasets.npz) and vs the oracle restatement
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def raw_dataset_dir(tmp_path_factory):
+    from helpers import GOLDEN, write_raw_dataset_files
+    d = tmp_path_factory.mktemp("raw_datasets")
+    fx = np.load(GOLDEN + "/datasets.npz")
+    write_raw_dataset_files(str(d), fx)
+    return str(d), fx
+
+
+@pytest.mark.parametrize("case,subjects,filt,stride", [("all", ["S1", "S9"], None, 1), ("walk_s2", ["S9", "S11"], ["walking"], 2),
+                                                       ("s11_sit", ["S11"], ["sittingdown"], 1)])
+def test_h36m_dataset_ingest_matches_reference_loaders(lib, raw_dataset_dir, case, subjects, filt, stride):
+    from manipose_amd.data import Human36mDataset, create_2d_data, fetch, read_3d_data
+    d, fx = raw_dataset_dir
+    ds = read_3d_data(Human36mDataset(d + "/data_3d_h36m.npz", n_joints=17))
+    kp = create_2d_data(d + "/data_2d_h36m_gt.npz", ds)
+    p3, p2, actions, cams = fetch(subjects, ds, kp, filt, stride)
+    assert len(p3) == len(p2) == int(fx[f"h36m.{case}.n"]) and actions == list(fx[f"h36m.{case}.actions"])
+    assert list(ds.skeleton.parents) == list(fx["h36m.parents"]) and list(ds.skeleton.joints_left) == list(fx["h36m.joints_left"])
+    worst = 0.0
+    for i in range(len(p3)):
+        assert p3[i].is_cuda and p2[i].is_cuda
+        np.testing.assert_array_equal(p2[i].cpu().numpy(), fx[f"h36m.{case}.p2.{i}"])                 # bit-exact
+        ref3 = fx[f"h36m.{case}.p3.{i}"]
+        worst = max(worst, float(np.abs(p3[i].cpu().numpy() - ref3).max()))
+        np.testing.assert_allclose(cams[i], fx[f"h36m.{case}.cam.{i}"], rtol=0, atol=0)
+    assert worst <= 2e-6, worst        # metres; the reference's torch.cross may contract multiply-adds, the kernel does not
+    print(f"h36m ingest {case}: {len(p3)} sequences, worst |d| = {worst:.2e} m")
+
+
+@pytest.mark.parametrize("split", ["train", "test"])
+def test_3dhp_dataset_ingest_matches_reference_loader_bit_exact(lib, raw_dataset_dir, split):
+    from types import SimpleNamespace as NS
+    from manipose_amd.data import Dataset3DHP
+    d, fx = raw_dataset_dir
+    cfg = NS(data=NS(dataset="3dhp", keypoints="gt", actions="*", seq_len=27), train=NS(flip_aug=True, batch_size=2, batch_size_test=2, tta=True))
+    hp = Dataset3DHP(cfg, d + "/", train=(split == "train"))
+    assert len(hp.poses) == len(hp.poses_2d) == int(fx[f"hp.{split}.n"])
+    for i in range(len(hp.poses)):
+        np.testing.assert_array_equal(hp.poses[i].cpu().numpy(), fx[f"hp.{split}.p3.{i}"])
+        np.testing.assert_array_equal(hp.poses_2d[i].cpu().numpy(), fx[f"hp.{split}.p2.{i}"])
+
+
+def test_ingested_sequences_feed_the_window_generator_without_leaving_the_device(lib, raw_dataset_dir):
+    """files -> ingest kernels -> resident generator -> window kernel; windows equal slices of the reference loader's sequences."""
+    from manipose_amd.data import Human36mDataset, PoseSequenceGenerator, create_2d_data, fetch, read_3d_data
+    d, fx = raw_dataset_dir
+    ds = read_3d_data(Human36mDataset(d + "/data_3d_h36m.npz"))
+    p3, p2, _, cams = fetch(["S1", "S9"], ds, create_2d_data(d + "/data_2d_h36m_gt.npz", ds))
+    gen = PoseSequenceGenerator(p3, p2, cams, seq_len=9, random_start=False, drop_last=True)
+    X, y = gen.batch(list(range(len(gen))))
+    n = 0
+    for i in range(len(p3)):
+        for k in range(p3[i].shape[0] // 9):
+            np.testing.assert_array_equal(X[n].cpu().numpy(), fx[f"h36m.all.p2.{i}"][9 * k:9 * k + 9])
+            assert np.abs(y[n].cpu().numpy() - fx[f"h36m.all.p3.{i}"][9 * k:9 * k + 9]).max() <= 2e-6
+            n += 1
+    assert n == len(gen) and torch.all(y[:, :, 0] == 0)
+
+
+def test_ingest_argument_errors_are_reported(lib):
+    from manipose_amd import _lib as L
+    from manipose_amd.data.ingest import ingest_pose2d, ingest_pose3d
+    raw = torch.zeros(4, 17, 3, device="cuda")
+    with pytest.raises(RuntimeError):
+        ingest_pose3d(raw, [0, 17])                                   # joint outside the raw array
+    with pytest.raises(RuntimeError):
+        ingest_pose3d(raw, list(range(17)), orientation=[1, 0, 0, 0])   # orientation without translation
+    with pytest.raises(RuntimeError):
+        ingest_pose2d(torch.zeros(4, 17, 2, device="cuda"), list(range(17)), 0, 1000)
+    assert ingest_pose3d(raw[:0].contiguous(), list(range(17))).shape == (0, 17, 3)
+
+
+@pytest.mark.parametrize("dataset", ["h36m", "3dhp"])
+def test_training_entry_reads_the_reference_file_formats(lib, raw_dataset_dir, tmp_path, monkeypatch, capsys, dataset):
+    """Entry point with data.data_dir: files in the reference's formats -> device ingest -> resident window generator -> one epoch
+    over the shuffled windows, validation, checkpoint, per-action (H36M, subject S11) / whole-set (3DHP) test tables."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hpe"))
+    from _entry import run
+    d, _ = raw_dataset_dir
+    monkeypatch.chdir(tmp_path)
+    best = run(["train.epochs=1", "train.batch_size=4", "train.batch_size_test=3", "data.seq_len=9", f"data.data_dir={d}",
+                "data.keypoints=gt", "model.channels=64", "model.layers=2", "model.nheads=4", "model.channels_seg=32",
+                "model.layers_seg=1", "model.nheads_seg=4", "multi_hyp.n_hyp=3", "run.test=true", "train.mpjpe_epoch_interval=1"],
+               extra_defaults={"data.dataset": dataset})
+    out = capsys.readouterr().out
+    assert np.isfinite(best) and best < 1e9
+    assert ">>> Training dataset length:" in out and "epoch 0:" in out and "eval:" in out
+    if dataset == "h36m":
+        assert "test [walking]:" in out and "test [sittingdown]:" in out and "test [average over groups]:" in out   # S11's two takes
+    else:
+        assert "test [all]:" in out and "pck" in out.lower()
+    assert any(f.endswith(".pth") for _, _, fs in os.walk(tmp_path) for f in fs)

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import manipose_ref as orc
-from helpers import fixture_masks, fixture_state, load_fixture
+from helpers import GOLDEN, fixture_masks, fixture_state, h36m_calibration, load_fixture, raw_dataset_dicts
 
 TOL = dict(rtol=1e-5, atol=2e-6)
 
@@ -241,3 +241,31 @@ def test_oracle_occlusion_patterns_match_reference_generator(mt):
         x, y = orc.sequence_window(p3, p2, i, 27, True, True, 0.5, miss_type=mt, miss_rate=0.3, noise_sigma=0.05)
         np.testing.assert_array_equal(x.numpy(), fx[f"miss.{mt}.X"][i])
         np.testing.assert_array_equal(y.numpy(), fx[f"miss.{mt}.y"][i])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# dataset ingest (on-disk formats): oracle restatement vs what the reference's loaders produced from the same raw dictionaries
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case,subjects,filt,stride", [("all", ["S1", "S9"], None, 1), ("walk_s2", ["S9", "S11"], ["walking"], 2),
+                                                       ("s11_sit", ["S11"], ["sittingdown"], 1)])
+def test_oracle_h36m_ingest_matches_reference_loaders(case, subjects, filt, stride):
+    fx = np.load(GOLDEN + "/datasets.npz")
+    h3, h2, _, _ = raw_dataset_dicts(fx)
+    p3, p2, actions, cams = orc.h36m_sequences(h3, h2, h36m_calibration(), subjects, filt, stride)
+    assert len(p3) == len(p2) == int(fx[f"h36m.{case}.n"]) and actions == list(fx[f"h36m.{case}.actions"])
+    for i in range(len(p3)):
+        np.testing.assert_array_equal(p2[i], fx[f"h36m.{case}.p2.{i}"])               # bit-exact: plain float32 / float64 arithmetic
+        np.testing.assert_allclose(p3[i], fx[f"h36m.{case}.p3.{i}"], rtol=0, atol=2e-6)  # torch.cross may contract to FMA
+        np.testing.assert_allclose(cams[i], fx[f"h36m.{case}.cam.{i}"], rtol=0, atol=0)
+        assert np.all(p3[i][:, 0] == 0)
+
+
+@pytest.mark.parametrize("split", ["train", "test"])
+def test_oracle_3dhp_ingest_matches_reference_loader(split):
+    fx = np.load(GOLDEN + "/datasets.npz")
+    _, _, tr, te = raw_dataset_dicts(fx)
+    p3, p2 = orc.hp3d_sequences(tr if split == "train" else te, split == "train")
+    assert len(p3) == int(fx[f"hp.{split}.n"])
+    for i in range(len(p3)):
+        np.testing.assert_array_equal(p3[i], fx[f"hp.{split}.p3.{i}"])
+        np.testing.assert_array_equal(p2[i], fx[f"hp.{split}.p2.{i}"])
