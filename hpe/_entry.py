@@ -239,7 +239,8 @@ def run(argv, extra_defaults=None):
     model.max_batch_hint = max(cfg.train.batch_size, 2 * cfg.train.batch_size_test)      # x2: flip-TTA batches the mirrored copy
     model = model.to(dev)
     trainer = LiftingTrainer(model, lr=cfg.train.lr, weight_decay=1e-6, w_loss=cfg.train.w_loss, vel_loss=cfg.train.vel_loss,
-                             smooth_reg=cfg.train.smooth_reg, rmcl_score_reg=cfg.train.rmcl_score_reg, seed=cfg.run.seed)
+                             smooth_reg=cfg.train.smooth_reg, rmcl_score_reg=cfg.train.rmcl_score_reg, seed=cfg.run.seed,
+                             sq_loss=cfg.train.sq_loss)
     broadcast_parameters(model.flat_parameters())
     start_epoch = 0
     if cfg.run.checkpoint_params:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 1
+#define MP_ABI_VERSION 2
 
 int mp_abi_version(void);
 const char* mp_last_error(void);
@@ -37,13 +37,15 @@ const char* mp_last_error(void);
 /* PoseDecoder.forward: architectures/pose_decoder.py:32-55 = _compute_rotation_mats (:57-83,
  * utils/rotation_tools.py:35-57) + build_t_pose_from_bone_lengths (:98-120) + forward_kinematics
  * (utils/forward_kinematics.py:6-48), root at the origin (rmcl_manifold_mix_ste.py:92).
- *   rot6d  : (K, B*T*17, rot_stride) head output, channels 0..5 are the 6-D rotation (rot_stride >= 6)
+ *   rot6d  : (K, B*T*17, rot_stride) head output, channels 0..rot_dim-1 are the rotation representation (rot_stride >= rot_dim)
+ *   rot_dim: 6 = two 3-vectors, Gram-Schmidt (rotation_tools.py:35-57); 4 = two 2-vectors -> R_theta R_phi
+ *            (rotation_tools.py:60-116; conf/config.yaml:47 model.rot_dim)
  *   lengths: (B, 16) segment lengths;  poses: (B, K, T, 17, 3) */
-int mp_fk_decode_fwd(const float* rot6d, int rot_stride, const float* lengths, float* poses, int B, int K, int T,
+int mp_fk_decode_fwd(const float* rot6d, int rot_stride, int rot_dim, const float* lengths, float* poses, int B, int K, int T,
                      void* stream);
-/* gradient of the above: d_rot6d has rot6d's layout (channels >= 6 untouched); d_len_pose: (B*K*T, 16)
+/* gradient of the above: d_rot6d has rot6d's layout (channels >= rot_dim untouched); d_len_pose: (B*K*T, 16)
  * per-pose segment-length gradients (summed over a window's poses by mp_bones_mean_bwd). */
-int mp_fk_decode_bwd(const float* rot6d, int rot_stride, const float* lengths, const float* d_poses, float* d_rot6d,
+int mp_fk_decode_bwd(const float* rot6d, int rot_stride, int rot_dim, const float* lengths, const float* d_poses, float* d_rot6d,
                      float* d_len_pose, int B, int K, int T, void* stream);
 
 /* Multi-hypothesis training loss with its gradient, metrics/losses.py:104-170 + :75-101 +
@@ -56,6 +58,7 @@ typedef struct mp_loss_config {
   float vel_loss;       /* conf/config.yaml:33 (2.0) */
   float smooth_reg;     /* conf/config.yaml:34 (0.5) */
   int w_loss;           /* conf/config.yaml:32: weight joints by STANDARD_H36M_WEIGHTS (losses.py:6-8) */
+  int sq_loss;          /* conf/config.yaml:31: squared distances in the WTA and velocity terms (losses.py:46-72,96-97,110-116) */
 } mp_loss_config;
 int mp_wta_loss(const float* poses, const float* scores, const float* target, const mp_loss_config* cfg, float* terms,
                 int32_t* argmin, float* d_poses, float* d_scores, int B, int K, int T, float* scratch,
@@ -126,6 +129,7 @@ typedef struct mp_model_config {
   float drop_path_rate;/* stochastic depth: linspace(0, rate, depth) per module (mix_ste.py:70) */
   int max_batch;       /* workspace is sized for this many windows; 0 = layout-only handle (no device memory) */
   int precision;       /* 0 = fp32 matrix cores (parity mode), 1 = bf16 matrix cores / fp32 accumulate */
+  int rot_rep_dim;     /* 6 (default when 0) or 4: rotation representation the heads emit (pose_decoder.py:22-31) */
 } mp_model_config;
 
 int mp_model_create(const mp_model_config* cfg, mp_model** out);

@@ -21,7 +21,7 @@ vp, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
 class LossConfig(C.Structure):
     """mp_loss_config; defaults = hpe/conf/config.yaml:32-38 of the reference."""
-    _fields_ = [("rmcl_score_reg", f32), ("vel_loss", f32), ("smooth_reg", f32), ("w_loss", i32)]
+    _fields_ = [("rmcl_score_reg", f32), ("vel_loss", f32), ("smooth_reg", f32), ("w_loss", i32), ("sq_loss", i32)]
 
 
 class ModelConfig(C.Structure):
@@ -29,14 +29,14 @@ class ModelConfig(C.Structure):
     _fields_ = [("arch", i32), ("num_frame", i32), ("num_joints", i32), ("num_bones", i32),
                 ("embed_dim_rot", i32), ("depth_rot", i32), ("num_heads_rot", i32),
                 ("embed_dim_seg", i32), ("depth_seg", i32), ("num_heads_seg", i32),
-                ("n_hyp", i32), ("drop_path_rate", f32), ("max_batch", i32), ("precision", i32)]
+                ("n_hyp", i32), ("drop_path_rate", f32), ("max_batch", i32), ("precision", i32), ("rot_rep_dim", i32)]
 
 
 _SIGNATURES = {
     "mp_abi_version": (i32, []),
     "mp_last_error": (C.c_char_p, []),
-    "mp_fk_decode_fwd": (i32, [vp, i32, vp, vp, i32, i32, i32, vp]),
-    "mp_fk_decode_bwd": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mp_fk_decode_fwd": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, vp]),
+    "mp_fk_decode_bwd": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "mp_wta_loss": (i32, [vp, vp, vp, C.POINTER(LossConfig), vp, vp, vp, vp, i32, i32, i32, vp, i64, vp]),
     "mp_single_loss": (i32, [vp, vp, C.POINTER(LossConfig), vp, vp, i32, i32, vp, i64, vp]),
     "mp_aggregate": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, vp]),
@@ -100,8 +100,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.mp_abi_version() != 1:
-        raise RuntimeError(f"manipose_amd: ABI version {lib.mp_abi_version()} != 1; rebuild the library")
+    if lib.mp_abi_version() != 2:
+        raise RuntimeError(f"manipose_amd: ABI version {lib.mp_abi_version()} != 2; rebuild the library")
     _lib = lib
     return lib
 

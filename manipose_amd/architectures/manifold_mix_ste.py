@@ -52,7 +52,7 @@ class ManifoldMixSTE(FusedLiftingMixin, nn.Module):
         self._init_fused("manifold", dict(num_frame=num_frame, num_joints=num_joints, num_bones=num_bones,
                                           embed_dim_rot=embed_dim_rot, depth_rot=depth_rot, num_heads_rot=num_heads_rot,
                                           embed_dim_seg=embed_dim_seg, depth_seg=depth_seg, num_heads_seg=num_heads_seg,
-                                          n_hyp=1, drop_path_rate=drop_path_rate))
+                                          n_hyp=1, drop_path_rate=drop_path_rate, rot_rep_dim=rot_rep_dim))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x (B, L, J, 2) -> poses (B, L, J, 3); root joint exactly 0 (reference :75-88)."""

@@ -1,4 +1,4 @@
-"""PoseDecoder: 6-D rotations + segment lengths -> 3-D joints through the fused HIP forward-kinematics kernel.
+"""PoseDecoder: 6-D (or 4-D, model.rot_dim=4) rotations + segment lengths -> 3-D joints through the fused HIP forward-kinematics kernel.
 
 Interface of hpe/mh_so3_hpe/architectures/pose_decoder.py:11-55 (``PoseDecoder(skeleton, rot_rep_dim)``,
 ``forward(rotations_repr (N,J,6), bones_lengths_repr (B,S,1), root_positions (N,3))``).  Differentiable
@@ -20,7 +20,8 @@ class _FKDecode(torch.autograd.Function):
         rot = rot.contiguous().float()
         lengths = lengths.contiguous().float()
         poses = torch.empty(B, K, T, 17, 3, dtype=torch.float32, device=rot.device)
-        _lib.check(lib.mp_fk_decode_fwd(_lib.ptr(rot), 6, _lib.ptr(lengths), _lib.ptr(poses), B, K, T, _lib.stream_ptr()),
+        D = int(rot.shape[-1])
+        _lib.check(lib.mp_fk_decode_fwd(_lib.ptr(rot), D, D, _lib.ptr(lengths), _lib.ptr(poses), B, K, T, _lib.stream_ptr()),
                    "mp_fk_decode_fwd")
         ctx.save_for_backward(rot, lengths)
         ctx.dims = (B, K, T)
@@ -33,16 +34,17 @@ class _FKDecode(torch.autograd.Function):
         B, K, T = ctx.dims
         d_rot = torch.empty_like(rot)
         d_len_pose = torch.empty(B * K * T, 16, dtype=torch.float32, device=rot.device)
-        _lib.check(lib.mp_fk_decode_bwd(_lib.ptr(rot), 6, _lib.ptr(lengths), _lib.ptr(d_poses.contiguous()), _lib.ptr(d_rot),
+        D = int(rot.shape[-1])
+        _lib.check(lib.mp_fk_decode_bwd(_lib.ptr(rot), D, D, _lib.ptr(lengths), _lib.ptr(d_poses.contiguous()), _lib.ptr(d_rot),
                                         _lib.ptr(d_len_pose), B, K, T, _lib.stream_ptr()), "mp_fk_decode_bwd")
         d_len = d_len_pose.view(B, K * T, 16).sum(dim=1)
         return d_rot, d_len.view_as(lengths), None, None, None
 
 
 def fk_decode(rot6d: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
-    """rot6d (K, B, T, 17, 6) or (K, B*T*17, 6); lengths (B, 16) -> poses (B, K, T, 17, 3)."""
-    K, B, T = rot6d.shape[0], rot6d.shape[1], rot6d.shape[2]
-    return _FKDecode.apply(rot6d.reshape(K, B * T * 17, 6), lengths.reshape(B, 16), B, K, T)
+    """rot6d (K, B, T, 17, D), D = 6 or 4; lengths (B, 16) -> poses (B, K, T, 17, 3)."""
+    K, B, T, D = rot6d.shape[0], rot6d.shape[1], rot6d.shape[2], rot6d.shape[-1]
+    return _FKDecode.apply(rot6d.reshape(K, B * T * 17, D), lengths.reshape(B, 16), B, K, T)
 
 
 class PoseDecoder(nn.Module):
@@ -51,8 +53,6 @@ class PoseDecoder(nn.Module):
         self.skeleton = skeleton
         self.rot_rep_dim = rot_rep_dim
         assert rot_rep_dim in [4, 6], f"Unsupported rotations representation dimension: {self.rot_rep_dim}"
-        if rot_rep_dim != 6:
-            raise NotImplementedError("manipose_amd: only the 6-D rotation representation (model.rot_dim=6) is accelerated")
         assert_h36m(skeleton)
 
     def forward(self, rotations_repr: torch.Tensor, bones_lengths_repr: torch.Tensor,
@@ -66,6 +66,6 @@ class PoseDecoder(nn.Module):
             raise NotImplementedError("manipose_amd: the decoder places the root joint at the origin (as both models do)")
         L = N // B
         # rows are ordered (b, l) like the reference's "(B H L)" flattening: one hypothesis slot, T = L
-        rot = rotations_repr.reshape(B, L, J, 6).unsqueeze(0)
+        rot = rotations_repr.reshape(B, L, J, self.rot_rep_dim).unsqueeze(0)
         poses = fk_decode(rot, bones_lengths_repr.reshape(B, 16))            # (B, 1, L, 17, 3)
         return poses.reshape(N, J, 3)

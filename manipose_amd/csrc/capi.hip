@@ -12,7 +12,7 @@ using namespace mp;
 
 static LossCfg to_cfg(const mp_loss_config* c) {
   LossCfg l;
-  l.beta = c->rmcl_score_reg; l.vel_w = c->vel_loss; l.smooth_w = c->smooth_reg; l.use_joint_weights = c->w_loss;
+  l.beta = c->rmcl_score_reg; l.vel_w = c->vel_loss; l.smooth_w = c->smooth_reg; l.use_joint_weights = c->w_loss; l.squared = c->sq_loss;
   return l;
 }
 
@@ -21,14 +21,15 @@ extern "C" {
 int mp_abi_version(void) { return MP_ABI_VERSION; }
 const char* mp_last_error(void) { return mp::last_error(); }
 
-int mp_fk_decode_fwd(const float* rot6d, int rot_stride, const float* lengths, float* poses, int B, int K, int T, void* stream) {
+int mp_fk_decode_fwd(const float* rot6d, int rot_stride, int rot_dim, const float* lengths, float* poses, int B, int K, int T,
+                     void* stream) {
   MP_CHECK(rot6d && lengths && poses, MP_ERR_ARG, "mp_fk_decode_fwd: null pointer");
-  return fk_decode_fwd(rot6d, rot_stride, lengths, poses, B, K, T, (hipStream_t)stream);
+  return fk_decode_fwd(rot6d, rot_stride, rot_dim, lengths, poses, B, K, T, (hipStream_t)stream);
 }
-int mp_fk_decode_bwd(const float* rot6d, int rot_stride, const float* lengths, const float* d_poses, float* d_rot6d,
+int mp_fk_decode_bwd(const float* rot6d, int rot_stride, int rot_dim, const float* lengths, const float* d_poses, float* d_rot6d,
                      float* d_len_pose, int B, int K, int T, void* stream) {
   MP_CHECK(rot6d && lengths && d_poses && d_rot6d && d_len_pose, MP_ERR_ARG, "mp_fk_decode_bwd: null pointer");
-  return fk_decode_bwd(rot6d, rot_stride, lengths, d_poses, d_rot6d, d_len_pose, B, K, T, (hipStream_t)stream);
+  return fk_decode_bwd(rot6d, rot_stride, rot_dim, lengths, d_poses, d_rot6d, d_len_pose, B, K, T, (hipStream_t)stream);
 }
 
 int mp_wta_loss(const float* poses, const float* scores, const float* target, const mp_loss_config* cfg, float* terms,

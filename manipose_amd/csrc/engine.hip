@@ -533,12 +533,15 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   MP_CHECK(cfg->embed_dim_rot % cfg->num_heads_rot == 0 && cfg->embed_dim_seg % cfg->num_heads_seg == 0, MP_ERR_ARG,
            "mp_model_create: embed dim must be divisible by heads");
   MP_CHECK(cfg->arch == 1 || (cfg->n_hyp >= 1 && cfg->n_hyp <= 8), MP_ERR_ARG, "mp_model_create: n_hyp in 1..8");
+  MP_CHECK(cfg->rot_rep_dim == 0 || cfg->rot_rep_dim == 4 || cfg->rot_rep_dim == 6, MP_ERR_ARG,
+           "mp_model_create: rot_rep_dim %d (4 or 6; 0 = 6)", cfg->rot_rep_dim);
   mp_model* m = new mp_model();
   m->cfg = *cfg;
+  if (cfg->rot_rep_dim == 0) m->cfg.rot_rep_dim = 6;
   if (cfg->arch == 1) m->cfg.n_hyp = 1;
   m->rot.prefix = "rotations_module."; m->rot.is_rot = true;
   m->rot.N = cfg->num_joints; m->rot.C = cfg->embed_dim_rot; m->rot.H = cfg->num_heads_rot; m->rot.depth = cfg->depth_rot;
-  m->rot.K = m->cfg.n_hyp; m->rot.O = (cfg->arch == 0) ? 7 : 6;
+  m->rot.K = m->cfg.n_hyp; m->rot.O = m->cfg.rot_rep_dim + ((cfg->arch == 0) ? 1 : 0);   // + the score-embedding channel
   m->seg.prefix = "segments_module."; m->seg.is_rot = false;
   m->seg.N = cfg->num_bones; m->seg.C = cfg->embed_dim_seg; m->seg.H = cfg->num_heads_seg; m->seg.depth = cfg->depth_seg;
   m->seg.K = 1; m->seg.O = 1;
@@ -723,7 +726,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
     MP_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
   }
   // manifold decoder (pose_decoder.py:32-55)
-  RUN(PC_OTHER, 0, fk_decode_fwd(m->rot.headout, m->rot.O, m->lengths, poses, B, K, T, st));
+  RUN(PC_OTHER, 0, fk_decode_fwd(m->rot.headout, m->rot.O, m->cfg.rot_rep_dim, m->lengths, poses, B, K, T, st));
   return MP_OK;
 }
 
@@ -735,7 +738,7 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   const long Mr = (long)B * T * J, Ms = (long)B * T * S;
   use_scratch(m, 0);
   // decoder
-  RUN(PC_OTHER, 0, fk_decode_bwd(m->rot.headout, m->rot.O, m->lengths, d_poses, m->rot.dheadout, m->dlen_pose, B, K, T, st));
+  RUN(PC_OTHER, 0, fk_decode_bwd(m->rot.headout, m->rot.O, m->cfg.rot_rep_dim, m->lengths, d_poses, m->rot.dheadout, m->dlen_pose, B, K, T, st));
   if (m->cfg.arch == 0) {
     ScoreParams sp;
     ScoreGrads sg;

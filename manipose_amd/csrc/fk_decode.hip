@@ -1,4 +1,5 @@
-// Fused manifold decoder: 6-D -> SO(3) Gram-Schmidt (rotation_tools.py:35-57), T-pose offsets from segment
+// Fused manifold decoder: 6-D -> SO(3) Gram-Schmidt (rotation_tools.py:35-57) or the 4-D "two unit 2-vectors" representation
+// (rotation_tools.py:60-116, model.rot_dim=4: R = R_theta R_phi, two planar rotations), T-pose offsets from segment
 // lengths (pose_decoder.py:98-120, closed form offset_j = op_j * len_{j-1}) and the forward-kinematics chain
 // over the 17-joint H36M tree (forward_kinematics.py:6-48), forward and backward, in one kernel each.
 //
@@ -103,6 +104,37 @@ __device__ __forceinline__ M3 gs_matrix(const GS& g) {
   return R;
 }
 
+// ---- 4-D representation (rotation_tools.py:60-116): (c1, s1) = normalize(r[0:2]), (c2, s2) = normalize(r[2:4]);
+//   R_theta = [theta_x | theta_y | e_z], theta_y = (c1, s1, 0), theta_x = theta_y x e_z = (s1, -c1, 0)
+//   R_phi   = [e_x | phi_y | phi_z],     phi_y = (0, c2, s2),   phi_z = e_x x phi_y = (0, -s2, c2)
+//   R = R_theta R_phi = [[s1, c1 c2, -c1 s2], [-c1, s1 c2, -s1 s2], [0, s2, c2]]
+struct R4 { float c1, s1, c2, s2, na, nb; };
+__device__ __forceinline__ R4 rot4_angles(const float* r4) {
+  R4 g;
+  g.na = __fsqrt_rn(__fadd_rn(__fmul_rn(r4[0], r4[0]), __fmul_rn(r4[1], r4[1])));
+  g.nb = __fsqrt_rn(__fadd_rn(__fmul_rn(r4[2], r4[2]), __fmul_rn(r4[3], r4[3])));
+  const float da = fmaxf(g.na, GS_EPS), db = fmaxf(g.nb, GS_EPS);
+  g.c1 = __fdiv_rn(r4[0], da); g.s1 = __fdiv_rn(r4[1], da);
+  g.c2 = __fdiv_rn(r4[2], db); g.s2 = __fdiv_rn(r4[3], db);
+  return g;
+}
+__device__ __forceinline__ M3 rot4_matrix(const R4& g) {
+  M3 R;
+  R.m[0] = g.s1;  R.m[1] = g.c1 * g.c2; R.m[2] = -(g.c1 * g.s2);
+  R.m[3] = -g.c1; R.m[4] = g.s1 * g.c2; R.m[5] = -(g.s1 * g.s2);
+  R.m[6] = 0.f;   R.m[7] = g.s2;        R.m[8] = g.c2;
+  return R;
+}
+// d(unit 2-vector) -> d(raw 2-vector), the normalize_vector backward (eps clamp like the 6-D path)
+__device__ __forceinline__ void unit2_bwd(float c, float s, float n, float dc, float ds, float* o) {
+  if (n > GS_EPS) {
+    const float dot = c * dc + s * ds, inv = 1.0f / n;
+    o[0] = (dc - c * dot) * inv; o[1] = (ds - s * dot) * inv;
+  } else {
+    o[0] = dc * (1.0f / GS_EPS); o[1] = ds * (1.0f / GS_EPS);
+  }
+}
+
 struct FkGeom { int n, j, slot, b, k, t; bool valid; long row; };
 __device__ __forceinline__ FkGeom fk_geom(int B, int K, int T) {
   FkGeom g;
@@ -121,6 +153,7 @@ __device__ __forceinline__ FkGeom fk_geom(int B, int K, int T) {
   return g;
 }
 
+template <int RD>
 __global__ __launch_bounds__(256) void fk_fwd_kernel(const float* __restrict__ rot, int rs, const float* __restrict__ lengths,
                                                       float* __restrict__ poses, int B, int K, int T) {
   const FkGeom g = fk_geom(B, K, T);
@@ -128,14 +161,15 @@ __global__ __launch_bounds__(256) void fk_fwd_kernel(const float* __restrict__ r
   float off[3] = {0.f, 0.f, 0.f};
   if (g.valid) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) r6[c] = rot[g.row * rs + c];
+    for (int c = 0; c < RD; ++c) r6[c] = rot[g.row * rs + c];
     if (g.j > 0) {
       const float len = lengths[g.b * (NJ - 1) + g.j - 1];
       off[0] = c_op[g.j][0] * len; off[1] = c_op[g.j][1] * len; off[2] = c_op[g.j][2] * len;
     }
   }
-  const GS gs = gram_schmidt(r6);
-  const M3 R = gs_matrix(gs);
+  M3 R;
+  if (RD == 6) R = gs_matrix(gram_schmidt(r6));
+  else R = rot4_matrix(rot4_angles(r6));
   M3 Rw = R;
   float p[3] = {0.f, 0.f, 0.f};
   const int plane = g.slot * NJ + max(c_parent[g.j], 0);
@@ -157,6 +191,7 @@ __global__ __launch_bounds__(256) void fk_fwd_kernel(const float* __restrict__ r
   }
 }
 
+template <int RD>
 __global__ __launch_bounds__(256) void fk_bwd_kernel(const float* __restrict__ rot, int rs, const float* __restrict__ lengths,
                                                       const float* __restrict__ dposes, float* __restrict__ drot,
                                                       float* __restrict__ dlen_pose, int B, int K, int T) {
@@ -166,7 +201,7 @@ __global__ __launch_bounds__(256) void fk_bwd_kernel(const float* __restrict__ r
   float G[3] = {0.f, 0.f, 0.f};
   if (g.valid) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) r6[c] = rot[g.row * rs + c];
+    for (int c = 0; c < RD; ++c) r6[c] = rot[g.row * rs + c];
     if (g.j > 0) {
       const float len = lengths[g.b * (NJ - 1) + g.j - 1];
       off[0] = c_op[g.j][0] * len; off[1] = c_op[g.j][1] * len; off[2] = c_op[g.j][2] * len;
@@ -174,8 +209,11 @@ __global__ __launch_bounds__(256) void fk_bwd_kernel(const float* __restrict__ r
       G[0] = gp[0]; G[1] = gp[1]; G[2] = gp[2];
     }
   }
-  const GS gs = gram_schmidt(r6);
-  const M3 R = gs_matrix(gs);
+  GS gs;
+  R4 g4;
+  M3 R;
+  if (RD == 6) { gs = gram_schmidt(r6); R = gs_matrix(gs); }
+  else { g4 = rot4_angles(r6); R = rot4_matrix(g4); }
   const int base = g.slot * NJ;
   const int plane = base + max(c_parent[g.j], 0);
   const int depth = c_depth[g.j];
@@ -228,6 +266,21 @@ __global__ __launch_bounds__(256) void fk_bwd_kernel(const float* __restrict__ r
 #pragma unroll
   for (int c = 0; c < 3; ++c) doff[c] = Rw.m[c] * G[0] + Rw.m[3 + c] * G[1] + Rw.m[6 + c] * G[2];
   const float dlen = c_op[g.j][0] * doff[0] + c_op[g.j][1] * doff[1] + c_op[g.j][2] * doff[2];
+  if (RD == 4) {      // R = [[s1, c1 c2, -c1 s2], [-c1, s1 c2, -s1 s2], [0, s2, c2]]
+    const float ds1 = dR.m[0] + dR.m[4] * g4.c2 - dR.m[5] * g4.s2;
+    const float dc1 = dR.m[1] * g4.c2 - dR.m[2] * g4.s2 - dR.m[3];
+    const float dc2 = dR.m[1] * g4.c1 + dR.m[4] * g4.s1 + dR.m[8];
+    const float ds2 = dR.m[7] - dR.m[2] * g4.c1 - dR.m[5] * g4.s1;
+    float da2[2], db2[2];
+    unit2_bwd(g4.c1, g4.s1, g4.na, dc1, ds1, da2);
+    unit2_bwd(g4.c2, g4.s2, g4.nb, dc2, ds2, db2);
+    if (g.valid) {
+      float* o = drot + g.row * rs;
+      o[0] = da2[0]; o[1] = da2[1]; o[2] = db2[0]; o[3] = db2[1];
+      if (g.j > 0) dlen_pose[(long)g.n * (NJ - 1) + g.j - 1] = dlen;
+    }
+    return;
+  }
   // Gram-Schmidt backward
   float dx[3] = {dR.m[0], dR.m[3], dR.m[6]}, dy[3] = {dR.m[1], dR.m[4], dR.m[7]}, dz[3] = {dR.m[2], dR.m[5], dR.m[8]};
   float t3[3];
@@ -268,19 +321,27 @@ __global__ __launch_bounds__(256) void fk_bwd_kernel(const float* __restrict__ r
 
 static int fk_grid(int N) { return cdiv(cdiv(N, 3), 4); }
 
-int fk_decode_fwd(const float* rot, int rot_stride, const float* lengths, float* poses, int B, int K, int T, hipStream_t st) {
-  MP_CHECK(B > 0 && K > 0 && T > 0 && rot_stride >= 6, MP_ERR_ARG, "fk_decode_fwd: bad dims B=%d K=%d T=%d stride=%d", B, K, T,
+int fk_decode_fwd(const float* rot, int rot_stride, int rot_dim, const float* lengths, float* poses, int B, int K, int T,
+                  hipStream_t st) {
+  MP_CHECK((rot_dim == 6 || rot_dim == 4), MP_ERR_ARG, "fk_decode: rotation representation of dimension %d (4 or 6)", rot_dim);
+  MP_CHECK(B > 0 && K > 0 && T > 0 && rot_stride >= rot_dim, MP_ERR_ARG, "fk_decode_fwd: bad dims B=%d K=%d T=%d stride=%d", B, K, T,
            rot_stride);
-  hipLaunchKernelGGL(fk_fwd_kernel, dim3(fk_grid(B * K * T)), dim3(256), 0, st, rot, rot_stride, lengths, poses, B, K, T);
+  if (rot_dim == 6) hipLaunchKernelGGL(fk_fwd_kernel<6>, dim3(fk_grid(B * K * T)), dim3(256), 0, st, rot, rot_stride, lengths, poses, B, K, T);
+  else hipLaunchKernelGGL(fk_fwd_kernel<4>, dim3(fk_grid(B * K * T)), dim3(256), 0, st, rot, rot_stride, lengths, poses, B, K, T);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
 
-int fk_decode_bwd(const float* rot, int rot_stride, const float* lengths, const float* dposes, float* drot, float* dlen_pose,
-                  int B, int K, int T, hipStream_t st) {
-  MP_CHECK(B > 0 && K > 0 && T > 0 && rot_stride >= 6, MP_ERR_ARG, "fk_decode_bwd: bad dims");
-  hipLaunchKernelGGL(fk_bwd_kernel, dim3(fk_grid(B * K * T)), dim3(256), 0, st, rot, rot_stride, lengths, dposes, drot, dlen_pose,
-                     B, K, T);
+int fk_decode_bwd(const float* rot, int rot_stride, int rot_dim, const float* lengths, const float* dposes, float* drot,
+                  float* dlen_pose, int B, int K, int T, hipStream_t st) {
+  MP_CHECK((rot_dim == 6 || rot_dim == 4), MP_ERR_ARG, "fk_decode: rotation representation of dimension %d (4 or 6)", rot_dim);
+  MP_CHECK(B > 0 && K > 0 && T > 0 && rot_stride >= rot_dim, MP_ERR_ARG, "fk_decode_bwd: bad dims");
+  if (rot_dim == 6)
+    hipLaunchKernelGGL(fk_bwd_kernel<6>, dim3(fk_grid(B * K * T)), dim3(256), 0, st, rot, rot_stride, lengths, dposes, drot, dlen_pose,
+                       B, K, T);
+  else
+    hipLaunchKernelGGL(fk_bwd_kernel<4>, dim3(fk_grid(B * K * T)), dim3(256), 0, st, rot, rot_stride, lengths, dposes, drot, dlen_pose,
+                       B, K, T);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

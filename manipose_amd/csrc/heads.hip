@@ -254,9 +254,11 @@ int heads_bwd(const float* x, const float* stats, const HeadParams& p, const Hea
   switch (O) {
     case 1: hipLaunchKernelGGL(heads_bwd_param_kernel<1>, g2, b2, 0, st, x, stats, p, K, dout, scratch, M, C); break;
     case 3: hipLaunchKernelGGL(heads_bwd_param_kernel<3>, g2, b2, 0, st, x, stats, p, K, dout, scratch, M, C); break;
+    case 4: hipLaunchKernelGGL(heads_bwd_param_kernel<4>, g2, b2, 0, st, x, stats, p, K, dout, scratch, M, C); break;
+    case 5: hipLaunchKernelGGL(heads_bwd_param_kernel<5>, g2, b2, 0, st, x, stats, p, K, dout, scratch, M, C); break;
     case 6: hipLaunchKernelGGL(heads_bwd_param_kernel<6>, g2, b2, 0, st, x, stats, p, K, dout, scratch, M, C); break;
     case 7: hipLaunchKernelGGL(heads_bwd_param_kernel<7>, g2, b2, 0, st, x, stats, p, K, dout, scratch, M, C); break;
-    default: MP_CHECK(false, MP_ERR_ARG, "heads_bwd: out features %d unsupported (1,3,6,7)", O);
+    default: MP_CHECK(false, MP_ERR_ARG, "heads_bwd: out features %d unsupported (1,3,4,5,6,7)", O);
   }
   MP_LAUNCH_CHECK();
   hipLaunchKernelGGL(heads_reduce_kernel, dim3(cdiv(nk, 256), K), dim3(256), 0, st, scratch, P, K, O, C, gp);

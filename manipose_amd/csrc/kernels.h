@@ -119,12 +119,12 @@ int bones_mean_bwd(const float* dlen_pose, int KT, float* dlengths, float* dhead
 
 // ---------------------------------------------------------------- fk_decode.hip
 // rot: element (k, m, c) at rot[(k*M + m)*rot_stride + c], m = (b*T+t)*J + j, c < 6; lengths [B][16]; poses [B][K][T][17][3]
-int fk_decode_fwd(const float* rot, int rot_stride, const float* lengths, float* poses, int B, int K, int T, hipStream_t st);
-int fk_decode_bwd(const float* rot, int rot_stride, const float* lengths, const float* dposes, float* drot,
+int fk_decode_fwd(const float* rot, int rot_stride, int rot_dim, const float* lengths, float* poses, int B, int K, int T, hipStream_t st);
+int fk_decode_bwd(const float* rot, int rot_stride, int rot_dim, const float* lengths, const float* dposes, float* drot,
                   float* dlen_pose, int B, int K, int T, hipStream_t st);
 
 // ---------------------------------------------------------------- wta_loss.hip
-struct LossCfg { float beta, vel_w, smooth_w; int use_joint_weights; };
+struct LossCfg { float beta, vel_w, smooth_w; int use_joint_weights, squared; };
 // terms[4] = (wloss, score_reg, vloss, sreg); total = sum. dposes/dscores (may be null) receive d total / d input.
 int wta_loss(const float* poses, const float* scores, const float* y, const LossCfg& cfg, float* terms, int* argmin,
              float* dposes, float* dscores, int B, int K, int T, float* scratch, long scratch_floats, hipStream_t st);

@@ -3,6 +3,8 @@
 //   score_reg = beta * BCE(scores, onehot(argmin_k))                            losses.py:141-170
 //   vloss     = vel_w * mean_{b,k,t<T-1,j} |d_t p - d_t y|   (ALL hypotheses)   losses.py:75-101, axis = 2
 //   sreg      = smooth_w * mean_{b,k,t<T-1,j,c} w_j (d_t p)^2                   regularizations.py:160-174
+// train.sq_loss (`squared`): wloss = mean_{b,t} min_k mean_{j,c} w_j (p - y)^2 (losses.py:46-72,110-116) and
+// vloss = vel_w * mean_{b,k,t,j,c} (d_t p - d_t y)^2 (losses.py:96-97); the other two terms do not change.
 // assembled as main_h36m_lifting.py:101-209 does (the reference evaluates the WTA part twice per step and
 // syncs the host 5 times; here it is one kernel + a 1-block finalize and no host sync).
 // One thread per frame (b,t).  K = 1 with scores == nullptr is the single-hypothesis loss of ManifoldMixSTE.
@@ -26,7 +28,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 __global__ __launch_bounds__(256) void wta_loss_kernel(const float* __restrict__ poses, const float* __restrict__ scores,
-                                                        const float* __restrict__ y, int use_w, LossScales sc,
+                                                        const float* __restrict__ y, int use_w, int squared, LossScales sc,
                                                         float* __restrict__ partial, int* __restrict__ argmin,
                                                         float* __restrict__ dposes, float* __restrict__ dscores, int B, int K,
                                                         int T) {
@@ -45,9 +47,10 @@ __global__ __launch_bounds__(256) void wta_loss_kernel(const float* __restrict__
       float e = 0.f;
       for (int j = 0; j < LJ; ++j) {
         const float dx = pr[3 * j] - yr[3 * j], dy = pr[3 * j + 1] - yr[3 * j + 1], dz = pr[3 * j + 2] - yr[3 * j + 2];
-        e += (use_w ? c_w[j] : 1.0f) * sqrtf(dx * dx + dy * dy + dz * dz);
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        e += (use_w ? c_w[j] : 1.0f) * (squared ? d2 : sqrtf(d2));
       }
-      e /= (float)LJ;
+      e /= squared ? (float)(LJ * 3) : (float)LJ;
       if (e < best) { best = e; kb = k; }
     }
     lw = best * sc.wta;
@@ -75,7 +78,10 @@ __global__ __launch_bounds__(256) void wta_loss_kernel(const float* __restrict__
         if (k == kb) {
           const float dx = p0 - y0, dy = p1 - y1, dz = p2 - y2;
           const float n = sqrtf(dx * dx + dy * dy + dz * dz);
-          if (n > 0.f) {
+          if (squared) {
+            const float c = sc.wta * wj * (2.0f / (float)(LJ * 3));
+            g0 += c * dx; g1 += c * dy; g2 += c * dz;
+          } else if (n > 0.f) {
             const float c = sc.wta * wj / ((float)LJ * n);
             g0 += c * dx; g1 += c * dy; g2 += c * dz;
           }
@@ -84,11 +90,11 @@ __global__ __launch_bounds__(256) void wta_loss_kernel(const float* __restrict__
           const float s0 = pr[LJ * 3 + 3 * j] - p0, s1 = pr[LJ * 3 + 3 * j + 1] - p1, s2 = pr[LJ * 3 + 3 * j + 2] - p2;
           const float u0 = s0 - (yr[LJ * 3 + 3 * j] - y0), u1 = s1 - (yr[LJ * 3 + 3 * j + 1] - y1),
                       u2 = s2 - (yr[LJ * 3 + 3 * j + 2] - y2);
-          const float n = sqrtf(u0 * u0 + u1 * u1 + u2 * u2);
-          lv += n * sc.vel;
+          const float n2 = u0 * u0 + u1 * u1 + u2 * u2, n = sqrtf(n2);
+          lv += (squared ? n2 : n) * sc.vel;
           ls += wj * (s0 * s0 + s1 * s1 + s2 * s2) * sc.smooth;
-          if (n > 0.f) {
-            const float c = sc.vel / n;
+          if (squared || n > 0.f) {
+            const float c = squared ? 2.0f * sc.vel : sc.vel / n;
             g0 -= c * u0; g1 -= c * u1; g2 -= c * u2;
           }
           const float c2 = 2.0f * sc.smooth * wj;
@@ -99,8 +105,8 @@ __global__ __launch_bounds__(256) void wta_loss_kernel(const float* __restrict__
           const float u0 = s0 - (y0 - yr[-LJ * 3 + 3 * j]), u1 = s1 - (y1 - yr[-LJ * 3 + 3 * j + 1]),
                       u2 = s2 - (y2 - yr[-LJ * 3 + 3 * j + 2]);
           const float n = sqrtf(u0 * u0 + u1 * u1 + u2 * u2);
-          if (n > 0.f) {
-            const float c = sc.vel / n;
+          if (squared || n > 0.f) {
+            const float c = squared ? 2.0f * sc.vel : sc.vel / n;
             g0 += c * u0; g1 += c * u1; g2 += c * u2;
           }
           const float c2 = 2.0f * sc.smooth * wj;
@@ -143,9 +149,9 @@ static int loss_impl(const float* poses, const float* scores, const float* y, co
   LossScales sc;
   sc.wta = 1.0f / ((float)B * T);
   sc.bce = (scores != nullptr) ? cfg.beta / ((float)B * K * T) : 0.f;
-  sc.vel = cfg.vel_w / ((float)B * K * (T - 1) * LJ);
+  sc.vel = cfg.vel_w / ((float)B * K * (T - 1) * LJ * (cfg.squared ? 3 : 1));
   sc.smooth = cfg.smooth_w / ((float)B * K * (T - 1) * LJ * 3);
-  hipLaunchKernelGGL(wta_loss_kernel, dim3(grid), dim3(256), 0, st, poses, scores, y, cfg.use_joint_weights, sc, scratch, argmin,
+  hipLaunchKernelGGL(wta_loss_kernel, dim3(grid), dim3(256), 0, st, poses, scores, y, cfg.use_joint_weights, cfg.squared, sc, scratch, argmin,
                      dposes, dscores, B, K, T);
   MP_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, grid, terms, 4, skip_bce);

@@ -34,11 +34,11 @@ class _FusedLoss(torch.autograd.Function):
     """terms = (wloss, score_reg, vloss, sreg) [rmcl] or (wloss, vloss, sreg) [single]; grads produced in the same launch."""
 
     @staticmethod
-    def forward(ctx, poses, scores, y, beta, vel_w, smooth_w, use_w):
+    def forward(ctx, poses, scores, y, beta, vel_w, smooth_w, use_w, squared=0):
         lib = _lib.load()
         poses = poses.contiguous().float()
         y = y.contiguous().float()
-        cfg = _lib.LossConfig(rmcl_score_reg=beta, vel_loss=vel_w, smooth_reg=smooth_w, w_loss=use_w)
+        cfg = _lib.LossConfig(rmcl_score_reg=beta, vel_loss=vel_w, smooth_reg=smooth_w, w_loss=use_w, sq_loss=int(squared))
         dev = poses.device
         need_grad = poses.requires_grad or (scores is not None and scores.requires_grad)
         if scores is not None:
@@ -73,24 +73,24 @@ class _FusedLoss(torch.autograd.Function):
         d_poses, d_scores = ctx.saved_tensors
         # the kernel's gradient is that of sum(terms); a caller weighting the terms differently is not supported
         if d_poses is None:
-            return (None,) * 7
+            return (None,) * 8
         # (no check of that here: it would force a host sync in the training step)
         g = g_terms
         gp = d_poses * g[0]
         gs = d_scores * g[0] if d_scores is not None else None
-        return gp, gs, None, None, None, None, None
+        return gp, gs, None, None, None, None, None, None
 
 
 def rmcl_training_loss(poses, scores, y, w_loss: bool = True, vel_loss: float = 2.0, smooth_reg: float = 0.5,
-                       rmcl_score_reg: float = 0.1) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-    """Whole default multi-hypothesis loss (make_loss with conf/config.yaml:32-38) in ONE kernel launch."""
-    terms, _ = _FusedLoss.apply(poses, scores, y, rmcl_score_reg, vel_loss, smooth_reg, int(w_loss))
+                       rmcl_score_reg: float = 0.1, sq_loss: bool = False) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    """Whole default multi-hypothesis loss (make_loss with conf/config.yaml:31-38) in ONE kernel launch."""
+    terms, _ = _FusedLoss.apply(poses, scores, y, rmcl_score_reg, vel_loss, smooth_reg, int(w_loss), int(sq_loss))
     names = ("wloss", "score_reg", "vloss", "sreg")
     return terms.sum(), {n: terms[i] for i, n in enumerate(names)}
 
 
-def manifold_training_loss(pred, y, w_loss: bool = True, vel_loss: float = 2.0, smooth_reg: float = 0.5):
-    terms, _ = _FusedLoss.apply(pred, None, y, 0.0, vel_loss, smooth_reg, int(w_loss))
+def manifold_training_loss(pred, y, w_loss: bool = True, vel_loss: float = 2.0, smooth_reg: float = 0.5, sq_loss: bool = False):
+    terms, _ = _FusedLoss.apply(pred, None, y, 0.0, vel_loss, smooth_reg, int(w_loss), int(sq_loss))
     names = ("wloss", "vloss", "sreg")
     return terms.sum(), {n: terms[i] for i, n in enumerate(names)}
 
@@ -99,8 +99,6 @@ def manifold_training_loss(pred, y, w_loss: bool = True, vel_loss: float = 2.0, 
 def wta_l2_loss_and_activate_head(hypothesis, y, weights=None, squared: bool = False):
     """losses.py:126-138 -> (per-frame WTA error (B, L), winner index (B, L)); not differentiable here (eval/oracle use);
     the differentiable WTA term is ``rmcl_training_loss``/``wta_with_scoring_loss``."""
-    if squared:
-        raise NotImplementedError("manipose_amd: train.sq_loss=True is outside the accelerated path")
     lib = _lib.load()
     B, K, T = hypothesis.shape[:3]
     hyp = hypothesis.detach().contiguous().float()
@@ -108,7 +106,7 @@ def wta_l2_loss_and_activate_head(hypothesis, y, weights=None, squared: bool = F
     # per-frame values: winner poses through the aggregation kernel, then per-frame weighted error
     use_w = _uses_h36m_weights(weights)
     import ctypes as C
-    cfg = _lib.LossConfig(rmcl_score_reg=0.0, vel_loss=0.0, smooth_reg=0.0, w_loss=use_w)
+    cfg = _lib.LossConfig(rmcl_score_reg=0.0, vel_loss=0.0, smooth_reg=0.0, w_loss=use_w, sq_loss=int(squared))
     terms = torch.empty(4, dtype=torch.float32, device=hyp.device)
     argmin = torch.empty(B, T, dtype=torch.int32, device=hyp.device)
     dummy = torch.full((B, K, T, 1), 1.0 / K, dtype=torch.float32, device=hyp.device)
@@ -118,15 +116,16 @@ def wta_l2_loss_and_activate_head(hypothesis, y, weights=None, squared: bool = F
     idx = argmin.long()
     win = hyp.gather(1, idx[:, None, :, None, None].expand(B, 1, T, 17, 3))[:, 0]
     w = (STANDARD_H36M_WEIGHTS if use_w else torch.ones(17)).to(hyp.device)
-    vals = (w * (win - gt).norm(dim=-1)).mean(dim=-1)
+    if squared:         # losses.py:110-116: mean over the coordinates, then over the joints
+        vals = (w[:, None] * (win - gt) ** 2).mean(dim=-1).mean(dim=-1)
+    else:
+        vals = (w * (win - gt).norm(dim=-1)).mean(dim=-1)
     return vals, idx
 
 
 def wta_with_scoring_loss(hypothesis, scores, y, beta: float, weights=None, squared: bool = False):
     """losses.py:141-170 -> (wta.mean() + beta*bce, beta*bce); beta == 0 returns the WTA mean alone."""
-    if squared:
-        raise NotImplementedError("manipose_amd: train.sq_loss=True is outside the accelerated path")
-    terms, _ = _FusedLoss.apply(hypothesis, scores, y, float(beta), 0.0, 0.0, _uses_h36m_weights(weights))
+    terms, _ = _FusedLoss.apply(hypothesis, scores, y, float(beta), 0.0, 0.0, _uses_h36m_weights(weights), int(squared))
     if beta == 0:
         return terms[0]
     return terms[0] + terms[1], terms[1]
@@ -134,15 +133,13 @@ def wta_with_scoring_loss(hypothesis, scores, y, beta: float, weights=None, squa
 
 def mean_velocity_error(predicted, target, axis: int = 1, squared: bool = False):
     """losses.py:75-101 (time axis 2 for (B,H,L,J,3) predictions, 1 for (B,L,J,3))."""
-    if squared:
-        raise NotImplementedError("manipose_amd: train.sq_loss=True is outside the accelerated path")
     if predicted.dim() == 5:
         assert axis == 2, "time axis of (B,H,L,J,3) hypotheses is 2"
         dummy = torch.full(predicted.shape[:3] + (1,), 1.0 / predicted.shape[1], device=predicted.device)
-        terms, _ = _FusedLoss.apply(predicted, dummy, target, 0.0, 1.0, 0.0, 0)
+        terms, _ = _FusedLoss.apply(predicted, dummy, target, 0.0, 1.0, 0.0, 0, int(squared))
         return terms[2]
     assert axis == 1 and predicted.shape == target.shape
-    terms, _ = _FusedLoss.apply(predicted, None, target, 0.0, 1.0, 0.0, 0)
+    terms, _ = _FusedLoss.apply(predicted, None, target, 0.0, 1.0, 0.0, 0, int(squared))
     return terms[1]
 
 
@@ -159,6 +156,14 @@ def smoothness_regularization(prediction, weights=None, axis: int = 1):
     assert axis == 1
     terms, _ = _FusedLoss.apply(prediction, None, zeros, 0.0, 0.0, 1.0, use_w)
     return terms[2]
+
+
+def weighted_mse_loss(prediction, target, weights=None, dims=None):
+    """losses.py:46-72 with dims=None on (B, L, J, 3) tensors (single-hypothesis wloss under train.sq_loss)."""
+    if dims is not None:
+        raise NotImplementedError("manipose_amd: dims != None is served by wta_l2_loss_and_activate_head(squared=True)")
+    terms, _ = _FusedLoss.apply(prediction, None, target, 0.0, 0.0, 0.0, _uses_h36m_weights(weights), 1)
+    return terms[0]
 
 
 def weighted_mpjpe_loss(prediction, target, weights=None, dims=None):

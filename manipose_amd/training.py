@@ -20,12 +20,12 @@ from .optim import FusedAdam
 class LiftingTrainer:
     def __init__(self, model, lr: float = 4e-5, weight_decay: float = 1e-6, w_loss: bool = True, vel_loss: float = 2.0,
                  smooth_reg: float = 0.5, rmcl_score_reg: float = 0.1, seed: int = 42, process_group=None,
-                 grad_buckets: int = 1):
+                 grad_buckets: int = 1, sq_loss: bool = False):
         self.model = model
         self.lib = _lib.load()
         self.opt = FusedAdam(model, lr=lr, weight_decay=weight_decay)
         self.loss_cfg = _lib.LossConfig(rmcl_score_reg=rmcl_score_reg, vel_loss=vel_loss, smooth_reg=smooth_reg,
-                                        w_loss=int(w_loss))
+                                        w_loss=int(w_loss), sq_loss=int(sq_loss))
         self.seed = seed
         self.step_no = 0
         self.pg = process_group

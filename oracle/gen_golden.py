@@ -74,7 +74,7 @@ def import_reference():
 
 def build_ref_model(ref, cfg, drop_path_rate):
     kw = dict(skeleton=ref["sk"], num_frame=cfg["T"], num_joints=cfg["J"], num_bones=cfg["num_bones"],
-              in_chans=2, rot_rep_dim=6, embed_dim_rot=cfg["C_rot"], depth_rot=cfg["depth_rot"],
+              in_chans=2, rot_rep_dim=cfg.get("rot_dim", 6), embed_dim_rot=cfg["C_rot"], depth_rot=cfg["depth_rot"],
               num_heads_rot=cfg["heads_rot"], embed_dim_seg=cfg["C_seg"], depth_seg=cfg["depth_seg"],
               num_heads_seg=cfg["heads_seg"], drop_path_rate=drop_path_rate)
     if cfg["n_hyp"] > 0:
@@ -82,13 +82,13 @@ def build_ref_model(ref, cfg, drop_path_rate):
     return ref["Manifold"](**kw)
 
 
-def ref_losses(ref, poses, scores, y):
-    """The four default loss terms exactly as main_h36m_lifting.py:101-209 assembles them."""
+def ref_losses(ref, poses, scores, y, squared=False):
+    """The four default loss terms exactly as main_h36m_lifting.py:101-209 assembles them (squared = train.sq_loss)."""
     M = ref["M"]
     w = M.STANDARD_H36M_WEIGHTS
-    wl = M.wta_l2_loss_and_activate_head(hypothesis=poses, y=y, weights=w, squared=False)[0].mean()
-    sr = M.wta_with_scoring_loss(hypothesis=poses, scores=scores, y=y, beta=0.1, weights=w, squared=False)[1]
-    vl = 2.0 * M.mean_velocity_error(predicted=poses, target=y, squared=False, axis=2)
+    wl = M.wta_l2_loss_and_activate_head(hypothesis=poses, y=y, weights=w, squared=squared)[0].mean()
+    sr = M.wta_with_scoring_loss(hypothesis=poses, scores=scores, y=y, beta=0.1, weights=w, squared=squared)[1]
+    vl = 2.0 * M.mean_velocity_error(predicted=poses, target=y, squared=squared, axis=2)
     sg = 0.5 * M.smoothness_regularization(prediction=poses, weights=w, axis=2)
     return wl, sr, vl, sg
 
@@ -108,7 +108,7 @@ def gen_model_fixture(ref, name, cfg, B, seed, drop_path_rate=0.0, train=False):
     RECORDED_MASKS.clear()
     out = {"cfg": np.array([cfg[k] for k in ("T", "J", "num_bones", "C_rot", "depth_rot", "heads_rot",
                                               "C_seg", "depth_seg", "heads_seg", "n_hyp")], dtype=np.int64),
-           "X": X.numpy(), "y": y.numpy(), "drop_path_rate": np.float64(drop_path_rate)}
+           "X": X.numpy(), "y": y.numpy(), "drop_path_rate": np.float64(drop_path_rate), "rot_dim": np.int64(cfg.get("rot_dim", 6))}
     if cfg["n_hyp"] > 0:
         rot, sc_only = model.rotations_module(X)
         RECORDED_MASKS.clear()
@@ -192,6 +192,29 @@ def gen_decoder_fixture(ref):
                         poses=poses.detach().numpy(), gpos=gp.numpy(), g_rot6d=rot.grad.numpy(),
                         g_bones=bl.grad.numpy(), tpose_lens=lens.numpy(), tpose=tp.detach().numpy())
     print("decoder: ok")
+    gen_rot4_decoder_fixture(ref)
+
+
+def gen_rot4_decoder_fixture(ref):
+    """model.rot_dim=4: the 4-D representation of rotation_tools.py:60-116 through the reference's PoseDecoder."""
+    torch.manual_seed(15)
+    dec = ref["PoseDecoder"](skeleton=ref["sk"], rot_rep_dim=4)
+    B, L = 3, 7
+    rot = torch.randn(B * L, 17, 4)
+    rot[2, 0, :] = torch.tensor([0., 1, 1, 0])      # c1 = 0, s1 = 1, c2 = 1, s2 = 0 -> the identity
+    bl = torch.randn(B, 16, 1) * 0.3
+    rot.requires_grad_(True)
+    bl.requires_grad_(True)
+    poses = dec(rotations_repr=rot, bones_lengths_repr=bl, root_positions=torch.zeros(B * L, 3))
+    gp = torch.randn_like(poses)
+    (poses * gp).sum().backward()
+    ident = torch.tensor([0., 1, 1, 0]).repeat(1, 17, 1)
+    lens = torch.tensor([.2, .5, .5, .2, .5, .5, .2, .2, .2, .2, .2, .4, .4, .2, .4, .4]).view(1, 16, 1)
+    tp = dec(rotations_repr=ident, bones_lengths_repr=lens, root_positions=torch.zeros(1, 3))
+    np.savez_compressed(os.path.join(OUT, "decoder_rot4.npz"), rot4d=rot.detach().numpy(), bones=bl.detach().numpy(),
+                        poses=poses.detach().numpy(), gpos=gp.numpy(), g_rot4d=rot.grad.numpy(), g_bones=bl.grad.numpy(),
+                        tpose_lens=lens.numpy(), tpose=tp.detach().numpy())
+    print("decoder_rot4: ok")
 
 
 def gen_loss_fixture(ref):
@@ -208,6 +231,32 @@ def gen_loss_fixture(ref):
                         y=y.numpy(), loss_terms=np.array([wl.item(), sr.item(), vl.item(), sg.item()]),
                         g_poses=poses.grad.numpy(), g_scores=scores.grad.numpy())
     print("loss: ok")
+    gen_sq_loss_fixture(ref)
+
+
+def gen_sq_loss_fixture(ref):
+    """train.sq_loss=True: the squared variants of the WTA / velocity terms, multi-hypothesis and single."""
+    M = ref["M"]
+    torch.manual_seed(19)
+    B, H, L, J = 2, 5, 9, 17
+    poses = (0.3 * torch.randn(B, H, L, J, 3)).requires_grad_(True)
+    scores = torch.randn(B, H, L, 1).softmax(dim=1).requires_grad_(True)
+    y = 0.3 * torch.randn(B, L, J, 3)
+    wl, sr, vl, sg = ref_losses(ref, poses, scores, y, squared=True)
+    (wl + sr + vl + sg).backward()
+    out = dict(poses=poses.detach().numpy(), scores=scores.detach().numpy(), y=y.numpy(),
+               loss_terms=np.array([wl.item(), sr.item(), vl.item(), sg.item()]), g_poses=poses.grad.numpy(), g_scores=scores.grad.numpy())
+    val, idx = M.wta_l2_loss_and_activate_head(hypothesis=poses.detach(), y=y, weights=M.STANDARD_H36M_WEIGHTS, squared=True)
+    out["wta_vals"], out["wta_idx"] = val.numpy(), idx.numpy()
+    for nm, w in (("w", M.STANDARD_H36M_WEIGHTS), ("nw", None)):      # single hypothesis (make_loss :113-127): weighted_mse_loss
+        p1 = poses.detach()[:, 0].clone().requires_grad_(True)
+        a = M.weighted_mse_loss(p1, y, weights=w)
+        b = 2.0 * M.mean_velocity_error(predicted=p1, target=y, squared=True, axis=1)
+        c = 0.5 * M.smoothness_regularization(prediction=p1, weights=w, axis=1)
+        (a + b + c).backward()
+        out[f"single_{nm}.terms"], out[f"single_{nm}.g"] = np.array([a.item(), b.item(), c.item()]), p1.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "loss_sq.npz"), **out)
+    print("loss_sq: ok", out["loss_terms"])
 
 
 def gen_metrics_fixture(ref):
@@ -402,6 +451,16 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "windows":       # regenerate the input-pipeline fixture only
         gen_windows_fixture(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "rot4":          # regenerate the 4-D rotation fixtures only
+        gen_rot4_decoder_fixture(ref)
+        gen_model_fixture(ref, "rmcl_tiny_rot4", dict(T=9, J=17, num_bones=16, C_rot=32, depth_rot=2, heads_rot=4, C_seg=16, depth_seg=1,
+                                                      heads_seg=4, n_hyp=3, rot_dim=4), B=2, seed=21)
+        gen_model_fixture(ref, "manifold_k1_rot4", dict(T=9, J=17, num_bones=16, C_rot=32, depth_rot=2, heads_rot=4, C_seg=16, depth_seg=1,
+                                                        heads_seg=4, n_hyp=0, rot_dim=4), B=2, seed=23)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "loss_sq":       # regenerate the squared-loss fixture only
+        gen_sq_loss_fixture(ref)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "datasets":      # regenerate the dataset-ingest fixture only
         gen_datasets_fixture(ref)
         return
@@ -415,6 +474,8 @@ def main():
     gen_model_fixture(ref, "rmcl_small", small, B=2, seed=12)
     gen_model_fixture(ref, "manifold_k1", k1, B=2, seed=13)
     gen_model_fixture(ref, "rmcl_tiny_droppath", tiny, B=3, seed=14, drop_path_rate=0.5, train=True)
+    gen_model_fixture(ref, "rmcl_tiny_rot4", dict(tiny, rot_dim=4), B=2, seed=21)
+    gen_model_fixture(ref, "manifold_k1_rot4", dict(tiny, n_hyp=0, rot_dim=4), B=2, seed=23)
     gen_decoder_fixture(ref)
     gen_loss_fixture(ref)
     gen_metrics_fixture(ref)

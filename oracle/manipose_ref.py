@@ -221,6 +221,22 @@ def rotation_from_ortho6d(p: Tensor) -> Tensor:
     return torch.stack((x, y, z), dim=2)
 
 
+def rotation_from_ortho4d(p: Tensor) -> Tensor:
+    """compute_rotation_matrix_from_ortho4d, rotation_tools.py:60-116 (model.rot_dim=4). (N,4)->(N,3,3) = R_theta @ R_phi, each a
+    planar rotation built from a normalised 2-vector: theta_y = (c1, s1, 0), theta_x = theta_y x e_z; phi_y = (0, c2, s2),
+    phi_z = e_x x phi_y; columns [theta_x | theta_y | e_z] and [e_x | phi_y | phi_z]."""
+    n = p.shape[0]
+    cs_theta, cs_phi = normalize_vector(p[:, 0:2]), normalize_vector(p[:, 2:4])
+    zero = torch.zeros(n, 1, dtype=p.dtype)
+    theta_y = torch.cat([cs_theta, zero], dim=1)
+    theta_z = torch.tensor([0.0, 0.0, 1.0], dtype=p.dtype).expand(n, -1)
+    theta_x = cross_product(theta_y, theta_z)
+    phi_y = torch.cat([zero, cs_phi], dim=1)
+    phi_x = torch.tensor([1.0, 0.0, 0.0], dtype=p.dtype).expand(n, -1)
+    phi_z = cross_product(phi_x, phi_y)
+    return torch.stack((theta_x, theta_y, theta_z), dim=2).bmm(torch.stack((phi_x, phi_y, phi_z), dim=2))
+
+
 def build_t_pose(bones_length: Tensor, parents=H36M_PARENTS) -> Tensor:
     """PoseDecoder.build_t_pose_from_bone_lengths, pose_decoder.py:98-120. (N,S,1)->(N,J,3)."""
     N = bones_length.shape[0]
@@ -249,13 +265,14 @@ def forward_kinematics(t_pose: Tensor, rotations: Tensor, root: Tensor, parents=
 
 
 def pose_decoder(rot6d: Tensor, bones_lengths: Tensor, parents=H36M_PARENTS) -> Tensor:
-    """PoseDecoder.forward, pose_decoder.py:32-55. rot6d (N,J,6); bones_lengths (B,S,1), N % B == 0."""
-    N, J, _ = rot6d.shape
+    """PoseDecoder.forward, pose_decoder.py:32-55. rot6d (N,J,6) or (N,J,4) (:69-82); bones_lengths (B,S,1), N % B == 0."""
+    N, J, D = rot6d.shape
     B = bones_lengths.shape[0]
     assert N % B == 0
     L = N // B
     bl = torch.stack([bones_lengths] * L, dim=1).reshape(N, -1, 1)                 # :85-96
-    R = rotation_from_ortho6d(rot6d.reshape(-1, 6)).reshape(N, J, 3, 3)           # :57-83
+    assert D in (4, 6), f"Unsupported rotations representation dimension: {D}"
+    R = (rotation_from_ortho6d if D == 6 else rotation_from_ortho4d)(rot6d.reshape(-1, D)).reshape(N, J, 3, 3)   # :57-83
     return forward_kinematics(build_t_pose(bl, parents), R, torch.zeros(N, 3, dtype=rot6d.dtype), parents)
 
 
@@ -294,26 +311,34 @@ def weighted_mpjpe_per_hyp(hyp: Tensor, y: Tensor, weights: Optional[Tensor]) ->
     return (w[None, None, :] * torch.norm(hyp - y[:, None], p=2, dim=-1)).mean(dim=3)
 
 
-def wta_l2_loss_and_activate_head(hyp, y, weights=None):
-    """losses.py:126-138 (squared=False)."""
-    return torch.min(weighted_mpjpe_per_hyp(hyp, y, weights), dim=1)
+def weighted_mse_per_hyp(hyp: Tensor, y: Tensor, weights: Optional[Tensor]) -> Tensor:
+    """_l2_loss_per_hyp(squared=True) (losses.py:110-116) -> weighted_mse_loss(dims=[4, 3]) (:46-72): mean over the coordinates, then
+    over the joints.  -> (B,H,L).  (With weights=None the reference returns a scalar F.mse_loss here and the WTA min fails; the
+    squared WTA loss exists only with train.w_loss=True.  Unit weights stand in for None below.)"""
+    w = torch.ones(y.shape[-2]) if weights is None else weights
+    return (w[None, None, :, None] * (hyp - y[:, None]) ** 2).mean(dim=4).mean(dim=3)
 
 
-def wta_with_scoring_loss(hyp, scores, y, beta, weights=None):
+def wta_l2_loss_and_activate_head(hyp, y, weights=None, squared=False):
+    """losses.py:126-138."""
+    return torch.min(weighted_mse_per_hyp(hyp, y, weights) if squared else weighted_mpjpe_per_hyp(hyp, y, weights), dim=1)
+
+
+def wta_with_scoring_loss(hyp, scores, y, beta, weights=None, squared=False):
     """losses.py:141-170. Returns (wta.mean() + beta*bce, beta*bce)."""
-    wta, idx = wta_l2_loss_and_activate_head(hyp, y, weights)
+    wta, idx = wta_l2_loss_and_activate_head(hyp, y, weights, squared)
     B, H, L = hyp.shape[:3]
     gt = F.one_hot(idx, H).permute(0, 2, 1).to(scores.dtype)                       # (B, H, L)
     bce = F.binary_cross_entropy(scores.view(B, H, L), gt)
     return wta.mean() + beta * bce, beta * bce
 
 
-def mean_velocity_error(pred, target, axis):
-    """losses.py:75-101 (squared=False)."""
+def mean_velocity_error(pred, target, axis, squared=False):
+    """losses.py:75-101."""
     if pred.dim() > target.dim():
         target = target.unsqueeze(1).expand_as(pred)
     dv = torch.diff(pred, dim=axis) - torch.diff(target, dim=axis)
-    return torch.norm(dv, dim=-1).mean()
+    return (dv ** 2).mean() if squared else torch.norm(dv, dim=-1).mean()
 
 
 def smoothness_regularization(pred, weights, axis):
@@ -329,6 +354,12 @@ def weighted_mpjpe_loss(pred, target, weights=None):
     return (w[None, None, :] * torch.norm(pred - target, p=2, dim=-1)).mean()
 
 
+def weighted_mse_loss(pred, target, weights=None):
+    """losses.py:46-72 with dims=None (single-hypothesis wloss under train.sq_loss)."""
+    w = torch.ones(target.shape[-2]) if weights is None else weights
+    return (w[None, None, :, None] * (pred - target) ** 2).mean()
+
+
 DEFAULT_TRAIN_CFG = dict(w_loss=True, vel_loss=2.0, smooth_reg=0.5, rmcl_score_reg=0.1)  # conf/config.yaml:32-38
 
 
@@ -339,10 +370,11 @@ def rmcl_training_loss(poses, scores, y, train_cfg=DEFAULT_TRAIN_CFG):
     """
     w = torch.tensor(STANDARD_H36M_WEIGHTS, dtype=poses.dtype) if train_cfg["w_loss"] else None
     terms = {}
-    terms["wloss"] = wta_l2_loss_and_activate_head(poses, y, w)[0].mean()
-    terms["score_reg"] = wta_with_scoring_loss(poses, scores, y, train_cfg["rmcl_score_reg"], w)[1]
+    sq = bool(train_cfg.get("sq_loss", False))                 # conf/config.yaml:31, forwarded as `squared=` by make_loss
+    terms["wloss"] = wta_l2_loss_and_activate_head(poses, y, w, sq)[0].mean()
+    terms["score_reg"] = wta_with_scoring_loss(poses, scores, y, train_cfg["rmcl_score_reg"], w, sq)[1]
     if train_cfg["vel_loss"] > 0:
-        terms["vloss"] = train_cfg["vel_loss"] * mean_velocity_error(poses, y, axis=2)
+        terms["vloss"] = train_cfg["vel_loss"] * mean_velocity_error(poses, y, axis=2, squared=sq)
     if train_cfg["smooth_reg"] > 0:
         terms["sreg"] = train_cfg["smooth_reg"] * smoothness_regularization(poses, w, axis=2)
     total = sum(terms.values())
@@ -352,9 +384,10 @@ def rmcl_training_loss(poses, scores, y, train_cfg=DEFAULT_TRAIN_CFG):
 def manifold_training_loss(pred, y, train_cfg=DEFAULT_TRAIN_CFG):
     """make_loss for single-hypothesis models (time axis 1), main_h36m_lifting.py:113-127,152-169."""
     w = torch.tensor(STANDARD_H36M_WEIGHTS, dtype=pred.dtype) if train_cfg["w_loss"] else None
-    terms = {"wloss": weighted_mpjpe_loss(pred, y, w)}
+    sq = bool(train_cfg.get("sq_loss", False))
+    terms = {"wloss": weighted_mse_loss(pred, y, w) if sq else weighted_mpjpe_loss(pred, y, w)}
     if train_cfg["vel_loss"] > 0:
-        terms["vloss"] = train_cfg["vel_loss"] * mean_velocity_error(pred, y, axis=1)
+        terms["vloss"] = train_cfg["vel_loss"] * mean_velocity_error(pred, y, axis=1, squared=sq)
     if train_cfg["smooth_reg"] > 0:
         terms["sreg"] = train_cfg["smooth_reg"] * smoothness_regularization(pred, w, axis=1)
     return sum(terms.values()), terms
@@ -743,9 +776,10 @@ def make_state(cfg: dict, seed: int = 0) -> Dict[str, Tensor]:
     """Random weights with the reference's key layout; LN affine and pos-embeds are perturbed
     away from their (1, 0, 0) defaults so that every parameter is exercised by parity tests.
 
-    cfg: T, J, num_bones, C_rot, depth_rot, heads_rot, C_seg, depth_seg, heads_seg, n_hyp
-    (n_hyp == 0 -> ManifoldMixSTE layout with a plain MixSTE head of out_dim 6).
+    cfg: T, J, num_bones, C_rot, depth_rot, heads_rot, C_seg, depth_seg, heads_seg, n_hyp [, rot_dim = 6]
+    (n_hyp == 0 -> ManifoldMixSTE layout with a plain MixSTE head of out_dim rot_dim).
     """
+    D = cfg.get("rot_dim", 6)
     gen = torch.Generator().manual_seed(seed)
     st: Dict[str, Tensor] = {}
     T, J, S = cfg["T"], cfg["J"], cfg["num_bones"]
@@ -757,12 +791,12 @@ def make_state(cfg: dict, seed: int = 0) -> Dict[str, Tensor]:
             hp = f"{rp}head.{k}."
             st[hp + "norm.weight"] = 1 + 0.1 * torch.randn(C, generator=gen)
             st[hp + "norm.bias"] = 0.1 * torch.randn(C, generator=gen)
-            st[hp + "prediction_head.weight"], st[hp + "prediction_head.bias"] = _linear_init(7, C, gen)
+            st[hp + "prediction_head.weight"], st[hp + "prediction_head.bias"] = _linear_init(D + 1, C, gen)
             st[hp + "score_head.weight"], st[hp + "score_head.bias"] = _linear_init(1, J, gen)
     else:
         st[rp + "head.0.weight"] = 1 + 0.1 * torch.randn(C, generator=gen)
         st[rp + "head.0.bias"] = 0.1 * torch.randn(C, generator=gen)
-        st[rp + "head.1.weight"], st[rp + "head.1.bias"] = _linear_init(6, C, gen)
+        st[rp + "head.1.weight"], st[rp + "head.1.bias"] = _linear_init(D, C, gen)
     _mixste_state(st, sp, gen, T, S, Cs, cfg["depth_seg"], 2, embed=False)
     st[sp + "head.0.weight"] = 1 + 0.1 * torch.randn(Cs, generator=gen)
     st[sp + "head.0.bias"] = 0.1 * torch.randn(Cs, generator=gen)

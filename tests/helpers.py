@@ -13,6 +13,7 @@ def load_fixture(name):
     out = {k: z[k] for k in z.files}
     if "cfg" in out:
         out["cfg"] = {k: int(v) for k, v in zip(CFG_KEYS, out["cfg"])}
+        out["cfg"]["rot_dim"] = int(out["rot_dim"]) if "rot_dim" in out else 6
     return out
 
 

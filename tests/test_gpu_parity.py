@@ -47,7 +47,7 @@ def test_fk_decode_forward_backward_vs_reference_fixture(lib):
     B, L = 3, 7
     lengths = dev(fx["bones"].reshape(B, 16))
     poses = torch.empty(B, 1, L, 17, 3, device="cuda")
-    _lib.check(lib.mp_fk_decode_fwd(rot.data_ptr(), 6, lengths.data_ptr(), poses.data_ptr(), B, 1, L, st()))
+    _lib.check(lib.mp_fk_decode_fwd(rot.data_ptr(), 6, 6, lengths.data_ptr(), poses.data_ptr(), B, 1, L, st()))
     # pose 1 / joint 5 has EXACTLY colinear 6-D halves (x cross b == rounding noise): its frame, hence joints 5 and 6 of
     # that pose, is ill-conditioned (the reference's own value changes with the BLAS/FMA build) and is excluded.
     ok = np.ones((B * L, 17), dtype=bool)
@@ -58,7 +58,7 @@ def test_fk_decode_forward_backward_vs_reference_fixture(lib):
     gp = dev(fx["gpos"]).view(B, 1, L, 17, 3).contiguous()
     drot = torch.zeros_like(rot)
     dlen = torch.zeros(B * L, 16, device="cuda")
-    _lib.check(lib.mp_fk_decode_bwd(rot.data_ptr(), 6, lengths.data_ptr(), gp.data_ptr(), drot.data_ptr(), dlen.data_ptr(),
+    _lib.check(lib.mp_fk_decode_bwd(rot.data_ptr(), 6, 6, lengths.data_ptr(), gp.data_ptr(), drot.data_ptr(), dlen.data_ptr(),
                                     B, 1, L, st()))
     want = fx["g_rot6d"]
     finite = np.isfinite(want)                  # the reference's autograd yields NaN at the two degenerate joints
@@ -239,7 +239,7 @@ def _build(fx, drop_path_rate=0.0):
     c = fx["cfg"]
     kw = dict(skeleton=h36m_skeleton(), num_frame=c["T"], embed_dim_rot=c["C_rot"], depth_rot=c["depth_rot"],
               num_heads_rot=c["heads_rot"], embed_dim_seg=c["C_seg"], depth_seg=c["depth_seg"], num_heads_seg=c["heads_seg"],
-              drop_path_rate=drop_path_rate)
+              drop_path_rate=drop_path_rate, rot_rep_dim=c.get("rot_dim", 6))
     model = RMCLManifoldMixSTE(n_hyp=c["n_hyp"], **kw) if c["n_hyp"] > 0 else ManifoldMixSTE(**kw)
     model.load_state_dict(fixture_state(fx), strict=True)
     return model.cuda()
@@ -936,3 +936,93 @@ def test_training_entry_reads_the_reference_file_formats(lib, raw_dataset_dir, t
     else:
         assert "test [all]:" in out and "pck" in out.lower()
     assert any(f.endswith(".pth") for _, _, fs in os.walk(tmp_path) for f in fs)
+
+
+def test_squared_loss_mode_vs_reference_fixture(lib):
+    """train.sq_loss=True: squared WTA + velocity terms and their gradients, multi-hypothesis and single-hypothesis,
+    against the reference's own loss functions (tests/golden/loss_sq.npz)."""
+    from manipose_amd import metrics as M
+    fx = load_fixture("loss_sq")
+    poses = dev(fx["poses"]).requires_grad_(True)
+    scores = dev(fx["scores"]).requires_grad_(True)
+    y = dev(fx["y"])
+    total, terms = M.rmcl_training_loss(poses, scores, y, sq_loss=True)
+    total.backward()
+    np.testing.assert_allclose([terms[k].item() for k in ("wloss", "score_reg", "vloss", "sreg")], fx["loss_terms"], rtol=2e-5)
+    close(poses.grad, fx["g_poses"], rtol=1e-4, atol=1e-8)
+    close(scores.grad, fx["g_scores"], rtol=1e-4, atol=1e-8)
+    val, idx = M.wta_l2_loss_and_activate_head(poses.detach(), y, weights=M.STANDARD_H36M_WEIGHTS, squared=True)
+    assert np.array_equal(idx.cpu().numpy(), fx["wta_idx"])
+    close(val, fx["wta_vals"], rtol=1e-5, atol=1e-8)
+    close(M.mean_velocity_error(poses.detach(), y, axis=2, squared=True) * 2.0, fx["loss_terms"][2], rtol=2e-5)
+    for nm, w_loss in (("w", True), ("nw", False)):
+        p1 = dev(fx["poses"][:, 0].copy()).requires_grad_(True)
+        tot, t = M.manifold_training_loss(p1, y, w_loss=w_loss, sq_loss=True)
+        tot.backward()
+        np.testing.assert_allclose([t[k].item() for k in ("wloss", "vloss", "sreg")], fx[f"single_{nm}.terms"], rtol=2e-5)
+        close(p1.grad, fx[f"single_{nm}.g"], rtol=1e-4, atol=1e-8)
+    close(M.weighted_mse_loss(dev(fx["poses"][:, 0].copy()), y, weights=M.STANDARD_H36M_WEIGHTS), fx["single_w.terms"][0], rtol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# model.rot_dim=4 (SURVEY 8f row 4): 4-D rotation representation (rotation_tools.py:60-116) in the decoder kernel and the engine
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_rot4_fk_decode_forward_backward_vs_reference_fixture(lib):
+    from manipose_amd import _lib, h36m_skeleton
+    from manipose_amd.architectures.pose_decoder import PoseDecoder
+    fx = load_fixture("decoder_rot4")
+    B, L = 3, 7
+    rot = dev(fx["rot4d"]).requires_grad_(True)
+    bl = dev(fx["bones"]).requires_grad_(True)
+    dec = PoseDecoder(h36m_skeleton(), rot_rep_dim=4)
+    poses = dec(rot, bl, torch.zeros(B * L, 3, device="cuda"))
+    close(poses, fx["poses"], rtol=1e-5, atol=2e-6)
+    (poses * dev(fx["gpos"])).sum().backward()
+    close(rot.grad, fx["g_rot4d"], rtol=2e-4, atol=2e-5)
+    close(bl.grad, fx["g_bones"], rtol=2e-4, atol=2e-5)
+    ident = torch.tensor([0.0, 1.0, 1.0, 0.0], device="cuda").repeat(1, 17, 1)
+    close(dec(ident, dev(fx["tpose_lens"])), fx["tpose"], atol=1e-7)
+    # strided C-ABI form the engine uses: 5 channels per joint (4-D rotation + score embedding), gradient leaves channel 4 alone
+    wide = torch.zeros(B * L, 17, 5, device="cuda")
+    wide[..., :4] = rot.detach()
+    out = torch.empty(B, 1, L, 17, 3, device="cuda")
+    _lib.check(lib.mp_fk_decode_fwd(wide.data_ptr(), 5, 4, bl.detach().reshape(B, 16).contiguous().data_ptr(), out.data_ptr(), B, 1, L, st()))
+    close(out.view(B * L, 17, 3), fx["poses"], rtol=1e-5, atol=2e-6)
+    assert lib.mp_fk_decode_fwd(wide.data_ptr(), 5, 5, bl.data_ptr(), out.data_ptr(), B, 1, L, st()) != 0      # only 4 and 6 exist
+
+
+def test_rot4_models_vs_reference(lib):
+    from manipose_amd.metrics import manifold_training_loss, rmcl_training_loss
+    fx = load_fixture("rmcl_tiny_rot4")
+    model = _build(fx).eval()
+    assert model.rotations_module.head[0].prediction_head.weight.shape[0] == 5
+    poses, scores = model(dev(fx["X"]))
+    close(poses, fx["poses"], rtol=1e-4, atol=2e-5)
+    close(scores, fx["scores"], rtol=1e-4, atol=1e-6)
+    total, terms = rmcl_training_loss(poses, scores, dev(fx["y"]))
+    np.testing.assert_allclose([terms[k].item() for k in ("wloss", "score_reg", "vloss", "sreg")], fx["loss_terms"], rtol=1e-4)
+    total.backward()
+    _check_grads(model, fx)
+    fx = load_fixture("manifold_k1_rot4")
+    model = _build(fx).eval()
+    pred = model(dev(fx["X"]))
+    close(pred, fx["poses"], rtol=1e-4, atol=2e-5)
+    total, _ = manifold_training_loss(pred, dev(fx["y"]))
+    np.testing.assert_allclose(total.item(), float(fx["loss_total"]), rtol=1e-4)
+    total.backward()
+    _check_grads(model, fx)
+
+
+def test_rot4_bf16_engine_and_training_step(lib):
+    """The 4-D variant on the bf16 engine through the fused trainer: finite loss that decreases over a few Adam steps."""
+    from manipose_amd.training import LiftingTrainer
+    fx = load_fixture("rmcl_tiny_rot4")
+    model = _build(fx)
+    model.precision = "bf16"
+    model._engine = None
+    tr = LiftingTrainer(model, lr=2e-3, sq_loss=True)
+    X, y = dev(fx["X"]), dev(fx["y"])
+    first = tr.train_step(X, y).sum().item()
+    for _ in range(8):
+        last = tr.train_step(X, y).sum().item()
+    assert np.isfinite(first) and np.isfinite(last) and last < first

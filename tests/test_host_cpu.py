@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/manipose_hip.h but not exported"
         assert n in _lib._SIGNATURES, f"{n} has no ctypes signature in manipose_amd/_lib.py"
-    assert lib.mp_abi_version() == 1
+    assert lib.mp_abi_version() == 2
 
 
 def test_state_dict_layout_matches_reference(golden_dir):
@@ -82,7 +82,7 @@ def test_no_cpu_fallback_and_argument_errors():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         rmcl_training_loss(torch.from_numpy(fx["poses"]), torch.from_numpy(fx["scores"]), torch.from_numpy(fx["y"]))
     lib = _lib.load()
-    rc = lib.mp_fk_decode_fwd(None, 6, None, None, 1, 1, 1, None)       # argument validation happens before any launch
+    rc = lib.mp_fk_decode_fwd(None, 6, 6, None, None, 1, 1, 1, None)       # argument validation happens before any launch
     assert rc == 1 and b"null" in lib.mp_last_error()
     cfg = _lib.ModelConfig(arch=7, num_frame=9, num_joints=17, num_bones=16, embed_dim_rot=32, depth_rot=1,
                            num_heads_rot=4, embed_dim_seg=16, depth_seg=1, num_heads_seg=4, n_hyp=3, max_batch=0)

@@ -269,3 +269,65 @@ def test_oracle_3dhp_ingest_matches_reference_loader(split):
     for i in range(len(p3)):
         np.testing.assert_array_equal(p3[i], fx[f"hp.{split}.p3.{i}"])
         np.testing.assert_array_equal(p2[i], fx[f"hp.{split}.p2.{i}"])
+
+
+def test_squared_loss_terms_and_grads():
+    """train.sq_loss=True: squared WTA / velocity terms (losses.py:46-72,96-97,110-116) against the reference's own functions."""
+    fx = load_fixture("loss_sq")
+    cfg = dict(orc.DEFAULT_TRAIN_CFG, sq_loss=True)
+    poses = torch.from_numpy(fx["poses"]).requires_grad_(True)
+    scores = torch.from_numpy(fx["scores"]).requires_grad_(True)
+    y = torch.from_numpy(fx["y"])
+    total, terms = orc.rmcl_training_loss(poses, scores, y, cfg)
+    total.backward()
+    np.testing.assert_allclose([terms[k].item() for k in ("wloss", "score_reg", "vloss", "sreg")], fx["loss_terms"], rtol=1e-6)
+    np.testing.assert_allclose(poses.grad.numpy(), fx["g_poses"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(scores.grad.numpy(), fx["g_scores"], rtol=1e-5, atol=1e-9)
+    val, idx = orc.wta_l2_loss_and_activate_head(poses.detach(), y, torch.tensor(orc.STANDARD_H36M_WEIGHTS), squared=True)
+    assert np.array_equal(idx.numpy(), fx["wta_idx"])
+    np.testing.assert_allclose(val.numpy(), fx["wta_vals"], rtol=1e-6)
+    for nm, w_loss in (("w", True), ("nw", False)):
+        p1 = torch.from_numpy(fx["poses"][:, 0].copy()).requires_grad_(True)
+        tot, t = orc.manifold_training_loss(p1, y, dict(cfg, w_loss=w_loss))
+        tot.backward()
+        np.testing.assert_allclose([t[k].item() for k in ("wloss", "vloss", "sreg")], fx[f"single_{nm}.terms"], rtol=1e-6)
+        np.testing.assert_allclose(p1.grad.numpy(), fx[f"single_{nm}.g"], rtol=1e-5, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# model.rot_dim=4 (SURVEY 8f row 4): the 4-D rotation representation, decoder and whole models
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_rot4_decoder_matches_reference_and_known_answer():
+    fx = load_fixture("decoder_rot4")
+    rot = torch.from_numpy(fx["rot4d"]).requires_grad_(True)
+    bl = torch.from_numpy(fx["bones"]).requires_grad_(True)
+    poses = orc.pose_decoder(rot, bl)
+    np.testing.assert_allclose(poses.detach().numpy(), fx["poses"], rtol=1e-5, atol=1e-6)
+    (poses * torch.from_numpy(fx["gpos"])).sum().backward()
+    np.testing.assert_allclose(rot.grad.numpy(), fx["g_rot4d"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(bl.grad.numpy(), fx["g_bones"], rtol=1e-4, atol=1e-6)
+    ident = torch.tensor([0.0, 1.0, 1.0, 0.0]).repeat(1, 17, 1)            # (c1, s1, c2, s2) of the identity rotation
+    np.testing.assert_allclose(orc.rotation_from_ortho4d(ident[0]).numpy(), np.broadcast_to(np.eye(3, dtype=np.float32), (17, 3, 3)), atol=0)
+    tp = orc.pose_decoder(ident, torch.from_numpy(fx["tpose_lens"]))
+    np.testing.assert_allclose(tp.numpy(), fx["tpose"], atol=1e-7)
+
+
+def test_rot4_models_forward_loss_grads():
+    fx = load_fixture("rmcl_tiny_rot4")
+    st, poses, scores, total, terms = _run_rmcl(fx)
+    assert st["rotations_module.head.0.prediction_head.weight"].shape[0] == 5
+    np.testing.assert_allclose(poses.detach().numpy(), fx["poses"], **TOL)
+    np.testing.assert_allclose(scores.detach().numpy(), fx["scores"], **TOL)
+    np.testing.assert_allclose(total.item(), float(fx["loss_total"]), rtol=1e-5)
+    for k, v in st.items():
+        np.testing.assert_allclose(v.grad.numpy(), fx["g::" + k], rtol=2e-4, atol=2e-6, err_msg=k)
+    fx = load_fixture("manifold_k1_rot4")
+    st = {k: v.requires_grad_(True) for k, v in fixture_state(fx).items()}
+    assert st["rotations_module.head.1.weight"].shape[0] == 4
+    pred = orc.manifold_forward(torch.from_numpy(fx["X"]), st, orc.oracle_cfg(fx["cfg"]))
+    np.testing.assert_allclose(pred.detach().numpy(), fx["poses"], **TOL)
+    total, _ = orc.manifold_training_loss(pred, torch.from_numpy(fx["y"]))
+    np.testing.assert_allclose(total.item(), float(fx["loss_total"]), rtol=1e-5)
+    total.backward()
+    for k, v in st.items():
+        np.testing.assert_allclose(v.grad.numpy(), fx["g::" + k], rtol=2e-4, atol=2e-6, err_msg=k)
