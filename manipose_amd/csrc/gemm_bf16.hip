@@ -696,36 +696,51 @@ static int launch_glds(const GemmB16Args& g, int splits, hipStream_t st) {
   return use_big_tile(g) ? launch_glds_bt<TRA, TRB, TC, EPI, 256>(g, splits, st) : launch_glds_bt<TRA, TRB, TC, EPI, 128>(g, splits, st);
 }
 
-// dW += sum of the split-K slabs, db += sum of the bias slabs, ONE launch: a float4 of outputs per thread, the slabs summed in their
-// fixed order (deterministic) with four independent loads in flight.
+// dW += sum of the split-K slabs, db += sum of the bias slabs, ONE launch.  A block owns 64 float4 outputs; its four waves each sum
+// a contiguous quarter of the slabs (eight independent loads in flight per lane), and wave 0 adds the four partial sums in fixed
+// order: deterministic, and four times the loads in flight of a thread-per-output loop (the kernel is latency-bound: 1-3 MB of
+// outputs, 21-64 slabs deep).
+constexpr int RS_OUT = 64;
 __global__ __launch_bounds__(256) void reduce_slabs_b16_kernel(const float* __restrict__ slabW, float* __restrict__ dW, long nW4,
                                                                const float* __restrict__ slabB, float* __restrict__ db, long nB4, int S) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float4 part[3][RS_OUT];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  long i = (long)blockIdx.x * RS_OUT + lane;
   const float* slab = slabW;
   float* out = dW;
   long n4 = nW4;
+  bool live = true;
   if (i >= nW4) {
     i -= nW4;
-    if (i >= nB4) return;
+    live = i < nB4;
     slab = slabB; out = db; n4 = nB4;
   }
-  const float4* p = reinterpret_cast<const float4*>(slab) + i;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  int k = 0;
-  for (; k + 4 <= S; k += 4) {
-    const float4 a = p[(long)k * n4], b = p[(long)(k + 1) * n4], c = p[(long)(k + 2) * n4], d = p[(long)(k + 3) * n4];
-    s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-    s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-    s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
-    s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+  if (live) {
+    const int per = (S + 3) >> 2, k0 = q * per, k1 = min(S, k0 + per);
+    const float4* p = reinterpret_cast<const float4*>(slab) + i;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(long)(k + u) * n4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; k < k1; ++k) {
+      const float4 a = p[(long)k * n4];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
   }
-  for (; k < S; ++k) {
-    const float4 a = p[(long)k * n4];
-    s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+  if (q > 0) part[q - 1][lane] = s;
+  __syncthreads();
+  if (q == 0 && live) {
+    float4 o = reinterpret_cast<float4*>(out)[i];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { s.x += part[r][lane].x; s.y += part[r][lane].y; s.z += part[r][lane].z; s.w += part[r][lane].w; }
+    o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+    reinterpret_cast<float4*>(out)[i] = o;
   }
-  float4 o = reinterpret_cast<float4*>(out)[i];
-  o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
-  reinterpret_cast<float4*>(out)[i] = o;
 }
 
 template <typename TA, int TRA, typename TB, int TRB, typename TC, int EPI>
@@ -786,7 +801,7 @@ int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, i
                   : launch_glds<1, 1, float, EPI_SLAB>(g, splits, st);
   if (rc) return rc;
   const long nW4 = (long)Nout * Kin / 4, nB4 = db != nullptr ? Nout / 4 : 0;        // Nout, Kin are multiples of 8
-  hipLaunchKernelGGL(reduce_slabs_b16_kernel, dim3(cdiv(nW4 + nB4, 256)), dim3(256), 0, st, slab, dW, nW4, g.bias_slab, db, nB4, splits);
+  hipLaunchKernelGGL(reduce_slabs_b16_kernel, dim3(cdiv(nW4, (long)RS_OUT) + cdiv(nB4, (long)RS_OUT)), dim3(256), 0, st, slab, dW, nW4, g.bias_slab, db, nB4, splits);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
