@@ -21,7 +21,8 @@ PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}                  # MI355X_MICROARC
 PEAK_HBM_GBPS = 8000.0                                         # HBM3E spec peak (measured copy peak on this pool: ~5.5-6.3 TB/s)
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction of
 # MI355X_MICROARCH.md section HBM, + WRITE_SIZE), see profiles/README.md; keyed by (precision, windows per GPU).
-PMC_TRAFFIC_PER_LAUNCH = {("bf16", 64): 1210.2e6}   # profiles/r01_final_bf16_B64_pmc_hbm_traffic.csv, last row: gemm_bf16_persist_kernel, all instantiations
+# profiles/r01_final_bf16_B{79,64}_pmc_hbm_traffic.csv, last row: gemm_bf16_persist_kernel, all instantiations (2 x FETCH_SIZE + WRITE_SIZE)
+PMC_TRAFFIC_PER_LAUNCH = {("bf16", 79): 1493.9e6, ("bf16", 64): 1210.2e6}
 
 
 def host_cores():
@@ -67,7 +68,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("MANIPOSE_BENCH_BATCH", "64")), help="windows per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MANIPOSE_BENCH_BATCH", "79")),
+                    help="windows per GPU (79: ceil(79*4131/256) = 1275 row panels, so the 2 / 4 / 6 column tiles of the four Linear shapes "
+                         "give 9.96 / 19.9 / 29.9 rounds of 256 persistent workgroups - no nearly empty last round; 64 gives 8.07 / 16.1 / 24.2)")
     ap.add_argument("--frames", type=int, default=243)
     ap.add_argument("--hyp", type=int, default=5)
     ap.add_argument("--precision", default=os.environ.get("MANIPOSE_PRECISION", "bf16"), choices=["bf16", "fp32"],

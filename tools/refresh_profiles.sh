@@ -5,7 +5,7 @@
 #   <tag>_pmc_hbm_traffic.csv         per-kernel FETCH_SIZE / WRITE_SIZE averages from two separate --pmc passes
 # The files are written under gpurun_out/ (merged back by gpurun); copy them into profiles/ afterwards.
 set -eu
-TAG="${1:-r01_final_bf16_B64}"
+TAG="${1:-r01_final_bf16_B79}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/profiles_new; rm -rf "$O"; mkdir -p "$O"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$O/stats.log" 2>&1
