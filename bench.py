@@ -37,7 +37,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MANIPOSE_CPU_THREADS", "64"))))
 
 
-def cpu_baseline(T, K, steps=3):
+def cpu_baseline(T, K, steps=10):
     """Oracle (CPU restatement of the reference, fp32, torch autograd + torch.optim.Adam) on a bounded sample:
     B=1 window of the same workload, 1 warm-up + `steps` timed training steps."""
     import torch

@@ -171,3 +171,28 @@ def test_pose_flip_semantics():
     a = orc.aggregate(pose_flip((hyp.clone(),), sk)[0], sc)
     b = pose_flip((orc.aggregate(hyp, sc),), sk)[0]
     np.testing.assert_allclose(a.numpy(), b.numpy(), atol=1e-6)
+
+
+def test_epoch_batches_deal_every_window_to_exactly_one_rank():
+    """hpe/_entry.py::epoch_batches (DistributedSampler-style dealing of the shuffled window indices, drop_last=False)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hpe"))
+    from _entry import epoch_batches
+
+    class FakeGen:
+        def __len__(self):
+            return 37
+
+        def batch(self, idx):
+            return list(idx), None
+
+    seen = []
+    for rank in range(3):
+        got = [b for b, _ in epoch_batches(FakeGen(), 4, shuffle=True, rank=rank, world=3, seed=5)]
+        assert all(len(b) == 4 for b in got[:-1]) and 1 <= len(got[-1]) <= 4
+        seen += [i for b in got for i in b]
+    assert sorted(seen) == list(range(37))
+    a = [b for b, _ in epoch_batches(FakeGen(), 4, shuffle=True, rank=1, world=3, seed=5)]
+    b = [b for b, _ in epoch_batches(FakeGen(), 4, shuffle=True, rank=1, world=3, seed=6)]
+    assert a != b                                                     # a new permutation every epoch
+    assert [i for bb, _ in epoch_batches(FakeGen(), 5, shuffle=False) for i in bb] == list(range(37))
