@@ -238,6 +238,12 @@ def run(argv, extra_defaults=None):
         model.load_state_dict(ck["model_pos"] if "model_pos" in ck else ck)
     model.max_batch_hint = max(cfg.train.batch_size, 2 * cfg.train.batch_size_test)      # x2: flip-TTA batches the mirrored copy
     model = model.to(dev)
+    if cfg.train.get("rigid_seg_reg", 0) > 0:
+        # main_h36m_lifting.py:170-177 permutes a 4-D (B, L, J, 3) prediction: the term exists for single-hypothesis models only, and on a
+        # manifold model (constant segment lengths over a window by construction) it is identically 0
+        raise NotImplementedError("train.rigid_seg_reg > 0: segments are rigid by construction in the manifold models this entry point builds")
+    if cfg.train.get("lat_sym_regularization", 0) > 0:
+        print("warning: Lateral symmetry regularization is not implemented yet!", flush=True)      # as main_h36m_lifting.py:109-110
     trainer = LiftingTrainer(model, lr=cfg.train.lr, weight_decay=1e-6, w_loss=cfg.train.w_loss, vel_loss=cfg.train.vel_loss,
                              smooth_reg=cfg.train.smooth_reg, rmcl_score_reg=cfg.train.rmcl_score_reg, seed=cfg.run.seed,
                              sq_loss=cfg.train.sq_loss)
