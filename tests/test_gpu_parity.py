@@ -1026,3 +1026,45 @@ def test_rot4_bf16_engine_and_training_step(lib):
     for _ in range(8):
         last = tr.train_step(X, y).sum().item()
     assert np.isfinite(first) and np.isfinite(last) and last < first
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config5_T81_K5_eval_mpjpe_pck_auc_vs_oracle(lib, precision):
+    """BASELINE config #5 shape (MPI-INF-3DHP lifting: T=81, K=5, full width) through the evaluation path of the entry points
+    (flip test-time augmentation batched into one forward, weighted-average / best-score / oracle aggregation, MPJPE in mm,
+    3DPCK@150 mm / AUC, P-MPJPE) against the CPU oracle composing the same procedure (eval_utils.py:16-223, pck.py:92-199) on
+    identical synthetic batches."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hpe"))
+    from _entry import evaluate
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    cfg = dict(orc.FULL_CFG, T=81)
+    st_ = orc.make_state(cfg, seed=5)
+    model = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=81, drop_path_rate=0.0)
+    model.load_state_dict(st_, strict=True)
+    model.precision = precision
+    model = model.cuda().eval()
+    X, y = orc.synthetic_batch(2, 81, seed=7)
+    y = 0.25 * y                                                   # errors around the 150 mm threshold, so PCK / AUC are informative
+    res = evaluate(model, X.cuda(), y.cuda(), batch=2, tta=True, analytics=True)
+    with torch.no_grad():
+        ocfg = orc.oracle_cfg(cfg)
+        p0, s0 = orc.rmcl_manifold_forward(X, st_, ocfg)
+        p1, s1 = orc.rmcl_manifold_forward(orc.flip_pose(X), st_, ocfg)
+        p1 = orc.flip_pose(p1)
+        agg = (orc.aggregate(p0, s0, "weighted_ave") + orc.aggregate(p1, s1, "weighted_ave")) / 2
+        best = (orc.aggregate(p0, s0, "best_score") + orc.aggregate(p1, s1, "best_score")) / 2
+        orac = (orc.aggregate(p0, mode="oracle", ground_truth=y)[1] + orc.aggregate(p1, mode="oracle", ground_truth=y)[1]) / 2
+        want = {"mpjpe": 1000 * orc.mpjpe_error(agg, y).item(), "ps_oracle_mpjpe": 1000 * orc.mpjpe_error(best, y).item(),
+                "oracle_mpjpe": 1000 * orc.mpjpe_error(orac, y).item()}
+        pck, auc = orc.keypoint_3d_pck_auc(1000 * agg.reshape(-1, 17, 3), 1000 * y.reshape(-1, 17, 3))
+        pmp = 1000 * orc.p_mpjpe(agg.reshape(-1, 17, 3), y.reshape(-1, 17, 3)).item()
+    tol_mm = 0.1 if precision == "fp32" else 10.0                   # north star: 0.1 mm; bf16: the documented drift bound
+    for k, v in want.items():
+        assert abs(res[k] - v) <= tol_mm, (k, res[k], v)
+    a = res["analytics"]
+    assert abs(a["mpjpe"] - want["mpjpe"]) <= tol_mm and abs(a["p_mpjpe"] - pmp) <= tol_mm
+    tol_pct = 0.2 if precision == "fp32" else 5.0
+    assert abs(a["pck"] - pck.item()) <= tol_pct and abs(a["auc"] - auc.item()) <= tol_pct, (a["pck"], pck.item(), a["auc"], auc.item())
+    assert 1.0 < a["pck"] < 99.0
+    print(f"T=81 K=5 {precision}: MPJPE {res['mpjpe']:.3f} mm (oracle {want['mpjpe']:.3f}), PCK {a['pck']:.2f} ({pck.item():.2f}), AUC {a['auc']:.2f} ({auc.item():.2f})")
