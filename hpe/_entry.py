@@ -248,11 +248,12 @@ def run(argv, extra_defaults=None):
                              smooth_reg=cfg.train.smooth_reg, rmcl_score_reg=cfg.train.rmcl_score_reg, seed=cfg.run.seed,
                              sq_loss=cfg.train.sq_loss)
     broadcast_parameters(model.flat_parameters())
-    start_epoch = 0
+    start_epoch, sched_state = 0, None
     if cfg.run.checkpoint_params:
         st = torch.load(cfg.run.checkpoint_params, map_location="cpu")
         trainer.opt.load_state_dict(st["optimizer"])
         start_epoch = st["epoch"]
+        sched_state = st.get("scheduler")
     T, B, Bt = cfg.data.seq_len, cfg.train.batch_size, cfg.train.batch_size_test
     out_dir = os.path.join(os.getcwd(), cfg.run.experiment)
     if rank == 0:
@@ -267,7 +268,12 @@ def run(argv, extra_defaults=None):
     else:
         Xv, yv = synthetic_windows(4 * Bt, T, dev, seed=10_000)
         valid_batches = lambda: tensor_batches(Xv, yv, Bt)
-    best_val, bad_epochs, lr = 1e10, 0, cfg.train.lr
+    from manipose_amd.optim import make_lr_scheduler
+    sched = make_lr_scheduler(trainer.opt, cfg.train.lr_scheduler, cfg.train.epochs, cfg.train.n_annealing, cfg.train.lr_min,
+                              cfg.train.lr_patience, cfg.train.lr_threshold)            # main_h36m_lifting.py:243-264
+    if sched_state is not None and sched_state.get("kind") == sched.state_dict()["kind"]:
+        sched.load_state_dict(sched_state)
+    best_val = 1e10
     if cfg.run.train:
         if real:
             gen = window_generator(cfg, seqs["train"], True, dev)       # sequences resident in HBM, one gather kernel per batch
@@ -292,25 +298,21 @@ def run(argv, extra_defaults=None):
             if (epoch + 1) % cfg.train.valid_epoch_interval == 0:
                 model.eval()
                 val = sum(trainer.eval_loss(xb, yb).sum().item() for xb, yb in valid_batches())
-                if val < best_val * (1 - cfg.train.lr_threshold):     # ReduceLROnPlateau(mode=min, rel threshold)
-                    bad_epochs = 0
-                else:
-                    bad_epochs += 1
-                if val < best_val:
+                if best_val > val:                                     # main_h36m_lifting.py:374-398
                     best_val = val
                     if rank == 0:
-                        save_state(model, trainer, {"best": best_val, "bad_epochs": bad_epochs}, epoch, out_dir, "best_val")
-                if cfg.train.lr_scheduler == "plateau" and bad_epochs > cfg.train.lr_patience:
-                    lr = max(lr * 0.5, cfg.train.lr_min)
-                    trainer.opt.param_groups[0]["lr"] = lr
-                    bad_epochs = 0
+                        save_state(model, trainer, sched.state_dict(), epoch, out_dir, "best_val")
+                if cfg.train.lr_scheduler == "plateau":                # :400-403: the plateau scheduler watches the running best
+                    sched.step(best_val)
+                else:
+                    sched.step()
             if rank == 0:
                 print(f"epoch {epoch}: tr_loss {sum(terms):.5f} wloss {terms[0]:.5f} score_reg {terms[1]:.5f} vloss {terms[2]:.5f} "
-                      f"sreg {terms[3]:.5f} | best val {best_val:.5f} lr {lr:.2e}", flush=True)
+                      f"sreg {terms[3]:.5f} | best val {best_val:.5f} lr {sched.get_last_lr()[0]:.2e}", flush=True)
             if (epoch + 1) % cfg.train.mpjpe_epoch_interval == 0 and rank == 0:
                 print("   eval:", {k: round(v, 3) for k, v in evaluate(model, valid_batches(), tta=cfg.train.tta).items()}, flush=True)
         if rank == 0:
-            save_state(model, trainer, {"best": best_val, "bad_epochs": bad_epochs}, cfg.train.epochs, out_dir, "end")
+            save_state(model, trainer, sched.state_dict(), cfg.train.epochs, out_dir, "end")
     if cfg.run.test and rank == 0:
         groups = {"synthetic": valid_batches}
         if real:        # per action (H36M: subject S11, main_h36m_lifting.py:884-990) or the whole 3DHP test set (main_3dhp.py:800-910)

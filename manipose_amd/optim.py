@@ -63,3 +63,74 @@ class FusedAdam:
         dev = self.model.flat_parameters().device
         self.exp_avg = sd["exp_avg"].to(dev) if sd["exp_avg"] is not None else None
         self.exp_avg_sq = sd["exp_avg_sq"].to(dev) if sd["exp_avg_sq"] is not None else None
+
+
+class CosineAnnealingLR:
+    """torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max, eta_min) as the reference builds it (main_h36m_lifting.py:244-250),
+    in closed form, for optimizers that only expose ``param_groups[0]["lr"]``; ``step()`` once per epoch."""
+
+    def __init__(self, optimizer, T_max: int, eta_min: float = 0.0):
+        self.optimizer, self.T_max, self.eta_min = optimizer, int(T_max), float(eta_min)
+        self.base_lr = float(optimizer.param_groups[0]["lr"])
+        self.last_epoch = 0
+
+    def get_last_lr(self):
+        return [self.optimizer.param_groups[0]["lr"]]
+
+    def step(self, metric=None) -> None:
+        import math
+        self.last_epoch += 1
+        lr = self.eta_min + (self.base_lr - self.eta_min) * (1 + math.cos(math.pi * self.last_epoch / self.T_max)) / 2
+        self.optimizer.param_groups[0]["lr"] = lr
+
+    def state_dict(self):
+        return {"kind": "cosine", "T_max": self.T_max, "eta_min": self.eta_min, "base_lr": self.base_lr, "last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd) -> None:
+        self.T_max, self.eta_min, self.base_lr, self.last_epoch = sd["T_max"], sd["eta_min"], sd["base_lr"], sd["last_epoch"]
+
+
+class ReduceLROnPlateau:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode="min", threshold_mode="rel", cooldown=0, eps=1e-8) as the reference builds it
+    (main_h36m_lifting.py:251-259); ``step(metric)`` after every validation."""
+
+    def __init__(self, optimizer, mode: str = "min", factor: float = 0.5, patience: int = 10, threshold: float = 1e-4, min_lr: float = 0.0,
+                 eps: float = 1e-8):
+        if mode != "min":
+            raise ValueError("only mode='min' is used by the lifting entry points")
+        self.optimizer, self.factor, self.patience, self.threshold, self.min_lr, self.eps = optimizer, factor, patience, threshold, min_lr, eps
+        self.best, self.num_bad_epochs, self.last_epoch = float("inf"), 0, 0
+
+    def get_last_lr(self):
+        return [self.optimizer.param_groups[0]["lr"]]
+
+    def step(self, metric) -> None:
+        current = float(metric)
+        self.last_epoch += 1
+        if current < self.best * (1.0 - self.threshold):
+            self.best, self.num_bad_epochs = current, 0
+        else:
+            self.num_bad_epochs += 1
+        if self.num_bad_epochs > self.patience:
+            old = float(self.optimizer.param_groups[0]["lr"])
+            new = max(old * self.factor, self.min_lr)
+            if old - new > self.eps:
+                self.optimizer.param_groups[0]["lr"] = new
+            self.num_bad_epochs = 0
+
+    def state_dict(self):
+        return {"kind": "plateau", "best": self.best, "num_bad_epochs": self.num_bad_epochs, "last_epoch": self.last_epoch,
+                "factor": self.factor, "patience": self.patience, "threshold": self.threshold, "min_lr": self.min_lr}
+
+    def load_state_dict(self, sd) -> None:
+        self.best, self.num_bad_epochs, self.last_epoch = sd["best"], sd["num_bad_epochs"], sd["last_epoch"]
+
+
+def make_lr_scheduler(optimizer, kind: str, epochs: int, n_annealing: int = 1, lr_min: float = 0.0, lr_patience: int = 11,
+                      lr_threshold: float = 0.1):
+    """The scheduler choice of the reference's train() (main_h36m_lifting.py:243-264)."""
+    if kind == "cosine":
+        return CosineAnnealingLR(optimizer, T_max=epochs // n_annealing, eta_min=lr_min)
+    if kind == "plateau":
+        return ReduceLROnPlateau(optimizer, mode="min", factor=0.5, min_lr=lr_min, patience=lr_patience, threshold=lr_threshold)
+    raise ValueError(f"Accepted lr_scheduler values are 'cosine' and 'plateau'.Got {kind}.")

@@ -196,3 +196,41 @@ def test_epoch_batches_deal_every_window_to_exactly_one_rank():
     b = [b for b, _ in epoch_batches(FakeGen(), 4, shuffle=True, rank=1, world=3, seed=6)]
     assert a != b                                                     # a new permutation every epoch
     assert [i for bb, _ in epoch_batches(FakeGen(), 5, shuffle=False) for i in bb] == list(range(37))
+
+
+def test_lr_schedulers_follow_torch():
+    """CosineAnnealingLR / ReduceLROnPlateau restated for the fused optimizer (manipose_amd/optim.py) against torch's own, configured as
+    the reference does (main_h36m_lifting.py:243-264)."""
+    from manipose_amd.optim import make_lr_scheduler
+
+    class Opt:
+        def __init__(self, lr):
+            self.param_groups = [{"lr": lr}]
+
+    def torch_opt(lr):
+        return torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=lr)
+
+    mine, ref = Opt(4e-5), torch_opt(4e-5)
+    a = make_lr_scheduler(mine, "cosine", epochs=20, n_annealing=2, lr_min=1e-6)
+    b = torch.optim.lr_scheduler.CosineAnnealingLR(ref, T_max=10, eta_min=1e-6)
+    ref.step()                                                  # torch wants an optimizer step before the first scheduler step
+    for _ in range(25):
+        a.step(); b.step()
+        assert abs(mine.param_groups[0]["lr"] - ref.param_groups[0]["lr"]) <= 1e-12
+    mine, ref = Opt(4e-5), torch_opt(4e-5)
+    a = make_lr_scheduler(mine, "plateau", epochs=0, lr_min=1e-6, lr_patience=2, lr_threshold=0.1)
+    b = torch.optim.lr_scheduler.ReduceLROnPlateau(ref, mode="min", factor=0.5, min_lr=1e-6, patience=2, threshold=0.1)
+    g = torch.Generator().manual_seed(0)
+    best = 1e10
+    for i in range(60):
+        val = float(10.0 / (1 + 0.2 * i) + 0.3 * torch.rand(1, generator=g))
+        best = min(best, val)
+        a.step(best); b.step(best)
+        assert abs(mine.param_groups[0]["lr"] - ref.param_groups[0]["lr"]) <= 1e-15, i
+    assert mine.param_groups[0]["lr"] < 4e-5
+    st = a.state_dict()
+    c = make_lr_scheduler(Opt(1.0), "plateau", epochs=0)
+    c.load_state_dict(st)
+    assert c.best == a.best and c.num_bad_epochs == a.num_bad_epochs
+    with pytest.raises(ValueError):
+        make_lr_scheduler(mine, "step", epochs=10)
