@@ -273,7 +273,8 @@ def run(argv, extra_defaults=None):
                               cfg.train.lr_patience, cfg.train.lr_threshold)            # main_h36m_lifting.py:243-264
     if sched_state is not None and sched_state.get("kind") == sched.state_dict()["kind"]:
         sched.load_state_dict(sched_state)
-    best_val = 1e10
+    best_val, best_mpjpe = 1e10, 1e10
+    train_curve, valid_curve = [], []
     if cfg.run.train:
         if real:
             gen = window_generator(cfg, seqs["train"], True, dev)       # sequences resident in HBM, one gather kernel per batch
@@ -295,9 +296,11 @@ def run(argv, extra_defaults=None):
                 acc += trainer.train_step(X, y)                      # device-side accumulation: no per-step host sync
                 steps += 1
             terms = (acc / max(steps, 1)).tolist()
+            train_curve.append(sum(terms))
             if (epoch + 1) % cfg.train.valid_epoch_interval == 0:
                 model.eval()
                 val = sum(trainer.eval_loss(xb, yb).sum().item() for xb, yb in valid_batches())
+                valid_curve.append(val)
                 if best_val > val:                                     # main_h36m_lifting.py:374-398
                     best_val = val
                     if rank == 0:
@@ -309,10 +312,16 @@ def run(argv, extra_defaults=None):
             if rank == 0:
                 print(f"epoch {epoch}: tr_loss {sum(terms):.5f} wloss {terms[0]:.5f} score_reg {terms[1]:.5f} vloss {terms[2]:.5f} "
                       f"sreg {terms[3]:.5f} | best val {best_val:.5f} lr {sched.get_last_lr()[0]:.2e}", flush=True)
-            if (epoch + 1) % cfg.train.mpjpe_epoch_interval == 0 and rank == 0:
-                print("   eval:", {k: round(v, 3) for k, v in evaluate(model, valid_batches(), tta=cfg.train.tta).items()}, flush=True)
+            if (epoch + 1) % cfg.train.mpjpe_epoch_interval == 0 and rank == 0:      # main_h36m_lifting.py:405-470
+                ev = evaluate(model, valid_batches(), tta=cfg.train.tta)
+                print("   eval:", {k: round(v, 3) for k, v in ev.items()}, flush=True)
+                if ev["mpjpe"] < best_mpjpe:
+                    best_mpjpe = ev["mpjpe"]
+                    save_state(model, trainer, sched.state_dict(), epoch, out_dir, "best_mpjpe")
         if rank == 0:
             save_state(model, trainer, sched.state_dict(), cfg.train.epochs, out_dir, "end")
+            np.save(os.path.join(out_dir, "train_loss.npy"), np.array(train_curve))           # :503-504
+            np.save(os.path.join(out_dir, "valid_loss.npy"), np.array(valid_curve))
     if cfg.run.test and rank == 0:
         groups = {"synthetic": valid_batches}
         if real:        # per action (H36M: subject S11, main_h36m_lifting.py:884-990) or the whole 3DHP test set (main_3dhp.py:800-910)
