@@ -273,7 +273,7 @@ def run(argv, extra_defaults=None):
                               cfg.train.lr_patience, cfg.train.lr_threshold)            # main_h36m_lifting.py:243-264
     if sched_state is not None and sched_state.get("kind") == sched.state_dict()["kind"]:
         sched.load_state_dict(sched_state)
-    best_val, best_mpjpe = 1e10, 1e10
+    best_val, best_eval = 1e10, {}
     train_curve, valid_curve = [], []
     if cfg.run.train:
         if real:
@@ -315,9 +315,10 @@ def run(argv, extra_defaults=None):
             if (epoch + 1) % cfg.train.mpjpe_epoch_interval == 0 and rank == 0:      # main_h36m_lifting.py:405-470
                 ev = evaluate(model, valid_batches(), tta=cfg.train.tta)
                 print("   eval:", {k: round(v, 3) for k, v in ev.items()}, flush=True)
-                if ev["mpjpe"] < best_mpjpe:
-                    best_mpjpe = ev["mpjpe"]
-                    save_state(model, trainer, sched.state_dict(), epoch, out_dir, "best_mpjpe")
+                for key, tag in (("mpjpe", "best_mpjpe"), ("oracle_mpjpe", "best_oracle_mpjpe"), ("ps_oracle_mpjpe", "best_ps_oracle_mpjpe")):
+                    if key in ev and ev[key] < best_eval.get(key, 1e10):           # tags of main_h36m_lifting.py:440-489
+                        best_eval[key] = ev[key]
+                        save_state(model, trainer, sched.state_dict(), epoch, out_dir, tag)
         if rank == 0:
             save_state(model, trainer, sched.state_dict(), cfg.train.epochs, out_dir, "end")
             np.save(os.path.join(out_dir, "train_loss.npy"), np.array(train_curve))           # :503-504

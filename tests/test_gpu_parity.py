@@ -793,6 +793,19 @@ def test_training_entry_runs_on_resident_sequences(lib, tmp_path, monkeypatch):
                 "model.nheads_seg=4", "multi_hyp.n_hyp=3", "data.synthetic_sequences=6", "run.test=true"])
     assert np.isfinite(best) and best < 1e9
     assert any(f.endswith(".pth") for _, _, fs in os.walk(tmp_path) for f in fs)
+    # resume (run.checkpoint_model / run.checkpoint_params, main_h36m_lifting.py:225-285,755-761): weights, Adam moments, scheduler, epoch
+    d = os.path.join(str(tmp_path), "default")
+    for f in ("model_end.pth", "params_end.pth", "model_best_val.pth", "params_best_val.pth", "train_loss.npy", "valid_loss.npy"):
+        assert os.path.exists(os.path.join(d, f)), f
+    st = torch.load(os.path.join(d, "params_end.pth"), map_location="cpu")
+    assert st["epoch"] == 1 and st["optimizer"]["step"] == 2 and st["scheduler"]["kind"] == "plateau"
+    best2 = run(["train.epochs=2", "train.steps_per_epoch=2", "train.batch_size=4", "train.batch_size_test=2", "data.seq_len=27",
+                 "model.channels=64", "model.layers=2", "model.nheads=4", "model.channels_seg=32", "model.layers_seg=1",
+                 "model.nheads_seg=4", "multi_hyp.n_hyp=3", "data.synthetic_sequences=6", "run.test=false", "run.experiment=resumed",
+                 f"run.checkpoint_model={d}/model_end.pth", f"run.checkpoint_params={d}/params_end.pth", "train.mpjpe_epoch_interval=1"])
+    st2 = torch.load(os.path.join(str(tmp_path), "resumed", "params_end.pth"), map_location="cpu")
+    assert st2["optimizer"]["step"] == 4 and np.isfinite(best2)        # one more epoch of two steps on top of the restored moments
+    assert os.path.exists(os.path.join(str(tmp_path), "resumed", "model_best_mpjpe.pth"))
 
 
 @pytest.mark.parametrize("mt", ["random", "random_left_arm_right_leg", "structured_joint", "structured_frame", "noisy", "all"])
