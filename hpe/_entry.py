@@ -164,12 +164,13 @@ def tensor_batches(X, y, batch):
 
 
 @torch.no_grad()
-def evaluate(model, X, y=None, batch=None, tta=True, analytics=False):
+def evaluate(model, X, y=None, batch=None, tta=True, analytics=False, distributed=False):
     """MPJPE (mm) of the aggregated / best-score / oracle hypotheses, with the reference's flip test-time augmentation
     (hpe/eval_utils.py:16-223).  The flipped copy is batched with the original into ONE forward of 2B windows
     instead of a second pass.  ``analytics=True`` adds the reference's evaluation table (main_h36m_lifting.py:933-990,
     main_3dhp.py:860-910: MPSSE, MPSCE, segment-length error, MSE / error variance, 3DPCK, AUC, per-joint errors) of the
-    aggregated prediction in millimetres, from the one-pass HIP analytics kernel."""
+    aggregated prediction in millimetres, from the one-pass HIP analytics kernel.  ``distributed=True``: every rank
+    evaluates its own share of the batches and the error sums / frame counts are sum-reduced at the end."""
     from manipose_amd import RMCLManifoldMixSTE
     from manipose_amd.augmentations import pose_flip
     from manipose_amd.metrics import mpjpe_error
@@ -209,10 +210,23 @@ def evaluate(model, X, y=None, batch=None, tta=True, analytics=False):
         if acc is not None:
             acc.add(pose_analytics(pred.detach().contiguous(), yb.contiguous(), pred_scale=1000.0, gt_scale=1000.0))
             acc.add_procrustes(procrustes_sums(pred.detach(), yb, pred_scale=1000.0, gt_scale=1000.0))
+    if distributed:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor([sums["mpjpe"], sums["ps_oracle_mpjpe"], sums["oracle_mpjpe"], float(n)], dtype=torch.float64, device=sk_device(model))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            sums = {"mpjpe": t[0].item(), "ps_oracle_mpjpe": t[1].item(), "oracle_mpjpe": t[2].item()}
+            n = t[3].item()
+            if acc is not None:
+                acc.all_reduce()
     out = {k: 1000.0 * v / n for k, v in sums.items() if v > 0}
     if acc is not None:
         out["analytics"] = acc.report()
     return out
+
+
+def sk_device(model):
+    return next(model.parameters()).device
 
 
 def save_state(model, trainer, scheduler_state, epoch, folder, tag=None):
@@ -259,15 +273,27 @@ def run(argv, extra_defaults=None):
     if rank == 0:
         os.makedirs(out_dir, exist_ok=True)
     real = bool(cfg.data.data_dir)
+    # evaluation is sharded over the ranks like training whenever every rank gets at least one window; the error sums and
+    # frame counts are sum-reduced inside evaluate(); otherwise rank 0 evaluates alone
+    def sharded(gen):
+        share = world > 1 and len(gen) >= world
+        return (lambda: epoch_batches(gen, Bt, shuffle=False, rank=rank if share else 0, world=world if share else 1)), share
+
+    def allsum(v):
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t)
+        return t.item()
+
     if real:
         seqs = load_sequences(cfg, dev)
         gen_valid = window_generator(cfg, seqs["valid"], False, dev)
-        valid_batches = lambda: epoch_batches(gen_valid, Bt, shuffle=False)
+        valid_batches, valid_shared = sharded(gen_valid)
         if rank == 0:
             print(f">>> Validation dataset length: {len(gen_valid)} windows of {T} frames", flush=True)
     else:
         Xv, yv = synthetic_windows(4 * Bt, T, dev, seed=10_000)
-        valid_batches = lambda: tensor_batches(Xv, yv, Bt)
+        valid_shared = world > 1 and Xv.shape[0] >= world
+        valid_batches = (lambda: tensor_batches(Xv[rank::world], yv[rank::world], Bt)) if valid_shared else (lambda: tensor_batches(Xv, yv, Bt))
     from manipose_amd.optim import make_lr_scheduler
     sched = make_lr_scheduler(trainer.opt, cfg.train.lr_scheduler, cfg.train.epochs, cfg.train.n_annealing, cfg.train.lr_min,
                               cfg.train.lr_patience, cfg.train.lr_threshold)            # main_h36m_lifting.py:243-264
@@ -300,6 +326,8 @@ def run(argv, extra_defaults=None):
             if (epoch + 1) % cfg.train.valid_epoch_interval == 0:
                 model.eval()
                 val = sum(trainer.eval_loss(xb, yb).sum().item() for xb, yb in valid_batches())
+                if valid_shared:
+                    val = allsum(val)
                 valid_curve.append(val)
                 if best_val > val:                                     # main_h36m_lifting.py:374-398
                     best_val = val
@@ -312,32 +340,34 @@ def run(argv, extra_defaults=None):
             if rank == 0:
                 print(f"epoch {epoch}: tr_loss {sum(terms):.5f} wloss {terms[0]:.5f} score_reg {terms[1]:.5f} vloss {terms[2]:.5f} "
                       f"sreg {terms[3]:.5f} | best val {best_val:.5f} lr {sched.get_last_lr()[0]:.2e}", flush=True)
-            if (epoch + 1) % cfg.train.mpjpe_epoch_interval == 0 and rank == 0:      # main_h36m_lifting.py:405-470
-                ev = evaluate(model, valid_batches(), tta=cfg.train.tta)
-                print("   eval:", {k: round(v, 3) for k, v in ev.items()}, flush=True)
+            if (epoch + 1) % cfg.train.mpjpe_epoch_interval == 0 and (rank == 0 or valid_shared):      # main_h36m_lifting.py:405-470
+                ev = evaluate(model, valid_batches(), tta=cfg.train.tta, distributed=valid_shared)
+                if rank == 0:
+                    print("   eval:", {k: round(v, 3) for k, v in ev.items()}, flush=True)
                 for key, tag in (("mpjpe", "best_mpjpe"), ("oracle_mpjpe", "best_oracle_mpjpe"), ("ps_oracle_mpjpe", "best_ps_oracle_mpjpe")):
                     if key in ev and ev[key] < best_eval.get(key, 1e10):           # tags of main_h36m_lifting.py:440-489
                         best_eval[key] = ev[key]
-                        save_state(model, trainer, sched.state_dict(), epoch, out_dir, tag)
+                        if rank == 0:
+                            save_state(model, trainer, sched.state_dict(), epoch, out_dir, tag)
         if rank == 0:
             save_state(model, trainer, sched.state_dict(), cfg.train.epochs, out_dir, "end")
             np.save(os.path.join(out_dir, "train_loss.npy"), np.array(train_curve))           # :503-504
             np.save(os.path.join(out_dir, "valid_loss.npy"), np.array(valid_curve))
-    if cfg.run.test and rank == 0:
-        groups = {"synthetic": valid_batches}
+    if cfg.run.test:
+        groups = {"synthetic": (valid_batches, valid_shared)}
         if real:        # per action (H36M: subject S11, main_h36m_lifting.py:884-990) or the whole 3DHP test set (main_3dhp.py:800-910)
-            groups = {}
-            for name, sq in seqs["test"].items():
-                g = window_generator(cfg, sq, False, dev)
-                groups[name] = (lambda g=g: epoch_batches(g, Bt, shuffle=False))
+            groups = {name: sharded(window_generator(cfg, sq, False, dev)) for name, sq in seqs["test"].items()}
         rows = {}
-        for name, make in groups.items():
-            res = evaluate(model, make(), tta=cfg.train.tta, analytics=True)
+        for name, (make, shared) in groups.items():
+            if rank != 0 and not shared:
+                continue
+            res = evaluate(model, make(), tta=cfg.train.tta, analytics=True, distributed=shared)
             table = res.pop("analytics")
             rows[name] = res
-            print(f"test [{name}]:", {k: round(v, 3) for k, v in res.items()}, flush=True)
-            print(f"test analytics [{name}] (mm):", {k: round(v, 4) for k, v in table.items() if not isinstance(v, list)}, flush=True)
-        if len(rows) > 1:
+            if rank == 0:
+                print(f"test [{name}]:", {k: round(v, 3) for k, v in res.items()}, flush=True)
+                print(f"test analytics [{name}] (mm):", {k: round(v, 4) for k, v in table.items() if not isinstance(v, list)}, flush=True)
+        if len(rows) > 1 and rank == 0:
             keys = sorted({k for r in rows.values() for k in r})
             print("test [average over groups]:", {k: round(float(np.mean([r[k] for r in rows.values() if k in r])), 3) for k in keys}, flush=True)
     return best_val

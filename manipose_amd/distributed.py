@@ -16,6 +16,10 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hooks (several ranks on ONE card with gloo carrying the collectives): MANIPOSE_DEVICE pins every rank to that device,
+    # MANIPOSE_DIST_BACKEND overrides the backend
+    local = int(os.environ.get("MANIPOSE_DEVICE", local))
+    backend = os.environ.get("MANIPOSE_DIST_BACKEND", backend)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -135,6 +135,43 @@ class AnalyticsAccumulator:
     def add_procrustes(self, sums: torch.Tensor) -> None:
         self.proc = sums.clone() if self.proc is None else self.proc + sums
 
+    def all_reduce(self, group=None) -> None:
+        """Merge the accumulators of all ranks (evaluation sharded over windows, SURVEY 8e: "a final sum-reduce of (sum of per-joint
+        error, count)"): one SUM all-reduce of the packed sums, one all-gather of the shifted variance sums, which are re-centred on
+        rank 0's reference before they are added.  Every rank ends with the merged accumulator."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        if self.scal is None:
+            raise RuntimeError("AnalyticsAccumulator.all_reduce: every rank must have added at least one batch")
+        world = dist.get_world_size(group)
+        has_proc = self.proc is not None
+        n_t = torch.tensor([self.n], dtype=torch.float64, device=self.scal.device)
+        parts = [self.scal, self.pairs.reshape(-1), self.joints.reshape(-1), self.bone_err.reshape(-1), n_t] + ([self.proc] if has_proc else [])
+        flat = torch.cat([p.reshape(-1).double() for p in parts])
+        var = torch.cat([self.ref, self.s1, self.s2, n_t])                       # (3 * 16 + 1,)
+        gathered = [torch.empty_like(var) for _ in range(world)]
+        dist.all_gather(gathered, var, group=group)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        o = 0
+        for name, shape in (("scal", (NS,)), ("pairs", (NP, 2)), ("joints", (NJ, 2)), ("bone_err", (NB, 2))):
+            k = 1
+            for d in shape:
+                k *= d
+            setattr(self, name, flat[o:o + k].reshape(shape).clone())
+            o += k
+        self.n = float(flat[o].item()); o += 1
+        if has_proc:
+            self.proc = flat[o:o + 5].clone()
+        ref0 = gathered[0][:NB]
+        s1, s2 = torch.zeros_like(self.s1), torch.zeros_like(self.s2)
+        for g in gathered:        # sum (x - c0) = S1 + n (c - c0);  sum (x - c0)^2 = S2 + 2 (c - c0) S1 + n (c - c0)^2
+            c, a1, a2, n = g[:NB], g[NB:2 * NB], g[2 * NB:3 * NB], g[3 * NB]
+            d = c - ref0
+            s1 += a1 + n * d
+            s2 += a2 + 2.0 * d * a1 + n * d * d
+        self.ref, self.s1, self.s2 = ref0.clone(), s1, s2
+
     def report(self) -> dict:
         s, n = self.scal, self.n
         nj = n * NJ

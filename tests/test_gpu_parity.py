@@ -1081,3 +1081,28 @@ def test_config5_T81_K5_eval_mpjpe_pck_auc_vs_oracle(lib, precision):
     assert abs(a["pck"] - pck.item()) <= tol_pct and abs(a["auc"] - auc.item()) <= tol_pct, (a["pck"], pck.item(), a["auc"], auc.item())
     assert 1.0 < a["pck"] < 99.0
     print(f"T=81 K=5 {precision}: MPJPE {res['mpjpe']:.3f} mm (oracle {want['mpjpe']:.3f}), PCK {a['pck']:.2f} ({pck.item():.2f}), AUC {a['auc']:.2f} ({auc.item():.2f})")
+
+
+def test_sharded_evaluation_two_ranks_equals_single_process(lib, raw_dataset_dir, tmp_path):
+    """The entry point's test pass with the windows dealt over two ranks (both on this GPU, gloo carrying the sum-reduce of the error sums /
+    frame counts and the gather of the shifted variance sums) prints the tables a single process prints."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d, _ = raw_dataset_dir
+    args = ["run.train=false", "run.test=true", "train.batch_size_test=3", "data.seq_len=9", f"data.data_dir={d}", "data.keypoints=gt",
+            "model.channels=64", "model.layers=2", "model.nheads=4", "model.channels_seg=32", "model.layers_seg=1", "model.nheads_seg=4",
+            "multi_hyp.n_hyp=3", "model.precision=fp32", "train.flip_aug=false"]     # (random flips of the evaluation windows - which the
+    # reference's loader also draws - swap left and right bones, so the per-bone consistency metric depends on the RNG stream)
+    env = dict(os.environ, MANIPOSE_DEVICE="0", MANIPOSE_DIST_BACKEND="gloo")
+    one = subprocess.run([sys.executable, os.path.join(root, "hpe", "main_h36m_lifting.py")] + args, capture_output=True, text=True,
+                         timeout=300, cwd=str(tmp_path), env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29519", os.path.join(root, "hpe", "main_h36m_lifting.py")] + args, capture_output=True, text=True,
+                         timeout=300, cwd=str(tmp_path), env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    num = lambda out: [[float(x) for x in re.findall(r"-?\d+\.\d+(?:e-?\d+)?", l)] for l in out.splitlines() if l.startswith("test")]
+    a, b = num(one.stdout), num(two.stdout)
+    assert len(a) == len(b) >= 5 and all(len(x) == len(y) and len(x) > 0 for x, y in zip(a, b)), (one.stdout[-1500:], two.stdout[-1500:])
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x, y, rtol=2e-4, atol=2e-3)
