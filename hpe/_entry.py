@@ -144,15 +144,18 @@ def window_generator(cfg, seqs, train, device):
                                  miss_rate=cfg.data.miss_rate, noise_sigma=cfg.data.get("noise_sigma", 5), transform=tf, device=device)
 
 
-def epoch_batches(gen, batch, shuffle, rank=0, world=1, seed=None):
+def epoch_batches(gen, batch, shuffle, rank=0, world=1, seed=None, pad=False):
     """DataLoader(shuffle, drop_last=False) over the generator's indices, dealt round-robin over the ranks (DistributedSampler-style:
-    every rank draws the same permutation from ``seed`` and keeps every world-th index)."""
+    every rank draws the same permutation from ``seed`` and keeps every world-th index).  ``pad=True`` (training) wraps the order
+    around to a multiple of ``world`` so that every rank runs the same number of steps - each step holds a collective."""
     n = len(gen)
     if shuffle:
         g = torch.Generator().manual_seed(seed) if seed is not None else None
         order = torch.randperm(n, generator=g).tolist()
     else:
         order = list(range(n))
+    if pad and world > 1 and n % world:
+        order = order + order[:world - n % world]
     order = order[rank::world]
     for i in range(0, len(order), batch):
         yield gen.batch(order[i:i + batch])
@@ -314,7 +317,7 @@ def run(argv, extra_defaults=None):
             model.train()
             acc = torch.zeros(4, device=dev)
             if real:       # one pass over the windows, shuffled, dealt over the ranks (main_h36m_lifting.py:597-610)
-                batches = epoch_batches(gen, B, shuffle=True, rank=rank, world=world, seed=cfg.run.seed + epoch)
+                batches = epoch_batches(gen, B, shuffle=True, rank=rank, world=world, seed=cfg.run.seed + epoch, pad=True)
             else:          # shuffled sampling with replacement over this rank's synthetic windows
                 batches = (gen.batch(torch.randint(0, len(gen), (B,)).tolist()) for _ in range(cfg.train.steps_per_epoch))
             steps = 0

@@ -1106,3 +1106,12 @@ def test_sharded_evaluation_two_ranks_equals_single_process(lib, raw_dataset_dir
     assert len(a) == len(b) >= 5 and all(len(x) == len(y) and len(x) > 0 for x, y in zip(a, b)), (one.stdout[-1500:], two.stdout[-1500:])
     for x, y in zip(a, b):
         np.testing.assert_allclose(x, y, rtol=2e-4, atol=2e-3)
+    # and one epoch of two-rank training on the same files: shuffled windows dealt over the ranks (padded to equal step counts), the
+    # gradient all-reduce in every step, the summed validation loss, the sharded MPJPE evaluation
+    targs = [a for a in args if not a.startswith("run.train")] + ["run.train=true", "train.epochs=1", "train.batch_size=4", "run.test=false",
+                                                                  "train.mpjpe_epoch_interval=1", "run.experiment=two_rank"]
+    tr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29521", os.path.join(root, "hpe", "main_h36m_lifting.py")] + targs, capture_output=True, text=True,
+                        timeout=300, cwd=str(tmp_path), env=env)
+    assert tr.returncode == 0, tr.stderr[-2000:]
+    assert "epoch 0:" in tr.stdout and "eval:" in tr.stdout and os.path.exists(os.path.join(str(tmp_path), "two_rank", "model_end.pth"))

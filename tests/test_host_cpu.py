@@ -196,6 +196,10 @@ def test_epoch_batches_deal_every_window_to_exactly_one_rank():
     b = [b for b, _ in epoch_batches(FakeGen(), 4, shuffle=True, rank=1, world=3, seed=6)]
     assert a != b                                                     # a new permutation every epoch
     assert [i for bb, _ in epoch_batches(FakeGen(), 5, shuffle=False) for i in bb] == list(range(37))
+    # training: padded to a multiple of the world size, so every rank runs the same number of (collective-holding) steps
+    shares = [[b for b, _ in epoch_batches(FakeGen(), 4, shuffle=True, rank=r, world=3, seed=5, pad=True)] for r in range(3)]
+    assert len({len(sh) for sh in shares}) == 1 and len({tuple(map(len, sh)) for sh in shares}) == 1
+    assert set(i for sh in shares for b in sh for i in b) == set(range(37)) and sum(len(b) for sh in shares for b in sh) == 39
 
 
 def test_lr_schedulers_follow_torch():
