@@ -49,8 +49,13 @@ def load_config(argv, extra_defaults=None):
 
 
 def instantiate_model(cfg):
-    from manipose_amd import ManifoldMixSTE, RMCLManifoldMixSTE, h36m_skeleton
+    from manipose_amd import ManifoldMixSTE, MixSTE, RMCLManifoldMixSTE, h36m_skeleton
     sk = h36m_skeleton()
+    if cfg.model.arch == "mixste":                          # main_h36m_lifting.py:617-628
+        model = MixSTE(num_frame=cfg.data.seq_len, num_joints=sk.num_joints, in_chans=2, out_dim=3, num_heads=cfg.model.nheads,
+                       depth=cfg.model.layers, embed_dim=cfg.model.channels, drop_path_rate=cfg.model.drop_path_rate, mup=cfg.model.mup)
+        model.precision = cfg.model.precision
+        return model
     kw = dict(skeleton=sk, num_frame=cfg.data.seq_len, num_joints=sk.num_joints, num_bones=sk.num_bones, in_chans=2,
               rot_rep_dim=cfg.model.rot_dim, num_heads_rot=cfg.model.nheads, depth_rot=cfg.model.layers,
               embed_dim_rot=cfg.model.channels, num_heads_seg=cfg.model.nheads_seg, depth_seg=cfg.model.layers_seg,
@@ -60,8 +65,7 @@ def instantiate_model(cfg):
     elif cfg.model.arch == "manifold":
         model = ManifoldMixSTE(**kw)
     else:
-        raise ValueError("Only Manifold-MixSTE and RMCL-Manifold-MixSTE are accelerated on MI355X. "
-                         f"Got option {cfg.model.arch}.")
+        raise ValueError(f"Only MixSTE, Manifold-MixSTE and RMCL-Manifold-MixSTE implemented for now. Got option {cfg.model.arch}.")
     model.precision = cfg.model.precision
     return model
 
@@ -180,7 +184,7 @@ def evaluate(model, X, y=None, batch=None, tta=True, analytics=False, distribute
     from manipose_amd.metrics.analytics import AnalyticsAccumulator, pose_analytics, procrustes_sums
     acc = AnalyticsAccumulator() if analytics else None
     model.eval()
-    sk = model.decoder.skeleton
+    sk = model.decoder.skeleton if hasattr(model, "decoder") else _h36m()
     rmcl = isinstance(model, RMCLManifoldMixSTE)
     sums = {"mpjpe": 0.0, "ps_oracle_mpjpe": 0.0, "oracle_mpjpe": 0.0}
     n = 0
@@ -228,6 +232,11 @@ def evaluate(model, X, y=None, batch=None, tta=True, analytics=False, distribute
     return out
 
 
+def _h36m():
+    from manipose_amd import h36m_skeleton
+    return h36m_skeleton()
+
+
 def sk_device(model):
     return next(model.parameters()).device
 
@@ -255,15 +264,11 @@ def run(argv, extra_defaults=None):
         model.load_state_dict(ck["model_pos"] if "model_pos" in ck else ck)
     model.max_batch_hint = max(cfg.train.batch_size, 2 * cfg.train.batch_size_test)      # x2: flip-TTA batches the mirrored copy
     model = model.to(dev)
-    if cfg.train.get("rigid_seg_reg", 0) > 0:
-        # main_h36m_lifting.py:170-177 permutes a 4-D (B, L, J, 3) prediction: the term exists for single-hypothesis models only, and on a
-        # manifold model (constant segment lengths over a window by construction) it is identically 0
-        raise NotImplementedError("train.rigid_seg_reg > 0: segments are rigid by construction in the manifold models this entry point builds")
     if cfg.train.get("lat_sym_regularization", 0) > 0:
         print("warning: Lateral symmetry regularization is not implemented yet!", flush=True)      # as main_h36m_lifting.py:109-110
     trainer = LiftingTrainer(model, lr=cfg.train.lr, weight_decay=1e-6, w_loss=cfg.train.w_loss, vel_loss=cfg.train.vel_loss,
                              smooth_reg=cfg.train.smooth_reg, rmcl_score_reg=cfg.train.rmcl_score_reg, seed=cfg.run.seed,
-                             sq_loss=cfg.train.sq_loss)
+                             sq_loss=cfg.train.sq_loss, rigid_seg_reg=cfg.train.get("rigid_seg_reg", 0.0))
     broadcast_parameters(model.flat_parameters())
     start_epoch, sched_state = 0, None
     if cfg.run.checkpoint_params:
@@ -341,8 +346,9 @@ def run(argv, extra_defaults=None):
                 else:
                     sched.step()
             if rank == 0:
-                print(f"epoch {epoch}: tr_loss {sum(terms):.5f} wloss {terms[0]:.5f} score_reg {terms[1]:.5f} vloss {terms[2]:.5f} "
-                      f"sreg {terms[3]:.5f} | best val {best_val:.5f} lr {sched.get_last_lr()[0]:.2e}", flush=True)
+                names = ("wloss", "score_reg", "vloss", "sreg") if trainer.rmcl else ("wloss", "vloss", "sreg", "rigid_seg_reg")
+                print(f"epoch {epoch}: tr_loss {sum(terms):.5f} " + " ".join(f"{n} {v:.5f}" for n, v in zip(names, terms))
+                      + f" | best val {best_val:.5f} lr {sched.get_last_lr()[0]:.2e}", flush=True)
             if (epoch + 1) % cfg.train.mpjpe_epoch_interval == 0 and (rank == 0 or valid_shared):      # main_h36m_lifting.py:405-470
                 ev = evaluate(model, valid_batches(), tta=cfg.train.tta, distributed=valid_shared)
                 if rank == 0:

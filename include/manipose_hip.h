@@ -67,6 +67,13 @@ int mp_wta_loss(const float* poses, const float* scores, const float* target, co
 int mp_single_loss(const float* poses, const float* target, const mp_loss_config* cfg, float* terms, float* d_poses,
                    int B, int T, float* scratch, int64_t scratch_floats, void* stream);
 
+/* The rigid_seg_reg term of make_loss (hpe/main_h36m_lifting.py:170-177): weight * segments_time_consistency(pred.permute(0,3,2,1),
+ * skeleton, mode="sum") (metrics/regularizations.py:8-45, metrics/utils.py:4-20) = weight * sum over windows and the 16 bones of the
+ * unbiased variance over time of the bone length, for (B, T, 17, 3) predictions of the single-hypothesis models.  term: 1 device float;
+ * d_poses (may be NULL): the gradient is ADDED to it (the other loss terms' gradient is already there).  scratch >= B floats. */
+int mp_rigid_segments_loss(const float* poses, float weight, float* term, float* d_poses, int B, int T, float* scratch,
+                           int64_t scratch_floats, void* stream);
+
 /* RMCLManifoldMixSTE.aggregate (rmcl_manifold_mix_ste.py:141-185): mode 0 "weighted_ave", 1 "best_score",
  * 2 "oracle" (needs target).  out: (B, T, 17, 3). */
 int mp_aggregate(const float* poses, const float* scores, const float* target, int mode, float* out, int B, int K, int T,
@@ -119,7 +126,9 @@ int mp_attention_bwd_bf16(const void* qkv, const void* out, const void* d_out, c
 typedef struct mp_model mp_model;
 
 typedef struct mp_model_config {
-  int arch;            /* 0 = "rmcl_manifold" (K heads + scores), 1 = "manifold" (single hypothesis) */
+  int arch;            /* 0 = "rmcl_manifold" (K heads + scores), 1 = "manifold" (single hypothesis), 2 = "mixste": the bare MixSTE
+                        * regressor of main_h36m_lifting.py:617-628 (mix_ste.py:175-191; out_dim 3, no bones net, no decoder;
+                        * state-dict keys without the "rotations_module." prefix) */
   int num_frame;       /* T  (cfg.data.seq_len) */
   int num_joints;      /* 17 */
   int num_bones;       /* 16 */

@@ -39,6 +39,7 @@ _SIGNATURES = {
     "mp_fk_decode_bwd": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "mp_wta_loss": (i32, [vp, vp, vp, C.POINTER(LossConfig), vp, vp, vp, vp, i32, i32, i32, vp, i64, vp]),
     "mp_single_loss": (i32, [vp, vp, C.POINTER(LossConfig), vp, vp, i32, i32, vp, i64, vp]),
+    "mp_rigid_segments_loss": (i32, [vp, f32, vp, vp, i32, i32, vp, i64, vp]),
     "mp_aggregate": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, vp]),
     "mp_mpjpe_sum": (i32, [vp, vp, i64, vp, vp, i64, vp]),
     "mp_adam_step": (i32, [vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, f32, vp]),

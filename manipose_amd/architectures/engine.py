@@ -20,7 +20,7 @@ class LiftEngine:
         self.lib = _lib.load()
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {list(PRECISIONS)}, got {precision}")
-        self.cfg = _lib.ModelConfig(arch={"rmcl_manifold": 0, "manifold": 1}[arch], num_frame=num_frame,
+        self.cfg = _lib.ModelConfig(arch={"rmcl_manifold": 0, "manifold": 1, "mixste": 2}[arch], num_frame=num_frame,
                                     num_joints=num_joints, num_bones=num_bones, embed_dim_rot=embed_dim_rot,
                                     depth_rot=depth_rot, num_heads_rot=num_heads_rot, embed_dim_seg=embed_dim_seg,
                                     depth_seg=depth_seg, num_heads_seg=num_heads_seg, n_hyp=max(1, n_hyp),

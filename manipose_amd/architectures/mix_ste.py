@@ -14,6 +14,8 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from ._fused import FusedLiftingMixin
+
 _ENGINE_ONLY = ("manipose_amd: {} holds parameters only; its arithmetic runs inside the fused HIP engine. Call the "
                 "owning model (RMCLManifoldMixSTE / ManifoldMixSTE) on a ROCm tensor instead.")
 
@@ -90,9 +92,11 @@ class Block(nn.Module):
         raise RuntimeError(_ENGINE_ONLY.format("Block"))
 
 
-class MixSTE(nn.Module):
-    """Backbone container. ``forward`` of a bare MixSTE (cfg ``model.arch=mixste``) is not part of the accelerated
-    path (BASELINE.json north_star = the manifold models) and raises."""
+class MixSTE(FusedLiftingMixin, nn.Module):
+    """The MixSTE backbone (reference mix_ste.py:12-191).  Inside ManifoldMixSTE / RMCLManifoldMixSTE it is a parameter container
+    (the owning model's engine runs it).  On its own - ``model.arch=mixste`` of the entry points (main_h36m_lifting.py:617-628):
+    ``MixSTE(num_frame, num_joints=17, in_chans=2, out_dim=3, ...)`` - ``forward`` maps (B, T, 17, 2) keypoints straight to
+    (B, T, 17, 3) poses through the same engine (arch 2: backbone + LayerNorm/Linear head, no bones net, no decoder)."""
 
     def __init__(self, num_frame=243, num_joints=17, in_chans=2, out_dim=3, embed_dim=512, depth=8, num_heads=8,
                  mlp_ratio=2.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.2,
@@ -121,6 +125,13 @@ class MixSTE(nn.Module):
         self.Spatial_norm = norm_layer(embed_dim)
         self.Temporal_norm = norm_layer(embed_dim)
         self.head = nn.Sequential(nn.LayerNorm(embed_dim), nn.Linear(embed_dim, out_dim))
+        self._standalone = in_chans == 2 and out_dim == 3 and num_joints == 17
+        self._init_fused("mixste", dict(num_frame=num_frame, num_joints=num_joints, num_bones=16, embed_dim_rot=embed_dim, depth_rot=depth,
+                                        num_heads_rot=num_heads, embed_dim_seg=128, depth_seg=1, num_heads_seg=8, n_hyp=1,
+                                        drop_path_rate=drop_path_rate))
 
     def forward(self, x):
-        raise RuntimeError(_ENGINE_ONLY.format(type(self).__name__))
+        """x (B, T, 17, 2) -> (B, T, 17, 3) (mix_ste.py:175-191)."""
+        if not self._standalone or type(self) is not MixSTE:
+            raise RuntimeError(_ENGINE_ONLY.format(type(self).__name__))
+        return self._run(x)[:, 0]

@@ -44,6 +44,11 @@ int mp_single_loss(const float* poses, const float* target, const mp_loss_config
   MP_CHECK(poses && target && cfg && terms && scratch, MP_ERR_ARG, "mp_single_loss: null pointer");
   return single_loss(poses, target, to_cfg(cfg), terms, d_poses, B, T, scratch, scratch_floats, (hipStream_t)stream);
 }
+int mp_rigid_segments_loss(const float* poses, float weight, float* term, float* d_poses, int B, int T, float* scratch, int64_t scratch_floats,
+                           void* stream) {
+  return rigid_segments_loss(poses, weight, term, d_poses, B, T, scratch, (long)scratch_floats, (hipStream_t)stream);
+}
+
 int mp_aggregate(const float* poses, const float* scores, const float* target, int mode, float* out, int B, int K, int T,
                  void* stream) {
   MP_CHECK(poses && out, MP_ERR_ARG, "mp_aggregate: null pointer");

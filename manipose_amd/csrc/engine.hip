@@ -62,6 +62,7 @@ struct mp_model {
   hipStream_t st3 = nullptr;
   hipEvent_t evE[2][4] = {}, evW[2][4] = {};
   bool wgrad_async = false;
+  bool has_seg = true;                       // false for arch 2 (bare MixSTE): no segments module, no decoder
   // state of the last forward
   int B = 0;
   bool train = false;
@@ -184,11 +185,11 @@ static void carve_all(mp_model* m, Bump& bp) {
   const long Mr = (long)Bm * T * m->rot.N, Ms = (long)Bm * T * m->seg.N;
   const int half = m->cfg.precision == 1;
   carve_module(m->rot, bp, Mr, T, Bm, half);
-  carve_module(m->seg, bp, Ms, T, Bm, half);
+  if (m->has_seg) carve_module(m->seg, bp, Ms, T, Bm, half);
   if (half) m->wbf = reinterpret_cast<bf16*>(bp.take((m->flat_size + 1) / 2));
   const int halfp = m->cfg.precision == 1;
   const Module* mods[2] = {&m->rot, &m->seg};
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < (m->has_seg ? 2 : 1); ++i) {
     const Module* md = mods[i];
     const long M = (i == 0) ? Mr : Ms, MC = M * md->C;
     mp_model::ScratchSet& sc = m->sets[i];
@@ -524,7 +525,6 @@ extern "C" {
 
 int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   MP_CHECK(cfg != nullptr && out != nullptr, MP_ERR_ARG, "mp_model_create: null argument");
-  MP_CHECK(cfg->arch == 0 || cfg->arch == 1, MP_ERR_ARG, "mp_model_create: arch %d (0 rmcl_manifold, 1 manifold)", cfg->arch);
   MP_CHECK(cfg->precision == 0 || cfg->precision == 1, MP_ERR_ARG, "mp_model_create: precision %d (0 = fp32, 1 = bf16)", cfg->precision);
   MP_CHECK(cfg->precision == 0 || (cfg->embed_dim_rot % 8 == 0 && cfg->embed_dim_seg % 8 == 0), MP_ERR_ARG,
            "mp_model_create: bf16 precision needs embedding widths that are multiples of 8");
@@ -532,21 +532,23 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   MP_CHECK(cfg->num_frame >= 2 && cfg->max_batch >= 0, MP_ERR_ARG, "mp_model_create: num_frame >= 2, max_batch >= 0");
   MP_CHECK(cfg->embed_dim_rot % cfg->num_heads_rot == 0 && cfg->embed_dim_seg % cfg->num_heads_seg == 0, MP_ERR_ARG,
            "mp_model_create: embed dim must be divisible by heads");
-  MP_CHECK(cfg->arch == 1 || (cfg->n_hyp >= 1 && cfg->n_hyp <= 8), MP_ERR_ARG, "mp_model_create: n_hyp in 1..8");
+  MP_CHECK(cfg->arch >= 0 && cfg->arch <= 2, MP_ERR_ARG, "mp_model_create: arch %d (0 rmcl_manifold, 1 manifold, 2 mixste)", cfg->arch);
+  MP_CHECK(cfg->arch != 0 || (cfg->n_hyp >= 1 && cfg->n_hyp <= 8), MP_ERR_ARG, "mp_model_create: n_hyp in 1..8");
   MP_CHECK(cfg->rot_rep_dim == 0 || cfg->rot_rep_dim == 4 || cfg->rot_rep_dim == 6, MP_ERR_ARG,
            "mp_model_create: rot_rep_dim %d (4 or 6; 0 = 6)", cfg->rot_rep_dim);
   mp_model* m = new mp_model();
   m->cfg = *cfg;
   if (cfg->rot_rep_dim == 0) m->cfg.rot_rep_dim = 6;
-  if (cfg->arch == 1) m->cfg.n_hyp = 1;
-  m->rot.prefix = "rotations_module."; m->rot.is_rot = true;
+  if (cfg->arch != 0) m->cfg.n_hyp = 1;
+  m->has_seg = cfg->arch != 2;          // arch 2: the bare MixSTE regressor (main_h36m_lifting.py:617-628): no bones net, no decoder
+  m->rot.prefix = m->has_seg ? "rotations_module." : ""; m->rot.is_rot = true;
   m->rot.N = cfg->num_joints; m->rot.C = cfg->embed_dim_rot; m->rot.H = cfg->num_heads_rot; m->rot.depth = cfg->depth_rot;
-  m->rot.K = m->cfg.n_hyp; m->rot.O = m->cfg.rot_rep_dim + ((cfg->arch == 0) ? 1 : 0);   // + the score-embedding channel
+  m->rot.K = m->cfg.n_hyp; m->rot.O = (cfg->arch == 2) ? 3 : m->cfg.rot_rep_dim + ((cfg->arch == 0) ? 1 : 0);   // + the score-embedding channel; mixste: xyz
   m->seg.prefix = "segments_module."; m->seg.is_rot = false;
   m->seg.N = cfg->num_bones; m->seg.C = cfg->embed_dim_seg; m->seg.H = cfg->num_heads_seg; m->seg.depth = cfg->depth_seg;
   m->seg.K = 1; m->seg.O = 1;
   build_module_params(m, m->rot);
-  build_module_params(m, m->seg);
+  if (m->has_seg) build_module_params(m, m->seg);
   m->rot.mask_base = 0;
   m->seg.mask_base = (int)m->rot.masks.size();
   if (cfg->max_batch == 0) {   // layout-only handle (parameter / mask layout queries, no device needed)
@@ -666,7 +668,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
                      const float* masks_override, uint64_t seed, uint64_t step, void* stream) {
   MP_CHECK(m && fp && x && poses, MP_ERR_ARG, "mp_model_forward: null argument");
   MP_CHECK(B >= 1 && B <= m->cfg.max_batch, MP_ERR_ARG, "mp_model_forward: batch %d outside 1..max_batch=%d", B, m->cfg.max_batch);
-  MP_CHECK(m->cfg.arch == 1 || scores != nullptr, MP_ERR_ARG, "mp_model_forward: scores buffer required for rmcl_manifold");
+  MP_CHECK(m->cfg.arch != 0 || scores != nullptr, MP_ERR_ARG, "mp_model_forward: scores buffer required for rmcl_manifold");
   hipStream_t st = (hipStream_t)stream;
   const int T = m->cfg.num_frame, J = m->cfg.num_joints, S = m->cfg.num_bones, K = m->rot.K;
   m->B = B;
@@ -707,6 +709,10 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
     for (int k = 0; k < K; ++k) { sp.w[k] = P(m, fp, m->rot.sw[k]); sp.b[k] = P(m, fp, m->rot.sb[k]); }
     RUN(PC_OTHER, 0, scores_fwd(m->rot.headout, sp, K, m->rot.O, scores, B, T, J, st));
   }
+  if (!m->has_seg) {   // MixSTE.forward (mix_ste.py:175-191): the head output IS the pose, rows (b, t, j) = the (B, 1, T, J, 3) layout
+    MP_HIP(hipMemcpyAsync(poses, m->rot.headout, sizeof(float) * Mr * 3, hipMemcpyDeviceToDevice, st));
+    return MP_OK;
+  }
   // bones net (manifold_mix_ste.py:139-154) on the side stream, concurrently with the rotations net enqueued above
   {
     hipStream_t main_st = st;
@@ -738,7 +744,8 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   const long Mr = (long)B * T * J, Ms = (long)B * T * S;
   use_scratch(m, 0);
   // decoder
-  RUN(PC_OTHER, 0, fk_decode_bwd(m->rot.headout, m->rot.O, m->cfg.rot_rep_dim, m->lengths, d_poses, m->rot.dheadout, m->dlen_pose, B, K, T, st));
+  if (m->has_seg) RUN(PC_OTHER, 0, fk_decode_bwd(m->rot.headout, m->rot.O, m->cfg.rot_rep_dim, m->lengths, d_poses, m->rot.dheadout, m->dlen_pose, B, K, T, st));
+  else MP_HIP(hipMemcpyAsync(m->rot.dheadout, d_poses, sizeof(float) * Mr * 3, hipMemcpyDeviceToDevice, st));
   if (m->cfg.arch == 0) {
     ScoreParams sp;
     ScoreGrads sg;
@@ -768,7 +775,7 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   RUN(PC_OTHER, 0, embed_bwd(m->g, m->x_in, G(m, fg, m->rot.emb_w), G(m, fg, m->rot.emb_b), G(m, fg, m->rot.spos), (int)Mr, m->rot.C, J,
                              m->small, m->small_floats, st));
   // segments module, on the side stream with its own scratch set
-  {
+  if (m->has_seg) {
     hipStream_t main_st = st;
     st = m->st2;
     use_scratch(m, 1);
@@ -795,7 +802,7 @@ int mp_model_peek(const mp_model* m, int which, const float** ptr, int64_t* nume
   MP_CHECK(m && ptr && numel && m->B >= 1, MP_ERR_ARG, "mp_model_peek: bad argument or no forward yet");
   const long Mr = (long)m->B * m->cfg.num_frame * m->cfg.num_joints;
   if (which == 0) { *ptr = m->rot.headout; *numel = (long)m->rot.K * Mr * m->rot.O; return MP_OK; }
-  if (which == 1) { *ptr = m->lengths; *numel = (long)m->B * m->cfg.num_bones; return MP_OK; }
+  if (which == 1 && m->has_seg) { *ptr = m->lengths; *numel = (long)m->B * m->cfg.num_bones; return MP_OK; }
   MP_CHECK(false, MP_ERR_ARG, "mp_model_peek: which=%d", which);
 }
 

@@ -131,6 +131,9 @@ int wta_loss(const float* poses, const float* scores, const float* y, const Loss
 // single-hypothesis loss (ManifoldMixSTE): terms[3] = (wloss, vloss, sreg)
 int single_loss(const float* poses, const float* y, const LossCfg& cfg, float* terms, float* dposes, int B, int T,
                 float* scratch, long scratch_floats, hipStream_t st);
+// rigid_seg_reg (main_h36m_lifting.py:170-177) of (B,T,17,3) poses: term[0] = weight * sum Var_t(bone length); dposes += gradient (may be null)
+int rigid_segments_loss(const float* poses, float weight, float* term, float* dposes, int B, int T, float* scratch, long scratch_floats,
+                        hipStream_t st);
 // eval: aggregate + MPJPE sums. mode 0 weighted_ave, 1 best_score, 2 oracle
 int aggregate_poses(const float* poses, const float* scores, const float* y, int mode, float* out, int B, int K, int T,
                     hipStream_t st);

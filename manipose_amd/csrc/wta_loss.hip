@@ -248,4 +248,89 @@ int mpjpe_sum(const float* pred, const float* gt, long njoints, float* out_sum, 
   return MP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// rigid_seg_reg term of make_loss (main_h36m_lifting.py:170-177): weight * segments_time_consistency(pred, mode="sum")
+// (metrics/regularizations.py:8-45, metrics/utils.py:4-20) = weight * sum_{window, bone} Var_t(bone length), unbiased variance over the
+// T frames of a window, for (B, T, 17, 3) predictions of the single-hypothesis models; forward and gradient in one kernel:
+// one workgroup per window, a thread per frame; d_poses is ACCUMULATED into (the other loss terms are already there).
+// ---------------------------------------------------------------------------------------------
+__constant__ int c_rs_parent[LJ] = {-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 8, 11, 12, 8, 14, 15};   // data/skeleton.py, bones = (j, parent_j)
+
+__global__ __launch_bounds__(256) void rigid_segments_kernel(const float* __restrict__ poses, float weight, float* __restrict__ partial,
+                                                              float* __restrict__ dposes, int T) {
+  __shared__ float s_sum[4][LJ - 1], s_sq[4][LJ - 1], s_mean[LJ - 1];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float* base = poses + (long)b * T * LJ * 3;
+  // frame-0 lengths as the common shift of the variance sums
+  float ref[LJ - 1];
+  for (int j = 1; j < LJ; ++j) {
+    const int p = c_rs_parent[j];
+    const float dx = base[3 * j] - base[3 * p], dy = base[3 * j + 1] - base[3 * p + 1], dz = base[3 * j + 2] - base[3 * p + 2];
+    ref[j - 1] = sqrtf(dx * dx + dy * dy + dz * dz);
+  }
+  float a1[LJ - 1], a2[LJ - 1];
+  for (int k = 0; k < LJ - 1; ++k) { a1[k] = 0.f; a2[k] = 0.f; }
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const float* fr = base + (long)t * LJ * 3;
+    for (int j = 1; j < LJ; ++j) {
+      const int p = c_rs_parent[j];
+      const float dx = fr[3 * j] - fr[3 * p], dy = fr[3 * j + 1] - fr[3 * p + 1], dz = fr[3 * j + 2] - fr[3 * p + 2];
+      const float d = sqrtf(dx * dx + dy * dy + dz * dz) - ref[j - 1];
+      a1[j - 1] += d; a2[j - 1] += d * d;
+    }
+  }
+  for (int k = 0; k < LJ - 1; ++k) {
+    const float u = wave_sum(a1[k]), v = wave_sum(a2[k]);
+    if (lane == 0) { s_sum[wv][k] = u; s_sq[wv][k] = v; }
+  }
+  __syncthreads();
+  float var_tot = 0.f;
+  if (threadIdx.x < LJ - 1) {
+    const int k = threadIdx.x;
+    const float u = s_sum[0][k] + s_sum[1][k] + s_sum[2][k] + s_sum[3][k], v = s_sq[0][k] + s_sq[1][k] + s_sq[2][k] + s_sq[3][k];
+    s_mean[k] = ref[k] + u / (float)T;
+    var_tot = fmaxf(v - u * u / (float)T, 0.f) / (float)(T - 1);
+  }
+  var_tot = wave_sum(var_tot);               // bones 0..15 live in wave 0
+  if (threadIdx.x == 0) partial[b] = weight * var_tot;
+  __syncthreads();
+  if (dposes == nullptr) return;
+  const float c = weight * 2.0f / (float)(T - 1);
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const float* fr = base + (long)t * LJ * 3;
+    float g[LJ][3];
+    for (int j = 0; j < LJ; ++j) { g[j][0] = 0.f; g[j][1] = 0.f; g[j][2] = 0.f; }
+    for (int j = 1; j < LJ; ++j) {
+      const int p = c_rs_parent[j];
+      const float dx = fr[3 * j] - fr[3 * p], dy = fr[3 * j + 1] - fr[3 * p + 1], dz = fr[3 * j + 2] - fr[3 * p + 2];
+      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+      if (len > 0.f) {
+        const float s = c * (len - s_mean[j - 1]) / len;
+        g[j][0] += s * dx; g[j][1] += s * dy; g[j][2] += s * dz;
+        g[p][0] -= s * dx; g[p][1] -= s * dy; g[p][2] -= s * dz;
+      }
+    }
+    float* o = dposes + ((long)b * T + t) * LJ * 3;
+    for (int j = 0; j < LJ; ++j) { o[3 * j] += g[j][0]; o[3 * j + 1] += g[j][1]; o[3 * j + 2] += g[j][2]; }
+  }
+}
+
+__global__ __launch_bounds__(256) void rigid_finalize_kernel(const float* __restrict__ partial, int B, float* __restrict__ term) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) s += partial[i];
+  const float tot = block_sum_256(s, red);
+  if (threadIdx.x == 0) term[0] = tot;
+}
+
+int rigid_segments_loss(const float* poses, float weight, float* term, float* dposes, int B, int T, float* scratch, long scratch_floats,
+                        hipStream_t st) {
+  MP_CHECK(poses && term && scratch && B > 0 && T >= 2 && scratch_floats >= B, MP_ERR_ARG, "rigid_segments_loss: bad argument (B=%d T=%d)", B, T);
+  hipLaunchKernelGGL(rigid_segments_kernel, dim3(B), dim3(256), 0, st, poses, weight, scratch, dposes, T);
+  MP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rigid_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, B, term);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
 }  // namespace mp

@@ -17,8 +17,36 @@ def _time_stat(joints_coords, skeleton, mode):
     raise ValueError(f"Unexpected value for 'mode' encoutered: {mode}.Accepted values are 'average', 'sum' and 'std.")
 
 
+class _RigidSegments(torch.autograd.Function):
+    """sum over (window, bone) of the unbiased time variance of the bone length, with its gradient (mp_rigid_segments_loss)."""
+
+    @staticmethod
+    def forward(ctx, poses):                       # (B, T, 17, 3) contiguous float32 on the device
+        from .. import _lib
+        B, T = poses.shape[:2]
+        term = torch.empty(1, dtype=torch.float32, device=poses.device)
+        grad = torch.zeros_like(poses) if poses.requires_grad else None
+        scratch = torch.empty(B, dtype=torch.float32, device=poses.device)
+        _lib.check(_lib.load().mp_rigid_segments_loss(_lib.ptr(poses), 1.0, _lib.ptr(term), _lib.ptr(grad), B, T, _lib.ptr(scratch), B,
+                                                      _lib.stream_ptr()), "mp_rigid_segments_loss")
+        ctx.save_for_backward(grad)
+        return term[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g if grad is not None else None
+
+
 def segments_time_consistency(joints_coords: torch.Tensor, skeleton, mode: str) -> torch.Tensor:
-    """regularizations.py:38-50: aggregate over (batch, bone) of the time variance (std for mode 'std') of every bone length."""
+    """regularizations.py:38-50: aggregate over (batch, bone) of the time variance (std for mode 'std') of every bone length.
+    With mode="sum" on a tensor that requires grad - the rigid_seg_reg term of make_loss (main_h36m_lifting.py:170-177) - the value comes
+    with its gradient from one fused kernel."""
+    if mode == "sum" and joints_coords.requires_grad:
+        if joints_coords.device.type != "cuda":
+            raise RuntimeError("manipose_amd: segments_time_consistency runs on the ROCm device only (HIP kernel, no CPU fallback)")
+        assert joints_coords.dim() == 4 and joints_coords.shape[1] == 3 and joints_coords.shape[2] == 17
+        return _RigidSegments.apply(joints_coords.permute(0, 3, 2, 1).contiguous().float())
     stat, agg = _time_stat(joints_coords, skeleton, mode)
     return agg(stat)
 

@@ -20,12 +20,16 @@ from .optim import FusedAdam
 class LiftingTrainer:
     def __init__(self, model, lr: float = 4e-5, weight_decay: float = 1e-6, w_loss: bool = True, vel_loss: float = 2.0,
                  smooth_reg: float = 0.5, rmcl_score_reg: float = 0.1, seed: int = 42, process_group=None,
-                 grad_buckets: int = 1, sq_loss: bool = False):
+                 grad_buckets: int = 1, sq_loss: bool = False, rigid_seg_reg: float = 0.0):
         self.model = model
         self.lib = _lib.load()
         self.opt = FusedAdam(model, lr=lr, weight_decay=weight_decay)
         self.loss_cfg = _lib.LossConfig(rmcl_score_reg=rmcl_score_reg, vel_loss=vel_loss, smooth_reg=smooth_reg,
                                         w_loss=int(w_loss), sq_loss=int(sq_loss))
+        self.rigid_seg_reg = float(rigid_seg_reg)      # main_h36m_lifting.py:170-177; single-hypothesis models only (4th loss term)
+        if self.rigid_seg_reg > 0 and model._arch == "rmcl_manifold":
+            raise NotImplementedError("train.rigid_seg_reg > 0 with the multi-hypothesis model: the reference's term permutes a 4-D "
+                                      "(B, L, J, 3) prediction and fails on (B, H, L, J, 3) hypotheses")
         self.seed = seed
         self.step_no = 0
         self.pg = process_group
@@ -42,7 +46,8 @@ class LiftingTrainer:
                 d_poses=torch.empty(B, K, T, 17, 3, device=device),
                 d_scores=torch.empty(B, K, T, 1, device=device) if self.rmcl else None,
                 terms=torch.zeros(4, device=device),
-                scratch=torch.empty(4 * ((B * T + 255) // 256) + 8, device=device))}
+                scratch=torch.empty(4 * ((B * T + 255) // 256) + 8, device=device),
+                rigid=torch.empty(B, device=device))}
         return self._bufs[key]
 
     def train_step(self, X: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
@@ -67,6 +72,9 @@ class LiftingTrainer:
             _lib.check(self.lib.mp_single_loss(_lib.ptr(poses), _lib.ptr(y), C.byref(self.loss_cfg), _lib.ptr(bf["terms"]),
                                                _lib.ptr(bf["d_poses"]), B, T, _lib.ptr(bf["scratch"]), bf["scratch"].numel(),
                                                st), "mp_single_loss")
+            if self.rigid_seg_reg > 0:
+                _lib.check(self.lib.mp_rigid_segments_loss(_lib.ptr(poses), self.rigid_seg_reg, C.c_void_p(bf["terms"].data_ptr() + 12),
+                                                           _lib.ptr(bf["d_poses"]), B, T, _lib.ptr(bf["rigid"]), B, st), "mp_rigid_segments_loss")
         if self.flat_grads is None or self.flat_grads.shape != m._flat.shape:
             self.flat_grads = torch.empty_like(m._flat)
         self.flat_grads.zero_()
@@ -95,4 +103,7 @@ class LiftingTrainer:
         else:
             _lib.check(self.lib.mp_single_loss(_lib.ptr(poses), _lib.ptr(y), C.byref(self.loss_cfg), _lib.ptr(bf["terms"]),
                                                None, B, T, _lib.ptr(bf["scratch"]), bf["scratch"].numel(), st), "mp_single_loss")
+            if self.rigid_seg_reg > 0:
+                _lib.check(self.lib.mp_rigid_segments_loss(_lib.ptr(poses), self.rigid_seg_reg, C.c_void_p(bf["terms"].data_ptr() + 12),
+                                                           None, B, T, _lib.ptr(bf["rigid"]), B, st), "mp_rigid_segments_loss")
         return bf["terms"].clone()

@@ -170,6 +170,50 @@ def gen_model_fixture(ref, name, cfg, B, seed, drop_path_rate=0.0, train=False):
     print(f"{name}: {os.path.getsize(path) / 1e3:.0f} kB, loss={total.item():.6f}, masks={len(masks)}")
 
 
+def gen_mixste_fixture(ref):
+    """model.arch=mixste (main_h36m_lifting.py:617-628): the bare MixSTE regressor with the single-hypothesis loss of make_loss."""
+    torch.manual_seed(31)
+    T, C, depth, heads = 9, 32, 2, 4
+    model = ref["MixSTE"](num_frame=T, num_joints=17, in_chans=2, out_dim=3, embed_dim=C, depth=depth, num_heads=heads, drop_path_rate=0.0)
+    g = torch.Generator().manual_seed(32)
+    with torch.no_grad():
+        for k, p in model.named_parameters():       # perturb the LN affines / zero-initialised position embeddings too
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+    model.eval()
+    X, y = orc.synthetic_batch(2, T, 17, seed=33)
+    out = {"cfg_mixste": np.array([T, C, depth, heads]), "X": X.numpy(), "y": y.numpy()}
+    out.update({"w::" + k: v.detach().numpy().copy() for k, v in model.state_dict().items()})
+    pred = model(X)
+    M = ref["M"]
+    w = M.STANDARD_H36M_WEIGHTS
+    wl = M.weighted_mpjpe_loss(pred, y, weights=w)
+    vl = 2.0 * M.mean_velocity_error(predicted=pred, target=y, squared=False, axis=1)
+    sg = 0.5 * M.smoothness_regularization(prediction=pred, weights=w, axis=1)
+    total = wl + vl + sg
+    total.backward()
+    out.update(poses=pred.detach().numpy(), loss_terms=np.array([wl.item(), vl.item(), sg.item()]), loss_total=np.float64(total.item()))
+    for k, p in model.named_parameters():
+        out["g::" + k] = p.grad.detach().numpy()
+    # the same step with train.rigid_seg_reg = 0.7 (make_loss :170-177): value, d term / d prediction, parameter gradients of the total
+    model.zero_grad()
+    pred = model(X)
+    pred.retain_grad()
+    rigid = 0.7 * M.segments_time_consistency(pred.permute(0, 3, 2, 1), skeleton=ref["sk"], mode="sum")
+    rigid.backward(retain_graph=True)
+    out["rigid_term"], out["rigid_g_pred"] = np.float64(rigid.item()), pred.grad.detach().numpy().copy()
+    model.zero_grad()
+    pred = model(X)
+    tot = (M.weighted_mpjpe_loss(pred, y, weights=w) + 2.0 * M.mean_velocity_error(predicted=pred, target=y, squared=False, axis=1)
+           + 0.5 * M.smoothness_regularization(prediction=pred, weights=w, axis=1)
+           + 0.7 * M.segments_time_consistency(pred.permute(0, 3, 2, 1), skeleton=ref["sk"], mode="sum"))
+    tot.backward()
+    out["rigid_total"] = np.float64(tot.item())
+    for k, p in model.named_parameters():
+        out["g_rigid::" + k] = p.grad.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "mixste_tiny.npz"), **out)
+    print("mixste_tiny: ok, loss", total.item(), "keys", len(model.state_dict()))
+
+
 def gen_decoder_fixture(ref):
     torch.manual_seed(5)
     dec = ref["PoseDecoder"](skeleton=ref["sk"], rot_rep_dim=6)
@@ -451,6 +495,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "windows":       # regenerate the input-pipeline fixture only
         gen_windows_fixture(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "mixste":        # regenerate the bare-MixSTE fixture only
+        gen_mixste_fixture(ref)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "rot4":          # regenerate the 4-D rotation fixtures only
         gen_rot4_decoder_fixture(ref)
         gen_model_fixture(ref, "rmcl_tiny_rot4", dict(T=9, J=17, num_bones=16, C_rot=32, depth_rot=2, heads_rot=4, C_seg=16, depth_seg=1,
@@ -476,6 +523,7 @@ def main():
     gen_model_fixture(ref, "rmcl_tiny_droppath", tiny, B=3, seed=14, drop_path_rate=0.5, train=True)
     gen_model_fixture(ref, "rmcl_tiny_rot4", dict(tiny, rot_dim=4), B=2, seed=21)
     gen_model_fixture(ref, "manifold_k1_rot4", dict(tiny, n_hyp=0, rot_dim=4), B=2, seed=23)
+    gen_mixste_fixture(ref)
     gen_decoder_fixture(ref)
     gen_loss_fixture(ref)
     gen_metrics_fixture(ref)

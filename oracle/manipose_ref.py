@@ -390,6 +390,8 @@ def manifold_training_loss(pred, y, train_cfg=DEFAULT_TRAIN_CFG):
         terms["vloss"] = train_cfg["vel_loss"] * mean_velocity_error(pred, y, axis=1, squared=sq)
     if train_cfg["smooth_reg"] > 0:
         terms["sreg"] = train_cfg["smooth_reg"] * smoothness_regularization(pred, w, axis=1)
+    if train_cfg.get("rigid_seg_reg", 0) > 0:                 # main_h36m_lifting.py:170-177
+        terms["rigid_seg_reg"] = train_cfg["rigid_seg_reg"] * segments_time_consistency(pred.permute(0, 3, 2, 1), "sum")
     return sum(terms.values()), terms
 
 

@@ -1115,3 +1115,79 @@ def test_sharded_evaluation_two_ranks_equals_single_process(lib, raw_dataset_dir
                         timeout=300, cwd=str(tmp_path), env=env)
     assert tr.returncode == 0, tr.stderr[-2000:]
     assert "epoch 0:" in tr.stdout and "eval:" in tr.stdout and os.path.exists(os.path.join(str(tmp_path), "two_rank", "model_end.pth"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# model.arch=mixste: the bare MixSTE regressor of the reference's entry points (main_h36m_lifting.py:617-628) through the engine
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_bare_mixste_model_vs_reference(lib, precision):
+    from manipose_amd import MixSTE
+    from manipose_amd.metrics import manifold_training_loss, mpjpe_error
+    fx = load_fixture("mixste_tiny")
+    T, C, depth, heads = [int(v) for v in fx["cfg_mixste"]]
+    model = MixSTE(num_frame=T, num_joints=17, in_chans=2, out_dim=3, embed_dim=C, depth=depth, num_heads=heads, drop_path_rate=0.0)
+    assert sorted(model.state_dict().keys()) == sorted(k[3:] for k in fx if k.startswith("w::"))      # the reference's state-dict keys
+    model.load_state_dict(fixture_state(fx), strict=True)
+    model.precision = precision
+    model = model.cuda().eval()
+    pred = model(dev(fx["X"]))
+    assert pred.shape == fx["poses"].shape
+    total, terms = manifold_training_loss(pred, dev(fx["y"]))
+    total.backward()
+    if precision == "fp32":
+        assert mpjpe_error(pred, dev(fx["poses"]), "average").item() <= MPJPE_TOL_M
+        close(pred, fx["poses"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose([terms[k].item() for k in ("wloss", "vloss", "sreg")], fx["loss_terms"], rtol=1e-4)
+        _check_grads(model, fx)
+    else:
+        assert mpjpe_error(pred, dev(fx["poses"]), "average").item() <= 3e-2          # un-normalised regression output: bf16 operand rounding
+        np.testing.assert_allclose(total.item(), float(fx["loss_total"]), rtol=3e-2)
+    with pytest.raises(RuntimeError):
+        model.STEblocks[0](pred)                          # blocks stay parameter containers
+
+
+def test_bare_mixste_entry_point_trains(lib, tmp_path, monkeypatch, capsys):
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hpe"))
+    from _entry import run
+    monkeypatch.chdir(tmp_path)
+    best = run(["model.arch=mixste", "train.epochs=1", "train.steps_per_epoch=2", "train.batch_size=4", "train.batch_size_test=2",
+                "data.seq_len=27", "model.channels=64", "model.layers=2", "model.nheads=4", "data.synthetic_sequences=6", "run.test=true",
+                "train.mpjpe_epoch_interval=1"])
+    out = capsys.readouterr().out
+    assert np.isfinite(best) and "epoch 0:" in out and "test [synthetic]:" in out and "mpjpe" in out
+
+
+def test_rigid_segments_term_kernel_and_training_step_vs_reference(lib):
+    """train.rigid_seg_reg (make_loss :170-177): the fused variance-of-bone-length kernel (value + gradient) against the reference's
+    segments_time_consistency autograd, through the reference-named function, the C ABI's accumulate-into-d_poses form, and one trainer
+    step of the bare MixSTE whose parameter gradients must equal those of the reference's 4-term total."""
+    from manipose_amd import MixSTE, _lib, h36m_skeleton
+    from manipose_amd.metrics.regularizations import segments_time_consistency
+    from manipose_amd.training import LiftingTrainer
+    fx = load_fixture("mixste_tiny")
+    T, C, depth, heads = [int(v) for v in fx["cfg_mixste"]]
+    pred = dev(fx["poses"]).requires_grad_(True)
+    r = 0.7 * segments_time_consistency(pred.permute(0, 3, 2, 1), h36m_skeleton(), mode="sum")
+    r.backward()
+    np.testing.assert_allclose(r.item(), float(fx["rigid_term"]), rtol=2e-5)
+    close(pred.grad, fx["rigid_g_pred"], rtol=2e-4, atol=1e-7)
+    # non-differentiable (analytics) path of the same function agrees
+    np.testing.assert_allclose(0.7 * segments_time_consistency(pred.detach().permute(0, 3, 2, 1), h36m_skeleton(), mode="sum").item(),
+                               float(fx["rigid_term"]), rtol=1e-4)
+    model = MixSTE(num_frame=T, num_joints=17, in_chans=2, out_dim=3, embed_dim=C, depth=depth, num_heads=heads, drop_path_rate=0.0)
+    model.load_state_dict(fixture_state(fx), strict=True)
+    model = model.cuda().eval()
+    tr = LiftingTrainer(model, lr=0.0, weight_decay=0.0, rigid_seg_reg=0.7)
+    terms = tr.train_step(dev(fx["X"]), dev(fx["y"]))
+    np.testing.assert_allclose(terms.sum().item(), float(fx["rigid_total"]), rtol=1e-4)
+    np.testing.assert_allclose(terms[3].item(), float(fx["rigid_term"]), rtol=1e-4)
+    flat = tr.flat_grads
+    for (name, off, n) in model.flat_layout():
+        want = fx["g_rigid::" + name].reshape(-1)
+        got = flat[off:off + n].cpu().numpy()
+        scale = np.abs(want).max() + 1e-12
+        np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-6 + 1e-4 * scale, err_msg=name)
+    with pytest.raises(NotImplementedError):
+        LiftingTrainer(_build(load_fixture("rmcl_tiny")), rigid_seg_reg=0.1)

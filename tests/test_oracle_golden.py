@@ -331,3 +331,38 @@ def test_rot4_models_forward_loss_grads():
     total.backward()
     for k, v in st.items():
         np.testing.assert_allclose(v.grad.numpy(), fx["g::" + k], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_bare_mixste_forward_loss_grads():
+    """model.arch=mixste (main_h36m_lifting.py:617-628): MixSTE.forward (mix_ste.py:175-191) + the single-hypothesis loss."""
+    fx = load_fixture("mixste_tiny")
+    T, C, depth, heads = [int(v) for v in fx["cfg_mixste"]]
+    st = {k: v.requires_grad_(True) for k, v in fixture_state(fx).items()}
+    pred = orc.mixste_forward(torch.from_numpy(fx["X"]), st, "", depth, heads)
+    np.testing.assert_allclose(pred.detach().numpy(), fx["poses"], **TOL)
+    total, terms = orc.manifold_training_loss(pred, torch.from_numpy(fx["y"]))
+    np.testing.assert_allclose([terms[k].item() for k in ("wloss", "vloss", "sreg")], fx["loss_terms"], rtol=1e-5)
+    total.backward()
+    for k, v in st.items():
+        np.testing.assert_allclose(v.grad.numpy(), fx["g::" + k], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_rigid_segments_term_matches_reference():
+    """train.rigid_seg_reg (make_loss :170-177): value, gradient wrt the prediction and parameter gradients of the 4-term total."""
+    fx = load_fixture("mixste_tiny")
+    T, C, depth, heads = [int(v) for v in fx["cfg_mixste"]]
+    st = {k: v.requires_grad_(True) for k, v in fixture_state(fx).items()}
+    pred = orc.mixste_forward(torch.from_numpy(fx["X"]), st, "", depth, heads)
+    pred.retain_grad()
+    r = 0.7 * orc.segments_time_consistency(pred.permute(0, 3, 2, 1), "sum")
+    r.backward(retain_graph=True)
+    np.testing.assert_allclose(r.item(), float(fx["rigid_term"]), rtol=1e-5)
+    np.testing.assert_allclose(pred.grad.numpy(), fx["rigid_g_pred"], rtol=1e-4, atol=1e-8)
+    for v in st.values():
+        v.grad = None
+    pred = orc.mixste_forward(torch.from_numpy(fx["X"]), st, "", depth, heads)
+    total, terms = orc.manifold_training_loss(pred, torch.from_numpy(fx["y"]), dict(orc.DEFAULT_TRAIN_CFG, rigid_seg_reg=0.7))
+    np.testing.assert_allclose(total.item(), float(fx["rigid_total"]), rtol=1e-5)
+    total.backward()
+    for k, v in st.items():
+        np.testing.assert_allclose(v.grad.numpy(), fx["g_rigid::" + k], rtol=2e-4, atol=2e-6, err_msg=k)
