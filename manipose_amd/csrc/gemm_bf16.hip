@@ -353,8 +353,12 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
 
+  // neighbouring tiles issue their two operand loads in opposite order: workgroups that share a panel then ask for it at different
+  // moments of the k-tile instead of all at once (measured on the weight-gradient shapes: 3-18 % fewer fabric reads, same isolated time)
+  const bool b_first = (tm + tn) & 1;
+  if (b_first) glds_tile<TRB, BT, NW>(smem + OPB, B, g.ldb, n0, kbeg, g.N, kend, lane, wave);
   glds_tile<TRA, BT, NW>(smem, A, g.lda, m0, kbeg, g.M, kend, lane, wave);
-  glds_tile<TRB, BT, NW>(smem + OPB, B, g.ldb, n0, kbeg, g.N, kend, lane, wave);
+  if (!b_first) glds_tile<TRB, BT, NW>(smem + OPB, B, g.ldb, n0, kbeg, g.N, kend, lane, wave);
   int stage = 0;
   for (int k0 = kbeg; k0 < kend; k0 += GBK, stage ^= 1) {
     __syncthreads();   // (vmcnt(0) + barrier): tile k0 has landed for every wave; nobody still reads the other stage
@@ -362,8 +366,9 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
     const char* Bs = As + OPB;
     if (k0 + GBK < kend && !(g.debug & 2)) {
       char* nx = smem + (stage ^ 1) * STAGE;
+      if (b_first) glds_tile<TRB, BT, NW>(nx + OPB, B, g.ldb, n0, k0 + GBK, g.N, kend, lane, wave);
       glds_tile<TRA, BT, NW>(nx, A, g.lda, m0, k0 + GBK, g.M, kend, lane, wave);
-      glds_tile<TRB, BT, NW>(nx + OPB, B, g.ldb, n0, k0 + GBK, g.N, kend, lane, wave);
+      if (!b_first) glds_tile<TRB, BT, NW>(nx + OPB, B, g.ldb, n0, k0 + GBK, g.N, kend, lane, wave);
     }
     if (g.debug & 1) continue;
     if (EPI == EPI_SLAB && TRA == 1) {
