@@ -1,0 +1,47 @@
+"""Longer bf16 training run on a fixed synthetic batch (memorisation): the loss must fall steadily and stay finite.
+python tools/train_sanity.py [steps] [batch] [lr]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+from manipose_amd.training import LiftingTrainer
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+lr = float(sys.argv[3]) if len(sys.argv) > 3 else 2e-4
+def run(precision, X, y, seed=0):
+    torch.manual_seed(seed)
+    model = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=243, n_hyp=5, drop_path_rate=0.1)
+    model.precision = precision
+    model = model.cuda().train()
+    tr = LiftingTrainer(model, lr=lr, weight_decay=1e-6, seed=seed)
+    hist = []
+    for i in range(steps):
+        terms = tr.train_step(X, y)
+        if i % max(1, steps // 12) == 0 or i == steps - 1:
+            v = terms.tolist()
+            hist.append(sum(v))
+            print(f"{precision} step {i:4d}: total {sum(v):.4f}  wloss {v[0]:.4f} score_reg {v[1]:.4f} vloss {v[2]:.4f} sreg {v[3]:.4f}", flush=True)
+    return hist
+
+
+# targets ON the manifold and learnable: hypothesis 0 of a teacher = the student's own initialisation with perturbed weights
+torch.manual_seed(0)
+teacher = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=243, n_hyp=5, drop_path_rate=0.0)
+gp = torch.Generator().manual_seed(5)
+with torch.no_grad():
+    for n, p in teacher.named_parameters():
+        p.add_(0.05 * p.abs().mean().clamp_min(0.02) * torch.randn(p.shape, generator=gp))
+teacher = teacher.cuda().eval()
+g = torch.Generator(device="cuda").manual_seed(1)
+t = torch.linspace(0, 1, 243, device="cuda")[None, :, None, None]
+X = (0.5 * torch.sin(6.28 * (1 + 2 * torch.rand(B, 1, 17, 2, device="cuda", generator=g)) * t + 6.28 * torch.rand(B, 1, 17, 2, device="cuda", generator=g))).contiguous()
+with torch.no_grad():
+    y = teacher(X)[0][:, 0].contiguous()
+del teacher
+torch.cuda.empty_cache()
+hists = {p: run(p, X, y) for p in ("fp32", "bf16")}
+for p, hist in hists.items():
+    assert all(torch.isfinite(torch.tensor(hist))), f"{p}: non-finite loss"
+    assert hist[-1] < 0.6 * hist[0], (p, hist[0], hist[-1])
+print("ok:", {p: (round(h[0], 4), round(h[-1], 4)) for p, h in hists.items()})
