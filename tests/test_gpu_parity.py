@@ -1191,3 +1191,26 @@ def test_rigid_segments_term_kernel_and_training_step_vs_reference(lib):
         np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-6 + 1e-4 * scale, err_msg=name)
     with pytest.raises(NotImplementedError):
         LiftingTrainer(_build(load_fixture("rmcl_tiny")), rigid_seg_reg=0.1)
+
+
+def test_caller_facing_helpers_of_the_rmcl_model(lib):
+    """concat_hyp_and_scores / poses_from_hyp_idx (rmcl_manifold_mix_ste.py:108-139, used by eval_utils.py) and the single-term loss
+    functions the reference's make_loss calls, on the fixture's outputs."""
+    from manipose_amd import metrics as M
+    from manipose_amd.data.skeleton import assert_h36m
+    fx = load_fixture("rmcl_tiny")
+    model = _build(fx).eval()
+    poses, scores = dev(fx["poses"]), dev(fx["scores"])
+    B, K, T = poses.shape[:3]
+    cat = model.concat_hyp_and_scores(poses, scores)
+    assert cat.shape == (B, K, T, 17, 4) and torch.equal(cat[..., :3], poses) and torch.equal(cat[..., 3], scores.expand(B, K, T, 17))
+    idx = torch.from_numpy(fx["wta_idx"]).cuda()
+    picked = model.poses_from_hyp_idx(poses, idx)
+    want = orc.poses_from_hyp_idx(torch.from_numpy(fx["poses"]), torch.from_numpy(fx["wta_idx"]))
+    assert torch.equal(picked.cpu(), want)
+    w = M.STANDARD_H36M_WEIGHTS
+    close(M.weighted_mpjpe_loss(poses[:, 0], dev(fx["y"]), weights=w), orc.weighted_mpjpe_loss(torch.from_numpy(fx["poses"][:, 0]), torch.from_numpy(fx["y"]), w), rtol=1e-5)
+    assert_h36m(model.decoder.skeleton)
+    from manipose_amd.data import Skeleton, T_POSE_OPERATORS
+    with pytest.raises(AssertionError):
+        assert_h36m(Skeleton([-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 8, 11, 12, 8, 14, 14], [4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16], T_POSE_OPERATORS))
