@@ -37,10 +37,12 @@ template <int D> struct ACfg {
 };
 
 // stage `rows` (frames) x D of a strided bf16 matrix into LDS, zero-filling frames >= T
-template <int D, int NTHREADS>
-__device__ __forceinline__ void stage_rows(char* __restrict__ S, const bf16* __restrict__ base, long row_stride, int T, int tid) {
+// rows: frames of the image (T rounded up to 32: the products reduce over 32-frame blocks; frames >= T are zero-filled)
+template <int D>
+__device__ __forceinline__ void stage_rows(char* __restrict__ S, const bf16* __restrict__ base, long row_stride, int T, int rows, int tid,
+                                           int nthreads) {
   constexpr int CH = ACfg<D>::CH, ROWB = ACfg<D>::ROWB;
-  for (int idx = tid; idx < TP * CH; idx += NTHREADS) {
+  for (int idx = tid; idx < rows * CH; idx += nthreads) {
     const int t = idx / CH, c = idx - t * CH;
     uint4 x = make_uint4(0u, 0u, 0u, 0u);
     if (t < T) x = *reinterpret_cast<const uint4*>(base + (long)t * row_stride + c * 8);
@@ -132,21 +134,24 @@ __global__ __launch_bounds__(512, 4) void attn_tmfma_fwd_kernel(const bf16* __re
                                                               float* __restrict__ lse, int T, int J, int C, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB;
+  // short windows (NTC == 0): the images hold round_up(T, 32) frames and the workgroup has one wave per 16-query strip (at most 8), so
+  // that many workgroups share a CU instead of one 64 KiB, 8-wave workgroup with most waves idle
+  const int rows = NTC ? TP : (T + 31) & ~31, nw = NTC ? 8 : (int)(blockDim.x >> 6);
   char* Ks = sm;
-  char* Vs = sm + TP * ROWB;
+  char* Vs = sm + rows * ROWB;
   const int unit = blockIdx.x, h = unit % H, bj = unit / H, j = bj % J, b = bj / J;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const long rs3 = (long)J * 3 * C;
   const bf16* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;
-  stage_rows<D, 512>(Ks, qb + C, rs3, T, tid);
-  stage_rows<D, 512>(Vs, qb + 2 * C, rs3, T, tid);
+  stage_rows<D>(Ks, qb + C, rs3, T, rows, tid, nw * 64);
+  stage_rows<D>(Vs, qb + 2 * C, rs3, T, rows, tid, nw * 64);
   __syncthreads();
   const int ntile = NTC ? NTC : (T + 15) >> 4;
   ImgRd<D> Kr, Vr;
   Kr.init(Ks, lane);
   Vr.init(Vs, lane);
   const float scale2 = scale * 1.4426950408889634f;    // softmax evaluated as 2^(x log2 e): one v_exp_f32 per score, no extra multiply
-  for (int qt = wave; qt < ntile; qt += 8) {
+  for (int qt = wave; qt < ntile; qt += nw) {
     const int tq = qt * 16 + l15;                      // this lane's query (column of every tile below)
     bf16x8_t bq[KS];
 #pragma unroll
@@ -228,24 +233,25 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
                                                                int debug) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB, NW = 16, UNR = NTC ? NTC / 2 : 1;
+  const int rows = NTC ? TP : (T + 31) & ~31, nw = NTC ? NW : (int)(blockDim.x >> 6);     // short windows: see the forward kernel
   char* Qs = sm;
-  char* Ks = Qs + TP * ROWB;
-  char* Vs = Ks + TP * ROWB;
-  char* Gs = Vs + TP * ROWB;                           // dO
-  float* Ls = reinterpret_cast<float*>(Gs + TP * ROWB);  // MINUS the log2-domain log-sum-exp per query (-inf for padding -> p = 0)
-  float* Dl = Ls + TP;                                 // MINUS delta = -sum_d dO * O per query
+  char* Ks = Qs + rows * ROWB;
+  char* Vs = Ks + rows * ROWB;
+  char* Gs = Vs + rows * ROWB;                           // dO
+  float* Ls = reinterpret_cast<float*>(Gs + rows * ROWB);  // MINUS the log2-domain log-sum-exp per query (-inf for padding -> p = 0)
+  float* Dl = Ls + rows;                                 // MINUS delta = -sum_d dO * O per query
   const int unit = blockIdx.x, h = unit % H, bj = unit / H, j = bj % J, b = bj / J;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const long rs3 = (long)J * 3 * C, rs1 = (long)J * C;
   const bf16* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;
   const bf16* ob = out + ((long)b * T * J + j) * C + h * D;
   const bf16* gb = dout + ((long)b * T * J + j) * C + h * D;
-  stage_rows<D, 1024>(Qs, qb, rs3, T, tid);
-  stage_rows<D, 1024>(Ks, qb + C, rs3, T, tid);
-  stage_rows<D, 1024>(Vs, qb + 2 * C, rs3, T, tid);
-  stage_rows<D, 1024>(Gs, gb, rs1, T, tid);
-  {   // delta and log-sum-exp: 4 threads per frame, each a quarter of the head dim
-    const int t = tid >> 2, part = tid & 3;
+  stage_rows<D>(Qs, qb, rs3, T, rows, tid, nw * 64);
+  stage_rows<D>(Ks, qb + C, rs3, T, rows, tid, nw * 64);
+  stage_rows<D>(Vs, qb + 2 * C, rs3, T, rows, tid, nw * 64);
+  stage_rows<D>(Gs, gb, rs1, T, rows, tid, nw * 64);
+  for (int t0 = 0; t0 < rows; t0 += nw * 16) {   // delta and log-sum-exp: 4 threads per frame, each a quarter of the head dim
+    const int t = t0 + (tid >> 2), part = tid & 3;
     float dl = 0.f;
     if (t < T) {
 #pragma unroll
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
     }
     dl += __shfl_xor(dl, 1, 64);
     dl += __shfl_xor(dl, 2, 64);
-    if (part == 0) {
+    if (part == 0 && t < rows) {
       Dl[t] = -dl;                                        // stored negated: ds = p (dp + (-delta)) is a packed add + a packed multiply
       Ls[t] = (t < T) ? lse[(long)unit * T + t] * -1.4426950408889634f : -INFINITY;    // MINUS lse in log2 units
     }
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
   Gr.init(Gs, lane);
 
   // ---- pass A: dQ (scores in the [key][query] orientation: query on the lane, 4 keys per accumulator) ----
-  for (int qt = wave; qt < ntile; qt += NW) {
+  for (int qt = wave; qt < ntile; qt += nw) {
     const int tq = qt * 16 + l15;
     bf16x8_t bq[KS], bg[KS];
 #pragma unroll
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
   if (debug & 2) return;                                 // timing ablation: no dK/dV pass
 
   // ---- pass B: dK, dV (scores in the [query][key] orientation) ----
-  for (int kt = wave; kt < ntile; kt += NW) {
+  for (int kt = wave; kt < ntile; kt += nw) {
     const int tk = kt * 16 + l15;
     bf16x8_t bk[KS], bv[KS];
 #pragma unroll
@@ -633,13 +639,15 @@ bool attn_tmfma_supported(int T, int D) { return T <= TP && (D == 64 || D == 16)
 
 template <int D, int NTC>
 static int launch_tmfma_fwd(const bf16* qkv, bf16* out, float* lse, int units, int T, int J, int C, int H, float scale, hipStream_t st) {
-  const size_t lds = 2 * TP * ACfg<D>::ROWB;
+  const int rows = NTC ? TP : (T + 31) & ~31, waves = NTC ? 8 : min(8, (T + 15) >> 4);
+  const size_t lds = 2 * (size_t)rows * ACfg<D>::ROWB;
   static bool attr_set = false;
   if (!attr_set) {
-    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_kernel<D, NTC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_kernel<D, NTC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(2 * TP * ACfg<D>::ROWB)));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_tmfma_fwd_kernel<D, NTC>), dim3(units), dim3(512), lds, st, qkv, out, lse, T, J, C, H, scale);
+  hipLaunchKernelGGL((attn_tmfma_fwd_kernel<D, NTC>), dim3(units), dim3(64 * waves), lds, st, qkv, out, lse, T, J, C, H, scale);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -656,13 +664,16 @@ int attn_tmfma_fwd(const bf16* qkv, bf16* out, float* lse, int B, int T, int J, 
 template <int D, int NTC>
 static int launch_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, const float* lse, bf16* dqkv, int units, int T, int J, int C,
                             int H, float scale, int dbg, hipStream_t st) {
-  const size_t lds = 4 * TP * ACfg<D>::ROWB + 2 * TP * sizeof(float);
+  const int rows = NTC ? TP : (T + 31) & ~31, waves = NTC ? 16 : min(16, (T + 15) >> 4);
+  const size_t lds = 4 * (size_t)rows * ACfg<D>::ROWB + 2 * rows * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_bwd_kernel<D, NTC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_bwd_kernel<D, NTC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(4 * TP * ACfg<D>::ROWB + 2 * TP * sizeof(float))));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_tmfma_bwd_kernel<D, NTC>), dim3(units), dim3(1024), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg);
+  hipLaunchKernelGGL((attn_tmfma_bwd_kernel<D, NTC>), dim3(units), dim3(64 * waves), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale,
+                     dbg);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
