@@ -639,7 +639,11 @@ bool attn_tmfma_supported(int T, int D) { return T <= TP && (D == 64 || D == 16)
 
 template <int D, int NTC>
 static int launch_tmfma_fwd(const bf16* qkv, bf16* out, float* lse, int units, int T, int J, int C, int H, float scale, hipStream_t st) {
-  const int rows = NTC ? TP : (T + 31) & ~31, waves = NTC ? 8 : min(8, (T + 15) >> 4);
+  // waves per workgroup: two 16-query strips per wave up to 128 frames (more, smaller workgroups per CU overlap their load / compute /
+  // store phases: T=81 602 -> 442 us, T=128 443 -> 428 us, T=27 411 -> 387 us at the bench's token count), 8 waves beyond
+  const int ntile = (T + 15) >> 4;
+  const int waves = NTC ? 8 : (ntile <= 8 ? (ntile + 1) / 2 : 8);
+  const int rows = NTC ? TP : (T + 31) & ~31;
   const size_t lds = 2 * (size_t)rows * ACfg<D>::ROWB;
   static bool attr_set = false;
   if (!attr_set) {
@@ -664,7 +668,10 @@ int attn_tmfma_fwd(const bf16* qkv, bf16* out, float* lse, int B, int T, int J, 
 template <int D, int NTC>
 static int launch_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, const float* lse, bf16* dqkv, int units, int T, int J, int C,
                             int H, float scale, int dbg, hipStream_t st) {
-  const int rows = NTC ? TP : (T + 31) & ~31, waves = NTC ? 16 : min(16, (T + 15) >> 4);
+  // waves per workgroup: one per 16-frame strip, except 4 for 5-7 strips (T=81: 971 -> 906 us; 8 strips and more measured best at one each)
+  const int ntile = (T + 15) >> 4;
+  const int waves = NTC ? 16 : ((ntile >= 5 && ntile <= 7) ? 4 : min(16, ntile));
+  const int rows = NTC ? TP : (T + 31) & ~31;
   const size_t lds = 4 * (size_t)rows * ACfg<D>::ROWB + 2 * rows * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

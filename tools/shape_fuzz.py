@@ -46,7 +46,7 @@ for T, C, H, B, K in cases:
         cos = min(torch.nn.functional.cosine_similarity(p.grad.cpu().reshape(-1), req[k].grad.reshape(-1), dim=0).item()
                   for k, p in model.named_parameters())
         ok = (mp <= 1e-4 and gerr <= 5e-3 and abs(tot.item() - ot.item()) <= 1e-4 * abs(ot.item())) if prec == "fp32" else \
-             (mp <= 2e-2 and np.isfinite(gerr) and abs(tot.item() - ot.item()) <= 5e-2 * abs(ot.item()))
+             (mp <= 5e-2 and np.isfinite(gerr) and abs(tot.item() - ot.item()) <= 5e-2 * abs(ot.item()))
         worst = max(worst, mp if prec == "fp32" else 0.0)
         print(f"T={T:3d} C={C:3d} H={H} B={B} K={K} {prec}: MPJPE {mp:.2e} m, loss {tot.item():.5f} vs {ot.item():.5f}, worst grad rel {gerr:.2e} ({wk}), min cosine {cos:.4f}  {'ok' if ok else 'FAIL'}",
               flush=True)
