@@ -44,40 +44,64 @@ __device__ __forceinline__ void head_row_xhat(const float* __restrict__ xr, int 
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
+// HR token rows per wave and iteration: every weight / gamma / beta vector fetched from cache serves HR rows (the one-row form
+// re-read the K * O weight vectors for every token: 70 KB of L1 traffic per row, which bounded the kernel), and the HR wave
+// reductions of an output are independent chains.  Per row the arithmetic and its order are unchanged.
+constexpr int HR = 4;
+
 __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ x, HeadParams p, int K, int O,
                                                          float* __restrict__ out, float* __restrict__ stats, int M, int C) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (int m = wave; m < M; m += nwaves) {
-    float mean, rstd;
-    float4 xh[HV];
-    head_row_xhat(x + (long)m * C, lane, C, 1e-5f, false, mean, rstd, xh);
-    if (lane == 0) {
-      stats[2 * (long)m] = mean;
-      stats[2 * (long)m + 1] = rstd;
+  for (int m0 = wave * HR; m0 < M; m0 += nwaves * HR) {
+    float4 xh[HR][HV];
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {
+      const int m = min(m0 + r, M - 1);                       // rows past the end recompute the last row and are not stored
+      float mean, rstd;
+      head_row_xhat(x + (long)m * C, lane, C, 1e-5f, false, mean, rstd, xh[r]);
+      if (lane == 0 && m0 + r < M) {
+        stats[2 * (long)m] = mean;
+        stats[2 * (long)m + 1] = rstd;
+      }
     }
     for (int k = 0; k < K; ++k) {
-      float4 y[HV];
+      float4 y[HR][HV];
 #pragma unroll
       for (int i = 0; i < HV; ++i) {
         const int c = lane * 4 + 256 * i;
         if (c < C) {
           const float4 g = ld4(p.gamma[k] + c), b = ld4(p.beta[k] + c);
-          y[i] = make_float4(xh[i].x * g.x + b.x, xh[i].y * g.y + b.y, xh[i].z * g.z + b.z, xh[i].w * g.w + b.w);
+#pragma unroll
+          for (int r = 0; r < HR; ++r)
+            y[r][i] = make_float4(xh[r][i].x * g.x + b.x, xh[r][i].y * g.y + b.y, xh[r][i].z * g.z + b.z, xh[r][i].w * g.w + b.w);
         } else {
-          y[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int r = 0; r < HR; ++r) y[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
       for (int o = 0; o < O; ++o) {
-        float s = 0.f;
+        float s[HR];
+#pragma unroll
+        for (int r = 0; r < HR; ++r) s[r] = 0.f;
 #pragma unroll
         for (int i = 0; i < HV; ++i) {
           const int c = lane * 4 + 256 * i;
-          if (c < C) s += dot4(y[i], ld4(p.W[k] + (long)o * C + c));
+          if (c < C) {
+            const float4 w = ld4(p.W[k] + (long)o * C + c);
+#pragma unroll
+            for (int r = 0; r < HR; ++r) s[r] += dot4(y[r][i], w);
+          }
         }
-        s = wave_sum(s);
-        if (lane == 0) out[((long)k * M + m) * O + o] = s + p.b[k][o];
+#pragma unroll
+        for (int r = 0; r < HR; ++r) s[r] = wave_sum(s[r]);
+        if (lane == 0) {
+          const float bias = p.b[k][o];
+#pragma unroll
+          for (int r = 0; r < HR; ++r)
+            if (m0 + r < M) out[((long)k * M + m0 + r) * O + o] = s[r] + bias;
+        }
       }
     }
   }
@@ -86,7 +110,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
 int heads_fwd(const float* x, const HeadParams& p, int K, int O, float* out, float* stats, int M, int C, hipStream_t st) {
   MP_CHECK(K >= 1 && K <= 8 && O >= 1 && O <= HMAXO && C % 4 == 0 && C <= 256 * HV, MP_ERR_ARG,
            "heads_fwd: K=%d O=%d C=%d unsupported", K, O, C);
-  hipLaunchKernelGGL(heads_fwd_kernel, dim3(max(1, min(cdiv(M, 4), 2048))), dim3(256), 0, st, x, p, K, O, out, stats, M, C);
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3(max(1, min(cdiv(M, 4 * HR), 2048))), dim3(256), 0, st, x, p, K, O, out, stats, M, C);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -98,25 +122,38 @@ __global__ __launch_bounds__(256) void heads_bwd_dx_kernel(const float* __restri
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (int m0 = wave; m0 < M; m0 += nwaves) {
-    const int m = __builtin_amdgcn_readfirstlane(m0);
-    float mean = stats[2 * (long)m], rstd = stats[2 * (long)m + 1];
-    float4 xh[HV], d[HV];
-    head_row_xhat(x + (long)m * C, lane, C, 1e-5f, true, mean, rstd, xh);
+  for (int mm = wave * HR; mm < M; mm += nwaves * HR) {
+    const int m0 = __builtin_amdgcn_readfirstlane(mm);
+    float4 xh[HR][HV], d[HR][HV];
+    float rstd[HR];
 #pragma unroll
-    for (int i = 0; i < HV; ++i) d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < HR; ++r) {
+      const int m = min(m0 + r, M - 1);
+      float mean = stats[2 * (long)m];
+      rstd[r] = stats[2 * (long)m + 1];
+      head_row_xhat(x + (long)m * C, lane, C, 1e-5f, true, mean, rstd[r], xh[r]);
+#pragma unroll
+      for (int i = 0; i < HV; ++i) d[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (int k = 0; k < K; ++k) {
-      float4 dy[HV];
+      float4 dy[HR][HV];
 #pragma unroll
-      for (int i = 0; i < HV; ++i) dy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = 0; r < HR; ++r)
+#pragma unroll
+        for (int i = 0; i < HV; ++i) dy[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int o = 0; o < O; ++o) {
-        const float g = dout[((long)k * M + m) * O + o];
+        float g[HR];
+#pragma unroll
+        for (int r = 0; r < HR; ++r) g[r] = dout[((long)k * M + min(m0 + r, M - 1)) * O + o];
 #pragma unroll
         for (int i = 0; i < HV; ++i) {
           const int c = lane * 4 + 256 * i;
           if (c < C) {
             const float4 w = ld4(p.W[k] + (long)o * C + c);
-            dy[i].x += g * w.x; dy[i].y += g * w.y; dy[i].z += g * w.z; dy[i].w += g * w.w;
+#pragma unroll
+            for (int r = 0; r < HR; ++r) {
+              dy[r][i].x += g[r] * w.x; dy[r][i].y += g[r] * w.y; dy[r][i].z += g[r] * w.z; dy[r][i].w += g[r] * w.w;
+            }
           }
         }
       }
@@ -125,24 +162,33 @@ __global__ __launch_bounds__(256) void heads_bwd_dx_kernel(const float* __restri
         const int c = lane * 4 + 256 * i;
         if (c < C) {
           const float4 gm = ld4(p.gamma[k] + c);
-          d[i].x += dy[i].x * gm.x; d[i].y += dy[i].y * gm.y; d[i].z += dy[i].z * gm.z; d[i].w += dy[i].w * gm.w;
+#pragma unroll
+          for (int r = 0; r < HR; ++r) {
+            d[r][i].x += dy[r][i].x * gm.x; d[r][i].y += dy[r][i].y * gm.y; d[r][i].z += dy[r][i].z * gm.z; d[r][i].w += dy[r][i].w * gm.w;
+          }
         }
       }
     }
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < HV; ++i) {
-      s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
-      s2 += dot4(d[i], xh[i]);
-    }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
+    for (int r = 0; r < HR; ++r) {
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < HV; ++i) {
-      const int c = lane * 4 + 256 * i;
-      if (c < C)
-        st4(dx + (long)m * C + c, make_float4(rstd * (d[i].x - s1 - xh[i].x * s2), rstd * (d[i].y - s1 - xh[i].y * s2),
-                                              rstd * (d[i].z - s1 - xh[i].z * s2), rstd * (d[i].w - s1 - xh[i].w * s2)));
+      for (int i = 0; i < HV; ++i) {
+        s1 += (d[r][i].x + d[r][i].y) + (d[r][i].z + d[r][i].w);
+        s2 += dot4(d[r][i], xh[r][i]);
+      }
+      s1 = wave_sum(s1) / (float)C;
+      s2 = wave_sum(s2) / (float)C;
+      if (m0 + r < M) {
+#pragma unroll
+        for (int i = 0; i < HV; ++i) {
+          const int c = lane * 4 + 256 * i;
+          if (c < C)
+            st4(dx + (long)(m0 + r) * C + c,
+                make_float4(rstd[r] * (d[r][i].x - s1 - xh[r][i].x * s2), rstd[r] * (d[r][i].y - s1 - xh[r][i].y * s2),
+                            rstd[r] * (d[r][i].z - s1 - xh[r][i].z * s2), rstd[r] * (d[r][i].w - s1 - xh[r][i].w * s2)));
+        }
+      }
     }
   }
 }
@@ -244,7 +290,7 @@ int heads_bwd(const float* x, const float* stats, const HeadParams& p, const Hea
               float* dx, int M, int C, float* scratch, long scratch_floats, hipStream_t st) {
   MP_CHECK(K >= 1 && K <= 8 && O >= 1 && O <= HMAXO && C % 4 == 0 && C <= 256 * HV, MP_ERR_ARG,
            "heads_bwd: K=%d O=%d C=%d unsupported", K, O, C);
-  hipLaunchKernelGGL(heads_bwd_dx_kernel, dim3(max(1, min(cdiv(M, 4), 2048))), dim3(256), 0, st, x, stats, p, K, O, dout, dx, M,
+  hipLaunchKernelGGL(heads_bwd_dx_kernel, dim3(max(1, min(cdiv(M, 4 * HR), 2048))), dim3(256), 0, st, x, stats, p, K, O, dout, dx, M,
                      C);
   MP_LAUNCH_CHECK();
   const int P = max(1, min(M, 4 * HB_GRID));                 // row streams = partial rows per head
