@@ -48,8 +48,9 @@ def cpu_baseline(T, K, steps=10):
     st = {k: v.requires_grad_(True) for k, v in orc.make_state(cfg, seed=0).items()}
     opt = torch.optim.Adam(list(st.values()), lr=4e-5, weight_decay=1e-6)
     X, y = orc.synthetic_batch(1, T, seed=42)
+    warm = 3
     times = []
-    for i in range(steps + 1):
+    for i in range(steps + warm):
         t0 = time.perf_counter()
         poses, scores = orc.rmcl_manifold_forward(X, st, orc.oracle_cfg(cfg))
         total, _ = orc.rmcl_training_loss(poses, scores, y)
@@ -57,10 +58,17 @@ def cpu_baseline(T, K, steps=10):
         total.backward()
         opt.step()
         times.append(time.perf_counter() - t0)
-    dt = sorted(times[1:])[len(times[1:]) // 2]
+    dt = sorted(times[warm:])[len(times[warm:]) // 2]
+    model_name = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model_name = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "?")
+    except OSError:
+        pass
     return {"value": T / dt, "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"B=1 window T={T} K={K}, eval-mode DropPath off, 1 warm-up + {steps} timed steps (median), "
-                      f"fwd+loss+bwd+Adam, torch {torch.__version__} CPU fp32"}
+            "sample": f"B=1 window T={T} K={K}, eval-mode DropPath off, {warm} warm-up + {steps} timed steps (median), "
+                      f"fwd+loss+bwd+Adam, torch {torch.__version__} CPU fp32, {torch.get_num_threads()} threads of os.cpu_count()="
+                      f"{os.cpu_count()} ({model_name})"}
 
 
 def main():
