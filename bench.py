@@ -74,8 +74,8 @@ def cpu_baseline(T, K, steps=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("MANIPOSE_BENCH_BATCH", "79")),
                     help="windows per GPU (79: ceil(79*4131/256) = 1275 row panels, so the 2 / 4 / 6 column tiles of the four Linear shapes "
                          "give 9.96 / 19.9 / 29.9 rounds of 256 persistent workgroups - no nearly empty last round; 64 gives 8.07 / 16.1 / 24.2)")
