@@ -56,7 +56,9 @@ struct mp_model {
   struct ScratchSet { float *g, *tmpC, *tmpMask, *delta, *slab, *small; bf16* g_b16; void *tmp2C, *tmp3C; long slab_floats, small_floats; };
   ScratchSet sets[2];
   hipStream_t st2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_heads = nullptr;
+  float *hsmall = nullptr, *sc_dlogit = nullptr;   // scratch of the head / score parameter-gradient kernels when they run on the wgrad stream
+  long hsmall_floats = 0;
   // weight-gradient GEMMs of the rotations net do not feed the backward chain: they run on a third stream, ordered against the
   // chain's scratch-buffer reuse by events (E = "operand ready", W = "wgrad done reading")
   hipStream_t st3 = nullptr;
@@ -217,6 +219,9 @@ static void carve_all(mp_model* m, Bump& bp) {
     for (const auto& b : md->masks) nm += b.spatial ? (long)Bm * T : (long)Bm * md->N;
   m->maskbuf = bp.take(nm + 64);
   m->dscore_zero = bp.take((long)Bm * m->rot.K * T);
+  m->hsmall_floats = 512L * m->rot.K * ((long)m->rot.O * m->rot.C + m->rot.O + 2 * m->rot.C) + 1024;
+  m->hsmall = bp.take(m->hsmall_floats);
+  m->sc_dlogit = bp.take((long)Bm * m->rot.K * T + 64);
 }
 
 static void use_scratch(mp_model* m, int i) {
@@ -583,6 +588,7 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
       for (int b = 0; b < 4 && ok; ++b)
         ok = hipEventCreateWithFlags(&m->evE[a][b], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&m->evW[a][b], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&m->ev_heads, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
       set_error("mp_model_create: could not create the wgrad stream / events");
       (void)hipFree(m->arena);
@@ -613,6 +619,7 @@ void mp_model_destroy(mp_model* m) {
     }
   if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
   if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+  if (m->ev_heads) (void)hipEventDestroy(m->ev_heads);
   if (m->arena) (void)hipFree(m->arena);
   delete m;
 }
@@ -743,6 +750,9 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   const int B = m->B, T = m->cfg.num_frame, J = m->cfg.num_joints, S = m->cfg.num_bones, K = m->rot.K;
   const long Mr = (long)B * T * J, Ms = (long)B * T * S;
   use_scratch(m, 0);
+  // parameter gradients of the heads / score heads are needed by nobody downstream: with the weight-gradient stream on they run there,
+  // at the start of the backward where that stream is idle (own scratch, ordered behind the last writer of dheadout)
+  hipStream_t pst = m->wgrad_async ? m->st3 : nullptr;
   // decoder
   if (m->has_seg) RUN(PC_OTHER, 0, fk_decode_bwd(m->rot.headout, m->rot.O, m->cfg.rot_rep_dim, m->lengths, d_poses, m->rot.dheadout, m->dlen_pose, B, K, T, st));
   else MP_HIP(hipMemcpyAsync(m->rot.dheadout, d_poses, sizeof(float) * Mr * 3, hipMemcpyDeviceToDevice, st));
@@ -757,7 +767,10 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     float* sc = m->tmpC;    // (B,K,T) scratch, free at this point of the backward
     RUN(PC_OTHER, 0, scores_fwd(m->rot.headout, sp, K, m->rot.O, sc, B, T, J, st));
     RUN(PC_OTHER, 0, scores_bwd(m->rot.headout, sc, d_scores ? d_scores : m->dscore_zero, sp, sg, K, m->rot.O, m->rot.dheadout, B, T, J,
-                                m->small, m->small_floats, st));
+                                pst ? m->sc_dlogit : m->small, pst ? (long)K * B * T : m->small_floats, st, pst, pst ? m->ev_heads : nullptr));
+  } else if (pst) {
+    MP_HIP(hipEventRecord(m->ev_heads, st));             // dheadout is final: the head parameter gradients may start on the other stream
+    MP_HIP(hipStreamWaitEvent(pst, m->ev_heads, 0));
   }
   // fork: the bones-net backward only needs the per-pose length gradients of the decoder backward
   MP_HIP(hipEventRecord(m->ev_fork, st));
@@ -768,8 +781,8 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   HeadGrads hg;
   head_params(m, m->rot, fp, hp);
   head_grads(m, m->rot, fg, hg);
-  RUN(PC_OTHER, 0, heads_bwd(m->rot.x_final, m->rot.hstats, hp, hg, K, m->rot.O, m->rot.dheadout, m->g, (int)Mr, m->rot.C, m->small,
-                             m->small_floats, st));
+  RUN(PC_OTHER, 0, heads_bwd(m->rot.x_final, m->rot.hstats, hp, hg, K, m->rot.O, m->rot.dheadout, m->g, (int)Mr, m->rot.C,
+                             pst ? m->hsmall : m->small, pst ? m->hsmall_floats : m->small_floats, st, pst));
   int rc = backbone_bwd(m, m->rot, fp, fg, B, st);
   if (rc) return rc;
   RUN(PC_OTHER, 0, embed_bwd(m->g, m->x_in, G(m, fg, m->rot.emb_w), G(m, fg, m->rot.emb_b), G(m, fg, m->rot.spos), (int)Mr, m->rot.C, J,
@@ -794,6 +807,10 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     st = main_st;
     use_scratch(m, 0);
     MP_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
+  }
+  if (pst) {                                              // everything queued on the weight-gradient stream belongs to this backward
+    MP_HIP(hipEventRecord(m->ev_heads, pst));
+    MP_HIP(hipStreamWaitEvent(st, m->ev_heads, 0));
   }
   return MP_OK;
 }

@@ -286,13 +286,16 @@ __global__ void heads_reduce_kernel(const float* __restrict__ partial, int P, in
 
 constexpr int HB_GRID = 128;  // 512 waves -> 512 partial rows per head
 
+// st_param: stream of the parameter-gradient kernels (nothing downstream on `st` needs them); null = `st`.  The caller orders it
+// after the producer of `dout` and owns `scratch` until those kernels are done.
 int heads_bwd(const float* x, const float* stats, const HeadParams& p, const HeadGrads& gp, int K, int O, const float* dout,
-              float* dx, int M, int C, float* scratch, long scratch_floats, hipStream_t st) {
+              float* dx, int M, int C, float* scratch, long scratch_floats, hipStream_t st, hipStream_t st_param) {
   MP_CHECK(K >= 1 && K <= 8 && O >= 1 && O <= HMAXO && C % 4 == 0 && C <= 256 * HV, MP_ERR_ARG,
            "heads_bwd: K=%d O=%d C=%d unsupported", K, O, C);
   hipLaunchKernelGGL(heads_bwd_dx_kernel, dim3(max(1, min(cdiv(M, 4 * HR), 2048))), dim3(256), 0, st, x, stats, p, K, O, dout, dx, M,
                      C);
   MP_LAUNCH_CHECK();
+  if (st_param != nullptr) st = st_param;
   const int P = max(1, min(M, 4 * HB_GRID));                 // row streams = partial rows per head
   const long nk = (long)O * C + O + 2 * C;
   MP_CHECK(scratch_floats >= (long)P * K * nk, MP_ERR_ARG, "heads_bwd: scratch too small");
@@ -392,13 +395,21 @@ __global__ __launch_bounds__(256) void scores_param_kernel(const float* __restri
   }
 }
 
+// ev / st_param: when given, the parameter kernel runs on st_param after `ev` (recorded here on `st` behind the kernel that fills
+// `scratch` and the score channel of dheadout); the caller owns `scratch` until it is done
 int scores_bwd(const float* headout, const float* scores, const float* dscores, const ScoreParams& p, const ScoreGrads& gp, int K,
-               int O, float* dheadout, int B, int T, int J, float* scratch, long scratch_floats, hipStream_t st) {
+               int O, float* dheadout, int B, int T, int J, float* scratch, long scratch_floats, hipStream_t st, hipStream_t st_param,
+               hipEvent_t ev) {
   MP_CHECK(K >= 1 && K <= 8 && J <= 32, MP_ERR_ARG, "scores_bwd: K=%d J=%d unsupported", K, J);
   MP_CHECK(scratch_floats >= (long)K * B * T, MP_ERR_ARG, "scores_bwd: scratch too small");
   hipLaunchKernelGGL(scores_bwd_kernel, dim3(cdiv(B * T, 128)), dim3(128), 0, st, scores, dscores, p, K, O, dheadout, scratch, B, T,
                      J);
   MP_LAUNCH_CHECK();
+  if (st_param != nullptr && ev != nullptr) {
+    MP_HIP(hipEventRecord(ev, st));
+    MP_HIP(hipStreamWaitEvent(st_param, ev, 0));
+    st = st_param;
+  }
   hipLaunchKernelGGL(scores_param_kernel, dim3(K), dim3(256), 0, st, headout, scratch, gp, K, O, B, T, J);
   MP_LAUNCH_CHECK();
   return MP_OK;

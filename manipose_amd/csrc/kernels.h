@@ -107,13 +107,13 @@ struct HeadParams { const float* gamma[8]; const float* beta[8]; const float* W[
 struct HeadGrads { float* gamma[8]; float* beta[8]; float* W[8]; float* b[8]; };
 int heads_fwd(const float* x, const HeadParams& p, int K, int O, float* out, float* stats, int M, int C, hipStream_t st);
 int heads_bwd(const float* x, const float* stats, const HeadParams& p, const HeadGrads& gp, int K, int O, const float* dout,
-              float* dx, int M, int C, float* scratch, long scratch_floats, hipStream_t st);
+              float* dx, int M, int C, float* scratch, long scratch_floats, hipStream_t st, hipStream_t st_param = nullptr);
 // score head: logit[b,k,t] = sum_j ws_k[j] * headout[k][(b,t,j)][O-1] + bs_k ; scores = softmax_k
 struct ScoreParams { const float* w[8]; const float* b[8]; };
 struct ScoreGrads { float* w[8]; float* b[8]; };
 int scores_fwd(const float* headout, const ScoreParams& p, int K, int O, float* scores, int B, int T, int J, hipStream_t st);
 int scores_bwd(const float* headout, const float* scores, const float* dscores, const ScoreParams& p, const ScoreGrads& gp,
-               int K, int O, float* dheadout, int B, int T, int J, float* scratch, long scratch_floats, hipStream_t st);
+               int K, int O, float* dheadout, int B, int T, int J, float* scratch, long scratch_floats, hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr);
 int bones_mean_fwd(const float* headout, float* lengths, int B, int T, int S, hipStream_t st);
 int bones_mean_bwd(const float* dlen_pose, int KT, float* dlengths, float* dheadout, int B, int T, int S, hipStream_t st);
 
