@@ -279,9 +279,22 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// The reduction of the per-workgroup partial sums into the parameter gradients is needed by nobody downstream on `st`: with
+// (st_param, ev) given it runs on st_param behind `ev`, recorded here on `st` after the kernel that wrote the partials (the caller
+// owns `scratch` until it has run).  Replaces `st` by the stream to launch on; false on a HIP error.
+static bool param_stream(hipStream_t& st, hipStream_t st_param, hipEvent_t ev) {
+  if (st_param == nullptr || ev == nullptr) return true;
+  if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(st_param, ev, 0) != hipSuccess) {
+    set_error("ln_bwd: could not order the partial-sum reduction on the parameter stream");
+    return false;
+  }
+  st = st_param;
+  return true;
+}
+
 int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
            const float* mask, int mask_mode, int T, int J, float* dgamma, float* dbeta, int M, int C, float* scratch,
-           long scratch_floats, hipStream_t st) {
+           long scratch_floats, hipStream_t st, hipStream_t st_param, hipEvent_t ev) {
   MP_CHECK(C % 4 == 0 && C <= 1024, MP_ERR_ARG, "ln_bwd: C=%d unsupported", C);
   const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
   MP_CHECK(scratch_floats >= (long)grid * 2 * C, MP_ERR_ARG, "ln_bwd: scratch too small");
@@ -293,6 +306,7 @@ int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, cons
 #undef MP_LN_BWD
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dgamma, dbeta, nullptr, nullptr}, {0, C, 2 * C, 2 * C, 2 * C}, {1, 1, 1, 1}};
+  if (!param_stream(st, st_param, ev)) return MP_ERR_HIP;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(2 * C, RP_OUT)), dim3(256), 0, st, scratch, grid, 2 * C, d);
   MP_LAUNCH_CHECK();
   return MP_OK;
@@ -424,7 +438,7 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
             const float* x0, const float* stats0, const float* gamma0, const float* beta0, float* dx, void* dx_b16, const float* mask,
             int mask_mode, int T,
             int J, float* dgamma1, float* dbeta1, float* dgamma0, float* dbeta0, int M, int C, float* scratch, long scratch_floats,
-            hipStream_t st) {
+            hipStream_t st, hipStream_t st_param, hipEvent_t ev) {
   MP_CHECK(C % 4 == 0 && C <= 512, MP_ERR_ARG, "ln_bwd2: C=%d unsupported", C);
   const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
   MP_CHECK(scratch_floats >= (long)grid * 4 * C, MP_ERR_ARG, "ln_bwd2: scratch too small");
@@ -436,6 +450,7 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
                        beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C);
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dgamma1, dbeta1, dgamma0, dbeta0}, {0, C, 2 * C, 3 * C, 4 * C}, {1, 1, 1, 1}};
+  if (!param_stream(st, st_param, ev)) return MP_ERR_HIP;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(4 * C, RP_OUT)), dim3(256), 0, st, scratch, grid, 4 * C, d);
   MP_LAUNCH_CHECK();
   return MP_OK;

@@ -59,6 +59,9 @@ struct mp_model {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_heads = nullptr;
   float *hsmall = nullptr, *sc_dlogit = nullptr;   // scratch of the head / score parameter-gradient kernels when they run on the wgrad stream
   long hsmall_floats = 0;
+  float* lnpart = nullptr;                   // one partial-sum slice per LayerNorm backward of the rotations net (reduced on the wgrad stream)
+  long lnpart_slice = 0;
+  int lnpart_n = 0;
   // weight-gradient GEMMs of the rotations net do not feed the backward chain: they run on a third stream, ordered against the
   // chain's scratch-buffer reuse by events (E = "operand ready", W = "wgrad done reading")
   hipStream_t st3 = nullptr;
@@ -222,6 +225,9 @@ static void carve_all(mp_model* m, Bump& bp) {
   m->hsmall_floats = 512L * m->rot.K * ((long)m->rot.O * m->rot.C + m->rot.O + 2 * m->rot.C) + 1024;
   m->hsmall = bp.take(m->hsmall_floats);
   m->sc_dlogit = bp.take((long)Bm * m->rot.K * T + 64);
+  m->lnpart_slice = 1024L * 4 * m->rot.C;                  // LNB_GRID rows x up to 4 C partial sums (ln_bwd2)
+  m->lnpart_n = 3 * 2 * m->rot.depth + 2;                  // at most three LayerNorm backwards per block
+  m->lnpart = bp.take(m->lnpart_slice * m->lnpart_n);
 }
 
 static void use_scratch(mp_model* m, int i) {
@@ -415,6 +421,12 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
   hipStream_t sw = wasync ? m->st3 : st;
   bool have_prev = false;       // a previous block's W events exist
   int par = 0;
+  // LayerNorm parameter gradients: the reduction of each call's partial sums runs on the weight-gradient stream, from its own slice
+  int ln_call = 0;
+  hipStream_t lst = wasync ? sw : nullptr;
+  hipEvent_t lev = wasync ? m->ev_heads : nullptr;
+  auto ln_scratch = [&]() -> float* { return (wasync && ln_call < m->lnpart_n) ? m->lnpart + (long)(ln_call++) * m->lnpart_slice : m->small; };
+  auto ln_floats = [&](float* p) -> long { return p == m->small ? m->small_floats : m->lnpart_slice; };
 #define E_READY(i) do { if (wasync) { MP_HIP(hipEventRecord(m->evE[par][i], st)); MP_HIP(hipStreamWaitEvent(sw, m->evE[par][i], 0)); } } while (0)
 #define W_DONE(i) do { if (wasync) MP_HIP(hipEventRecord(m->evW[par][i], sw)); } while (0)
 #define WAIT_W(p, i) do { if (wasync) MP_HIP(hipStreamWaitEvent(st, m->evW[p][i], 0)); } while (0)
@@ -428,9 +440,10 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
     const float* mk2 = branch_mask(m, md, l, 1, B, m->train);
     if (!post_done) {
       if (l == 0) RUN(PC_OTHER, 0, tpos_grad(g, G(m, fg, md.tpos), B, T, N, C, st));
+      float* lsc = ln_scratch();
       RUN(PC_LN, 0, ln_bwd(g, 0, w.x_out, w.stp, P(m, fp, spatial ? md.sn_w : md.tn_w), nullptr, g, m->g_b16, mk2, mode, T, N,
-                           G(m, fg, spatial ? md.sn_w : md.tn_w), G(m, fg, spatial ? md.sn_b : md.tn_b), (int)M, C, m->small,
-                           m->small_floats, st));
+                           G(m, fg, spatial ? md.sn_w : md.tn_w), G(m, fg, spatial ? md.sn_b : md.tn_b), (int)M, C, lsc,
+                           ln_floats(lsc), st, lsc == m->small ? nullptr : lst, lev));
     }
     post_done = false;
     // (b) mlp branch: fc2 (gb = DropPath-scaled branch gradient; a bf16 copy emitted by the LN backward in precision 1)
@@ -456,8 +469,9 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
     WAIT_W(par, 0);                                                // the fc2 wgrad must be done with gb before (d) rewrites it
     // (d) norm2 + skip
     const float* mk1 = branch_mask(m, md, l, 0, B, m->train);
+    float* lsc2 = ln_scratch();
     RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, m->g_b16, mk1, mode, T, N, G(m, fg, q.n2w),
-                         G(m, fg, q.n2b), (int)M, C, m->small, m->small_floats, st));
+                         G(m, fg, q.n2b), (int)M, C, lsc2, ln_floats(lsc2), st, lsc2 == m->small ? nullptr : lst, lev));
     // (e) attention branch: proj
     gb = half ? (const void*)m->g_b16 : (const void*)g;
     if (mk1 && !half) {
@@ -490,14 +504,16 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
       BlockWS& wp = md.ws[l - 1];
       const bool pspatial = ((l - 1) % 2 == 0);
       const float* mkp = branch_mask(m, md, l - 1, 1, B, m->train);
+      float* lsc3 = ln_scratch();
       RUN(PC_LN, 0, ln_bwd2(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, wp.x_out, wp.stp, P(m, fp, pspatial ? md.sn_w : md.tn_w),
                             P(m, fp, pspatial ? md.sn_b : md.tn_b), g, m->g_b16, mkp, pspatial ? 1 : 2, T, N, G(m, fg, q.n1w), G(m, fg, q.n1b),
-                            G(m, fg, pspatial ? md.sn_w : md.tn_w), G(m, fg, pspatial ? md.sn_b : md.tn_b), (int)M, C, m->small,
-                            m->small_floats, st));
+                            G(m, fg, pspatial ? md.sn_w : md.tn_w), G(m, fg, pspatial ? md.sn_b : md.tn_b), (int)M, C, lsc3,
+                            ln_floats(lsc3), st, lsc3 == m->small ? nullptr : lst, lev));
       post_done = true;
     } else {
+      float* lsc4 = ln_scratch();
       RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, g, nullptr, nullptr, 0, T, N, G(m, fg, q.n1w),
-                           G(m, fg, q.n1b), (int)M, C, m->small, m->small_floats, st));
+                           G(m, fg, q.n1b), (int)M, C, lsc4, ln_floats(lsc4), st, lsc4 == m->small ? nullptr : lst, lev));
     }
   }
   if (wasync && have_prev) {    // the last block's fc1 / qkv weight gradients

@@ -71,11 +71,11 @@ int ln_fwd(const LnFwdArgs& a, int out_bf16, hipStream_t st);
 // dx = [dskip +] LN'(dy); partial param grads are reduced and ADDED into dgamma/dbeta.
 int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
            const float* mask, int mask_mode, int T, int J, float* dgamma, float* dbeta, int M, int C, float* scratch,
-           long scratch_floats, hipStream_t st);
+           long scratch_floats, hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr);
 int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, const float* gamma1, const float* dskip,
             const float* x0, const float* stats0, const float* gamma0, const float* beta0 /* non-null: x1 == LN0(x0) is recomputed */,
             float* dx, void* dx_b16, const float* mask, int mask_mode, int T, int J, float* dgamma1, float* dbeta1, float* dgamma0, float* dbeta0, int M, int C, float* scratch, long scratch_floats,
-            hipStream_t st);
+            hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr);
 
 int embed_fwd(const float* xin, const float* W, const float* b, const float* spos, float* out, int M, int C, int J,
               hipStream_t st);
