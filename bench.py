@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TRAIN_GFLOP_PER_POSE = {243: 3.705, 81: 3.562, 27: 3.513}      # SURVEY.md 8d (3 x forward GEMM+attention FLOPs)
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}                  # MI355X_MICROARCH.md: dense matrix peaks
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}                  # MI355X_MICROARCH.md: dense matrix peaks
 PEAK_HBM_GBPS = 8000.0                                         # HBM3E spec peak (measured copy peak on this pool: ~5.5-6.3 TB/s)
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction of
 # MI355X_MICROARCH.md section HBM, + WRITE_SIZE), see profiles/README.md; keyed by (precision, windows per GPU).
@@ -81,7 +81,7 @@ def main():
                          "give 9.96 / 19.9 / 29.9 rounds of 256 persistent workgroups - no nearly empty last round; 64 gives 8.07 / 16.1 / 24.2)")
     ap.add_argument("--frames", type=int, default=243)
     ap.add_argument("--hyp", type=int, default=5)
-    ap.add_argument("--precision", default=os.environ.get("MANIPOSE_PRECISION", "bf16"), choices=["bf16", "fp32"],
+    ap.add_argument("--precision", default=os.environ.get("MANIPOSE_PRECISION", "bf16"), choices=["bf16", "bf16x3", "fp32"],
                     help="bf16 = BASELINE config #3 (bf16 matrix cores, fp32 accumulate/residual/softmax); fp32 = parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 2
+#define MP_ABI_VERSION 3
 
 int mp_abi_version(void);
 const char* mp_last_error(void);
@@ -118,6 +118,21 @@ int mp_attention_fwd_bf16(const void* qkv, void* out, float* lse, int temporal, 
 int mp_attention_bwd_bf16(const void* qkv, const void* out, const void* d_out, const float* lse, float* delta, void* d_qkv,
                           int temporal, int B, int T, int J, int C, int H, void* stream);
 
+/* Split precision "bf16x3" (precision 2 of the engine): a value x is carried as two bf16 numbers hi = bf16(x), lo = bf16(x - hi)
+ * in two planes of the same shape, and every product a*b of a Linear layer (architectures/mix_ste.py:216-222,257-261,280-281) or of
+ * the attention core (:271-279) is evaluated as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on the bf16 matrix cores with fp32 accumulation:
+ * 16 significand bits per operand, which keeps the model within the 1e-4 m MPJPE bound of the fp32 reference at matrix-core speed.
+ * mp_split_bf16: fp32 -> (hi, lo) planes (n a multiple of 4). */
+int mp_split_bf16(const float* src, void* hi, void* lo, int64_t n, void* stream);
+/* y = x W^T + b on planar operands.  epilogue 0: y planar (y = hi plane, y_lo); 1: GELU, y planar and z = gelu'(pre-activation) as
+ * plain bf16; 2: y = r + (x W^T + b) in fp32 (y_lo unused). */
+int mp_linear_fwd_bf16x3(const void* x_hi, const void* x_lo, const void* W_hi, const void* W_lo, const float* b, void* y, void* y_lo,
+                         void* z, const float* r, int M, int N, int K, int epilogue, void* stream);
+/* attention core on a planar fused qkv buffer, planar output.  scratch: 4*M*C floats, needed only where no MFMA kernel covers the
+ * shape (spatial: 16 <= J <= 32 tokens, head dim 64 or 16, <= 8 heads; temporal: T <= 256, head dim 64 or 16); NULL otherwise. */
+int mp_attention_fwd_bf16x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, float* scratch, int temporal,
+                            int B, int T, int J, int C, int H, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Model engine: RMCLManifoldMixSTE / ManifoldMixSTE forward + backward as one native launch sequence
  * (replaces RMCLManifoldMixSTE.forward, architectures/rmcl_manifold_mix_ste.py:83-106 and everything it
@@ -137,7 +152,8 @@ typedef struct mp_model_config {
   int n_hyp;           /* K (ignored for arch 1) */
   float drop_path_rate;/* stochastic depth: linspace(0, rate, depth) per module (mix_ste.py:70) */
   int max_batch;       /* workspace is sized for this many windows; 0 = layout-only handle (no device memory) */
-  int precision;       /* 0 = fp32 matrix cores (parity mode), 1 = bf16 matrix cores / fp32 accumulate */
+  int precision;       /* 0 = fp32 matrix cores; 1 = bf16 matrix cores / fp32 accumulate; 2 = "bf16x3": split-precision forward (planar hi/lo
+                        * bf16 operands, three matrix-core products each: within the 1e-4 m MPJPE bound), bf16 backward on the hi planes */
   int rot_rep_dim;     /* 6 (default when 0) or 4: rotation representation the heads emit (pose_decoder.py:22-31) */
 } mp_model_config;
 

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("MANIPOSE_HIP_LIB") or os.path.join(_HERE, "libmanipos
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "manipose_hip.h")
 
 _lib: Optional[C.CDLL] = None
+ABI_VERSION = 3
 
 vp, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
@@ -54,6 +55,9 @@ _SIGNATURES = {
     "mp_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mp_attention_fwd_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mp_attention_bwd_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mp_split_bf16": (i32, [vp, vp, vp, i64, vp]),
+    "mp_linear_fwd_bf16x3": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mp_attention_fwd_bf16x3": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mp_model_create": (i32, [C.POINTER(ModelConfig), C.POINTER(vp)]),
     "mp_model_destroy": (None, [vp]),
     "mp_model_workspace_bytes": (i64, [vp]),
@@ -101,8 +105,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.mp_abi_version() != 2:
-        raise RuntimeError(f"manipose_amd: ABI version {lib.mp_abi_version()} != 2; rebuild the library")
+    if lib.mp_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"manipose_amd: ABI version {lib.mp_abi_version()} != {ABI_VERSION}; rebuild the library")
     _lib = lib
     return lib
 

@@ -87,6 +87,22 @@ template <int D> struct ImgRd {
     if (D < 32 && zero) return z;
     return *(lds_ptr8)(size_t)(unsigned)(fr[ks] + row0 * ACfg<D>::ROWB);
   }
+  // the same accesses on a second image `delta` bytes (wave-uniform) behind this one: the lo plane of a planar pair
+  __device__ __forceinline__ bf16x8_t rows(int ks, int row0, int delta) const {
+    typedef const bf16x8_t __attribute__((address_space(3))) * lds_ptr8;
+    bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (D < 32 && zero) return z;
+    return *(lds_ptr8)(size_t)(unsigned)(fr[ks] + delta + row0 * ACfg<D>::ROWB);
+  }
+  __device__ __forceinline__ bf16x8_t cols(int db, int t0, int delta) const {
+    typedef bf16x4_t __attribute__((address_space(3))) * lds_ptr;
+    const unsigned a0 = (unsigned)(tc[db] + delta + t0 * ACfg<D>::ROWB);
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(size_t)(a0));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(size_t)(a0 + 16 * ACfg<D>::ROWB));
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  }
   __device__ __forceinline__ bf16x8_t cols(int db, int t0) const {
     typedef bf16x4_t __attribute__((address_space(3))) * lds_ptr;
     const unsigned a0 = (unsigned)(tc[db] + t0 * ACfg<D>::ROWB);
@@ -633,6 +649,297 @@ int attn_smfma_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, int B, int T, 
   }
   MP_LAUNCH_CHECK();
   return MP_OK;
+}
+
+
+// =============================================================================================
+// Split precision ("bf16x3", common.h): q, k, v and the output are planar hi/lo bf16 pairs; every matrix product is evaluated as
+// lo.hi + hi.lo + hi.hi on the bf16 matrix cores (fp32 accumulate), the probabilities are split into hi/lo in registers.
+// Same structure as the bf16 kernels above with twice the LDS images.
+// =============================================================================================
+__device__ __forceinline__ void pack_acc_x2(const f32x4& a, const f32x4& b, bf16x8_t& hi, bf16x8_t& lo) {
+  union { uint4 u; bf16x8_t v; } h, l;
+  split_bf16x2(a[0], a[1], h.u.x, l.u.x); split_bf16x2(a[2], a[3], h.u.y, l.u.y);
+  split_bf16x2(b[0], b[1], h.u.z, l.u.z); split_bf16x2(b[2], b[3], h.u.w, l.u.w);
+  hi = h.v; lo = l.v;
+}
+__device__ __forceinline__ void store4_x2(bf16* ph, bf16* pl, const f32x4& v, float s) {
+  uint2 h, l;
+  split_bf16x2(v[0] * s, v[1] * s, h.x, l.x);
+  split_bf16x2(v[2] * s, v[3] * s, h.y, l.y);
+  *reinterpret_cast<uint2*>(ph) = h;
+  *reinterpret_cast<uint2*>(pl) = l;
+}
+#define MP_MFMA3(acc, a_hi, a_lo, b_hi, b_lo)                                   \
+  do {                                                                          \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, acc, 0, 0, 0);    \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo, acc, 0, 0, 0);    \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, acc, 0, 0, 0);    \
+  } while (0)
+
+// temporal: one wave per 16-query strip (up to 16 waves), K/V hi and lo images staged once (4 x rows x ROWB bytes)
+template <int D>
+__global__ __launch_bounds__(1024) void attn_tmfma_fwd_x3_kernel(const bf16* __restrict__ qkv_hi, const bf16* __restrict__ qkv_lo,
+                                                                  bf16* __restrict__ out_hi, bf16* __restrict__ out_lo,
+                                                                  float* __restrict__ lse, int T, int J, int C, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB;
+  const int rows = (T + 31) & ~31, nw = (int)(blockDim.x >> 6);
+  char* Khs = sm;
+  char* Kls = Khs + rows * ROWB;
+  char* Vhs = Kls + rows * ROWB;
+  char* Vls = Vhs + rows * ROWB;
+  const int unit = blockIdx.x, h = unit % H, bj = unit / H, j = bj % J, b = bj / J;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const long rs3 = (long)J * 3 * C;
+  const long qoff = ((long)b * T * J + j) * 3 * C + h * D;
+  const bf16* qh = qkv_hi + qoff;
+  const bf16* ql = qkv_lo + qoff;
+  stage_rows<D>(Khs, qh + C, rs3, T, rows, tid, nw * 64);
+  stage_rows<D>(Kls, ql + C, rs3, T, rows, tid, nw * 64);
+  stage_rows<D>(Vhs, qh + 2 * C, rs3, T, rows, tid, nw * 64);
+  stage_rows<D>(Vls, ql + 2 * C, rs3, T, rows, tid, nw * 64);
+  __syncthreads();
+  const int ntile = (T + 15) >> 4;
+  ImgRd<D> Khr, Vhr;
+  Khr.init(Khs, lane);
+  Vhr.init(Vhs, lane);
+  const int dlo = __builtin_amdgcn_readfirstlane(rows * ROWB);      // hi image -> lo image of K and of V
+  (void)Kls; (void)Vls;
+  const float scale2 = scale * 1.4426950408889634f;
+  for (int qt = wave; qt < ntile; qt += nw) {
+    const int tq = qt * 16 + l15;
+    bf16x8_t bqh[KS], bql[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = 32 * ks + 8 * g;
+      bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+      const bool ok = tq < T && d0 < D;
+      bqh[ks] = ok ? *reinterpret_cast<const bf16x8_t*>(qh + (long)tq * rs3 + d0) : z;
+      bql[ks] = ok ? *reinterpret_cast<const bf16x8_t*>(ql + (long)tq * rs3 + d0) : z;
+    }
+    f32x4 s[NTILE];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NTILE; ++kt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (kt < ntile) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8_t kh = Khr.rows(ks, kt * 16), kl = Khr.rows(ks, kt * 16, dlo);
+          MP_MFMA3(acc, kh, kl, bqh[ks], bql[ks]);
+        }
+        acc *= scale2;
+        if (kt == ntile - 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kt * 16 + 4 * g + r >= T) acc[r] = -INFINITY;
+        }
+        mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+      } else {
+        acc = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      }
+      s[kt] = acc;
+    }
+    mx = group_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NTILE; ++kt) {
+      if (kt < ntile) {
+        const f32x4 t = s[kt] - mx;
+        f32x4 e;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+        s[kt] = e;
+        sum += (e[0] + e[1]) + (e[2] + e[3]);
+      } else {
+        s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    sum = group_sum(sum);
+    f32x4 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kp = 0; kp < NTILE / 2; ++kp) {
+      if (2 * kp < ntile) {
+        bf16x8_t bph, bpl;
+        pack_acc_x2(s[2 * kp], s[2 * kp + 1], bph, bpl);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          const bf16x8_t vh = Vhr.cols(db, kp * 32), vl = Vhr.cols(db, kp * 32, dlo);
+          MP_MFMA3(o[db], vh, vl, bph, bpl);
+        }
+      }
+    }
+    if (tq < T) {
+      const float inv = 1.0f / sum;
+      const long oo = ((long)(b * T + tq) * J + j) * C + h * D;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) store4_x2(out_hi + oo + 16 * db + 4 * g, out_lo + oo + 16 * db + 4 * g, o[db], inv);
+      if (g == 0) lse[(long)unit * T + tq] = (mx + __log2f(sum)) * 0.6931471805599453f;
+    }
+  }
+}
+
+// spatial: workgroup per frame, wave per head; the frame's hi and lo qkv blocks are both staged
+template <int D>
+__global__ __launch_bounds__(512) void attn_smfma_fwd_x3_kernel(const bf16* __restrict__ qkv_hi, const bf16* __restrict__ qkv_lo,
+                                                                 bf16* __restrict__ out_hi, bf16* __restrict__ out_lo, int N, int C, int H,
+                                                                 float scale) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int KS = ACfg<D>::KS, DB = ACfg<D>::DB;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int pitch = 6 * C + 16;
+  char* sh = sm;
+  char* sl = sm + N * pitch;
+  stage_block(sh, pitch, qkv_hi + (long)f * N * 3 * C, N, 6 * C, tid, blockDim.x);
+  stage_block(sl, pitch, qkv_lo + (long)f * N * 3 * C, N, 6 * C, tid, blockDim.x);
+  __syncthreads();
+  const int oq = h * D * 2, ok = 2 * C + oq, ov = 4 * C + oq;
+  bf16x8_t kfh[2][KS], kfl[2][KS];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kfh[t][ks] = frag_tok<D>(sh, pitch, ok, 16 * t, ks, lane, N);
+      kfl[t][ks] = frag_tok<D>(sl, pitch, ok, 16 * t, ks, lane, N);
+    }
+  bf16x8_t vTh[DB], vTl[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db) {
+    vTh[db] = frag_tokT<D>(sh, pitch, ov, db, lane, N);
+    vTl[db] = frag_tokT<D>(sl, pitch, ov, db, lane, N);
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    if (qt * 16 >= N) break;
+    bf16x8_t qfh[KS], qfl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qfh[ks] = frag_tok<D>(sh, pitch, oq, 16 * qt, ks, lane, N);
+      qfl[ks] = frag_tok<D>(sl, pitch, oq, 16 * qt, ks, lane, N);
+    }
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      MP_MFMA3(s0, kfh[0][ks], kfl[0][ks], qfh[ks], qfl[ks]);
+      MP_MFMA3(s1, kfh[1][ks], kfl[1][ks], qfh[ks], qfl[ks]);
+    }
+    col_softmax(s0, s1, g, N, scale);
+    bf16x8_t bph, bpl;
+    pack_acc_x2(s0, s1, bph, bpl);
+    const int tq = qt * 16 + l15;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      MP_MFMA3(o, vTh[db], vTl[db], bph, bpl);
+      if (tq < N) {
+        const long oo = ((long)f * N + tq) * C + h * D + 16 * db + 4 * g;
+        store4_x2(out_hi + oo, out_lo + oo, o, 1.0f);
+      }
+    }
+  }
+}
+
+// planar <-> fp32 (fallback path of the split-precision attention for shapes the MFMA kernels do not cover; small models only)
+__global__ void join_planes_kernel(const bf16p* __restrict__ hi, long lo_off, float* __restrict__ out, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) st4(out + 4 * i, ld4(hi + 4 * i, lo_off));
+}
+__global__ void split_planes_kernel(const float* __restrict__ in, bf16p* __restrict__ hi, long lo_off, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) st4(hi + 4 * i, ld4(in + 4 * i), lo_off);
+}
+int join_planes(const bf16* hi, const bf16* lo, float* out, long n, hipStream_t st) {
+  MP_CHECK(n % 4 == 0, MP_ERR_ARG, "join_planes: n %% 4");
+  hipLaunchKernelGGL(join_planes_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, reinterpret_cast<const bf16p*>(hi), (long)(lo - hi), out, n / 4);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+int split_planes(const float* in, bf16* hi, bf16* lo, long n, hipStream_t st) {
+  MP_CHECK(n % 4 == 0, MP_ERR_ARG, "split_planes: n %% 4");
+  hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, in, reinterpret_cast<bf16p*>(hi), (long)(lo - hi), n / 4);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+bool attn_tmfma_supported(int T, int D);
+bool attn_x3_needs_scratch(int temporal, int T, int J, int C, int H) {
+  const int D = C / H;
+  return temporal ? !(attn_tmfma_supported(T, D) && C % 8 == 0) : !(attn_smfma_supported(J, D, H) && C % 8 == 0);
+}
+
+int attn_spatial_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* scratch, int B, int T, int J, int C, int H,
+                        hipStream_t st) {
+  MP_CHECK(C % H == 0 && C % 4 == 0, MP_ERR_ARG, "attn_spatial_fwd_x3: C=%d H=%d", C, H);
+  const int D = C / H;
+  const long M = (long)B * T * J;
+  if (attn_x3_needs_scratch(0, T, J, C, H)) {
+    MP_CHECK(scratch != nullptr, MP_ERR_ARG, "attn_spatial_fwd_x3: J=%d D=%d H=%d needs the fp32 scratch", J, D, H);
+    int rc = join_planes(qkv_hi, qkv_lo, scratch, 3 * M * C, st);
+    if (rc) return rc;
+    rc = attn_spatial_fwd(scratch, scratch + 3 * M * C, 0, B, T, J, C, H, st);
+    if (rc) return rc;
+    return split_planes(scratch + 3 * M * C, out_hi, out_lo, M * C, st);
+  }
+  const float scale = 1.0f / sqrtf((float)D);
+  const size_t lds = 2 * (size_t)J * (6 * C + 16);
+  MP_CHECK(lds <= 160 * 1024, MP_ERR_ARG, "attn_spatial_fwd_x3: frame block of %zu bytes exceeds the LDS", lds);
+  if (D == 64) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      MP_HIP(hipFuncSetAttribute((const void*)attn_smfma_fwd_x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_smfma_fwd_x3_kernel<64>, dim3(B * T), dim3(H * 64), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, J, C, H, scale);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      MP_HIP(hipFuncSetAttribute((const void*)attn_smfma_fwd_x3_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_smfma_fwd_x3_kernel<16>, dim3(B * T), dim3(H * 64), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, J, C, H, scale);
+  }
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+template <int D>
+static int launch_tmfma_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* lse, int units, int T, int J, int C,
+                               int H, float scale, hipStream_t st) {
+  const int ntile = (T + 15) >> 4;
+  const int waves = min(16, ntile);
+  const int rows = (T + 31) & ~31;
+  const size_t lds = 4 * (size_t)rows * ACfg<D>::ROWB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * ACfg<D>::ROWB)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_tmfma_fwd_x3_kernel<D>), dim3(units), dim3(64 * waves), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, T, J, C, H, scale);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+int attn_temporal_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* lse, float* scratch, int B, int T, int J,
+                         int C, int H, hipStream_t st) {
+  MP_CHECK(C % H == 0 && C % 4 == 0, MP_ERR_ARG, "attn_temporal_fwd_x3: C=%d H=%d", C, H);
+  const int D = C / H;
+  const long M = (long)B * T * J;
+  if (attn_x3_needs_scratch(1, T, J, C, H)) {
+    MP_CHECK(scratch != nullptr, MP_ERR_ARG, "attn_temporal_fwd_x3: T=%d D=%d needs the fp32 scratch", T, D);
+    int rc = join_planes(qkv_hi, qkv_lo, scratch, 3 * M * C, st);
+    if (rc) return rc;
+    rc = attn_temporal_fwd(scratch, scratch + 3 * M * C, lse, 0, B, T, J, C, H, st);
+    if (rc) return rc;
+    return split_planes(scratch + 3 * M * C, out_hi, out_lo, M * C, st);
+  }
+  const float scale = 1.0f / sqrtf((float)D);
+  const int units = B * J * H;
+  if (D == 64) return launch_tmfma_fwd_x3<64>(qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, st);
+  return launch_tmfma_fwd_x3<16>(qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, st);
 }
 
 bool attn_tmfma_supported(int T, int D) { return T <= TP && (D == 64 || D == 16); }

@@ -147,6 +147,30 @@ int mp_attention_bwd_bf16(const void* qkv, const void* out, const void* d_out, c
                   : attn_spatial_bwd(qkv, d_out, d_qkv, 1, B, T, J, C, H, (hipStream_t)stream);
 }
 
+/* split precision ("bf16x3"): planar hi/lo bf16 operands, three matrix-core products per k-tile */
+int mp_split_bf16(const float* src, void* hi, void* lo, int64_t n, void* stream) {
+  MP_CHECK(src && hi && lo && n > 0, MP_ERR_ARG, "mp_split_bf16: bad argument");
+  return split_planes(src, (bf16*)hi, (bf16*)lo, (long)n, (hipStream_t)stream);
+}
+int mp_linear_fwd_bf16x3(const void* x_hi, const void* x_lo, const void* W_hi, const void* W_lo, const float* b, void* y, void* y_lo,
+                         void* z, const float* r, int M, int N, int K, int epilogue, void* stream) {
+  MP_CHECK(x_hi && x_lo && W_hi && W_lo && y && epilogue >= 0 && epilogue <= 2, MP_ERR_ARG, "mp_linear_fwd_bf16x3: bad argument");
+  MP_CHECK((epilogue == 2 || y_lo) && (epilogue != 1 || z) && (epilogue != 2 || r), MP_ERR_ARG, "mp_linear_fwd_bf16x3: epilogue operand missing");
+  GemmB16Args g = {};
+  g.A = x_hi; g.A_lo = x_lo; g.lda = K; g.B = W_hi; g.B_lo = W_lo; g.ldb = K; g.C = y; g.C_lo = y_lo; g.ldc = N; g.M = M; g.N = N; g.K = K;
+  g.bias = b; g.Z = z; g.R = r;
+  const int epi = epilogue == 0 ? EPI_BIAS : (epilogue == 1 ? EPI_BIAS_GELU : EPI_BIAS_RESID);
+  return gemm_bf16x3(g, epilogue == 2, epi, (hipStream_t)stream);
+}
+int mp_attention_fwd_bf16x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, float* scratch, int temporal,
+                            int B, int T, int J, int C, int H, void* stream) {
+  MP_CHECK(qkv_hi && qkv_lo && out_hi && out_lo && (!temporal || lse), MP_ERR_ARG, "mp_attention_fwd_bf16x3: null pointer");
+  return temporal ? attn_temporal_fwd_x3((const bf16*)qkv_hi, (const bf16*)qkv_lo, (bf16*)out_hi, (bf16*)out_lo, lse, scratch, B, T, J, C, H,
+                                         (hipStream_t)stream)
+                  : attn_spatial_fwd_x3((const bf16*)qkv_hi, (const bf16*)qkv_lo, (bf16*)out_hi, (bf16*)out_lo, scratch, B, T, J, C, H,
+                                        (hipStream_t)stream);
+}
+
 int mp_gather_windows(const float* poses_2d, const float* poses_3d, const int64_t* seq_offset, int S, const int32_t* win_seq,
                       const int32_t* win_start, const uint8_t* win_flip, const int32_t* mirror, const float* mask2d, const float* noise2d,
                       int B, int T, int J, float* X, float* y, void* stream) {

@@ -67,6 +67,30 @@ __device__ __forceinline__ void st4(bf16* p, float4 v) {
   *reinterpret_cast<uint2*>(p) = r;
 }
 
+// ---- split precision ("bf16x3"): a value is carried as TWO bf16 numbers hi = bf16(x), lo = bf16(x - hi) (16 significand bits
+// together) stored in two planes of the same shape; a product a b is evaluated as a_lo b_hi + a_hi b_lo + a_hi b_hi on the bf16
+// matrix cores with fp32 accumulation (the dropped a_lo b_lo term is 2^-16 relative).  The hi plane alone IS the bf16 tensor, so
+// bf16 kernels can read a planar buffer unchanged.  `bf16p` tags a pointer to the hi plane of such a pair.
+struct bf16p { unsigned short v; };
+__device__ __forceinline__ void split_bf16x2(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16x2(a, b);
+  lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+// lo_off: element offset from the hi plane to the lo plane
+__device__ __forceinline__ void st4(bf16p* p, float4 v, long lo_off) {
+  uint2 h, l;
+  split_bf16x2(v.x, v.y, h.x, l.x);
+  split_bf16x2(v.z, v.w, h.y, l.y);
+  *reinterpret_cast<uint2*>(p) = h;
+  *reinterpret_cast<uint2*>(p + lo_off) = l;
+}
+__device__ __forceinline__ void st4(float* p, float4 v, long) { st4(p, v); }
+__device__ __forceinline__ void st4(bf16* p, float4 v, long) { st4(p, v); }
+__device__ __forceinline__ float4 ld4(const bf16p* p, long lo_off) {
+  const float4 h = ld4(reinterpret_cast<const bf16*>(p)), l = ld4(reinterpret_cast<const bf16*>(p + lo_off));
+  return make_float4(h.x + l.x, h.y + l.y, h.z + l.z, h.w + l.w);
+}
+
 // ---- wave (64-lane) reductions ----------------------------------------------------------------
 // DPP cross-lane operands (no LDS crossbar: a __shfl_xor butterfly is six dependent ds_bpermute_b32, ~100 clocks each):
 // quad_perm [1,0,3,2] and [2,3,0,1], row_half_mirror, row_mirror leave every lane with the result over its row of 16;

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
       float mean, rstd;
       row_stats<V>(v, lane, C, a.eps2, mean, rstd);
       T* yr = reinterpret_cast<T*>(a.y2) + (long)m * C;
+      const long lo_off = a.y2_lo != nullptr ? reinterpret_cast<T*>(a.y2_lo) - reinterpret_cast<T*>(a.y2) : 0;   // planar output only
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         const int c = lane * 4 + 256 * i;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
           o.y = (v[i].y - mean) * rstd * g2[i].y + b2[i].y;
           o.z = (v[i].z - mean) * rstd * g2[i].z + b2[i].z;
           o.w = (v[i].w - mean) * rstd * g2[i].w + b2[i].w;
-          st4(yr + c, o);
+          st4(yr + c, o, lo_off);
         }
       }
       if (lane == 0) {
@@ -129,13 +130,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
 
 static int row_grid(int M) { return max(1, min(cdiv(M, 4), 256 * 8)); }
 
-int ln_fwd(const LnFwdArgs& a, int out_bf16, hipStream_t st) {
+int ln_fwd(const LnFwdArgs& a_in, int out_mode, hipStream_t st) {
+  LnFwdArgs a = a_in;
   MP_CHECK(a.C % 4 == 0 && a.C <= 256 * LN_MAXV, MP_ERR_ARG, "ln_fwd: C=%d must be a multiple of 4 and <= 1024", a.C);
   MP_CHECK(a.g1 != nullptr || a.g2 != nullptr, MP_ERR_ARG, "ln_fwd: no stage requested");
+  MP_CHECK(out_mode != 2 || a.g2 == nullptr || a.y2_lo != nullptr, MP_ERR_ARG, "ln_fwd: planar output without its lo plane");
+  if (out_mode != 2) a.y2_lo = nullptr;
 #define MP_LN_FWD(TT, V) hipLaunchKernelGGL((ln_fwd_kernel<TT, V>), dim3(row_grid(a.M)), dim3(256), 0, st, a)
-  if (a.C <= 256)      { if (out_bf16) MP_LN_FWD(bf16, 1); else MP_LN_FWD(float, 1); }
-  else if (a.C <= 512) { if (out_bf16) MP_LN_FWD(bf16, 2); else MP_LN_FWD(float, 2); }
-  else                 { if (out_bf16) MP_LN_FWD(bf16, 4); else MP_LN_FWD(float, 4); }
+#define MP_LN_FWD_V(V) do { if (out_mode == 2) MP_LN_FWD(bf16p, V); else if (out_mode == 1) MP_LN_FWD(bf16, V); else MP_LN_FWD(float, V); } while (0)
+  if (a.C <= 256)      MP_LN_FWD_V(1);
+  else if (a.C <= 512) MP_LN_FWD_V(2);
+  else                 MP_LN_FWD_V(4);
+#undef MP_LN_FWD_V
 #undef MP_LN_FWD
   MP_LAUNCH_CHECK();
   return MP_OK;

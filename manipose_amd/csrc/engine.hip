@@ -16,7 +16,11 @@ long wgrad_f32_slab_floats(int Mtok, int Nout, int Kin);
 
 struct ParamDesc { std::string name; long offset, numel; };
 struct BlockP { int n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b; };
-struct BlockWS { float *x_in, *st1, *lse, *x_mid, *st2, *x_out, *stp; void *a1, *qkv, *ao, *a2, *z, *f; };   // void*: fp32 or bf16 by precision
+struct BlockWS {
+  float *x_in, *st1, *lse, *x_mid, *st2, *x_out, *stp;
+  void *a1, *qkv, *ao, *a2, *z, *f;        // void*: fp32 or bf16 by precision
+  void *a1l, *qkvl, *aol, *a2l, *fl;       // precision 2 (split, common.h): the lo planes; a1 ... f are then the hi planes (= the bf16 tensors the backward reads)
+};
 struct MaskBranch { std::string name; float keep; int spatial; };
 
 struct Module {
@@ -48,7 +52,10 @@ struct mp_model {
   float *g = nullptr, *tmpC = nullptr, *tmpMask = nullptr, *delta = nullptr;
   bf16* g_b16 = nullptr;                     // bf16 copy of the gradient stream (A operand of dgrad/wgrad in precision 1)
   void *tmp2C = nullptr, *tmp3C = nullptr;   // dz / dqkv: fp32 or bf16 by precision
-  bf16* wbf = nullptr;                       // bf16 shadow of the flat parameter buffer (precision 1)
+  bf16* wbf = nullptr;                       // bf16 shadow of the flat parameter buffer (precision 1; precision 2: its hi plane)
+  bf16* wbf_lo = nullptr;                    // precision 2: lo plane of the shadow
+  long xattn_half = 0;
+  float* xattn = nullptr;                    // precision 2, attention shapes without an MFMA kernel: fp32 scratch (4 M C floats) of the join -> fp32 kernel -> split route
   float *slab = nullptr, *small = nullptr, *lengths = nullptr, *dlen_pose = nullptr, *maskbuf = nullptr, *dscore_zero = nullptr;
   long slab_floats = 0, small_floats = 0;
   // The bones net runs concurrently with the rotations net on a second stream with its own scratch set; the host code stays
@@ -156,9 +163,11 @@ struct Bump {
   }
 };
 
-static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int half) {
+static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int precision) {
   const long C = md.C;
+  const int half = precision >= 1;
   auto act = [&](long n) -> void* { return bp.take(half ? (n + 1) / 2 : n); };   // bf16 activations take half the floats
+  auto lo = [&](long n) -> void* { return precision == 2 ? bp.take((n + 1) / 2) : nullptr; };   // lo plane of a planar activation
   md.ws.resize(2 * md.depth);
   for (size_t l = 0; l < md.ws.size(); ++l) {
     BlockWS& w = md.ws[l];
@@ -168,6 +177,7 @@ static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int half
     w.lse = bp.take((long)Bmax * md.N * md.H * T);
     w.ao = act(M * C);         w.x_mid = bp.take(M * C);   w.st2 = bp.take(M * 2);  w.a2 = act(M * C);
     w.z = act(M * 2 * C);      w.f = act(M * 2 * C);       w.x_out = bp.take(M * C); w.stp = bp.take(M * 2);
+    w.a1l = lo(M * C); w.qkvl = lo(M * 3 * C); w.aol = lo(M * C); w.a2l = lo(M * C); w.fl = lo(M * 2 * C);
   }
   md.x_final = bp.take(M * C);
   md.hstats = bp.take(M * 2);
@@ -188,11 +198,21 @@ static long small_scratch_floats(const mp_model* m) {
 static void carve_all(mp_model* m, Bump& bp) {
   const int Bm = m->cfg.max_batch, T = m->cfg.num_frame;
   const long Mr = (long)Bm * T * m->rot.N, Ms = (long)Bm * T * m->seg.N;
-  const int half = m->cfg.precision == 1;
-  carve_module(m->rot, bp, Mr, T, Bm, half);
-  if (m->has_seg) carve_module(m->seg, bp, Ms, T, Bm, half);
+  const int half = m->cfg.precision >= 1;
+  carve_module(m->rot, bp, Mr, T, Bm, m->cfg.precision);
+  if (m->has_seg) carve_module(m->seg, bp, Ms, T, Bm, m->cfg.precision);
   if (half) m->wbf = reinterpret_cast<bf16*>(bp.take((m->flat_size + 1) / 2));
-  const int halfp = m->cfg.precision == 1;
+  if (m->cfg.precision == 2) {
+    m->wbf_lo = reinterpret_cast<bf16*>(bp.take((m->flat_size + 1) / 2));
+    long need = 0;
+    if (attn_x3_needs_scratch(0, T, m->rot.N, m->rot.C, m->rot.H) || attn_x3_needs_scratch(1, T, m->rot.N, m->rot.C, m->rot.H)) need = max(need, 4 * Mr * m->rot.C);
+    if (m->has_seg && (attn_x3_needs_scratch(0, T, m->seg.N, m->seg.C, m->seg.H) || attn_x3_needs_scratch(1, T, m->seg.N, m->seg.C, m->seg.H)))
+      need = max(need, 4 * Ms * m->seg.C);
+    // the two nets run concurrently on two streams: one scratch each
+    m->xattn = need ? bp.take(2 * need) : nullptr;
+    m->xattn_half = need;
+  }
+  const int halfp = m->cfg.precision >= 1;
   const Module* mods[2] = {&m->rot, &m->seg};
   for (int i = 0; i < (m->has_seg ? 2 : 1); ++i) {
     const Module* md = mods[i];
@@ -282,7 +302,7 @@ static float* G(const mp_model* m, float* flat, int idx) { return flat + m->para
 // rstats / rgamma / rbeta (bf16 mode, residual epilogue): the residual is LayerNorm(R) recomputed in the epilogue (kernels.h)
 static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* A, int widx, int bidx, void* Cc, long M, int N, int K,
                       int epi, void* Z, const float* R, const float* mask, int mask_mode, int T, int J, const float* rstats = nullptr,
-                      const float* rgamma = nullptr, const float* rbeta = nullptr) {
+                      const float* rgamma = nullptr, const float* rbeta = nullptr, const void* A_lo = nullptr, void* C_lo = nullptr) {
   if (m->cfg.precision == 0) {
     GemmF32Args g = {};
     g.A = (const float*)A; g.lda = K; g.B = P(m, fp, widx); g.ldb = K; g.C = (float*)Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
@@ -295,6 +315,13 @@ static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* 
   g.A = A; g.lda = K; g.B = m->wbf + m->params[widx].offset; g.ldb = K; g.C = Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
   g.bias = P(m, fp, bidx); g.Z = Z; g.R = R; g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
   g.rstats = rstats; g.rgamma = rgamma; g.rbeta = rbeta;
+  if (m->cfg.precision == 2) {
+    // split precision: planar hi/lo A and weights (both planes read), planar outputs (+ the plain-bf16 gelu'), fp32 residual in + out
+    g.A_lo = A_lo; g.B_lo = m->wbf_lo + m->params[widx].offset; g.C_lo = C_lo;
+    const double ob = epi == EPI_BIAS_RESID ? 8.0 * M * N : 4.0 * M * N + (epi == EPI_BIAS_GELU ? 2.0 * M * N : 0.0);
+    RUNB(PC_GEMM_FWD, 6.0 * M * N * K, 4.0 * (M * K + (double)N * K) + ob, gemm_bf16x3(g, epi == EPI_BIAS_RESID ? 1 : 0, epi, st));
+    return MP_OK;
+  }
   // bf16 A and weights; output bf16 (+ a second bf16 output gelu') or, for the residual epilogue, fp32 in + fp32 out
   const double obytes = epi == EPI_BIAS_RESID ? 8.0 * M * N : 2.0 * M * N * (epi == EPI_BIAS_GELU ? 2 : 1);
   RUNB(PC_GEMM_FWD, 2.0 * M * N * K, 2.0 * (M * K + (double)N * K) + obytes, gemm_bf16(g, 0, 0, 0, epi == EPI_BIAS_RESID ? 1 : 0, epi, st));
@@ -345,18 +372,20 @@ static const float* branch_mask(const mp_model* m, const Module& md, int l, int 
 // blocks >= 2 (no embedding / positional table behind them), C <= 512 (their backward then runs through ln_bwd2, which
 // recomputes it as well).
 static bool lazy_block_input(const mp_model* m, const Module& md, int l) {
-  return m->cfg.precision == 1 && l >= 2 && md.C <= 512;
+  return m->cfg.precision >= 1 && l >= 2 && md.C <= 512;
 }
 
 static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStream_t st) {
   const int T = m->cfg.num_frame, N = md.N, C = md.C, H = md.H, L = 2 * md.depth;
-  const int half = m->cfg.precision == 1;
+  const int half = m->cfg.precision;          // LayerNorm output mode: 0 fp32, 1 bf16, 2 planar hi/lo bf16
+  const bool x3 = m->cfg.precision == 2;
+  float* const xattn = (x3 && m->xattn) ? m->xattn + (st == m->st2 ? m->xattn_half : 0) : nullptr;
   const long M = (long)B * T * N;
   // norm1 of block 0 (the input embedding has already been written to ws[0].x_in)
   {
     LnFwdArgs a = {};
     a.x = md.ws[0].x_in; a.M = (int)M; a.C = C;
-    a.g2 = P(m, fp, md.bp[0].n1w); a.b2 = P(m, fp, md.bp[0].n1b); a.eps2 = 1e-6f; a.y2 = md.ws[0].a1; a.stats2 = md.ws[0].st1;
+    a.g2 = P(m, fp, md.bp[0].n1w); a.b2 = P(m, fp, md.bp[0].n1b); a.eps2 = 1e-6f; a.y2 = md.ws[0].a1; a.y2_lo = md.ws[0].a1l; a.stats2 = md.ws[0].st1;
     RUN(PC_LN, 0, ln_fwd(a, half, st));
   }
   for (int l = 0; l < L; ++l) {
@@ -364,9 +393,13 @@ static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStre
     BlockWS& w = md.ws[l];
     const bool spatial = (l % 2 == 0);
     const int mode = spatial ? 1 : 2;
-    int rc = linear_fwd(m, st, fp, w.a1, q.qkvw, q.qkvb, w.qkv, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, 0, T, N);
+    int rc = linear_fwd(m, st, fp, w.a1, q.qkvw, q.qkvb, w.qkv, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr,
+                        w.a1l, w.qkvl);
     if (rc) return rc;
-    if (spatial) RUN(PC_ATTN, 4.0 * B * T * N * N * C, attn_spatial_fwd(w.qkv, w.ao, half, B, T, N, C, H, st));
+    if (x3) {
+      if (spatial) RUN(PC_ATTN, 12.0 * B * T * N * N * C, attn_spatial_fwd_x3((const bf16*)w.qkv, (const bf16*)w.qkvl, (bf16*)w.ao, (bf16*)w.aol, xattn, B, T, N, C, H, st));
+      else RUN(PC_ATTN, 12.0 * B * N * (double)T * T * C, attn_temporal_fwd_x3((const bf16*)w.qkv, (const bf16*)w.qkvl, (bf16*)w.ao, (bf16*)w.aol, w.lse, xattn, B, T, N, C, H, st));
+    } else if (spatial) RUN(PC_ATTN, 4.0 * B * T * N * N * C, attn_spatial_fwd(w.qkv, w.ao, half, B, T, N, C, H, st));
     else RUN(PC_ATTN, 4.0 * B * N * (double)T * T * C, attn_temporal_fwd(w.qkv, w.ao, w.lse, half, B, T, N, C, H, st));
     // block input: materialised (blocks 0 and 1: embedding / positional table involved), or - bf16 mode - recomputed in the
     // residual epilogue as the shared post-norm of the previous block's output (ln_fwd below does not store it then)
@@ -375,22 +408,22 @@ static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStre
       const bool pspatial = ((l - 1) % 2 == 0);
       rc = linear_fwd(m, st, fp, w.ao, q.pw, q.pb, w.x_mid, M, C, C, EPI_BIAS_RESID, nullptr, md.ws[l - 1].x_out,
                       branch_mask(m, md, l, 0, B, m->train), mode, T, N, md.ws[l - 1].stp, P(m, fp, pspatial ? md.sn_w : md.tn_w),
-                      P(m, fp, pspatial ? md.sn_b : md.tn_b));
+                      P(m, fp, pspatial ? md.sn_b : md.tn_b), w.aol);
     } else {
       rc = linear_fwd(m, st, fp, w.ao, q.pw, q.pb, w.x_mid, M, C, C, EPI_BIAS_RESID, nullptr, w.x_in,
-                      branch_mask(m, md, l, 0, B, m->train), mode, T, N);
+                      branch_mask(m, md, l, 0, B, m->train), mode, T, N, nullptr, nullptr, nullptr, w.aol);
     }
     if (rc) return rc;
     {
       LnFwdArgs a = {};
       a.x = w.x_mid; a.M = (int)M; a.C = C;
-      a.g2 = P(m, fp, q.n2w); a.b2 = P(m, fp, q.n2b); a.eps2 = 1e-6f; a.y2 = w.a2; a.stats2 = w.st2;
+      a.g2 = P(m, fp, q.n2w); a.b2 = P(m, fp, q.n2b); a.eps2 = 1e-6f; a.y2 = w.a2; a.y2_lo = w.a2l; a.stats2 = w.st2;
       RUN(PC_LN, 0, ln_fwd(a, half, st));
     }
-    rc = linear_fwd(m, st, fp, w.a2, q.f1w, q.f1b, w.f, M, 2 * C, C, EPI_BIAS_GELU, w.z, nullptr, nullptr, 0, T, N);
+    rc = linear_fwd(m, st, fp, w.a2, q.f1w, q.f1b, w.f, M, 2 * C, C, EPI_BIAS_GELU, w.z, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr, w.a2l, w.fl);
     if (rc) return rc;
     rc = linear_fwd(m, st, fp, w.f, q.f2w, q.f2b, w.x_out, M, C, 2 * C, EPI_BIAS_RESID, nullptr, w.x_mid,
-                    branch_mask(m, md, l, 1, B, m->train), mode, T, N);
+                    branch_mask(m, md, l, 1, B, m->train), mode, T, N, nullptr, nullptr, nullptr, w.fl);
     if (rc) return rc;
     // shared post-norm (mix_ste.py:143,154,166,170), Temporal_pos_embed after the first spatial block (:149),
     // fused with the next block's norm1
@@ -402,7 +435,7 @@ static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStre
     a.stats1 = w.stp;
     if (l + 1 < L) {
       a.g2 = P(m, fp, md.bp[l + 1].n1w); a.b2 = P(m, fp, md.bp[l + 1].n1b); a.eps2 = 1e-6f;
-      a.y2 = md.ws[l + 1].a1; a.stats2 = md.ws[l + 1].st1;
+      a.y2 = md.ws[l + 1].a1; a.y2_lo = md.ws[l + 1].a1l; a.stats2 = md.ws[l + 1].st1;
     }
     RUN(PC_LN, 0, ln_fwd(a, half, st));
   }
@@ -413,7 +446,7 @@ static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStre
 static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int B, hipStream_t st) {
   const int T = m->cfg.num_frame, N = md.N, C = md.C, H = md.H, L = 2 * md.depth;
   const long M = (long)B * T * N;
-  const int half = m->cfg.precision == 1;
+  const int half = m->cfg.precision >= 1;       // precision 2: the backward runs in bf16 on the hi planes
   float* g = m->g;
   bool post_done = false;
   // asynchronous weight gradients (rotations net on the main stream only)
@@ -546,7 +579,7 @@ extern "C" {
 
 int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   MP_CHECK(cfg != nullptr && out != nullptr, MP_ERR_ARG, "mp_model_create: null argument");
-  MP_CHECK(cfg->precision == 0 || cfg->precision == 1, MP_ERR_ARG, "mp_model_create: precision %d (0 = fp32, 1 = bf16)", cfg->precision);
+  MP_CHECK(cfg->precision >= 0 && cfg->precision <= 2, MP_ERR_ARG, "mp_model_create: precision %d (0 = fp32, 1 = bf16, 2 = bf16x3)", cfg->precision);
   MP_CHECK(cfg->precision == 0 || (cfg->embed_dim_rot % 8 == 0 && cfg->embed_dim_seg % 8 == 0), MP_ERR_ARG,
            "mp_model_create: bf16 precision needs embedding widths that are multiples of 8");
   MP_CHECK(cfg->num_joints == 17 && cfg->num_bones == 16, MP_ERR_ARG, "mp_model_create: the decoder is built for the 17-joint H36M tree");
@@ -714,6 +747,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
     }
   }
   if (m->cfg.precision == 1) RUN(PC_OTHER, 0, cast_to_bf16(fp, m->wbf, m->flat_size, st));
+  if (m->cfg.precision == 2) RUN(PC_OTHER, 0, cast_to_bf16x2(fp, m->wbf, m->wbf_lo, m->flat_size, st));
   // fork: the side stream may start once the masks / bf16 weights above are in place
   MP_HIP(hipEventRecord(m->ev_fork, st));
   MP_HIP(hipStreamWaitEvent(m->st2, m->ev_fork, 0));

@@ -93,6 +93,15 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* __restrict__ S, int ob
   }
 }
 
+// planar (split-precision) outputs: element offset from the hi plane C to the lo plane C_lo; 0 for plain outputs
+template <typename TC> __device__ __forceinline__ long c_lo_off(const GemmB16Args&) { return 0; }
+template <> __device__ __forceinline__ long c_lo_off<bf16p>(const GemmB16Args& g) {
+  return reinterpret_cast<const bf16p*>(g.C_lo) - reinterpret_cast<const bf16p*>(g.C);
+}
+// storage of the second output gelu' (kept for the backward): plain bf16 next to a planar C (the backward runs on the hi planes)
+template <typename TC> struct ZType { typedef TC type; };
+template <> struct ZType<bf16p> { typedef bf16 type; };
+
 template <typename TC> __device__ __forceinline__ void store_c(TC* p, float v);
 template <> __device__ __forceinline__ void store_c<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_c<bf16>(bf16* p, float v) { *p = __float2bfloat16(v); }
@@ -320,7 +329,10 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
 }
 
 // BT x BT output tile (BT = 128: 4 waves, 256: 8 waves); waves laid out 2 x (BT/64); each wave (BT/2) x 64.
-template <int TRA, int TRB, typename TC, int EPI, int BT>
+// SPLIT = 1 (split precision, common.h): A and B are the hi planes of planar operands; every 64-wide k-tile is multiplied three
+// times - (A_lo, B_hi), (A_hi, B_lo), (A_hi, B_hi) - into the same fp32 accumulators, i.e. the k loop runs over 3 x the k-tiles
+// and only the DMA source plane changes from step to step.
+template <int TRA, int TRB, typename TC, int EPI, int BT, int SPLIT = 0>
 __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = BT / 32, WN = BT / 64, MI = BT / 32, OPB = BT * 128, STAGE = 2 * OPB;
@@ -357,9 +369,29 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   // moments of the k-tile instead of all at once (measured on the weight-gradient shapes: 3-18 % fewer fabric reads, same isolated time)
   const bool b_first = (tm + tn) & 1;
   if (b_first) glds_tile<TRB, BT, NW>(smem + OPB, B, g.ldb, n0, kbeg, g.N, kend, lane, wave);
-  glds_tile<TRA, BT, NW>(smem, A, g.lda, m0, kbeg, g.M, kend, lane, wave);
+  glds_tile<TRA, BT, NW>(smem, SPLIT ? reinterpret_cast<const bf16*>(g.A_lo) : A, g.lda, m0, kbeg, g.M, kend, lane, wave);
   if (!b_first) glds_tile<TRB, BT, NW>(smem + OPB, B, g.ldb, n0, kbeg, g.N, kend, lane, wave);
   int stage = 0;
+  if constexpr (SPLIT) {
+    // step s = 3 kt + term; term 0: (A_lo, B_hi) - the step whose operands the prologue above must have fetched, see below
+    const bf16* const A_lo = reinterpret_cast<const bf16*>(g.A_lo);
+    const bf16* const B_lo = reinterpret_cast<const bf16*>(g.B_lo);
+    const int nst = 3 * ((kend - kbeg + GBK - 1) / GBK);
+    for (int s = 0, term = 0, k0 = kbeg; s < nst; ++s, stage ^= 1) {
+      __syncthreads();
+      const char* As = smem + stage * STAGE;
+      const char* Bs = As + OPB;
+      int nterm = term + 1, nk0 = k0;
+      if (nterm == 3) { nterm = 0; nk0 += GBK; }
+      if (s + 1 < nst) {
+        char* nx = smem + (stage ^ 1) * STAGE;
+        glds_tile<TRA, BT, NW>(nx, nterm == 0 ? A_lo : A, g.lda, m0, nk0, g.M, kend, lane, wave);
+        glds_tile<TRB, BT, NW>(nx + OPB, nterm == 1 ? B_lo : B, g.ldb, n0, nk0, g.N, kend, lane, wave);
+      }
+      mma_stage<TRA, TRB, BT>(As, Bs, acc, wr, wc, lane);
+      term = nterm; k0 = nk0;
+    }
+  } else {
   for (int k0 = kbeg; k0 < kend; k0 += GBK, stage ^= 1) {
     __syncthreads();   // (vmcnt(0) + barrier): tile k0 has landed for every wave; nobody still reads the other stage
     const char* As = smem + stage * STAGE;
@@ -380,6 +412,7 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
     }
     mma_stage<TRA, TRB, BT>(As, Bs, acc, wr, wc, lane);
   }
+  }
 
   if ((g.debug & 4) && acc[0][0][0] != 12345.678f) return;
   // ---- epilogue through LDS: the accumulators (transposed-tile layout: lane = row, 4 consecutive columns per register
@@ -391,7 +424,8 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
     if (TRA == 1 && tn == 0 && tid < BT && m0 + tid < g.M && g.bias_slab != nullptr)
       g.bias_slab[(long)tz * g.M + m0 + tid] = bsum;
   }
-  TC* Z = reinterpret_cast<TC*>(g.Z);
+  typename ZType<TC>::type* Z = reinterpret_cast<typename ZType<TC>::type*>(g.Z);
+  const long lo_off = c_lo_off<TC>(g);
   __syncthreads();                                   // every wave is done with the operand stages: reuse them
   float* img = reinterpret_cast<float*>(smem + wave * 16384);
   const int l15 = lane & 15, gq = lane >> 4;
@@ -437,7 +471,7 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
         const float4 z = ld4(Z + o);
         v = make_float4(v.x * z.x, v.y * z.y, v.z * z.z, v.w * z.w);      // Z holds gelu'(pre-activation)
       }
-      st4(C + o, v);
+      st4(C + o, v, lo_off);
     }
   }
 }
@@ -482,8 +516,9 @@ __device__ __forceinline__ void persist_dma(char* __restrict__ S, const char* __
 // loads of a pass are issued together ahead of its stores.
 template <typename TC, int EPI, bool FULL>
 __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32x4 (&acc)[8][4], float* __restrict__ img, int row0, int col,
-                                                 const float4& bias4, TC* __restrict__ C, TC* __restrict__ Z, int l15, int gq) {
+                                                 const float4& bias4, TC* __restrict__ C, typename ZType<TC>::type* __restrict__ Z, int l15, int gq) {
   constexpr bool LOADS = (EPI == EPI_BIAS_RESID || EPI == EPI_DGELU);
+  const long lo_off = c_lo_off<TC>(g);
   float4 in_nxt[4];
   float ds_nxt[4];
   // residual = LayerNorm(R) recomputed from R and its row statistics (GemmB16Args::rstats): per-lane gamma / beta of its 4 columns
@@ -539,12 +574,13 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
       } else if (EPI == EPI_DGELU) {
         v = make_float4(v.x * in[it].x, v.y * in[it].y, v.z * in[it].z, v.w * in[it].w);      // Z holds gelu'(pre-activation)
       }
-      if (FULL || row < g.M) st4(C + o, v);
+      if (FULL || row < g.M) st4(C + o, v, lo_off);
     }
   }
 }
 
-template <int TRB, typename TC, int EPI>
+// SPLIT: see gemm_bf16_glds_kernel (three steps per k-tile, the DMA source planes rotate)
+template <int TRB, typename TC, int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, int tiles_n, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BT = 256, WN = 4, MI = 8, OPB = BT * 128, STAGE = 2 * OPB;
@@ -556,20 +592,37 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   const int per_xcd = gridDim.x >> 3;                       // gridDim.x is a multiple of 8
   int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (id >= ntiles) return;
-  const int nk = g.K / GBK;                                 // K % 64 == 0, nk >= 2 (launcher)
+  const int nk = (SPLIT ? 3 : 1) * (g.K / GBK);             // K % 64 == 0, nk >= 2 (launcher)
   int m0 = (id / tiles_n) * BT, n0 = (id % tiles_n) * BT;
   unsigned aoff[4], boff[4];
   persist_offsets<0>(aoff, g.lda, m0, g.M, lane, wave);
   persist_offsets<TRB>(boff, g.ldb, 0, BT, lane, wave);     // N % 256 == 0: the same for every tile
   // byte address of (tile origin, reduction index k) of each operand
-  auto a_base = [&](int mm, int k) { return A + ((long)mm * g.lda + k) * 2; };
-  auto b_base = [&](int nn, int k) { return TRB ? B + ((long)k * g.ldb + nn) * 2 : B + ((long)nn * g.ldb + k) * 2; };
+  // (tile origin, step s) -> byte address; SPLIT: step s = 3 kt + term multiplies k-tile kt of (A_lo, B), (A, B_lo), (A, B)
+  auto a_base = [&](int mm, int s) {
+    if constexpr (SPLIT) {
+      const int kt = s / 3, term = s - 3 * kt;
+      return (term == 0 ? reinterpret_cast<const char*>(g.A_lo) : A) + ((long)mm * g.lda + kt * GBK) * 2;
+    } else {
+      return A + ((long)mm * g.lda + s * GBK) * 2;
+    }
+  };
+  auto b_base = [&](int nn, int s) {
+    const char* Bp = B;
+    int k = s * GBK;
+    if constexpr (SPLIT) {
+      const int kt = s / 3, term = s - 3 * kt;
+      if (term == 1) Bp = reinterpret_cast<const char*>(g.B_lo);
+      k = kt * GBK;
+    }
+    return TRB ? Bp + ((long)k * g.ldb + nn) * 2 : Bp + ((long)nn * g.ldb + k) * 2;
+  };
   persist_dma(smem, a_base(m0, 0), aoff, wave);
   persist_dma(smem + OPB, b_base(n0, 0), boff, wave);
   int stage = 0;
   bool landed = false;                                      // this tile's first k-tile was already waited for (before the previous epilogue)
   TC* const C = reinterpret_cast<TC*>(g.C);
-  TC* const Z = reinterpret_cast<TC*>(g.Z);
+  typename ZType<TC>::type* const Z = reinterpret_cast<typename ZType<TC>::type*>(g.Z);
   float* const img = reinterpret_cast<float*>(smem + 2 * STAGE + wave * 4096);
   const bool has_bias = EPI != EPI_DGELU && g.bias != nullptr;
 
@@ -595,8 +648,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       const bool last = ks + 1 == nk;
       if (!(g.debug & 2) && (!last || has_next)) {
         if (last) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
-        persist_dma(nx, a_base(last ? m0n : m0, last ? 0 : (ks + 1) * GBK), aoff, wave);
-        persist_dma(nx + OPB, b_base(last ? n0n : n0, last ? 0 : (ks + 1) * GBK), boff, wave);
+        persist_dma(nx, a_base(last ? m0n : m0, last ? 0 : ks + 1), aoff, wave);
+        persist_dma(nx + OPB, b_base(last ? n0n : n0, last ? 0 : ks + 1), boff, wave);
       }
       if (last && has_bias) {      // this wave's 64 bias values -> its (idle) epilogue image, 4 bytes per lane; covered by the vmcnt(0) below
         typedef __attribute__((address_space(3))) void* lptr;
@@ -651,17 +704,17 @@ static int persist_workgroups() {
 static thread_local int g_last_persist = 0;
 int gemm_bf16_take_last_persist() { const int v = g_last_persist; g_last_persist = 0; return v; }
 
-template <int TRB, typename TC, int EPI>
+template <int TRB, typename TC, int EPI, int SPLIT = 0>
 static int launch_persist(const GemmB16Args& g, int wgs, hipStream_t st) {
   g_last_persist = 1;
   constexpr size_t lds = 2 * 2 * 256 * 128 + 8 * 4096;     // two operand stages + the epilogue images = 160 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    MP_HIP(hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<TRB, TC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MP_HIP(hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<TRB, TC, EPI, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   const int tiles_n = cdiv(g.N, 256), ntiles = tiles_n * cdiv(g.M, 256);
-  hipLaunchKernelGGL((gemm_bf16_persist_kernel<TRB, TC, EPI>), dim3(wgs), dim3(512), lds, st, g, tiles_n, ntiles);
+  hipLaunchKernelGGL((gemm_bf16_persist_kernel<TRB, TC, EPI, SPLIT>), dim3(wgs), dim3(512), lds, st, g, tiles_n, ntiles);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -669,16 +722,16 @@ static int launch_persist(const GemmB16Args& g, int wgs, hipStream_t st) {
 static bool g_force_small_tile = false;    // test hook: exercise the 128x128 instantiation on big shapes too
 void gemm_bf16_force_small_tile(bool on) { g_force_small_tile = on; }
 
-template <int TRA, int TRB, typename TC, int EPI, int BT>
+template <int TRA, int TRB, typename TC, int EPI, int BT, int SPLIT = 0>
 static int launch_glds_bt(const GemmB16Args& g, int splits, hipStream_t st) {
   constexpr size_t lds = 2 * 2 * BT * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    MP_HIP(hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<TRA, TRB, TC, EPI, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MP_HIP(hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<TRA, TRB, TC, EPI, BT, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid(cdiv(g.N, BT), cdiv(g.M, BT), splits);
-  hipLaunchKernelGGL((gemm_bf16_glds_kernel<TRA, TRB, TC, EPI, BT>), grid, dim3(BT * 2), lds, st, g);
+  hipLaunchKernelGGL((gemm_bf16_glds_kernel<TRA, TRB, TC, EPI, BT, SPLIT>), grid, dim3(BT * 2), lds, st, g);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -690,15 +743,15 @@ static bool use_big_tile(const GemmB16Args& g) {
   if (env == 128 || g_force_small_tile) return false;
   return g.M >= 256 && g.N >= 256 && g.N % 256 == 0;
 }
-template <int TRA, int TRB, typename TC, int EPI>
+template <int TRA, int TRB, typename TC, int EPI, int SPLIT = 0>
 static int launch_glds(const GemmB16Args& g, int splits, hipStream_t st) {
   if constexpr (TRA == 0 && EPI != EPI_SLAB) {
     const int wgs = persist_workgroups();
     if (wgs > 0 && splits == 1 && use_big_tile(g) && g.K >= 2 * GBK && g.K % GBK == 0 && (long)cdiv(g.N, 256) * cdiv(g.M, 256) >= (g_persist_min_tiles > 0 ? (long)g_persist_min_tiles : 2L * wgs) &&
         256L * g.lda * 2 < (1L << 31) && 64L * g.ldb * 2 < (1L << 31) && 256L * g.ldb * 2 < (1L << 31))
-      return launch_persist<TRB, TC, EPI>(g, wgs, st);
+      return launch_persist<TRB, TC, EPI, SPLIT>(g, wgs, st);
   }
-  return use_big_tile(g) ? launch_glds_bt<TRA, TRB, TC, EPI, 256>(g, splits, st) : launch_glds_bt<TRA, TRB, TC, EPI, 128>(g, splits, st);
+  return use_big_tile(g) ? launch_glds_bt<TRA, TRB, TC, EPI, 256, SPLIT>(g, splits, st) : launch_glds_bt<TRA, TRB, TC, EPI, 128, SPLIT>(g, splits, st);
 }
 
 // dW += sum of the split-K slabs, db += sum of the bias slabs, ONE launch.  A block owns 64 float4 outputs; its four waves each sum
@@ -779,6 +832,20 @@ int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, 
   MP_CHECK(false, MP_ERR_ARG, "gemm_bf16: unsupported variant a_f32=%d a_tr=%d b_tr=%d c_f32=%d epi=%d", a_f32, a_tr, b_tr, c_f32, epi);
 }
 
+int gemm_bf16x3(GemmB16Args g, int c_f32, int epi, hipStream_t st) {
+  g.debug = 0;
+  MP_CHECK(g.M > 0 && g.N > 0 && g.K > 0, MP_ERR_ARG, "gemm_bf16x3: empty problem");
+  MP_CHECK(g.K % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.N % 4 == 0 && g.ldc % 4 == 0, MP_ERR_ARG,
+           "gemm_bf16x3: K and the leading dimensions must be multiples of 8, N of 4 (M=%d N=%d K=%d)", g.M, g.N, g.K);
+  MP_CHECK(g.A_lo && g.B_lo && (c_f32 || g.C_lo), MP_ERR_ARG, "gemm_bf16x3: lo plane missing");
+  g.k_per_split = ((g.K + GBK - 1) / GBK) * GBK;
+  if (!c_f32 && epi == EPI_BIAS) return launch_glds<0, 0, bf16p, EPI_BIAS, 1>(g, 1, st);
+  if (!c_f32 && epi == EPI_BIAS_GELU) return launch_glds<0, 0, bf16p, EPI_BIAS_GELU, 1>(g, 1, st);
+  if (c_f32 && epi == EPI_BIAS) return launch_glds<0, 0, float, EPI_BIAS, 1>(g, 1, st);
+  if (c_f32 && epi == EPI_BIAS_RESID) return launch_glds<0, 0, float, EPI_BIAS_RESID, 1>(g, 1, st);
+  MP_CHECK(false, MP_ERR_ARG, "gemm_bf16x3: unsupported variant c_f32=%d epi=%d", c_f32, epi);
+}
+
 static void wgrad_split_b16(int Mtok, int Nout, int Kin, int bt, int& splits, int& kper) {
   const int tiles = cdiv(Nout, bt) * cdiv(Kin, bt);
   // 256^2 tiles run one workgroup per CU: fill the 256 CUs exactly once (a 257th workgroup would double the kernel time);
@@ -815,6 +882,17 @@ int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, i
 __global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long n4) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) st4(dst + 4 * i, ld4(src + 4 * i));
+}
+// the same as planar hi/lo shadows (split precision)
+__global__ void cast_bf16x2_kernel(const float* __restrict__ src, bf16p* __restrict__ hi, long lo_off, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) st4(hi + 4 * i, ld4(src + 4 * i), lo_off);
+}
+int cast_to_bf16x2(const float* src, bf16* hi, bf16* lo, long n, hipStream_t st) {
+  MP_CHECK(n % 4 == 0, MP_ERR_ARG, "cast_to_bf16x2: n %% 4");
+  hipLaunchKernelGGL(cast_bf16x2_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, src, reinterpret_cast<bf16p*>(hi), (long)(lo - hi), n / 4);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
 }
 int cast_to_bf16(const float* src, bf16* dst, long n, hipStream_t st) {
   MP_CHECK(n % 4 == 0, MP_ERR_ARG, "cast_to_bf16: n %% 4");

@@ -45,8 +45,16 @@ struct GemmB16Args {
   float* bias_slab;
   int k_per_split;
   int debug;           // timing-ablation bits (MANIPOSE_GEMM_DEBUG), 0 in production
+  // split precision (gemm_bf16x3): lo planes of A, B and (planar outputs) C; A / B / C are the hi planes (common.h: bf16p)
+  const void* A_lo;
+  const void* B_lo;
+  void* C_lo;
 };
 int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, hipStream_t st);
+// C = A B^T on planar hi/lo operands ("N","N" layouts: the forward Linear), three bf16 MFMA products per k-tile, fp32 accumulate.
+// epi EPI_BIAS / EPI_BIAS_GELU: C planar (C, C_lo), Z = gelu' as plain bf16; EPI_BIAS_RESID: C fp32 (c_f32 must be 1)
+int gemm_bf16x3(GemmB16Args g, int c_f32, int epi, hipStream_t st);
+int cast_to_bf16x2(const float* src, bf16* hi, bf16* lo, long n, hipStream_t st);
 int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
                float* slab, long slab_floats, hipStream_t st);
 int cast_to_bf16(const float* src, bf16* dst, long n, hipStream_t st);
@@ -66,8 +74,9 @@ struct LnFwdArgs {
   // stage 2 (optional, g2 != null): y2 = LN(stage-1 output or x; g2,b2,eps2)
   const float* g2; const float* b2; float eps2;
   void* y2; float* stats2;
+  void* y2_lo;           // out mode 2 (planar hi/lo bf16, common.h): the lo plane
 };
-int ln_fwd(const LnFwdArgs& a, int out_bf16, hipStream_t st);
+int ln_fwd(const LnFwdArgs& a, int out_mode /* 0 fp32, 1 bf16, 2 planar bf16 hi/lo */, hipStream_t st);
 // dx = [dskip +] LN'(dy); partial param grads are reduced and ADDED into dgamma/dbeta.
 int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
            const float* mask, int mask_mode, int T, int J, float* dgamma, float* dbeta, int M, int C, float* scratch,
@@ -100,6 +109,15 @@ int attn_spatial_bwd(const void* qkv, const void* dout, void* dqkv, int is_bf16,
 int attn_temporal_fwd(const void* qkv, void* out, float* lse, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st);
 int attn_temporal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int is_bf16,
                       int B, int T, int J, int C, int H, hipStream_t st);
+// split-precision forward (planar hi/lo qkv and output, common.h).  scratch (4 M C floats) is only used for shapes the MFMA kernels
+// do not cover (the planes are joined to fp32, the fp32 kernels run, the result is split again); may be null otherwise.
+bool attn_x3_needs_scratch(int temporal, int T, int J, int C, int H);
+int attn_spatial_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* scratch, int B, int T, int J, int C, int H,
+                        hipStream_t st);
+int attn_temporal_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* lse, float* scratch, int B, int T, int J,
+                         int C, int H, hipStream_t st);
+int join_planes(const bf16* hi, const bf16* lo, float* out, long n, hipStream_t st);
+int split_planes(const float* in, bf16* hi, bf16* lo, long n, hipStream_t st);
 
 // ---------------------------------------------------------------- heads.hip
 // K heads of LayerNorm(C, eps 1e-5) + Linear(C, O): out[k][m][o]

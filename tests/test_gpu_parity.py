@@ -379,7 +379,10 @@ def test_cpu_tensor_is_refused_loudly(lib):
 
 
 # --------------------------------------------------------------------------------------------- bf16 precision (throughput mode)
-BF16_MPJPE_TOL_M = 1e-2     # documented drift bound of the bf16 matrix-core mode vs the fp32 reference
+# measured drift of the bf16 matrix-core mode vs the fp32 reference: 3.1-3.5 mm (fixtures and full size);
+# the bound is that + ~25 % margin, so a real accuracy regression of the bf16 kernels fails.  The mode that meets the north-star
+# bound (1e-4 m) at matrix-core speed is "bf16x3" below.
+BF16_MPJPE_TOL_M = 4.5e-3
 
 
 @pytest.mark.parametrize("M,N,K", [(306, 96, 32), (130, 48, 16), (4131, 1536, 512), (1000, 512, 1024), (66100, 512, 512)])
@@ -1215,3 +1218,163 @@ def test_caller_facing_helpers_of_the_rmcl_model(lib):
     from manipose_amd.data import Skeleton, T_POSE_OPERATORS
     with pytest.raises(AssertionError):
         assert_h36m(Skeleton([-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 8, 11, 12, 8, 14, 14], [4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16], T_POSE_OPERATORS))
+
+
+# --------------------------------------------------------------------------------------------- bf16x3: split precision (parity at matrix-core speed)
+def _split(t):
+    hi = t.bfloat16()
+    lo = (t - hi.float()).bfloat16()
+    return hi, lo
+
+
+def _join(hi, lo):
+    return hi.float() + lo.float()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 96, 64), (1027, 512, 512), (4131, 1536, 512), (777, 512, 1024), (66100, 512, 512), (520, 128, 128),
+                                   (64, 32, 32)])
+def test_bf16x3_linear_forward_epilogues(lib, M, N, K):
+    """Split-precision Linear forward (planar hi/lo bf16 operands, three MFMA products per k-tile; persistent, 256- and 128-tile
+    kernels) against an fp64 product of the fp32 operands: 2^-16 operand precision instead of bf16's 2^-9."""
+    from manipose_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    xd, Wd = x.cuda(), W.cuda()
+    xh, xl, Wh, Wl = (torch.empty(t.shape, device="cuda", dtype=torch.bfloat16) for t in (x, x, W, W))
+    _lib.check(lib.mp_split_bf16(xd.data_ptr(), xh.data_ptr(), xl.data_ptr(), xd.numel(), st()))
+    _lib.check(lib.mp_split_bf16(Wd.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), Wd.numel(), st()))
+    eh, el = _split(x)
+    assert torch.equal(xh.cpu(), eh) and torch.equal(xl.cpu(), el)          # hi = bf16(x), lo = bf16(x - hi), bit for bit
+    bd, rd = b.cuda(), r.cuda()
+    pre = (x.double() @ W.double().t() + b.double())
+    scale = float(pre.abs().max())
+    yh, yl = torch.empty(M, N, device="cuda", dtype=torch.bfloat16), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.mp_linear_fwd_bf16x3(xh.data_ptr(), xl.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), bd.data_ptr(), yh.data_ptr(), yl.data_ptr(),
+                                        None, None, M, N, K, 0, st()))
+    err = (_join(yh, yl).cpu().double() - pre).abs().max().item() / scale
+    assert err < 4e-5, err                                                     # bf16 operands: ~4e-3
+    z = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.mp_linear_fwd_bf16x3(xh.data_ptr(), xl.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), bd.data_ptr(), yh.data_ptr(), yl.data_ptr(),
+                                        z.data_ptr(), None, M, N, K, 1, st()))
+    want = torch.nn.functional.gelu(pre)
+    assert (_join(yh, yl).cpu().double() - want).abs().max().item() / scale < 4e-5
+    pf = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(pf).sum().backward()
+    close(z.float(), pf.grad, rtol=1e-2, atol=1e-2)                          # gelu' is kept as plain bf16 (the backward is bf16)
+    y32 = torch.empty(M, N, device="cuda")
+    _lib.check(lib.mp_linear_fwd_bf16x3(xh.data_ptr(), xl.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), bd.data_ptr(), y32.data_ptr(), None,
+                                        None, rd.data_ptr(), M, N, K, 2, st()))
+    assert (y32.cpu().double() - (pre + r.double())).abs().max().item() / scale < 4e-5
+
+
+@pytest.mark.parametrize("temporal,B,T,J,C,H", [(1, 2, 243, 3, 128, 2), (1, 1, 81, 17, 512, 8), (1, 2, 27, 16, 128, 8), (1, 1, 256, 2, 64, 1),
+                                                (1, 1, 17, 2, 32, 2), (1, 1, 300, 2, 128, 2), (1, 1, 100, 2, 64, 4),
+                                                (0, 1, 9, 17, 128, 2), (0, 2, 5, 17, 512, 8), (0, 1, 7, 16, 128, 8), (0, 1, 3, 17, 64, 4)])
+def test_bf16x3_attention_forward(lib, temporal, B, T, J, C, H):
+    """Split-precision attention forward (MFMA kernels with hi/lo images; fp32 route for the other shapes) against the fp32 formula
+    on the fp32 q/k/v."""
+    from manipose_amd import _lib
+    g = torch.Generator().manual_seed(T * 13 + C)
+    M = B * T * J
+    qkv = torch.randn(M, 3 * C, generator=g)
+    ref = _attn_ref(qkv, B, T, J, C, H, temporal)
+    qd = qkv.cuda()
+    qh, ql = torch.empty_like(qd, dtype=torch.bfloat16), torch.empty_like(qd, dtype=torch.bfloat16)
+    _lib.check(lib.mp_split_bf16(qd.data_ptr(), qh.data_ptr(), ql.data_ptr(), qd.numel(), st()))
+    oh, ol = torch.zeros(M, C, device="cuda", dtype=torch.bfloat16), torch.zeros(M, C, device="cuda", dtype=torch.bfloat16)
+    lse = torch.zeros(B * J * H * T, device="cuda")
+    scratch = torch.empty(4 * M * C, device="cuda")
+    _lib.check(lib.mp_attention_fwd_bf16x3(qh.data_ptr(), ql.data_ptr(), oh.data_ptr(), ol.data_ptr(), lse.data_ptr(), scratch.data_ptr(),
+                                           temporal, B, T, J, C, H, st()))
+    err = (_join(oh, ol).cpu() - ref).abs().max().item() / float(ref.abs().max())
+    assert err < 1e-4, err                                                     # bf16 kernels: ~1e-2
+
+
+@pytest.mark.parametrize("name", ["rmcl_tiny", "rmcl_small"])
+def test_bf16x3_model_meets_the_parity_bound_on_the_reference_fixtures(lib, name):
+    """precision="bf16x3": forward within the north-star bound of the REFERENCE's outputs; loss within 1e-3; gradients (bf16 backward
+    on the hi planes) aligned with the reference's."""
+    from manipose_amd.metrics import mpjpe_error, rmcl_training_loss
+    fx = load_fixture(name)
+    model = _build(fx)
+    model.precision = "bf16x3"
+    model = model.eval()
+    poses, scores = model(dev(fx["X"]))
+    mp = mpjpe_error(poses, dev(fx["poses"]), "average").item()
+    print(f"\n[bf16x3 drift] {name}: MPJPE vs fp32 reference = {mp * 1e3:.5f} mm")
+    assert mp <= MPJPE_TOL_M
+    close(scores, fx["scores"], rtol=1e-3, atol=1e-5)
+    total, _ = rmcl_training_loss(poses, scores, dev(fx["y"]))
+    assert abs(total.item() - float(fx["loss_total"])) <= 1e-3 * abs(float(fx["loss_total"]))
+    total.backward()
+    cs = {k: _cos(p.grad.cpu(), torch.from_numpy(fx["g::" + k])) for k, p in model.named_parameters()}
+    worst = min(cs.items(), key=lambda kv: kv[1])
+    print(f"[bf16x3 drift] {name}: worst gradient cosine {worst[1]:.5f} at {worst[0]}")
+    assert worst[1] > 0.98, worst
+
+
+def test_bf16x3_full_size_model_meets_the_parity_bound(lib):
+    """BASELINE config #3 shape (T=243 K=5 C=512 depth 8) at B=1 and B=3 in the split precision against the fp32 CPU oracle:
+    MPJPE <= 1e-4 m (the north-star bound), loss, gradient alignment, manifold property."""
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    from manipose_amd.metrics import mpjpe_error, rmcl_training_loss
+    cfg = orc.FULL_CFG
+    st_ = orc.make_state(cfg, seed=3)
+    model = RMCLManifoldMixSTE(h36m_skeleton(), drop_path_rate=0.0)
+    model.load_state_dict(st_, strict=True)
+    model.precision = "bf16x3"
+    model.max_batch_hint = 3
+    model = model.cuda().eval()
+    X, y = orc.synthetic_batch(3, 243, seed=42)
+    with torch.no_grad():
+        o3, _ = orc.rmcl_manifold_forward(X, st_, orc.oracle_cfg(cfg))
+        p3, _ = model(X.cuda())
+    mp3 = mpjpe_error(p3, o3.cuda(), "average").item()
+    X, y = X[:1].contiguous(), y[:1].contiguous()
+    poses, scores = model(X.cuda())
+    req = {k: v.clone().requires_grad_(True) for k, v in st_.items()}
+    o_poses, o_scores = orc.rmcl_manifold_forward(X, req, orc.oracle_cfg(cfg))
+    mp = mpjpe_error(poses, o_poses.detach().cuda(), "average").item()
+    print(f"\n[bf16x3 drift] full size T=243 K=5: MPJPE vs fp32 oracle = {mp * 1e3:.5f} mm (B=1), {mp3 * 1e3:.5f} mm (B=3)")
+    assert mp <= MPJPE_TOL_M and mp3 <= MPJPE_TOL_M
+    close(scores, o_scores.detach(), rtol=1e-3, atol=1e-5)
+    total, _ = rmcl_training_loss(poses, scores, y.cuda())
+    o_total, _ = orc.rmcl_training_loss(o_poses, o_scores, y)
+    assert abs(total.item() - o_total.item()) <= 1e-3 * abs(o_total.item())
+    total.backward()
+    o_total.backward()
+    cs = {k: _cos(p.grad.cpu(), req[k].grad) for k, p in model.named_parameters()}
+    worst = min(cs.items(), key=lambda kv: kv[1])
+    mean = sum(cs.values()) / len(cs)
+    print(f"[bf16x3 drift] full size: gradient cosine mean {mean:.5f}, worst {worst[1]:.5f} at {worst[0]}")
+    assert worst[1] > 0.9 and mean > 0.99, (worst, mean)
+    par = torch.tensor(orc.H36M_PARENTS[1:], device="cuda")
+    seg = (poses[..., 1:, :] - poses[..., par, :]).norm(dim=-1)
+    lens = model._engine.peek(1).view(1, 1, 1, 16).abs()
+    close(seg, lens.expand_as(seg), rtol=1e-4, atol=2e-6)
+
+
+def test_bf16x3_training_step_and_droppath(lib):
+    """Train-mode DropPath (injected masks) in the split precision vs the reference fixture, then fused trainer steps whose loss
+    falls."""
+    from manipose_amd.metrics import mpjpe_error, rmcl_training_loss
+    from manipose_amd.training import LiftingTrainer
+    fx = load_fixture("rmcl_tiny_droppath")
+    model = _build(fx, drop_path_rate=float(fx["drop_path_rate"]))
+    model.precision = "bf16x3"
+    model = model.train()
+    model.set_droppath_masks({k: v.cuda() for k, v in fixture_masks(fx).items()})
+    poses, scores = model(dev(fx["X"]))
+    mp = mpjpe_error(poses, dev(fx["poses"]), "average").item()
+    print(f"\n[bf16x3 drift] droppath fixture: {mp * 1e3:.5f} mm")
+    assert mp <= MPJPE_TOL_M
+    total, _ = rmcl_training_loss(poses, scores, dev(fx["y"]))
+    np.testing.assert_allclose(total.item(), float(fx["loss_total"]), rtol=1e-3)
+    model.set_droppath_masks(None)
+    tr = LiftingTrainer(model, lr=1e-3, weight_decay=0.0, seed=1)
+    X, y = dev(fx["X"]), dev(fx["y"])
+    losses = [float(tr.train_step(X, y).sum().item()) for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
