@@ -3,9 +3,19 @@
 
 One "step" = forward + WTA multi-hypothesis loss + backward + gradient all-reduce + Adam on a synthetic batch of
 B windows per GPU of H36M shape (T=243, J=17, K=5, C=512, depth 8), inputs resident in HBM.
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank/GPU)
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = gemm_bf16_persist_kernel, the forward + dgrad Linear
-GEMMs; HIP events inside the engine on the stream each launch goes to) and `cpu_baseline` (oracle/manipose_ref.py timed on the host cores, rank 0, N=1 only).
+    python bench.py --gpus N --steps K --warmup W
+N > 1: one rank per GPU over RCCL.  Under torch.distributed.run (WORLD_SIZE set) this process IS a rank; without it the
+process spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself (before anything touches a GPU) and
+relays its output.
+Prints ONE JSON line on rank 0 with
+  `roofline`      dominant kernel = gemm_bf16_persist_kernel, the forward + dgrad Linear GEMMs; HIP events inside the engine on the
+                  stream each launch goes to;
+  `parity`        MPJPE of the TIMED precision against the fp32 CPU oracle at full size (T=243 K=5, B=1, the bench's own weights),
+                  measured in this run, with the north-star bound 1e-4 m (the oracle forward runs in a CPU child process);
+  `other_precisions`  (N=1) poses/s and the same parity figure of the other two precisions, a few steps each;
+  `cpu_baseline`  oracle/manipose_ref.py timed on the host cores (rank 0, N=1 only).
+Default precision: "bf16x3" (split bf16 hi/lo operands, three matrix-core products per product, fp32 accumulate) - the fastest
+precision whose drift stays inside the 1e-4 m bound; "bf16" (BASELINE config #3's wording) is faster but drifts ~3 mm.
 """
 import argparse
 import json
@@ -71,6 +81,30 @@ def cpu_baseline(T, K, steps=10):
                       f"{os.cpu_count()} ({model_name})"}
 
 
+def parity_oracle(io_dir):
+    """(CPU child) fp32 oracle forward on the weights / input the parent saved; writes the poses and scores next to them."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import manipose_ref as orc
+    torch.set_num_threads(host_cores())
+    blob = torch.load(os.path.join(io_dir, "parity_in.pt"))
+    cfg = dict(orc.FULL_CFG, T=blob["T"], n_hyp=blob["K"])
+    with torch.no_grad():
+        poses, scores = orc.rmcl_manifold_forward(blob["X"], blob["state"], orc.oracle_cfg(cfg))
+    torch.save({"poses": poses, "scores": scores}, os.path.join(io_dir, "parity_out.pt"))
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+PARITY_BOUND_M = 1e-4          # BASELINE.json north_star: outputs within 1e-4 on MPJPE
+EXTRA_BATCH = {"fp32": 16, "bf16": 79, "bf16x3": 79}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,32 +115,79 @@ def main():
                          "give 9.96 / 19.9 / 29.9 rounds of 256 persistent workgroups - no nearly empty last round; 64 gives 8.07 / 16.1 / 24.2)")
     ap.add_argument("--frames", type=int, default=243)
     ap.add_argument("--hyp", type=int, default=5)
-    ap.add_argument("--precision", default=os.environ.get("MANIPOSE_PRECISION", "bf16"), choices=["bf16", "bf16x3", "fp32"],
-                    help="bf16 = BASELINE config #3 (bf16 matrix cores, fp32 accumulate/residual/softmax); fp32 = parity mode")
+    ap.add_argument("--precision", default=os.environ.get("MANIPOSE_PRECISION", "bf16x3"), choices=["bf16", "bf16x3", "fp32"],
+                    help="bf16x3 (default) = split bf16 hi/lo operands, 3 matrix-core products per product: inside the 1e-4 m parity bound; "
+                         "bf16 = plain bf16 matrix cores (fp32 accumulate/residual/softmax), ~3 mm drift; fp32 = fp32 matrix cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
-    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) time the CPU oracle and print its JSON")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity measurement (profiling passes)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the few-step runs of the other precisions (N=1 only)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) CPU child: time the CPU oracle and print its JSON")
+    ap.add_argument("--parity-io", default=None, help="(internal) CPU child: directory with parity_in.pt; the oracle forward is written next to it")
     args = ap.parse_args()
-    if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.frames, args.hyp)), flush=True)
+    if args.cpu_baseline_only or args.parity_io:
+        if args.parity_io:
+            parity_oracle(args.parity_io)
+        print(json.dumps(cpu_baseline(args.frames, args.hyp) if args.cpu_baseline_only else {}), flush=True)
         return
-    cpu_json = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_cpu_baseline:
-        # timed in a child process BEFORE this process touches the GPU, with a hard wall-clock bound
-        import subprocess
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--frames", str(args.frames),
-                                "--hyp", str(args.hyp)], capture_output=True, text=True, timeout=240)
-            cpu_json = json.loads(r.stdout.strip().splitlines()[-1])
-        except Exception as e:       # noqa: BLE001
-            cpu_json = {"value": None, "unit": "poses/s", "cores": host_cores(), "kind": "port",
-                        "sample": f"CPU oracle did not finish inside its 240 s bound ({type(e).__name__})"}
+    import subprocess
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start one rank per GPU as fresh child processes (this process never touches a GPU) and relay
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
 
+    import tempfile
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # the model is built on the CPU first: its initial weights and one full-size window go to the CPU child, which returns the fp32
+    # oracle's outputs for the parity block (and, at N=1, the CPU baseline timing).  Nothing here has touched the GPU yet.
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    from manipose_amd.training import LiftingTrainer
+
+    def build_model(precision, batch):
+        torch.manual_seed(42)
+        mdl = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=args.frames, n_hyp=args.hyp, drop_path_rate=0.1)
+        with torch.no_grad():                      # exercise the (zero-initialised) positional tables too
+            for n, p in mdl.named_parameters():
+                if n.endswith("pos_embed"):
+                    p.normal_(0.0, 0.02)
+        mdl.precision = precision
+        mdl.max_batch_hint = batch
+        return mdl
+
+    model = build_model(args.precision, args.batch)
+    cpu_json, oracle_out, X_par = None, None, None
+    want_cpu = world == 1 and args.gpus == 1 and not args.no_cpu_baseline
+    if rank == 0 and (want_cpu or not args.no_parity):
+        io_dir = tempfile.mkdtemp(prefix="manipose_bench_")
+        child = [sys.executable, os.path.abspath(__file__), "--frames", str(args.frames), "--hyp", str(args.hyp)]
+        if not args.no_parity:
+            gp = torch.Generator().manual_seed(4242)
+            X_par = (0.3 * torch.randn(1, args.frames, 17, 2, generator=gp)).clamp(-1, 1)
+            torch.save({"state": {k: v.detach().clone() for k, v in model.state_dict().items()}, "X": X_par, "T": args.frames, "K": args.hyp},
+                       os.path.join(io_dir, "parity_in.pt"))
+            child += ["--parity-io", io_dir]
+        if want_cpu:
+            child += ["--cpu-baseline-only"]
+        try:
+            r = subprocess.run(child, capture_output=True, text=True, timeout=300)
+            js = json.loads(r.stdout.strip().splitlines()[-1])
+            if want_cpu:
+                cpu_json = js
+            if not args.no_parity:
+                oracle_out = torch.load(os.path.join(io_dir, "parity_out.pt"))
+        except Exception as e:       # noqa: BLE001
+            if want_cpu:
+                cpu_json = {"value": None, "unit": "poses/s", "cores": host_cores(), "kind": "port",
+                            "sample": f"CPU oracle did not finish inside its 300 s bound ({type(e).__name__})"}
+        import shutil
+        shutil.rmtree(io_dir, ignore_errors=True)
+
     # rehearsal hooks (a one-GPU box cannot host two RCCL ranks): MANIPOSE_BENCH_DEVICE pins every rank to one device and
     # MANIPOSE_BENCH_BACKEND=gloo carries the collectives through the host; the driver's multi-GPU runs use neither
     if os.environ.get("MANIPOSE_BENCH_DEVICE"):
@@ -119,19 +200,22 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
-    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
-    from manipose_amd.training import LiftingTrainer
-    torch.manual_seed(42)
-    model = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=args.frames, n_hyp=args.hyp, drop_path_rate=0.1)
-    with torch.no_grad():                      # exercise the (zero-initialised) positional tables too
-        for n, p in model.named_parameters():
-            if n.endswith("pos_embed"):
-                p.normal_(0.0, 0.02)
-    model.precision = args.precision
-    model.max_batch_hint = args.batch
-    model = model.cuda().train()
+    def parity_of(mdl):
+        """MPJPE (m) of mdl's eval-mode forward on the parity window against the oracle's poses; None without the oracle output."""
+        if oracle_out is None:
+            return None
+        with torch.no_grad():
+            p, sc = mdl.eval()(X_par.cuda())
+        d = (p - oracle_out["poses"].cuda()).norm(dim=-1)
+        return {"mpjpe_m": d.mean().item(), "max_joint_err_m": d.max().item(),
+                "score_max_abs_diff": (sc - oracle_out["scores"].cuda()).abs().max().item()}
+
+    model = model.cuda()
+    parity = parity_of(model) if rank == 0 else None          # on the initial weights, before any optimisation step
+    model = model.train()
     trainer = LiftingTrainer(model, lr=4e-5, weight_decay=1e-6, seed=42)
     B, T = args.batch, args.frames
     g = torch.Generator(device="cuda").manual_seed(42 + rank)
@@ -171,6 +255,43 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     loss = float(terms.sum().item())
+
+    # N=1: the other precisions on the same workload, a few steps each (their own batch sizes), with the same parity measurement
+    other = {}
+    if rank == 0 and world == 1 and not args.no_extra:
+        del trainer, terms, eng
+        model._engine = None
+        del model
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        for prec in ("bf16x3", "bf16", "fp32"):
+            if prec == args.precision:
+                continue
+            try:
+                Bx = EXTRA_BATCH[prec]
+                mx = build_model(prec, Bx).cuda()
+                par = parity_of(mx)
+                tx = LiftingTrainer(mx.train(), lr=4e-5, weight_decay=1e-6, seed=42)
+                Xx = X[:Bx] if Bx <= B else X.repeat((Bx + B - 1) // B, 1, 1, 1)[:Bx]
+                yx = y[:Bx] if Bx <= B else y.repeat((Bx + B - 1) // B, 1, 1, 1)[:Bx]
+                nst = 5 if prec != "fp32" else 3
+                tx.train_step(Xx, yx)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(nst):
+                    tx.train_step(Xx, yx)
+                torch.cuda.synchronize()
+                dtx = (time.perf_counter() - t1) / nst
+                other[prec] = {"poses_per_s": Bx * T / dtx, "ms_per_step": 1e3 * dtx, "windows_per_gpu": Bx, "steps": nst, "warmup": 1,
+                               "parity_mpjpe_m": par["mpjpe_m"] if par else None,
+                               "within_bound": (par["mpjpe_m"] <= PARITY_BOUND_M) if par else None}
+                log(f"{prec}: {other[prec]['poses_per_s']:.0f} poses/s, parity {other[prec]['parity_mpjpe_m']}")
+                mx._engine = None
+                del tx, mx
+                torch.cuda.empty_cache()
+            except Exception as e:       # noqa: BLE001
+                other[prec] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         poses_per_s = world * B * T * args.steps / dt
         gf = TRAIN_GFLOP_PER_POSE.get(T, 3.705)
@@ -181,17 +302,25 @@ def main():
                                       f"fwd+WTA loss+bwd+allreduce+Adam", "windows_per_gpu": B, "global_batch": world * B,
                           "seq_len": T, "parallelism": f"dp{world}", "precision": args.precision, "drop_path_rate": 0.1},
                "loss": loss, "model_tflops": poses_per_s * gf / 1e3}
+        if parity is not None:
+            out["parity"] = dict(parity, precision=args.precision, bound_m=PARITY_BOUND_M, within_bound=parity["mpjpe_m"] <= PARITY_BOUND_M,
+                                 sample=f"T={T} K={args.hyp} B=1 eval-mode forward on the bench model's initial weights (seed 42) vs the fp32 CPU "
+                                        f"oracle (oracle/manipose_ref.py) run in a CPU child process of this job")
+        if other:
+            out["other_precisions"] = other
         if prof is not None:
             # dominant kernel = the one with the largest share of the step: gemm_bf16_persist_kernel (forward + dgrad Linear GEMMs,
             # ~45 % of the kernel time) in the bf16 mode, the fp32 MFMA GEMM of the forward in the fp32 mode
             sub = prof.pop("gemm_persist")
-            if args.precision == "bf16" and sub["launches"] > 0:
+            if args.precision != "fp32" and sub["launches"] > 0:
                 k = sub
                 kname = ("gemm_bf16_persist_kernel (forward + dgrad Linear GEMMs: persistent, direct-to-LDS 256x256x64 tiles, "
-                         "v_mfma_f32_16x16x32_bf16; all instantiations)")
+                         "v_mfma_f32_16x16x32_bf16; all instantiations" +
+                         ("; the split-precision forward instantiations read planar hi/lo operands and issue 3 products per k-tile: "
+                          "flops = issued matrix-core flops (6 M N K), bytes = both planes)" if args.precision == "bf16x3" else ")"))
             else:
                 k = prof["gemm_fwd"]
-                kname = ("gemm_bf16_glds_kernel (forward Linear GEMMs)" if args.precision == "bf16"
+                kname = ("gemm_bf16_glds_kernel (forward Linear GEMMs)" if args.precision != "fp32"
                          else "gemm_f32_kernel<AL=0,BL=0,*> (forward Linear GEMMs, v_mfma_f32_32x32x2_f32)")
             # Which roof?  Arithmetic intensity of the average launch (algorithmic FLOPs / algorithmic bytes: operands read once,
             # outputs written once) against the ridge peak_flops / peak_bw of the dtype.  Below the ridge the launch is HBM-bound

@@ -30,10 +30,11 @@ class LiftingTrainer:
         if self.rigid_seg_reg > 0 and model._arch == "rmcl_manifold":
             raise NotImplementedError("train.rigid_seg_reg > 0 with the multi-hypothesis model: the reference's term permutes a 4-D "
                                       "(B, L, J, 3) prediction and fails on (B, H, L, J, 3) hypotheses")
-        self.seed = seed
         self.step_no = 0
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        # every rank draws its own DropPath masks (the reference draws independent per-sample masks over the whole batch)
+        self.seed = seed + (dist.get_rank(process_group) if self.world > 1 else 0)
         self.flat_grads: Optional[torch.Tensor] = None
         self.rmcl = model._arch == "rmcl_manifold"
         self._bufs = {}

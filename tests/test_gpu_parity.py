@@ -839,20 +839,47 @@ def test_window_generator_occlusion_patterns_match_reference(lib, mt):
 
 
 def test_bench_two_rank_path_rehearsal_on_one_gpu(lib):
-    """bench.py launched by torch.distributed.run with two ranks pinned to this GPU and gloo carrying the collectives (a one-GPU box
-    cannot host two RCCL ranks): init, barrier, gradient all-reduce, max-over-ranks timing, one JSON line from rank 0."""
+    """`python bench.py --gpus 2` with NO launcher around it: bench.py spawns torch.distributed.run itself (before touching a GPU); the two
+    ranks are pinned to this GPU with gloo carrying the collectives (a one-GPU box cannot host two RCCL ranks): init, barrier, gradient
+    all-reduce, max-over-ranks timing, one JSON line from rank 0 with the in-run parity block."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MANIPOSE_BENCH_DEVICE="0", MANIPOSE_BENCH_BACKEND="gloo")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--batch", "2", "--frames", "27"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MANIPOSE_BENCH_DEVICE="0", MANIPOSE_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--frames", "27"], capture_output=True, text=True, timeout=400, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     assert "cpu_baseline" not in d and d["roofline"]["launches"] >= 0
+    assert d["dtype"] == "bf16x3" and d["parity"]["within_bound"] and d["parity"]["mpjpe_m"] <= 1e-4, d.get("parity")
+
+
+def test_rccl_backend_single_rank_collectives_on_the_flat_gradient_buffer(lib):
+    """backend="nccl" (= RCCL) on this GPU with world size 1: init with device_id, broadcast of the flat parameter buffer, SUM
+    all-reduce of a flat gradient buffer of the real size, barrier, destroy - the calls training.py / distributed.py make per step."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from manipose_amd.distributed import broadcast_parameters\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "g = torch.full((34_450_000,), 2.0, device='cuda')\n"
+        "dist.all_reduce(g, op=dist.ReduceOp.SUM)\n"
+        "broadcast_parameters(g, 0)\n"
+        "dist.broadcast(g, src=0)\n"
+        "dist.barrier()\n"
+        "torch.cuda.synchronize()\n"
+        "assert float(g.sum().item()) == 2.0 * g.numel()\n"
+        "dist.destroy_process_group()\n"
+        "print('rccl ok', dist.is_nccl_available())\n")
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0 and "rccl ok True" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
