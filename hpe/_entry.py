@@ -31,20 +31,60 @@ class Cfg(dict):
         return Cfg({k: Cfg.wrap(v) if isinstance(v, dict) else v for k, v in d.items()})
 
 
+def parse_value(text):
+    """A command-line value the way Hydra's override grammar reads it: int, float (incl. `4e-5`, `1.`, which YAML 1.1 leaves as
+    strings), true/false, null, quoted string; anything else through YAML (lists, dicts) or as a bare string."""
+    t = text.strip()
+    for conv in (int, float):
+        try:
+            return conv(t)
+        except ValueError:
+            pass
+    low = t.lower()
+    if low in ("true", "false"):
+        return low == "true"
+    if low in ("null", "none", "~"):
+        return None
+    try:
+        return yaml.safe_load(t)
+    except yaml.YAMLError:
+        return t
+
+
 def load_config(argv, extra_defaults=None):
-    with open(os.path.join(ROOT, "hpe", "conf", "config.yaml")) as f:
+    """hpe/conf/config.yaml + overrides in the reference's Hydra grammar (main_h36m_lifting.py:711, README.md:54-111):
+      group=name | +group=name   merge hpe/conf/<group>/<name>.yaml into that group (new keys allowed, e.g. data.pad)
+      group.key=value            set an EXISTING key (a typo such as run.tran=False is an error, as with Hydra)
+      +group.key=value           add a new key
+    Errors are SystemExit with a message, never a traceback from the parser."""
+    conf = os.path.join(ROOT, "hpe", "conf")
+    with open(os.path.join(conf, "config.yaml")) as f:
         cfg = yaml.safe_load(f)
     for k, v in (extra_defaults or {}).items():
         grp, key = k.split(".")
         cfg[grp][key] = v
     for arg in argv:
         if "=" not in arg:
-            raise SystemExit(f"expected group.key=value overrides, got {arg!r}")
-        path, val = arg.lstrip("+").split("=", 1)
+            raise SystemExit(f"expected `group.key=value` or `group=name` overrides, got {arg!r}")
+        path, val = arg.split("=", 1)
+        add = path.startswith("+")
+        path = path.lstrip("+")
+        if "." not in path:                                   # config group selection
+            if path not in cfg:
+                raise SystemExit(f"unknown config group {path!r} (groups: {sorted(cfg)})")
+            fn = os.path.join(conf, path, val + ".yaml")
+            if not os.path.exists(fn):
+                have = sorted(x[:-5] for x in os.listdir(os.path.join(conf, path))) if os.path.isdir(os.path.join(conf, path)) else []
+                raise SystemExit(f"no config {path}/{val}.yaml (available for {path!r}: {have})")
+            with open(fn) as f:
+                cfg[path].update(yaml.safe_load(f) or {})
+            continue
         grp, key = path.split(".", 1)
         if grp not in cfg:
-            raise SystemExit(f"unknown config group {grp!r}")
-        cfg[grp][key] = yaml.safe_load(val)
+            raise SystemExit(f"unknown config group {grp!r} (groups: {sorted(cfg)})")
+        if key not in cfg[grp] and not add:
+            raise SystemExit(f"unknown key {grp}.{key} (keys of {grp!r}: {sorted(cfg[grp])}); prefix with + to add a new key")
+        cfg[grp][key] = parse_value(val)
     return Cfg.wrap(cfg)
 
 
@@ -274,6 +314,7 @@ def run(argv, extra_defaults=None):
     if cfg.run.checkpoint_params:
         st = torch.load(cfg.run.checkpoint_params, map_location="cpu")
         trainer.opt.load_state_dict(st["optimizer"])
+        trainer.step_no = trainer.opt.step_count          # DropPath masks are a function of (seed, step): continue, do not replay
         start_epoch = st["epoch"]
         sched_state = st.get("scheduler")
     T, B, Bt = cfg.data.seq_len, cfg.train.batch_size, cfg.train.batch_size_test
@@ -308,6 +349,7 @@ def run(argv, extra_defaults=None):
     if sched_state is not None and sched_state.get("kind") == sched.state_dict()["kind"]:
         sched.load_state_dict(sched_state)
     best_val, best_eval = 1e10, {}
+    best_model_state = None                  # main_h36m_lifting.py:390,491: weights of the best validation loss / best MPJPE, reloaded before the test
     train_curve, valid_curve = [], []
     if cfg.run.train:
         if real:
@@ -339,6 +381,7 @@ def run(argv, extra_defaults=None):
                 valid_curve.append(val)
                 if best_val > val:                                     # main_h36m_lifting.py:374-398
                     best_val = val
+                    best_model_state = copy.deepcopy(model.state_dict())
                     if rank == 0:
                         save_state(model, trainer, sched.state_dict(), epoch, out_dir, "best_val")
                 if cfg.train.lr_scheduler == "plateau":                # :400-403: the plateau scheduler watches the running best
@@ -356,12 +399,16 @@ def run(argv, extra_defaults=None):
                 for key, tag in (("mpjpe", "best_mpjpe"), ("oracle_mpjpe", "best_oracle_mpjpe"), ("ps_oracle_mpjpe", "best_ps_oracle_mpjpe")):
                     if key in ev and ev[key] < best_eval.get(key, 1e10):           # tags of main_h36m_lifting.py:440-489
                         best_eval[key] = ev[key]
+                        if key == "mpjpe":
+                            best_model_state = copy.deepcopy(model.state_dict())
                         if rank == 0:
                             save_state(model, trainer, sched.state_dict(), epoch, out_dir, tag)
         if rank == 0:
             save_state(model, trainer, sched.state_dict(), cfg.train.epochs, out_dir, "end")
             np.save(os.path.join(out_dir, "train_loss.npy"), np.array(train_curve))           # :503-504
             np.save(os.path.join(out_dir, "valid_loss.npy"), np.array(valid_curve))
+        if best_model_state is not None:                   # "load best weights" (main_h36m_lifting.py:506-507): the test below runs on them
+            model.load_state_dict(best_model_state)
     if cfg.run.test:
         groups = {"synthetic": (valid_batches, valid_shared)}
         if real:        # per action (H36M: subject S11, main_h36m_lifting.py:884-990) or the whole 3DHP test set (main_3dhp.py:800-910)

@@ -57,8 +57,9 @@ typedef struct mp_loss_config {
   float rmcl_score_reg; /* beta, conf/config.yaml:36 (0.1) */
   float vel_loss;       /* conf/config.yaml:33 (2.0) */
   float smooth_reg;     /* conf/config.yaml:34 (0.5) */
-  int w_loss;           /* conf/config.yaml:32: weight joints by STANDARD_H36M_WEIGHTS (losses.py:6-8) */
+  int w_loss;           /* conf/config.yaml:32: 1 = weight joints by STANDARD_H36M_WEIGHTS (losses.py:6-8); 0 = unweighted; 2 = joint_weights below */
   int sq_loss;          /* conf/config.yaml:31: squared distances in the WTA and velocity terms (losses.py:46-72,96-97,110-116) */
+  float joint_weights[17]; /* w_loss == 2: the caller's per-joint weights (the `weights` argument of losses.py:14-43,104-138, regularizations.py:160-174) */
 } mp_loss_config;
 int mp_wta_loss(const float* poses, const float* scores, const float* target, const mp_loss_config* cfg, float* terms,
                 int32_t* argmin, float* d_poses, float* d_scores, int B, int K, int T, float* scratch,
@@ -246,6 +247,10 @@ int mp_ingest_pose2d(const float* raw, int raw_joints, int raw_channels, const i
  *   sum (l-r)^2;  per joint (17): sum ||e||, sum ||e||^2.   len0: (B,16) bone lengths of frame 0 (the shift of the variance sums).
  * scratch: >= B * ceil(L/128) * row_floats floats. */
 int mp_pose_metrics_row_floats(void);
+/* segments_len_err(..., mode="no_agg") (metrics/mean_joint_errors.py:83-130): out (B*L, 16) = ground-truth minus predicted bone length per
+ * frame and bone (absolute value unless signed_diff); strides as in mp_pose_metrics. */
+int mp_bone_length_table(const float* pred, const int64_t* pred_strides, const float* gt, const int64_t* gt_strides, int B, int L, int signed_diff,
+                         float* out, void* stream);
 int mp_pose_metrics(const float* pred, const int64_t* pred_strides, const float* gt, const int64_t* gt_strides, const uint8_t* mask, int B,
                     int L, int J, float pred_scale, float gt_scale, float pck_threshold, float auc_max, int auc_steps, int scale_align,
                     float* out, float* len0, float* scratch, int64_t scratch_floats, void* stream);

@@ -22,7 +22,7 @@ vp, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
 class LossConfig(C.Structure):
     """mp_loss_config; defaults = hpe/conf/config.yaml:32-38 of the reference."""
-    _fields_ = [("rmcl_score_reg", f32), ("vel_loss", f32), ("smooth_reg", f32), ("w_loss", i32), ("sq_loss", i32)]
+    _fields_ = [("rmcl_score_reg", f32), ("vel_loss", f32), ("smooth_reg", f32), ("w_loss", i32), ("sq_loss", i32), ("joint_weights", f32 * 17)]
 
 
 class ModelConfig(C.Structure):
@@ -76,6 +76,7 @@ _SIGNATURES = {
     "mp_ingest_pose2d": (i32, [vp, i32, i32, vp, i64, C.POINTER(i32), i32, f32, f32, vp, vp]),
     "mp_procrustes_errors": (i32, [vp, vp, vp, i64, i32, f32, f32, f32, f32, i32, vp, vp, i64, vp]),
     "mp_pose_metrics_row_floats": (i32, []),
+    "mp_bone_length_table": (i32, [vp, C.POINTER(i64), vp, C.POINTER(i64), i32, i32, i32, vp, vp]),
     "mp_pose_metrics": (i32, [vp, C.POINTER(i64), vp, C.POINTER(i64), vp, i32, i32, i32, f32, f32, f32, f32, i32, i32, vp, vp, vp, i64, vp]),
     "mp_set_option": (i32, [C.c_char_p, i32]),
     "mp_prof_enable": (i32, [vp, i32]),

@@ -13,6 +13,7 @@ using namespace mp;
 static LossCfg to_cfg(const mp_loss_config* c) {
   LossCfg l;
   l.beta = c->rmcl_score_reg; l.vel_w = c->vel_loss; l.smooth_w = c->smooth_reg; l.use_joint_weights = c->w_loss; l.squared = c->sq_loss;
+  for (int j = 0; j < 17; ++j) l.joint_weights[j] = c->joint_weights[j];
   return l;
 }
 
@@ -198,6 +199,13 @@ int mp_procrustes_errors(const float* pred, const float* gt, const uint8_t* mask
 }
 
 int mp_pose_metrics_row_floats(void) { return pose_metrics_row_floats(); }
+int mp_bone_length_table(const float* pred, const int64_t* pred_strides, const float* gt, const int64_t* gt_strides, int B, int L, int signed_diff,
+                         float* out, void* stream) {
+  MP_CHECK(pred && pred_strides && gt && gt_strides && out, MP_ERR_ARG, "mp_bone_length_table: null pointer");
+  long ps[4], gs[4];
+  for (int i = 0; i < 4; ++i) { ps[i] = (long)pred_strides[i]; gs[i] = (long)gt_strides[i]; }
+  return bone_length_table(pred, ps, gt, gs, B, L, signed_diff, out, (hipStream_t)stream);
+}
 int mp_pose_metrics(const float* pred, const int64_t* pred_strides, const float* gt, const int64_t* gt_strides, const uint8_t* mask, int B,
                     int L, int J, float pred_scale, float gt_scale, float pck_threshold, float auc_max, int auc_steps, int scale_align,
                     float* out, float* len0, float* scratch, int64_t scratch_floats, void* stream) {

@@ -738,7 +738,7 @@ int adam_step(float* p, const float* g, float* m, float* v, long n, int step, fl
 // DropPath masks (timm DropPath semantics: Bernoulli(keep) / keep per sample of dim 0), counter-based
 // hash RNG so that the masks are a pure function of (seed, step, branch, sample).
 // ---------------------------------------------------------------------------------------------
-struct MaskDescs { MaskDesc d[48]; int n; };
+struct MaskDescs { MaskDesc d[48]; int n, base; };
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
   z += 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -747,9 +747,9 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
 }
 __global__ void droppath_masks_kernel(float* __restrict__ masks, MaskDescs ds, unsigned long long seed,
                                       unsigned long long step) {
-  const int k = blockIdx.y;
-  if (k >= ds.n) return;
-  const MaskDesc d = ds.d[k];
+  if ((int)blockIdx.y >= ds.n) return;
+  const MaskDesc d = ds.d[blockIdx.y];
+  const int k = ds.base + blockIdx.y;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.count; i += gridDim.x * blockDim.x) {
     const unsigned long long r = splitmix64(splitmix64(seed ^ (step * 0xD1342543DE82EF95ull)) ^ ((unsigned long long)k << 40) ^ i);
     const float u = (float)(r >> 40) * (1.0f / 16777216.0f);
@@ -759,13 +759,16 @@ __global__ void droppath_masks_kernel(float* __restrict__ masks, MaskDescs ds, u
 
 int droppath_masks(float* masks, const MaskDesc* descs, int ndesc, unsigned long long seed, unsigned long long step,
                    hipStream_t st) {
-  MP_CHECK(ndesc <= 48, MP_ERR_ARG, "droppath_masks: too many branches (%d)", ndesc);
-  if (ndesc == 0) return MP_OK;
-  MaskDescs ds;
-  ds.n = ndesc;
-  for (int i = 0; i < ndesc; ++i) ds.d[i] = descs[i];
-  hipLaunchKernelGGL(droppath_masks_kernel, dim3(8, ndesc), dim3(256), 0, st, masks, ds, seed, step);
-  MP_LAUNCH_CHECK();
+  // any number of branches (4 per block of both nets: 4 (layers + layers_seg)), 48 descriptors per launch; the branch index that
+  // seeds the hash is the global one
+  for (int base = 0; base < ndesc; base += 48) {
+    MaskDescs ds;
+    ds.n = min(48, ndesc - base);
+    ds.base = base;
+    for (int i = 0; i < ds.n; ++i) ds.d[i] = descs[base + i];
+    hipLaunchKernelGGL(droppath_masks_kernel, dim3(8, ds.n), dim3(256), 0, st, masks, ds, seed, step);
+    MP_LAUNCH_CHECK();
+  }
   return MP_OK;
 }
 

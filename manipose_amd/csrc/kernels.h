@@ -142,7 +142,7 @@ int fk_decode_bwd(const float* rot, int rot_stride, int rot_dim, const float* le
                   float* dlen_pose, int B, int K, int T, hipStream_t st);
 
 // ---------------------------------------------------------------- wta_loss.hip
-struct LossCfg { float beta, vel_w, smooth_w; int use_joint_weights, squared; };
+struct LossCfg { float beta, vel_w, smooth_w; int use_joint_weights /* 0 none, 1 STANDARD_H36M_WEIGHTS, 2 joint_weights[] */, squared; float joint_weights[17]; };
 // terms[4] = (wloss, score_reg, vloss, sreg); total = sum. dposes/dscores (may be null) receive d total / d input.
 int wta_loss(const float* poses, const float* scores, const float* y, const LossCfg& cfg, float* terms, int* argmin,
              float* dposes, float* dscores, int B, int K, int T, float* scratch, long scratch_floats, hipStream_t st);
@@ -160,6 +160,8 @@ int mpjpe_sum(const float* pred, const float* gt, long njoints, float* out_sum, 
 
 // ---------------------------------------------------------------- pose_metrics.hip
 int pose_metrics_row_floats();
+// segments_len_err(mode="no_agg") (mean_joint_errors.py:83-130): out[(b*L + t)*16 + k] = gt bone length - predicted bone length (|.| if !signed_)
+int bone_length_table(const float* pred, const long* ps, const float* gt, const long* gs, int B, int L, int signed_, float* out, hipStream_t st);
 int pose_metrics(const float* pred, const long* ps, const float* gt, const long* gs, const unsigned char* mask, int B, int L, int J,
                  float pred_scale, float gt_scale, float pck_thr, float auc_max, int auc_n, int scale_align, float* out, float* len0,
                  float* scratch, long scratch_floats, hipStream_t st);

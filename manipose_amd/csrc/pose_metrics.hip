@@ -262,4 +262,35 @@ int pose_metrics(const float* pred, const long* ps, const float* gt, const long*
   return MP_OK;
 }
 
+// segments_len_err(mode="no_agg") (mean_joint_errors.py:83-130): the per-frame table gt - predicted bone length, (B*L, 16);
+// thread per frame, inputs through element strides like pose_metrics (the reference passes (B,3,J,L) views)
+__global__ void bone_length_table_kernel(const float* __restrict__ pred, const float* __restrict__ gt, long p0, long p1, long p2, long p3,
+                                         long g0, long g1, long g2, long g3, int B, int L, int signed_, float* __restrict__ out) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= B * L) return;
+  const int b = f / L, t = f - b * L;
+  const float* pb = pred + b * p0 + t * p1;
+  const float* gb = gt + b * g0 + t * g1;
+#pragma unroll
+  for (int k = 0; k < PM_NB; ++k) {
+    const int j = k + 1, q = PM_PARENT[j];
+    float lp = 0.f, lg = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float dp = pb[j * p2 + c * p3] - pb[q * p2 + c * p3], dg = gb[j * g2 + c * g3] - gb[q * g2 + c * g3];
+      lp += dp * dp; lg += dg * dg;
+    }
+    const float d = sqrtf(lg) - sqrtf(lp);
+    out[(long)f * PM_NB + k] = signed_ ? d : fabsf(d);
+  }
+}
+
+int bone_length_table(const float* pred, const long* ps, const float* gt, const long* gs, int B, int L, int signed_, float* out, hipStream_t st) {
+  MP_CHECK(B > 0 && L > 0, MP_ERR_ARG, "bone_length_table: B=%d L=%d", B, L);
+  hipLaunchKernelGGL(bone_length_table_kernel, dim3(cdiv((long)B * L, 256)), dim3(256), 0, st, pred, gt, ps[0], ps[1], ps[2], ps[3], gs[0], gs[1],
+                     gs[2], gs[3], B, L, signed_, out);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
 }  // namespace mp

@@ -14,7 +14,8 @@
 namespace mp {
 
 constexpr int LJ = 17;
-__constant__ float c_w[LJ] = {1, 1, 2.5f, 2.5f, 1, 2.5f, 2.5f, 1, 1, 1, 1.5f, 1.5f, 4, 4, 1.5f, 4, 4};   // losses.py:6-8
+static const float H36M_W[LJ] = {1, 1, 2.5f, 2.5f, 1, 2.5f, 2.5f, 1, 1, 1, 1.5f, 1.5f, 4, 4, 1.5f, 4, 4};   // STANDARD_H36M_WEIGHTS, losses.py:6-8
+struct JointW { float w[LJ]; };        // per-joint weights of the WTA / smoothness terms, passed by value (kernel argument)
 
 struct LossScales { float wta, bce, vel, smooth; };
 
@@ -28,7 +29,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 __global__ __launch_bounds__(256) void wta_loss_kernel(const float* __restrict__ poses, const float* __restrict__ scores,
-                                                        const float* __restrict__ y, int use_w, int squared, LossScales sc,
+                                                        const float* __restrict__ y, JointW jw, int squared, LossScales sc,
                                                         float* __restrict__ partial, int* __restrict__ argmin,
                                                         float* __restrict__ dposes, float* __restrict__ dscores, int B, int K,
                                                         int T) {
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void wta_loss_kernel(const float* __restrict__
       for (int j = 0; j < LJ; ++j) {
         const float dx = pr[3 * j] - yr[3 * j], dy = pr[3 * j + 1] - yr[3 * j + 1], dz = pr[3 * j + 2] - yr[3 * j + 2];
         const float d2 = dx * dx + dy * dy + dz * dz;
-        e += (use_w ? c_w[j] : 1.0f) * (squared ? d2 : sqrtf(d2));
+        e += jw.w[j] * (squared ? d2 : sqrtf(d2));
       }
       e /= squared ? (float)(LJ * 3) : (float)LJ;
       if (e < best) { best = e; kb = k; }
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void wta_loss_kernel(const float* __restrict__
       const long fo = (((long)b * K + k) * T + t) * LJ * 3;
       const float* pr = poses + fo;
       for (int j = 0; j < LJ; ++j) {
-        const float wj = use_w ? c_w[j] : 1.0f;
+        const float wj = jw.w[j];
         const float p0 = pr[3 * j], p1 = pr[3 * j + 1], p2 = pr[3 * j + 2];
         const float y0 = yr[3 * j], y1 = yr[3 * j + 1], y2 = yr[3 * j + 2];
         float g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -151,7 +152,10 @@ static int loss_impl(const float* poses, const float* scores, const float* y, co
   sc.bce = (scores != nullptr) ? cfg.beta / ((float)B * K * T) : 0.f;
   sc.vel = cfg.vel_w / ((float)B * K * (T - 1) * LJ * (cfg.squared ? 3 : 1));
   sc.smooth = cfg.smooth_w / ((float)B * K * (T - 1) * LJ * 3);
-  hipLaunchKernelGGL(wta_loss_kernel, dim3(grid), dim3(256), 0, st, poses, scores, y, cfg.use_joint_weights, cfg.squared, sc, scratch, argmin,
+  MP_CHECK(cfg.use_joint_weights >= 0 && cfg.use_joint_weights <= 2, MP_ERR_ARG, "wta_loss: w_loss %d (0 none, 1 H36M weights, 2 custom)", cfg.use_joint_weights);
+  JointW jw;
+  for (int j = 0; j < LJ; ++j) jw.w[j] = cfg.use_joint_weights == 1 ? H36M_W[j] : (cfg.use_joint_weights == 2 ? cfg.joint_weights[j] : 1.0f);
+  hipLaunchKernelGGL(wta_loss_kernel, dim3(grid), dim3(256), 0, st, poses, scores, y, jw, cfg.squared, sc, scratch, argmin,
                      dposes, dscores, B, K, T);
   MP_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, grid, terms, 4, skip_bce);

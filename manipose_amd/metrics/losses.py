@@ -17,13 +17,26 @@ from .. import _lib
 STANDARD_H36M_WEIGHTS = torch.Tensor([1, 1, 2.5, 2.5, 1, 2.5, 2.5, 1, 1, 1, 1.5, 1.5, 4, 4, 1.5, 4, 4])
 
 
-def _uses_h36m_weights(weights) -> int:
+def _uses_h36m_weights(weights):
+    """mp_loss_config.w_loss for a `weights` argument of the reference's loss functions: 0 (None), 1 (STANDARD_H36M_WEIGHTS), or the
+    tuple (2, 17 floats) for any other per-joint weights (passed to the kernel in mp_loss_config.joint_weights)."""
     if weights is None:
         return 0
-    w = torch.as_tensor(weights, dtype=torch.float32).cpu()
-    if w.shape == STANDARD_H36M_WEIGHTS.shape and torch.equal(w, STANDARD_H36M_WEIGHTS):
+    w = torch.as_tensor(weights, dtype=torch.float32).detach().cpu().reshape(-1)
+    if w.numel() != 17:
+        raise ValueError(f"expected 17 per-joint weights, got {w.numel()}")
+    if torch.equal(w, STANDARD_H36M_WEIGHTS):
         return 1
-    raise NotImplementedError("manipose_amd: joint weights must be None or STANDARD_H36M_WEIGHTS (compiled into the kernel)")
+    return (2, tuple(float(v) for v in w))
+
+
+def _loss_config(beta, vel_w, smooth_w, use_w, squared):
+    cfg = _lib.LossConfig(rmcl_score_reg=beta, vel_loss=vel_w, smooth_reg=smooth_w, w_loss=use_w[0] if isinstance(use_w, tuple) else int(use_w),
+                          sq_loss=int(squared))
+    if isinstance(use_w, tuple):
+        for j, v in enumerate(use_w[1]):
+            cfg.joint_weights[j] = v
+    return cfg
 
 
 def _scratch(B: int, T: int, device) -> torch.Tensor:
@@ -38,7 +51,7 @@ class _FusedLoss(torch.autograd.Function):
         lib = _lib.load()
         poses = poses.contiguous().float()
         y = y.contiguous().float()
-        cfg = _lib.LossConfig(rmcl_score_reg=beta, vel_loss=vel_w, smooth_reg=smooth_w, w_loss=use_w, sq_loss=int(squared))
+        cfg = _loss_config(beta, vel_w, smooth_w, use_w, squared)
         dev = poses.device
         need_grad = poses.requires_grad or (scores is not None and scores.requires_grad)
         if scores is not None:
@@ -106,7 +119,7 @@ def wta_l2_loss_and_activate_head(hypothesis, y, weights=None, squared: bool = F
     # per-frame values: winner poses through the aggregation kernel, then per-frame weighted error
     use_w = _uses_h36m_weights(weights)
     import ctypes as C
-    cfg = _lib.LossConfig(rmcl_score_reg=0.0, vel_loss=0.0, smooth_reg=0.0, w_loss=use_w, sq_loss=int(squared))
+    cfg = _loss_config(0.0, 0.0, 0.0, use_w, squared)
     terms = torch.empty(4, dtype=torch.float32, device=hyp.device)
     argmin = torch.empty(B, T, dtype=torch.int32, device=hyp.device)
     dummy = torch.full((B, K, T, 1), 1.0 / K, dtype=torch.float32, device=hyp.device)
@@ -115,7 +128,7 @@ def wta_l2_loss_and_activate_head(hypothesis, y, weights=None, squared: bool = F
                                None, None, B, K, T, _lib.ptr(sc), sc.numel(), _lib.stream_ptr()), "mp_wta_loss")
     idx = argmin.long()
     win = hyp.gather(1, idx[:, None, :, None, None].expand(B, 1, T, 17, 3))[:, 0]
-    w = (STANDARD_H36M_WEIGHTS if use_w else torch.ones(17)).to(hyp.device)
+    w = (torch.tensor(use_w[1]) if isinstance(use_w, tuple) else (STANDARD_H36M_WEIGHTS if use_w else torch.ones(17))).to(hyp.device)
     if squared:         # losses.py:110-116: mean over the coordinates, then over the joints
         vals = (w[:, None] * (win - gt) ** 2).mean(dim=-1).mean(dim=-1)
     else:

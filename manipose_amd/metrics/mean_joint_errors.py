@@ -71,9 +71,17 @@ def jointwise_mse(batch_imp: torch.Tensor, batch_gt: torch.Tensor, mode: str) ->
 def segments_len_err(batch_imp: torch.Tensor, batch_gt: torch.Tensor, skeleton, mode: str, signed: bool = True) -> torch.Tensor:
     """mean_joint_errors.py:83-130: gt - predicted bone lengths over (frame, bone); inputs (B, 3, J, L) like the reference."""
     from .analytics import pose_analytics
-    if mode == "no_agg":
-        raise NotImplementedError("manipose_amd: segments_len_err(mode='no_agg') (per-frame table) is not provided; use "
-                                  "'average' or 'sum'")
+    if mode == "no_agg":                     # the per-frame table (B*L, 16), one thread per frame reading the (B, 3, J, L) views in place
+        from .. import _lib
+        from .analytics import _dptr, _strides
+        a, g = batch_imp.detach().float(), batch_gt.detach().float()
+        B, _, J, L = a.shape
+        if J != 17 or g.shape != a.shape:
+            raise ValueError(f"expected (B, 3, 17, L) predictions and targets of the same shape, got {tuple(a.shape)} / {tuple(g.shape)}")
+        out = torch.empty(B * L, 16, dtype=torch.float32, device=a.device)
+        _lib.check(_lib.load().mp_bone_length_table(_dptr(a), _strides(a, (0, 3, 2, 1)), _dptr(g), _strides(g, (0, 3, 2, 1)), B, L,
+                                                    int(signed), _lib.ptr(out), _lib.stream_ptr()), "mp_bone_length_table")
+        return out
     _mode(mode)
     r = pose_analytics(batch_imp.detach().float(), batch_gt.detach().float(), layout="BCJL", skeleton=skeleton)
     tot = r.scalar(5 if signed else 4)

@@ -54,15 +54,51 @@ class FusedAdam:
         self.model._last_flat_grad = None
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "lr": self.param_groups[0]["lr"]}
+        """torch.optim.Adam's state_dict layout ({"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]}, parameter i =
+        i-th entry of model.parameters()), so that params{tag}.pth files (main_h36m_lifting.py:75-98) are interchangeable with the
+        reference's.  The moments are copies cut out of the flat buffers."""
+        m = self.model
+        m.flat_parameters()
+        index = {id(p): i for i, p in enumerate(m.parameters())}
+        state = {}
+        if self.exp_avg is not None:
+            for (off, n), p in zip(m._slots, m._plist):
+                state[index[id(p)]] = {"step": torch.tensor(float(self.step_count)),
+                                       "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                                       "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        group = {"lr": self.param_groups[0]["lr"], "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(index)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        """Accepts torch.optim.Adam's layout (a reference checkpoint, or one written by state_dict() above) and the flat layout
+        {"step", "exp_avg", "exp_avg_sq"} this class wrote before."""
+        m = self.model
+        flat = m.flat_parameters()
+        if "param_groups" in sd:
+            g = sd["param_groups"][0]
+            self.param_groups[0]["lr"] = g.get("lr", self.lr)
+            params = list(m.parameters())
+            if len(g["params"]) != len(params):
+                raise ValueError(f"optimizer state has {len(g['params'])} parameters, the model {len(params)}")
+            slot = {id(p): s for s, p in zip(m._slots, m._plist)}
+            self.exp_avg, self.exp_avg_sq, self.step_count = torch.zeros_like(flat), torch.zeros_like(flat), 0
+            for i, pid in enumerate(g["params"]):
+                st = sd["state"].get(pid)
+                if st is None:
+                    continue
+                off, n = slot[id(params[i])]
+                if st["exp_avg"].numel() != n:
+                    raise ValueError(f"optimizer state of parameter {i} has {st['exp_avg'].numel()} elements, expected {n}")
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1).to(flat.device, torch.float32))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(flat.device, torch.float32))
+                self.step_count = max(self.step_count, int(float(st["step"])))
+            return
         self.step_count = int(sd["step"])
         self.param_groups[0]["lr"] = sd.get("lr", self.lr)
-        dev = self.model.flat_parameters().device
-        self.exp_avg = sd["exp_avg"].to(dev) if sd["exp_avg"] is not None else None
-        self.exp_avg_sq = sd["exp_avg_sq"].to(dev) if sd["exp_avg_sq"] is not None else None
+        self.exp_avg = sd["exp_avg"].to(flat.device) if sd["exp_avg"] is not None else None
+        self.exp_avg_sq = sd["exp_avg_sq"].to(flat.device) if sd["exp_avg_sq"] is not None else None
 
 
 class CosineAnnealingLR:

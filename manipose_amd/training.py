@@ -20,7 +20,7 @@ from .optim import FusedAdam
 class LiftingTrainer:
     def __init__(self, model, lr: float = 4e-5, weight_decay: float = 1e-6, w_loss: bool = True, vel_loss: float = 2.0,
                  smooth_reg: float = 0.5, rmcl_score_reg: float = 0.1, seed: int = 42, process_group=None,
-                 grad_buckets: int = 1, sq_loss: bool = False, rigid_seg_reg: float = 0.0):
+                 sq_loss: bool = False, rigid_seg_reg: float = 0.0):
         self.model = model
         self.lib = _lib.load()
         self.opt = FusedAdam(model, lr=lr, weight_decay=weight_decay)

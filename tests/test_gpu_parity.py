@@ -802,13 +802,15 @@ def test_training_entry_runs_on_resident_sequences(lib, tmp_path, monkeypatch):
     for f in ("model_end.pth", "params_end.pth", "model_best_val.pth", "params_best_val.pth", "train_loss.npy", "valid_loss.npy"):
         assert os.path.exists(os.path.join(d, f)), f
     st = torch.load(os.path.join(d, "params_end.pth"), map_location="cpu")
-    assert st["epoch"] == 1 and st["optimizer"]["step"] == 2 and st["scheduler"]["kind"] == "plateau"
+    assert st["epoch"] == 1 and st["scheduler"]["kind"] == "plateau"
+    opt_state = st["optimizer"]                                        # torch.optim.Adam's layout (interchangeable with the reference's files)
+    assert float(opt_state["state"][0]["step"]) == 2 and opt_state["param_groups"][0]["lr"] == 4e-5 and len(opt_state["state"]) > 50
     best2 = run(["train.epochs=2", "train.steps_per_epoch=2", "train.batch_size=4", "train.batch_size_test=2", "data.seq_len=27",
                  "model.channels=64", "model.layers=2", "model.nheads=4", "model.channels_seg=32", "model.layers_seg=1",
                  "model.nheads_seg=4", "multi_hyp.n_hyp=3", "data.synthetic_sequences=6", "run.test=false", "run.experiment=resumed",
                  f"run.checkpoint_model={d}/model_end.pth", f"run.checkpoint_params={d}/params_end.pth", "train.mpjpe_epoch_interval=1"])
     st2 = torch.load(os.path.join(str(tmp_path), "resumed", "params_end.pth"), map_location="cpu")
-    assert st2["optimizer"]["step"] == 4 and np.isfinite(best2)        # one more epoch of two steps on top of the restored moments
+    assert float(st2["optimizer"]["state"][0]["step"]) == 4 and np.isfinite(best2)    # one more epoch of two steps on top of the restored moments
     assert os.path.exists(os.path.join(str(tmp_path), "resumed", "model_best_mpjpe.pth"))
 
 
@@ -1405,3 +1407,41 @@ def test_bf16x3_training_step_and_droppath(lib):
     X, y = dev(fx["X"]), dev(fx["y"])
     losses = [float(tr.train_step(X, y).sum().item()) for _ in range(8)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_custom_joint_weights_and_no_agg_segment_table_vs_oracle(lib):
+    """The `weights` argument of the reference's loss functions with arbitrary per-joint weights (losses.py:14-43,104-138,
+    regularizations.py:160-174) and segments_len_err(mode="no_agg") (mean_joint_errors.py:83-130) against the oracle."""
+    from manipose_amd import h36m_skeleton
+    from manipose_amd.metrics import (segments_len_err, smoothness_regularization, weighted_mpjpe_loss, wta_l2_loss_and_activate_head,
+                                      wta_with_scoring_loss)
+    g = torch.Generator().manual_seed(5)
+    B, K, T = 3, 4, 11
+    hyp = torch.randn(B, K, T, 17, 3, generator=g)
+    sc = torch.softmax(torch.randn(B, K, T, 1, generator=g), dim=1)
+    y = torch.randn(B, T, 17, 3, generator=g)
+    w = torch.rand(17, generator=g) * 3 + 0.1
+    hd = hyp.cuda().requires_grad_(True)
+    sd = sc.cuda().requires_grad_(True)
+    tot, reg = wta_with_scoring_loss(hd, sd, y.cuda(), 0.1, weights=w)
+    ho, so = hyp.clone().requires_grad_(True), sc.clone().requires_grad_(True)
+    o_tot, o_reg = orc.wta_with_scoring_loss(ho, so, y, 0.1, weights=w)
+    close(tot, o_tot.detach(), rtol=1e-5, atol=1e-6)
+    tot.backward()
+    o_tot.backward()
+    close(hd.grad, ho.grad, rtol=1e-4, atol=1e-7)
+    vals, idx = wta_l2_loss_and_activate_head(hyp.cuda(), y.cuda(), weights=w)
+    o_vals, o_idx = orc.wta_l2_loss_and_activate_head(hyp, y, weights=w)
+    assert torch.equal(idx.cpu(), o_idx)
+    close(vals, o_vals, rtol=1e-5, atol=1e-6)
+    close(smoothness_regularization(hyp.cuda(), w, axis=2), orc.smoothness_regularization(hyp, w, 2), rtol=1e-5)
+    close(weighted_mpjpe_loss(hyp[:, 0].cuda().contiguous(), y.cuda(), w), orc.weighted_mpjpe_loss(hyp[:, 0], y, w), rtol=1e-5)
+    # per-frame segment-length table on the reference's (B, 3, J, L) views
+    pred, gt = hyp[:, 0].permute(0, 3, 2, 1), y.permute(0, 3, 2, 1)
+    for signed in (True, False):
+        got = segments_len_err(pred.cuda(), gt.cuda(), h36m_skeleton(), "no_agg", signed=signed)
+        lp = orc.measure_bones_length(pred).permute(0, 2, 1).reshape(B * T, -1)
+        lg = orc.measure_bones_length(gt).permute(0, 2, 1).reshape(B * T, -1)
+        want = lg - lp if signed else (lg - lp).abs()
+        assert got.shape == (B * T, 16)
+        close(got, want, rtol=1e-5, atol=1e-6)

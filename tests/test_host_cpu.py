@@ -238,3 +238,116 @@ def test_lr_schedulers_follow_torch():
     assert c.best == a.best and c.num_bad_epochs == a.num_bad_epochs
     with pytest.raises(ValueError):
         make_lr_scheduler(mine, "step", epochs=10)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# boundary documents and entry-point grammar
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _header_prototypes():
+    import re
+    text = open(os.path.join(ROOT, "include", "manipose_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for name, args in re.findall(r"\b(mp_\w+)\s*\(([^()]*)\)\s*;", text):
+        a = args.strip()
+        protos[name] = 0 if a in ("", "void") else a.count(",") + 1
+    structs = {}
+    for body, name in re.findall(r"typedef struct \w+ \{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                fields += [re.sub(r"\[.*\]", "", f.strip().split()[-1].lstrip("*")) for f in decl.split(",")]
+        structs[name] = fields
+    version = int(re.search(r"#define MP_ABI_VERSION (\d+)", text).group(1))
+    return protos, structs, version
+
+
+def test_integration_doc_matches_the_header():
+    """the generated ctypes declarations are up to date with manipose_amd/_lib.py, and every argtypes list, structure
+    and `lib.mp_*(...)` call in the document's code blocks agrees with include/manipose_hip.h (argument counts, field lists, ABI)."""
+    import ast, re, subprocess
+    from manipose_amd import _lib
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_integration_stub.py"), "--check"]).returncode == 0, \
+        "INTEGRATION.md is stale: run python tools/gen_integration_stub.py"
+    protos, structs, version = _header_prototypes()
+    assert version == _lib.ABI_VERSION
+    for name, (_, args) in _lib._SIGNATURES.items():           # the binding itself against the header
+        assert protos[name] == len(args), f"{name}: header has {protos[name]} parameters, _lib.py {len(args)}"
+    assert [n for n, _ in _lib.ModelConfig._fields_] == structs["mp_model_config"]
+    assert [n for n, _ in _lib.LossConfig._fields_] == structs["mp_loss_config"]
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", doc, flags=re.S)
+    n_argtypes = n_calls = n_structs = 0
+    for code in blocks:
+        tree = ast.parse(code)
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Attribute) and node.targets[0].attr == "argtypes":
+                fn = node.targets[0].value.attr
+                assert len(node.value.elts) == protos[fn], f"INTEGRATION.md: {fn}.argtypes has {len(node.value.elts)} entries, header {protos[fn]}"
+                n_argtypes += 1
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and isinstance(node.func.value, ast.Name) \
+                    and node.func.value.id == "lib" and node.func.attr.startswith("mp_"):
+                assert len(node.args) == protos[node.func.attr], f"INTEGRATION.md: call of {node.func.attr} with {len(node.args)} arguments, header {protos[node.func.attr]}"
+                n_calls += 1
+            if isinstance(node, ast.ClassDef) and node.name in ("ModelConfig", "LossConfig"):
+                fl = [e.elts[0].value for e in node.body[0].value.elts]
+                assert fl == structs["mp_model_config" if node.name == "ModelConfig" else "mp_loss_config"]
+                n_structs += 1
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id == "ModelConfig":
+                assert {k.arg for k in node.keywords} == set(structs["mp_model_config"])
+    assert n_argtypes >= 15 and n_calls >= 6 and n_structs == 2
+
+
+def test_entry_point_override_grammar_and_readme_commands():
+    """The reference's documented command lines (README.md:54-72,100-111) parse; config groups merge; Hydra-style scalars; typos fail."""
+    sys.path.insert(0, os.path.join(ROOT, "hpe"))
+    from _entry import load_config, parse_value
+    c = load_config(["run.checkpoint_model=hpe/checkpoints/manipose_h36m.pth", "run.train=False", "run.test=True", "data.data_dir=/PATH/TO/H36M/DATA/"])
+    assert c.run.train is False and c.run.test is True and c.data.data_dir == "/PATH/TO/H36M/DATA/" and c.data.seq_len == 243
+    assert c.model.precision == "bf16x3"                               # the entry points default to the precision inside the parity bound
+    c = load_config(["run.checkpoint_model=hpe/checkpoints/manipose_3dhp.pth", "+data=mpi_inf_3dhp", "train.batch_size=30", "train.batch_size_test=30",
+                     "run.train=False", "run.test=True", "data.data_dir=/PATH/TO/MPI/DATA/"], {"data.dataset": "3dhp"})
+    assert c.data.dataset == "3dhp" and c.data.seq_len == 27 and c.data.keypoints == "gt" and c.data.pad == 0 and c.data.out_all is True
+    assert c.data.downsample == 1 and c.train.batch_size == 30 and c.data.data_dir == "/PATH/TO/MPI/DATA/"
+    c = load_config(["model=small", "train=debug", "train.lr=4e-5", "train.lr_min=1e-6", "train.vel_loss=2.", "data.seq_len=81", "+data.stride=3"])
+    assert c.model.channels == 64 and c.model.channels_seg == 64 and c.train.epochs == 1 and c.train.mpjpe_epoch_interval == 1
+    assert isinstance(c.train.lr, float) and c.train.lr == 4e-5 and c.train.lr_min == 1e-6 and c.train.vel_loss == 2.0 and c.data.stride == 3
+    c = load_config(["train=mix_ste"])
+    assert c.train.epochs == 500 and c.train.batch_size == 25 and c.train.workers == 10 and c.train.lr == 0.00004
+    assert parse_value("4e-5") == 4e-5 and parse_value("0.") == 0.0 and parse_value("True") is True and parse_value("null") is None
+    assert parse_value("cpn_ft_h36m_dbb") == "cpn_ft_h36m_dbb" and parse_value("[1, 2]") == [1, 2] and parse_value("'27'") == "27"
+    for bad in (["run.tran=False"], ["run.mlfow_on=True"], ["runs.train=False"], ["+data=no_such_dataset"], ["model=huge"], ["train"], ["+optim=adam"]):
+        with pytest.raises(SystemExit):
+            load_config(bad)
+
+
+def test_fused_adam_state_dict_is_interchangeable_with_torch_adam():
+    """params{tag}.pth (main_h36m_lifting.py:75-98): FusedAdam emits and accepts torch.optim.Adam's state_dict layout (per-parameter
+    exp_avg / exp_avg_sq in model.parameters() order); the flat layout written by earlier versions still loads."""
+    from manipose_amd.optim import FusedAdam
+    fx = load_fixture("rmcl_tiny")
+    m = _tiny_model(fx)
+    ref = torch.optim.Adam(m.parameters(), lr=4e-5, weight_decay=1e-6)
+    g = torch.Generator().manual_seed(0)
+    for p in m.parameters():
+        p.grad = torch.randn(p.shape, generator=g)
+    ref.step(); ref.step()
+    sd = ref.state_dict()
+    opt = FusedAdam(m, lr=1.0)
+    opt.load_state_dict(sd)
+    assert opt.step_count == 2 and opt.param_groups[0]["lr"] == 4e-5
+    lay = {n: (o, k) for n, o, k in m.flat_layout()}
+    for i, (n, p) in enumerate(m.named_parameters()):
+        o, k = lay[n]
+        assert torch.equal(opt.exp_avg[o:o + k], sd["state"][i]["exp_avg"].reshape(-1)), n
+        assert torch.equal(opt.exp_avg_sq[o:o + k], sd["state"][i]["exp_avg_sq"].reshape(-1)), n
+    out = opt.state_dict()
+    ref2 = torch.optim.Adam(m.parameters(), lr=1.0)
+    ref2.load_state_dict(out)                                          # torch accepts what FusedAdam wrote
+    assert ref2.state_dict()["param_groups"][0]["lr"] == 4e-5 and len(ref2.state_dict()["state"]) == len(list(m.parameters()))
+    for i in range(len(sd["state"])):
+        assert torch.equal(ref2.state_dict()["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"])
+    legacy = {"step": 7, "exp_avg": opt.exp_avg.clone(), "exp_avg_sq": opt.exp_avg_sq.clone(), "lr": 1e-3}
+    opt.load_state_dict(legacy)
+    assert opt.step_count == 7 and opt.param_groups[0]["lr"] == 1e-3
