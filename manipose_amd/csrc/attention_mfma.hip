@@ -670,6 +670,7 @@ __device__ __forceinline__ void store4_x2(bf16* ph, bf16* pl, const f32x4& v, fl
   *reinterpret_cast<uint2*>(ph) = h;
   *reinterpret_cast<uint2*>(pl) = l;
 }
+__device__ __forceinline__ int img_off(int img, int img_bytes) { return img * img_bytes; }
 #define MP_MFMA3(acc, a_hi, a_lo, b_hi, b_lo)                                   \
   do {                                                                          \
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, acc, 0, 0, 0);    \
@@ -677,169 +678,254 @@ __device__ __forceinline__ void store4_x2(bf16* ph, bf16* pl, const f32x4& v, fl
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, acc, 0, 0, 0);    \
   } while (0)
 
-// temporal: one wave per 16-query strip (up to 16 waves), K/V hi and lo images staged once (4 x rows x ROWB bytes)
+// temporal.  PERSISTENT: a workgroup (<= 8 waves, two 16-query strips per wave) walks the (window, joint, head) units u, u + G, ...;
+// the four LDS images (K_hi, K_lo, V_hi, V_lo: 128 KiB at T = 243, one workgroup per CU) of unit u + G and its Q fragments are
+// PREFETCHED INTO REGISTERS while unit u is computed (the loads are issued right after the images of u were written to LDS), so the
+// HBM / L2 latency of the staging - as long as the compute of a unit when it is not overlapped - is hidden behind the MFMAs of the
+// previous unit.  (The bf16 kernel above overlaps staging and compute by running two 64 KiB workgroups per CU instead.)
 template <int D>
-__global__ __launch_bounds__(1024) void attn_tmfma_fwd_x3_kernel(const bf16* __restrict__ qkv_hi, const bf16* __restrict__ qkv_lo,
-                                                                  bf16* __restrict__ out_hi, bf16* __restrict__ out_lo,
-                                                                  float* __restrict__ lse, int T, int J, int C, int H, float scale) {
+__global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __restrict__ qkv_hi, const bf16* __restrict__ qkv_lo,
+                                                                 bf16* __restrict__ out_hi, bf16* __restrict__ out_lo,
+                                                                 float* __restrict__ lse, int nunits, int T, int J, int C, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
-  constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB;
-  const int rows = (T + 31) & ~31, nw = (int)(blockDim.x >> 6);
-  char* Khs = sm;
-  char* Kls = Khs + rows * ROWB;
-  char* Vhs = Kls + rows * ROWB;
-  char* Vls = Vhs + rows * ROWB;
-  const int unit = blockIdx.x, h = unit % H, bj = unit / H, j = bj % J, b = bj / J;
+  constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB, CH = ACfg<D>::CH, PER = 4;
+  const int rows = (T + 31) & ~31, nw = (int)(blockDim.x >> 6), nthreads = (int)blockDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const long rs3 = (long)J * 3 * C;
-  const long qoff = ((long)b * T * J + j) * 3 * C + h * D;
-  const bf16* qh = qkv_hi + qoff;
-  const bf16* ql = qkv_lo + qoff;
-  stage_rows<D>(Khs, qh + C, rs3, T, rows, tid, nw * 64);
-  stage_rows<D>(Kls, ql + C, rs3, T, rows, tid, nw * 64);
-  stage_rows<D>(Vhs, qh + 2 * C, rs3, T, rows, tid, nw * 64);
-  stage_rows<D>(Vls, ql + 2 * C, rs3, T, rows, tid, nw * 64);
-  __syncthreads();
   const int ntile = (T + 15) >> 4;
+  const int img_bytes = rows * ROWB, nchunk = rows * CH;      // per image; nchunk <= PER * nthreads (launcher)
   ImgRd<D> Khr, Vhr;
-  Khr.init(Khs, lane);
-  Vhr.init(Vhs, lane);
-  const int dlo = __builtin_amdgcn_readfirstlane(rows * ROWB);      // hi image -> lo image of K and of V
-  (void)Kls; (void)Vls;
+  Khr.init(sm, lane);
+  Vhr.init(sm + 2 * img_bytes, lane);
+  const int dlo = __builtin_amdgcn_readfirstlane(img_bytes);  // hi image -> lo image of K and of V
   const float scale2 = scale * 1.4426950408889634f;
-  for (int qt = wave; qt < ntile; qt += nw) {
-    const int tq = qt * 16 + l15;
-    bf16x8_t bqh[KS], bql[KS];
+
+  uint4 pre[4][PER];                                          // next unit's images: K_hi, K_lo, V_hi, V_lo
+  bf16x8_t qn_h[2][KS], qn_l[2][KS];                          // Q fragments of this wave's two strips: the current unit's until its last
+                                                              // score strip is done, then (re-requested) the next unit's
+  auto unit_base = [&](int unit) -> long {
+    const int h = unit % H, bj = unit / H, j = bj % J, b = bj / J;
+    return ((long)b * T * J + j) * 3 * C + h * D;
+  };
+  auto fetch_q = [&](int unit) {
+    const long qoff = unit_base(unit);
+    const bf16* qh = qkv_hi + qoff;
+    const bf16* ql = qkv_lo + qoff;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int d0 = 32 * ks + 8 * g;
-      bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-      const bool ok = tq < T && d0 < D;
-      bqh[ks] = ok ? *reinterpret_cast<const bf16x8_t*>(qh + (long)tq * rs3 + d0) : z;
-      bql[ks] = ok ? *reinterpret_cast<const bf16x8_t*>(ql + (long)tq * rs3 + d0) : z;
-    }
-    f32x4 s[NTILE];
-    float mx = -INFINITY;
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const int tq = (wave + sidx * nw) * 16 + l15;
 #pragma unroll
-    for (int kt = 0; kt < NTILE; ++kt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      if (kt < ntile) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8_t kh = Khr.rows(ks, kt * 16), kl = Khr.rows(ks, kt * 16, dlo);
-          MP_MFMA3(acc, kh, kl, bqh[ks], bql[ks]);
-        }
-        acc *= scale2;
-        if (kt == ntile - 1) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (kt * 16 + 4 * g + r >= T) acc[r] = -INFINITY;
-        }
-        mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
-      } else {
-        acc = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      }
-      s[kt] = acc;
-    }
-    mx = group_max(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NTILE; ++kt) {
-      if (kt < ntile) {
-        const f32x4 t = s[kt] - mx;
-        f32x4 e;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
-        s[kt] = e;
-        sum += (e[0] + e[1]) + (e[2] + e[3]);
-      } else {
-        s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = 32 * ks + 8 * g;
+        bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool ok = tq < T && d0 < D;
+        qn_h[sidx][ks] = ok ? *reinterpret_cast<const bf16x8_t*>(qh + (long)tq * rs3 + d0) : z;
+        qn_l[sidx][ks] = ok ? *reinterpret_cast<const bf16x8_t*>(ql + (long)tq * rs3 + d0) : z;
       }
     }
-    sum = group_sum(sum);
-    f32x4 o[DB];
+  };
+  auto fetch = [&](int unit) {
+    const long qoff = unit_base(unit);
+    const bf16* qh = qkv_hi + qoff;
+    const bf16* ql = qkv_lo + qoff;
 #pragma unroll
-    for (int db = 0; db < DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int img = 0; img < 4; ++img) {
+      const bf16* src = ((img & 1) ? ql : qh) + ((img >> 1) ? 2 * C : C);
 #pragma unroll
-    for (int kp = 0; kp < NTILE / 2; ++kp) {
-      if (2 * kp < ntile) {
-        bf16x8_t bph, bpl;
-        pack_acc_x2(s[2 * kp], s[2 * kp + 1], bph, bpl);
-#pragma unroll
-        for (int db = 0; db < DB; ++db) {
-          const bf16x8_t vh = Vhr.cols(db, kp * 32), vl = Vhr.cols(db, kp * 32, dlo);
-          MP_MFMA3(o[db], vh, vl, bph, bpl);
-        }
+      for (int i = 0; i < PER; ++i) {
+        const int idx = tid + i * nthreads, t = idx / CH, c = idx - t * CH;
+        uint4 x = make_uint4(0u, 0u, 0u, 0u);
+        if (idx < nchunk && t < T) x = *reinterpret_cast<const uint4*>(src + (long)t * rs3 + c * 8);
+        pre[img][i] = x;
       }
     }
-    if (tq < T) {
-      const float inv = 1.0f / sum;
-      const long oo = ((long)(b * T + tq) * J + j) * C + h * D;
+  };
+  auto commit = [&]() {
 #pragma unroll
-      for (int db = 0; db < DB; ++db) store4_x2(out_hi + oo + 16 * db + 4 * g, out_lo + oo + 16 * db + 4 * g, o[db], inv);
-      if (g == 0) lse[(long)unit * T + tq] = (mx + __log2f(sum)) * 0.6931471805599453f;
+    for (int img = 0; img < 4; ++img)
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int idx = tid + i * nthreads, t = idx / CH, c = idx - t * CH;
+        if (idx < nchunk) *reinterpret_cast<uint4*>(sm + img_off(img, img_bytes) + t * ROWB + ((c ^ ACfg<D>::swz(t)) << 4)) = pre[img][i];
+      }
+  };
+
+  int unit = blockIdx.x;
+  if (unit >= nunits) return;
+  fetch_q(unit);
+  fetch(unit);
+  while (true) {
+    __syncthreads();                       // every wave is done with the previous unit's images
+    commit();
+    __syncthreads();
+    const int next = unit + gridDim.x;
+    if (next < nunits) fetch(next);        // in flight during the compute below
+    bool q_fetched = false;                // the next unit's Q fragments are requested once this wave's last score strip is done
+    const int h = unit % H, bj = unit / H, j = bj % J, b = bj / J;
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const int qt = wave + sidx * nw;
+      if (qt >= ntile) break;
+      const int tq = qt * 16 + l15;
+      f32x4 s[NTILE];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NTILE; ++kt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (kt < ntile) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t kh = Khr.rows(ks, kt * 16), kl = Khr.rows(ks, kt * 16, dlo);
+            MP_MFMA3(acc, kh, kl, qn_h[sidx][ks], qn_l[sidx][ks]);
+          }
+          acc *= scale2;
+          if (kt == ntile - 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kt * 16 + 4 * g + r >= T) acc[r] = -INFINITY;
+          }
+          mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+        } else {
+          acc = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+        s[kt] = acc;
+      }
+      if (sidx == 1 && next < nunits) { fetch_q(next); q_fetched = true; }
+      mx = group_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NTILE; ++kt) {
+        if (kt < ntile) {
+          const f32x4 t = s[kt] - mx;
+          f32x4 e;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+          s[kt] = e;
+          sum += (e[0] + e[1]) + (e[2] + e[3]);
+        } else {
+          s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      sum = group_sum(sum);
+      f32x4 o[DB];
+#pragma unroll
+      for (int db = 0; db < DB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kp = 0; kp < NTILE / 2; ++kp) {
+        if (2 * kp < ntile) {
+          bf16x8_t bph, bpl;
+          pack_acc_x2(s[2 * kp], s[2 * kp + 1], bph, bpl);
+#pragma unroll
+          for (int db = 0; db < DB; ++db) {
+            const bf16x8_t vh = Vhr.cols(db, kp * 32), vl = Vhr.cols(db, kp * 32, dlo);
+            MP_MFMA3(o[db], vh, vl, bph, bpl);
+          }
+        }
+      }
+      if (tq < T) {
+        const float inv = 1.0f / sum;
+        const long oo = ((long)(b * T + tq) * J + j) * C + h * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) store4_x2(out_hi + oo + 16 * db + 4 * g, out_lo + oo + 16 * db + 4 * g, o[db], inv);
+        if (g == 0) lse[(long)unit * T + tq] = (mx + __log2f(sum)) * 0.6931471805599453f;
+      }
     }
+    if (next >= nunits) break;
+    if (!q_fetched) fetch_q(next);
+    unit = next;
   }
 }
 
-// spatial: workgroup per frame, wave per head; the frame's hi and lo qkv blocks are both staged
+// spatial: workgroup per frame, wave per head; the frame's hi and lo qkv blocks (2 x N x 6C bytes, contiguous in HBM) are both staged.
+// Persistent with register prefetch of the next frame's blocks like the temporal kernel (105 KiB of LDS at C = 512: one workgroup per CU).
 template <int D>
 __global__ __launch_bounds__(512) void attn_smfma_fwd_x3_kernel(const bf16* __restrict__ qkv_hi, const bf16* __restrict__ qkv_lo,
-                                                                 bf16* __restrict__ out_hi, bf16* __restrict__ out_lo, int N, int C, int H,
-                                                                 float scale) {
+                                                                 bf16* __restrict__ out_hi, bf16* __restrict__ out_lo, int nframes, int N, int C,
+                                                                 int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
-  constexpr int KS = ACfg<D>::KS, DB = ACfg<D>::DB;
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int KS = ACfg<D>::KS, DB = ACfg<D>::DB, PER = 7;            // 2 x PER 16-byte chunks per thread: N * 6C / 16 <= PER * threads (launcher)
+  const int tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6), nthreads = (int)blockDim.x;
   const int g = lane >> 4, l15 = lane & 15;
-  const int pitch = 6 * C + 16;
+  const int pitch = 6 * C + 16, cpr = (6 * C) >> 4, nchunk = N * cpr;
   char* sh = sm;
   char* sl = sm + N * pitch;
-  stage_block(sh, pitch, qkv_hi + (long)f * N * 3 * C, N, 6 * C, tid, blockDim.x);
-  stage_block(sl, pitch, qkv_lo + (long)f * N * 3 * C, N, 6 * C, tid, blockDim.x);
-  __syncthreads();
-  const int oq = h * D * 2, ok = 2 * C + oq, ov = 4 * C + oq;
-  bf16x8_t kfh[2][KS], kfl[2][KS];
+  uint4 pre[2][PER];
+  auto fetch = [&](int f) {
+    const char* bh = reinterpret_cast<const char*>(qkv_hi + (long)f * N * 3 * C);
+    const char* bl = reinterpret_cast<const char*>(qkv_lo + (long)f * N * 3 * C);
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      kfh[t][ks] = frag_tok<D>(sh, pitch, ok, 16 * t, ks, lane, N);
-      kfl[t][ks] = frag_tok<D>(sl, pitch, ok, 16 * t, ks, lane, N);
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + i * nthreads;
+      uint4 a = make_uint4(0u, 0u, 0u, 0u), c = a;
+      if (idx < nchunk) { a = *reinterpret_cast<const uint4*>(bh + (long)idx * 16); c = *reinterpret_cast<const uint4*>(bl + (long)idx * 16); }
+      pre[0][i] = a; pre[1][i] = c;
     }
-  bf16x8_t vTh[DB], vTl[DB];
+  };
+  auto commit = [&]() {
 #pragma unroll
-  for (int db = 0; db < DB; ++db) {
-    vTh[db] = frag_tokT<D>(sh, pitch, ov, db, lane, N);
-    vTl[db] = frag_tokT<D>(sl, pitch, ov, db, lane, N);
-  }
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    if (qt * 16 >= N) break;
-    bf16x8_t qfh[KS], qfl[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      qfh[ks] = frag_tok<D>(sh, pitch, oq, 16 * qt, ks, lane, N);
-      qfl[ks] = frag_tok<D>(sl, pitch, oq, 16 * qt, ks, lane, N);
-    }
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      MP_MFMA3(s0, kfh[0][ks], kfl[0][ks], qfh[ks], qfl[ks]);
-      MP_MFMA3(s1, kfh[1][ks], kfl[1][ks], qfh[ks], qfl[ks]);
-    }
-    col_softmax(s0, s1, g, N, scale);
-    bf16x8_t bph, bpl;
-    pack_acc_x2(s0, s1, bph, bpl);
-    const int tq = qt * 16 + l15;
-#pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
-      MP_MFMA3(o, vTh[db], vTl[db], bph, bpl);
-      if (tq < N) {
-        const long oo = ((long)f * N + tq) * C + h * D + 16 * db + 4 * g;
-        store4_x2(out_hi + oo, out_lo + oo, o, 1.0f);
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + i * nthreads, r = idx / cpr, k = idx - r * cpr;
+      if (idx < nchunk) {
+        *reinterpret_cast<uint4*>(sh + r * pitch + k * 16) = pre[0][i];
+        *reinterpret_cast<uint4*>(sl + r * pitch + k * 16) = pre[1][i];
       }
     }
+  };
+  const int oq = h * D * 2, ok = 2 * C + oq, ov = 4 * C + oq;
+  int f = blockIdx.x;
+  if (f >= nframes) return;
+  fetch(f);
+  while (true) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    const int next = f + gridDim.x;
+    if (next < nframes) fetch(next);
+    bf16x8_t kfh[2][KS], kfl[2][KS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        kfh[t][ks] = frag_tok<D>(sh, pitch, ok, 16 * t, ks, lane, N);
+        kfl[t][ks] = frag_tok<D>(sl, pitch, ok, 16 * t, ks, lane, N);
+      }
+    bf16x8_t vTh[DB], vTl[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      vTh[db] = frag_tokT<D>(sh, pitch, ov, db, lane, N);
+      vTl[db] = frag_tokT<D>(sl, pitch, ov, db, lane, N);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      if (qt * 16 >= N) break;
+      bf16x8_t qfh[KS], qfl[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        qfh[ks] = frag_tok<D>(sh, pitch, oq, 16 * qt, ks, lane, N);
+        qfl[ks] = frag_tok<D>(sl, pitch, oq, 16 * qt, ks, lane, N);
+      }
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        MP_MFMA3(s0, kfh[0][ks], kfl[0][ks], qfh[ks], qfl[ks]);
+        MP_MFMA3(s1, kfh[1][ks], kfl[1][ks], qfh[ks], qfl[ks]);
+      }
+      col_softmax(s0, s1, g, N, scale);
+      bf16x8_t bph, bpl;
+      pack_acc_x2(s0, s1, bph, bpl);
+      const int tq = qt * 16 + l15;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        MP_MFMA3(o, vTh[db], vTl[db], bph, bpl);
+        if (tq < N) {
+          const long oo = ((long)f * N + tq) * C + h * D + 16 * db + 4 * g;
+          store4_x2(out_hi + oo, out_lo + oo, o, 1.0f);
+        }
+      }
+    }
+    if (next >= nframes) break;
+    f = next;
   }
 }
 
@@ -865,6 +951,15 @@ int split_planes(const float* in, bf16* hi, bf16* lo, long n, hipStream_t st) {
   return MP_OK;
 }
 
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, c = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    n = c;
+  }
+  return n;
+}
 bool attn_tmfma_supported(int T, int D);
 bool attn_x3_needs_scratch(int temporal, int T, int J, int C, int H) {
   const int D = C / H;
@@ -887,20 +982,24 @@ int attn_spatial_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf
   const float scale = 1.0f / sqrtf((float)D);
   const size_t lds = 2 * (size_t)J * (6 * C + 16);
   MP_CHECK(lds <= 160 * 1024, MP_ERR_ARG, "attn_spatial_fwd_x3: frame block of %zu bytes exceeds the LDS", lds);
+  MP_CHECK((long)J * (6 * C / 16) <= 7L * H * 64, MP_ERR_ARG, "attn_spatial_fwd_x3: frame block too large for the register prefetch (J=%d C=%d H=%d)", J, C, H);
+  const int nframes = B * T;
+  const int per_cu = (int)max((size_t)1, min((size_t)4, (size_t)(160 * 1024) / lds));
+  const int grid = min(nframes, num_cus() * per_cu);
   if (D == 64) {
     static bool attr_set = false;
     if (!attr_set) {
       MP_HIP(hipFuncSetAttribute((const void*)attn_smfma_fwd_x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
-    hipLaunchKernelGGL(attn_smfma_fwd_x3_kernel<64>, dim3(B * T), dim3(H * 64), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, J, C, H, scale);
+    hipLaunchKernelGGL(attn_smfma_fwd_x3_kernel<64>, dim3(grid), dim3(H * 64), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, nframes, J, C, H, scale);
   } else {
     static bool attr_set = false;
     if (!attr_set) {
       MP_HIP(hipFuncSetAttribute((const void*)attn_smfma_fwd_x3_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
-    hipLaunchKernelGGL(attn_smfma_fwd_x3_kernel<16>, dim3(B * T), dim3(H * 64), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, J, C, H, scale);
+    hipLaunchKernelGGL(attn_smfma_fwd_x3_kernel<16>, dim3(grid), dim3(H * 64), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, nframes, J, C, H, scale);
   }
   MP_LAUNCH_CHECK();
   return MP_OK;
@@ -910,15 +1009,18 @@ template <int D>
 static int launch_tmfma_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* lse, int units, int T, int J, int C,
                                int H, float scale, hipStream_t st) {
   const int ntile = (T + 15) >> 4;
-  const int waves = min(16, ntile);
   const int rows = (T + 31) & ~31;
+  // waves: two query strips each, and enough threads that an image is at most 4 chunks per thread (register prefetch)
+  const int waves = min(8, max((ntile + 1) / 2, cdiv((long)rows * ACfg<D>::CH, 256)));
   const size_t lds = 4 * (size_t)rows * ACfg<D>::ROWB;
   static bool attr_set = false;
   if (!attr_set) {
     MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * ACfg<D>::ROWB)));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_tmfma_fwd_x3_kernel<D>), dim3(units), dim3(64 * waves), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, T, J, C, H, scale);
+  const int per_cu = (int)max((size_t)1, min((size_t)4, (size_t)(160 * 1024) / lds));
+  const int grid = min(units, num_cus() * per_cu);
+  hipLaunchKernelGGL((attn_tmfma_fwd_x3_kernel<D>), dim3(grid), dim3(64 * waves), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

@@ -330,8 +330,8 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
 
 // BT x BT output tile (BT = 128: 4 waves, 256: 8 waves); waves laid out 2 x (BT/64); each wave (BT/2) x 64.
 // SPLIT = 1 (split precision, common.h): A and B are the hi planes of planar operands; every 64-wide k-tile is multiplied three
-// times - (A_lo, B_hi), (A_hi, B_lo), (A_hi, B_hi) - into the same fp32 accumulators, i.e. the k loop runs over 3 x the k-tiles
-// and only the DMA source plane changes from step to step.
+// times - (A_lo, B_hi), (A_hi, B_hi), (A_hi, B_lo) - into the same fp32 accumulators: three main-loop steps per k-tile over four
+// fetched operand tiles (see the loop).
 template <int TRA, int TRB, typename TC, int EPI, int BT, int SPLIT = 0>
 __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -373,24 +373,34 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   if (!b_first) glds_tile<TRB, BT, NW>(smem + OPB, B, g.ldb, n0, kbeg, g.N, kend, lane, wave);
   int stage = 0;
   if constexpr (SPLIT) {
-    // step s = 3 kt + term; term 0: (A_lo, B_hi) - the step whose operands the prologue above must have fetched, see below
+    // Three steps per k-tile kt, each one mma_stage over 64 reduction indices, with FOUR operand tiles fetched (not six): the buffers are
+    // A0 | B0 | A1 | B1 (the two stages of the plain kernel) and
+    //   step 0 multiplies (A0 = A_lo[kt], B0 = B_hi[kt])   while A1 <- A_hi[kt] is fetched
+    //   step 1 multiplies (A1 = A_hi[kt], B0 = B_hi[kt])   while B1 <- B_lo[kt]
+    //   step 2 multiplies (A1 = A_hi[kt], B1 = B_lo[kt])   while A0 <- A_lo[kt+1], B0 <- B_hi[kt+1]
+    // every buffer is rewritten at least one barrier after its last reader.  The prologue above fetched (A_lo[0], B_hi[0]).
     const bf16* const A_lo = reinterpret_cast<const bf16*>(g.A_lo);
     const bf16* const B_lo = reinterpret_cast<const bf16*>(g.B_lo);
-    const int nst = 3 * ((kend - kbeg + GBK - 1) / GBK);
-    for (int s = 0, term = 0, k0 = kbeg; s < nst; ++s, stage ^= 1) {
+    char* const A0 = smem;
+    char* const B0 = smem + OPB;
+    char* const A1 = smem + STAGE;
+    char* const B1 = smem + STAGE + OPB;
+    for (int k0 = kbeg, term = 0; k0 < kend;) {       // one loop body for the three steps (a single copy of the MFMA stage)
       __syncthreads();
-      const char* As = smem + stage * STAGE;
-      const char* Bs = As + OPB;
-      int nterm = term + 1, nk0 = k0;
-      if (nterm == 3) { nterm = 0; nk0 += GBK; }
-      if (s + 1 < nst) {
-        char* nx = smem + (stage ^ 1) * STAGE;
-        glds_tile<TRA, BT, NW>(nx, nterm == 0 ? A_lo : A, g.lda, m0, nk0, g.M, kend, lane, wave);
-        glds_tile<TRB, BT, NW>(nx + OPB, nterm == 1 ? B_lo : B, g.ldb, n0, nk0, g.N, kend, lane, wave);
+      const char* As = term == 0 ? A0 : A1;
+      const char* Bs = term == 2 ? B1 : B0;
+      if (term == 0) {
+        glds_tile<TRA, BT, NW>(A1, A, g.lda, m0, k0, g.M, kend, lane, wave);
+      } else if (term == 1) {
+        glds_tile<TRB, BT, NW>(B1, B_lo, g.ldb, n0, k0, g.N, kend, lane, wave);
+      } else if (k0 + GBK < kend) {
+        glds_tile<TRA, BT, NW>(A0, A_lo, g.lda, m0, k0 + GBK, g.M, kend, lane, wave);
+        glds_tile<TRB, BT, NW>(B0, B, g.ldb, n0, k0 + GBK, g.N, kend, lane, wave);
       }
       mma_stage<TRA, TRB, BT>(As, Bs, acc, wr, wc, lane);
-      term = nterm; k0 = nk0;
+      if (++term == 3) { term = 0; k0 += GBK; }
     }
+    (void)stage;
   } else {
   for (int k0 = kbeg; k0 < kend; k0 += GBK, stage ^= 1) {
     __syncthreads();   // (vmcnt(0) + barrier): tile k0 has landed for every wave; nobody still reads the other stage
@@ -592,32 +602,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   const int per_xcd = gridDim.x >> 3;                       // gridDim.x is a multiple of 8
   int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (id >= ntiles) return;
-  const int nk = (SPLIT ? 3 : 1) * (g.K / GBK);             // K % 64 == 0, nk >= 2 (launcher)
+  const int nk = g.K / GBK;                                 // K % 64 == 0, nk >= 2 (launcher)
   int m0 = (id / tiles_n) * BT, n0 = (id % tiles_n) * BT;
   unsigned aoff[4], boff[4];
   persist_offsets<0>(aoff, g.lda, m0, g.M, lane, wave);
   persist_offsets<TRB>(boff, g.ldb, 0, BT, lane, wave);     // N % 256 == 0: the same for every tile
   // byte address of (tile origin, reduction index k) of each operand
-  // (tile origin, step s) -> byte address; SPLIT: step s = 3 kt + term multiplies k-tile kt of (A_lo, B), (A, B_lo), (A, B)
-  auto a_base = [&](int mm, int s) {
-    if constexpr (SPLIT) {
-      const int kt = s / 3, term = s - 3 * kt;
-      return (term == 0 ? reinterpret_cast<const char*>(g.A_lo) : A) + ((long)mm * g.lda + kt * GBK) * 2;
-    } else {
-      return A + ((long)mm * g.lda + s * GBK) * 2;
-    }
-  };
-  auto b_base = [&](int nn, int s) {
-    const char* Bp = B;
-    int k = s * GBK;
-    if constexpr (SPLIT) {
-      const int kt = s / 3, term = s - 3 * kt;
-      if (term == 1) Bp = reinterpret_cast<const char*>(g.B_lo);
-      k = kt * GBK;
-    }
-    return TRB ? Bp + ((long)k * g.ldb + nn) * 2 : Bp + ((long)nn * g.ldb + k) * 2;
-  };
-  persist_dma(smem, a_base(m0, 0), aoff, wave);
+  // byte address of (tile origin, k-tile kt) of each operand plane
+  auto a_base = [&](int mm, int kt) { return A + ((long)mm * g.lda + kt * GBK) * 2; };
+  auto b_base = [&](int nn, int kt) { return TRB ? B + ((long)kt * GBK * g.ldb + nn) * 2 : B + ((long)nn * g.ldb + kt * GBK) * 2; };
+  // SPLIT: A / B above are the hi planes; the lo planes lie at these byte distances
+  const long a_lo = SPLIT ? reinterpret_cast<const char*>(g.A_lo) - A : 0, b_lo = SPLIT ? reinterpret_cast<const char*>(g.B_lo) - B : 0;
+  persist_dma(smem, a_base(m0, 0) + a_lo, aoff, wave);       // SPLIT: the first step multiplies (A_lo, B_hi)
   persist_dma(smem + OPB, b_base(n0, 0), boff, wave);
   int stage = 0;
   bool landed = false;                                      // this tile's first k-tile was already waited for (before the previous epilogue)
@@ -636,6 +632,42 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (SPLIT) {
+      // three steps per k-tile over four fetched operand tiles; buffers A0 | B0 | A1 | B1 = the two stages (see gemm_bf16_glds_kernel)
+      char* const A0 = smem;
+      char* const B0 = smem + OPB;
+      char* const A1 = smem + STAGE;
+      char* const B1 = smem + STAGE + OPB;
+      // one loop body for the three steps (a single copy of the MFMA stage: three inlined copies spill at the 256-VGPR limit); the
+      // buffers of a step are wave-uniform selects
+      for (int kt = 0, term = 0; kt < nk;) {
+        if (kt == 0 && term == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only: (A_lo, B_hi) of this tile were waited for before the previous epilogue
+        else __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_s_barrier();
+        const char* As = term == 0 ? A0 : A1;
+        const char* Bs = term == 2 ? B1 : B0;
+        if (term == 0) {
+          persist_dma(A1, a_base(m0, kt), aoff, wave);                    // A_hi[kt]
+        } else if (term == 1) {
+          persist_dma(B1, b_base(n0, kt) + b_lo, boff, wave);             // B_lo[kt]
+        } else {
+          const bool last = kt + 1 == nk;
+          if (!last || has_next) {
+            if (last) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+            persist_dma(A0, a_base(last ? m0n : m0, last ? 0 : kt + 1) + a_lo, aoff, wave);      // A_lo, B_hi of the next k-tile / tile
+            persist_dma(B0, b_base(last ? n0n : n0, last ? 0 : kt + 1), boff, wave);
+          }
+          if (last && has_bias) {
+            typedef __attribute__((address_space(3))) void* lptr;
+            typedef const __attribute__((address_space(1))) void* gptr;
+            __builtin_amdgcn_global_load_lds((gptr)(g.bias + n0 + wc * 64 + lane), (lptr)img, 4, 0, 0);
+          }
+        }
+        mma_stage<0, TRB, BT>(As, Bs, acc, wr, wc, lane);               // term 0: A_lo B_hi, 1: A_hi B_hi, 2: A_hi B_lo
+        if (++term == 3) { term = 0; ++kt; }
+      }
+      (void)stage;
+    } else {
     for (int ks = 0; ks < nk; ++ks, stage ^= 1) {
       // k-tile ks has landed for every wave and nobody still reads the other stage.  On a tile's first k-tile the DMA was
       // waited for before the previous epilogue: do not wait for that epilogue's stores here, they drain under this k-tile.
@@ -657,6 +689,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
         __builtin_amdgcn_global_load_lds((gptr)(g.bias + n0 + wc * 64 + lane), (lptr)img, 4, 0, 0);
       }
       if (!(g.debug & 1)) mma_stage<0, TRB, BT>(As, Bs, acc, wr, wc, lane);
+    }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): the next tile's first k-tile (issued one k-tile ago)
     landed = true;

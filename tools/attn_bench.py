@@ -20,3 +20,8 @@ for temporal in (1, 0):
     b = t(lambda: lib.mp_attention_bwd_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), temporal, B, T, J, C, H, st))
     byt_f, byt_b = M * C * 2 * 4, M * C * 2 * (3 + 2 + 3)
     print(f"{'temporal' if temporal else 'spatial '} B={B} dbg={os.environ.get('MANIPOSE_ATTN_DEBUG','0')}: fwd {f:7.1f} us ({byt_f / f / 1e6:5.2f} TB/s)  bwd {b:7.1f} us ({byt_b / b / 1e6:5.2f} TB/s)", flush=True)
+# split precision (bf16x3): planar hi/lo qkv and output
+ql = (torch.randn(M, 3 * C, device="cuda") * 2 ** -8).bfloat16(); ol = torch.empty_like(out)
+for temporal in (1, 0):
+    f = t(lambda: lib.mp_attention_fwd_bf16x3(qkv.data_ptr(), ql.data_ptr(), out.data_ptr(), ol.data_ptr(), lse.data_ptr(), None, temporal, B, T, J, C, H, st))
+    print(f"{'temporal' if temporal else 'spatial '} B={B} bf16x3 fwd {f:7.1f} us ({M * C * 2 * 8 / f / 1e6:5.2f} TB/s of planar bytes)", flush=True)
