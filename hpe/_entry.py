@@ -23,69 +23,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-class Cfg(dict):
-    __getattr__ = dict.__getitem__
-
-    @staticmethod
-    def wrap(d):
-        return Cfg({k: Cfg.wrap(v) if isinstance(v, dict) else v for k, v in d.items()})
-
-
-def parse_value(text):
-    """A command-line value the way Hydra's override grammar reads it: int, float (incl. `4e-5`, `1.`, which YAML 1.1 leaves as
-    strings), true/false, null, quoted string; anything else through YAML (lists, dicts) or as a bare string."""
-    t = text.strip()
-    for conv in (int, float):
-        try:
-            return conv(t)
-        except ValueError:
-            pass
-    low = t.lower()
-    if low in ("true", "false"):
-        return low == "true"
-    if low in ("null", "none", "~"):
-        return None
-    try:
-        return yaml.safe_load(t)
-    except yaml.YAMLError:
-        return t
+from manipose_amd.hydra_lite import Cfg, parse_value  # noqa: E402,F401
+from manipose_amd import hydra_lite  # noqa: E402
 
 
 def load_config(argv, extra_defaults=None):
-    """hpe/conf/config.yaml + overrides in the reference's Hydra grammar (main_h36m_lifting.py:711, README.md:54-111):
-      group=name | +group=name   merge hpe/conf/<group>/<name>.yaml into that group (new keys allowed, e.g. data.pad)
-      group.key=value            set an EXISTING key (a typo such as run.tran=False is an error, as with Hydra)
-      +group.key=value           add a new key
-    Errors are SystemExit with a message, never a traceback from the parser."""
-    conf = os.path.join(ROOT, "hpe", "conf")
-    with open(os.path.join(conf, "config.yaml")) as f:
-        cfg = yaml.safe_load(f)
-    for k, v in (extra_defaults or {}).items():
-        grp, key = k.split(".")
-        cfg[grp][key] = v
-    for arg in argv:
-        if "=" not in arg:
-            raise SystemExit(f"expected `group.key=value` or `group=name` overrides, got {arg!r}")
-        path, val = arg.split("=", 1)
-        add = path.startswith("+")
-        path = path.lstrip("+")
-        if "." not in path:                                   # config group selection
-            if path not in cfg:
-                raise SystemExit(f"unknown config group {path!r} (groups: {sorted(cfg)})")
-            fn = os.path.join(conf, path, val + ".yaml")
-            if not os.path.exists(fn):
-                have = sorted(x[:-5] for x in os.listdir(os.path.join(conf, path))) if os.path.isdir(os.path.join(conf, path)) else []
-                raise SystemExit(f"no config {path}/{val}.yaml (available for {path!r}: {have})")
-            with open(fn) as f:
-                cfg[path].update(yaml.safe_load(f) or {})
-            continue
-        grp, key = path.split(".", 1)
-        if grp not in cfg:
-            raise SystemExit(f"unknown config group {grp!r} (groups: {sorted(cfg)})")
-        if key not in cfg[grp] and not add:
-            raise SystemExit(f"unknown key {grp}.{key} (keys of {grp!r}: {sorted(cfg[grp])}); prefix with + to add a new key")
-        cfg[grp][key] = parse_value(val)
-    return Cfg.wrap(cfg)
+    """hpe/conf/config.yaml + overrides in the reference's Hydra grammar (main_h36m_lifting.py:711, README.md:54-111): see
+    manipose_amd/hydra_lite.py.  Both evaluation commands of the reference's README parse unchanged."""
+    return hydra_lite.load_config(os.path.join(ROOT, "hpe", "conf"), argv, extra_defaults)
 
 
 def instantiate_model(cfg):

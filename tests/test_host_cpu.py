@@ -351,3 +351,114 @@ def test_fused_adam_state_dict_is_interchangeable_with_torch_adam():
     legacy = {"step": 7, "exp_avg": opt.exp_avg.clone(), "exp_avg_sq": opt.exp_avg_sq.clone(), "lr": 1e-3}
     opt.load_state_dict(legacy)
     assert opt.step_count == 7 and opt.param_groups[0]["lr"] == 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# toy experiment (BASELINE config #1: 1-D -> 2-D circle-manifold MLPs on the CPU) against vectors produced by the reference's own
+# toy_experiment package (oracle/gen_golden_toy.py -> tests/golden/toy.npz)
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def toy():
+    sys.path.insert(0, os.path.join(ROOT, "toy_experiment"))
+    import circle_toy
+    return circle_toy, np.load(os.path.join(ROOT, "tests", "golden", "toy.npz"))
+
+
+def test_toy_scenarios_sample_bit_identically_to_the_reference(toy):
+    ct, fx = toy
+    for name in ("easy", "hard-1", "hard-2", "hard-4"):
+        ds = ct.LiftingDataset(ct.scenario(name, 1.0, 42), 1000, 1000, 1000)
+        assert np.array_equal(ds.X_train.numpy(), fx[f"data.{name}.X_train"]) and np.array_equal(ds.Y_train.numpy(), fx[f"data.{name}.Y_train"])
+        assert np.array_equal(ds.X_val[:32].numpy(), fx[f"data.{name}.X_val_head"]) and np.array_equal(ds.Y_test[:32].numpy(), fx[f"data.{name}.Y_test_head"])
+        sums = [t.double().sum().item() for t in (ds.X_train, ds.X_val, ds.X_test, ds.Y_train, ds.Y_val, ds.Y_test)]
+        np.testing.assert_allclose(sums, fx[f"data.{name}.sums"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(ct.scenario(name, 1.0, 0).pdf(np.linspace(-np.pi, np.pi, 41)), fx[f"data.{name}.pdf"], rtol=1e-12)
+        assert ds.X_train.shape == (1000, 1) and ds.Y_train.shape == (1000, 2)
+        np.testing.assert_allclose(ds.Y_train.norm(dim=1).numpy(), 1.0, atol=1e-6)            # every target lies on the circle
+    assert abs(float(ct.LiftingDataset(ct.HardBimodalDist(radius=1, random_state=42), 1000, 1000, 1000).X_train[0]) - 0.5287) < 1e-4
+    with pytest.raises(ValueError):
+        ct.scenario("torus", 1.0, 0)
+
+
+def test_toy_models_match_the_reference_forward_and_state_dict(toy):
+    ct, fx = toy
+    X = torch.from_numpy(fx["data.hard-2.X_train"])[:64]
+    for tag, act in (("tanh", torch.nn.Tanh), ("relu", torch.nn.ReLU), ("sqrelu", ct.SquaredReLU)):
+        torch.manual_seed(42)
+        m = ct.Mlp(in_features=1, hidden_features=32, out_features=2, n_layers=2, act_layer=act)
+        want = {k[len(f"mlp.{tag}.w::"):]: v for k, v in fx.items() if k.startswith(f"mlp.{tag}.w::")}
+        assert list(m.state_dict()) == list(want) or set(m.state_dict()) == set(want)
+        for k, v in m.state_dict().items():
+            assert np.array_equal(v.numpy(), want[k]), k                                            # same initialiser draws in the same order
+        np.testing.assert_allclose(m.train()(X).detach().numpy(), fx[f"mlp.{tag}.train_out"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(m.eval()(X).detach().numpy(), fx[f"mlp.{tag}.eval_out"], rtol=1e-6, atol=1e-7)
+    torch.manual_seed(42)
+    c = ct.ConstrainedMlp(in_features=1, hidden_features=32, out_features=1, n_layers=2, act_layer=torch.nn.Tanh, radius=1.0)
+    for k, v in c.state_dict().items():
+        assert np.array_equal(v.numpy(), fx["constrained.w::" + k]), k
+    out = c.train()(X).detach()
+    np.testing.assert_allclose(out.numpy(), fx["constrained.train_out"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(out.norm(dim=1).numpy(), 1.0, atol=1e-6)                             # the manifold constraint holds by construction
+    torch.manual_seed(42)
+    r = ct.ConstrainedMlpRmcl(in_features=1, hidden_features=32, out_features=1, n_layers=2, act_layer=torch.nn.Tanh, radius=1.0, n_hyp=5, beta=0.1)
+    for k, v in r.state_dict().items():
+        assert np.array_equal(v.numpy(), fx["rmcl.w::" + k]), k
+    hyp = r.train()(X).detach()
+    np.testing.assert_allclose(hyp.numpy(), fx["rmcl.train_hyp"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r.aggregate(hyp).numpy(), fx["rmcl.weighted_ave"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(hyp[..., 2].sum(dim=1).numpy(), 1.0, atol=1e-6)
+    # rMCL loss (the reference's 2-D helpers are shadowed at HEAD): closed form on a hand-made case
+    h = torch.tensor([[[1.0, 0.0, 0.8], [0.0, 1.0, 0.2]]])
+    y = torch.tensor([[0.0, 1.0]])
+    want = 0.0 + 0.1 * (-(np.log(1 - 0.8) + np.log(0.2)) / 2)                                       # winner = head 1 (exact), BCE vs one-hot (0, 1)
+    assert abs(r.wta_with_scoring_l2_loss(h, y).item() - want) < 1e-6
+    assert torch.equal(r.aggregate(h, "best_score"), torch.tensor([[1.0, 0.0]])) and abs(ct.oracle_multihyp_mpjpe(h, y)) < 1e-7
+    with pytest.raises(ValueError):
+        r.aggregate(h, "median")
+
+
+@pytest.mark.parametrize("tag,lr", [("constrained", 1e-2), ("mlp", 1e-3)])
+def test_toy_trainer_reproduces_the_reference_training_curves(toy, tmp_path, tag, lr):
+    """Three epochs of the reference's Trainer (Adam, ReduceLROnPlateau, MSE, shuffled batches from the torch RNG, best-validation
+    checkpoint reloaded at the end), then its evaluation metrics."""
+    import types
+    ct, fx = toy
+    ds = ct.LiftingDataset(ct.HardBimodalDist(radius=1.0, random_state=42), 1000, 1000, 1000)
+    torch.manual_seed(42)
+    model = (ct.ConstrainedMlp(in_features=1, hidden_features=32, out_features=1, n_layers=2, act_layer=torch.nn.Tanh, radius=1.0) if tag == "constrained"
+             else ct.Mlp(in_features=1, hidden_features=32, out_features=2, n_layers=2, act_layer=torch.nn.Tanh))
+    tr = ct.Trainer(model=model, optim_cls=torch.optim.Adam, sched_cls=torch.optim.lr_scheduler.ReduceLROnPlateau, checkpointing_dir=tmp_path, lr=lr,
+                    config_train=types.SimpleNamespace(lr_min=0.0, lr_patience=10, lr_threshold=1e-4))
+    tr.train(epochs=3, loader=ds.get_tr_loader(batch_size=100, num_workers=0), loss_func=torch.nn.functional.mse_loss, val_data=ds.validation_set, log=None)
+    np.testing.assert_allclose(tr.loss_list, fx[f"train.{tag}.loss_list"], rtol=1e-5)
+    np.testing.assert_allclose(tr.val_loss_list, fx[f"train.{tag}.val_loss_list"], rtol=1e-5)
+    (val_mpjpe, test_mpjpe), (_, pred), _ = tr.eval((ds.validation_set, ds.test_set), ct.calc_mpjpe)
+    (val_dtc, test_dtc), _, _ = tr.eval((ds.validation_set, ds.test_set), ct.distance_to_circle)
+    np.testing.assert_allclose([val_mpjpe, test_mpjpe, val_dtc, test_dtc], fx[f"train.{tag}.metrics"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(pred[:32].numpy(), fx[f"train.{tag}.test_pred_head"], rtol=1e-4, atol=1e-5)
+    assert (tmp_path / "model_best_val.pth").exists() and (tmp_path / "params_best_val.pth").exists()
+
+
+def test_toy_entry_point_runs_the_readme_recipes(tmp_path, monkeypatch):
+    """`cd toy_experiment; python main.py model.arch=constrained +train=constrained_easy` end to end, shortened."""
+    sys.path.insert(0, os.path.join(ROOT, "toy_experiment"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("toy_main", os.path.join(ROOT, "toy_experiment", "main.py"))
+    toy_main = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(toy_main)
+    monkeypatch.chdir(tmp_path)
+    v = toy_main.main(["model.arch=constrained", "+train=constrained_easy", "train.epochs=4", "train.workers=0", "run.experiment=t1"])
+    assert 0 < v < 0.2                                                       # the easy scenario is unimodal: the constrained MLP fits it
+    for f in ("model_best_val.pth", "train_loss.npy", "test_predictions.npy"):
+        assert (tmp_path / "outputs" / "t1" / f).exists()
+    pred = np.load(tmp_path / "outputs" / "t1" / "test_predictions.npy")
+    np.testing.assert_allclose(np.linalg.norm(pred, axis=1), 1.0, atol=1e-5)         # on the circle
+    v2 = toy_main.main(["model.arch=constrained_rmcl", "+train=rmcl_constrained_hard2", "data.scenario=hard-2", "train.epochs=3", "train.workers=0"])
+    assert np.isfinite(v2)
+    v3 = toy_main.main(["model.arch=mlp", "+train=mlp_hard2", "data.scenario=hard-2", "train.epochs=2", "train.workers=0", "model.act=sqrelu"])
+    assert np.isfinite(v3)
+    for bad in (["data.scenario=torus-2Dto3D"], ["+train=nope"], ["model.arc=mlp"]):
+        with pytest.raises(SystemExit):
+            toy_main.main(bad)
+    with pytest.raises(ValueError):
+        toy_main.main(["model.arch=transformer", "train.epochs=1"])

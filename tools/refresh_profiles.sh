@@ -5,14 +5,14 @@
 #   <tag>_pmc_hbm_traffic.csv         per-kernel FETCH_SIZE / WRITE_SIZE averages from two separate --pmc passes
 # The files are written under gpurun_out/ (merged back by gpurun); copy them into profiles/ afterwards.
 set -eu
-TAG="${1:-r01_final_bf16_B79}"
+TAG="${1:-r02_bf16x3_B79}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/profiles_new; rm -rf "$O"; mkdir -p "$O"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$O/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-extra > "$O/stats.log" 2>&1
 find "$O/stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$O/${TAG}_kernel_stats.csv"
 grep "^{" "$O/stats.log" > "$O/${TAG}_bench_under_rocprof.json"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_$c" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > "$O/pmc_$c.log" 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_$c" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra --no-prof > "$O/pmc_$c.log" 2>&1
   find "$O/pmc_$c" -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} "$O/pmc_$c.csv"
 done
 python - "$O" "$TAG" <<'PY'
