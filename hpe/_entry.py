@@ -247,6 +247,16 @@ def run(argv, extra_defaults=None):
     if cfg.run.checkpoint_model:
         ck = torch.load(cfg.run.checkpoint_model, map_location="cpu")
         model.load_state_dict(ck["model_pos"] if "model_pos" in ck else ck)
+    mup_mults = None
+    if cfg.model.mup:                          # create_model / set_mup_base_shapes (main_h36m_lifting.py:673-708) + re-initialisation (:762-764)
+        from manipose_amd.mup_lite import make_base_shapes, mu_init_params, mup_lr_multipliers, set_base_shapes
+        small, big = copy.deepcopy(cfg), copy.deepcopy(cfg)
+        small["model"]["channels"], small["model"]["channels_seg"], small["data"]["seq_len"] = 64, 64, 27
+        big["model"]["channels"], big["model"]["channels_seg"], big["data"]["seq_len"] = 128, 128, 81
+        set_base_shapes(model, make_base_shapes(instantiate_model(Cfg.wrap(small)), instantiate_model(Cfg.wrap(big))))
+        if not cfg.run.checkpoint_model:
+            mu_init_params(model)
+        mup_mults = mup_lr_multipliers(model)
     model.max_batch_hint = max(cfg.train.batch_size, 2 * cfg.train.batch_size_test)      # x2: flip-TTA batches the mirrored copy
     model = model.to(dev)
     if cfg.train.get("lat_sym_regularization", 0) > 0:
@@ -254,6 +264,8 @@ def run(argv, extra_defaults=None):
     trainer = LiftingTrainer(model, lr=cfg.train.lr, weight_decay=1e-6, w_loss=cfg.train.w_loss, vel_loss=cfg.train.vel_loss,
                              smooth_reg=cfg.train.smooth_reg, rmcl_score_reg=cfg.train.rmcl_score_reg, seed=cfg.run.seed,
                              sq_loss=cfg.train.sq_loss, rigid_seg_reg=cfg.train.get("rigid_seg_reg", 0.0))
+    if mup_mults is not None:                  # MuAdam (main_h36m_lifting.py:227-232): matrix-like parameters train with lr / width_mult
+        trainer.opt.set_multipliers(mup_mults)
     broadcast_parameters(model.flat_parameters())
     start_epoch, sched_state = 0, None
     if cfg.run.checkpoint_params:

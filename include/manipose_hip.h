@@ -89,6 +89,12 @@ int mp_mpjpe_sum(const float* pred, const float* target, int64_t n_joints, float
 int mp_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,
                  float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
+/* The same with per-element multipliers of the learning rate and of the weight decay (flat buffers in the parameter layout):
+ * mup.optim.MuAdam as the reference builds it under model.mup (hpe/main_h36m_lifting.py:227-232) - parameters with two width
+ * dimensions train with lr / width_mult and weight_decay * width_mult. */
+int mp_adam_step_scaled(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, float grad_scale, const float* lr_mult, const float* wd_mult, void* stream);
+
 /* Building blocks exposed for unit parity tests (same kernels the model engine launches). */
 int mp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* stats, int M, int C,
                      void* stream);
@@ -156,6 +162,13 @@ typedef struct mp_model_config {
   int precision;       /* 0 = fp32 matrix cores; 1 = bf16 matrix cores / fp32 accumulate; 2 = "bf16x3": split-precision forward (planar hi/lo
                         * bf16 operands, three matrix-core products each: within the 1e-4 m MPJPE bound), bf16 backward on the hi planes */
   int rot_rep_dim;     /* 6 (default when 0) or 4: rotation representation the heads emit (pose_decoder.py:22-31) */
+  /* mu-parametrisation (model.mup, conf/config.yaml:52) and explicit attention scales; per backbone (rotations / segments), 0 = default:
+   *   qk_scale      softmax scale of Attention (mix_ste.py:243-244): default head_dim^-0.5; muP 1 / head_dim
+   *   resid_scale   Block.residual_scale (mix_ste.py:330,353-358): x = x * resid_scale + branch; default 1; muP 1 / sqrt(depth)
+   *   readout_mult  multiplier on the input of the head's last Linear, mup.MuReadout (mix_ste.py:118-121, rmcl_manifold_mix_ste.py:278-285):
+   *                 y = W (readout_mult * x) + b with readout_mult = output_mult / width_mult; default 1 */
+  float qk_scale_rot, resid_scale_rot, readout_mult_rot;
+  float qk_scale_seg, resid_scale_seg, readout_mult_seg;
 } mp_model_config;
 
 int mp_model_create(const mp_model_config* cfg, mp_model** out);

@@ -30,7 +30,9 @@ class ModelConfig(C.Structure):
     _fields_ = [("arch", i32), ("num_frame", i32), ("num_joints", i32), ("num_bones", i32),
                 ("embed_dim_rot", i32), ("depth_rot", i32), ("num_heads_rot", i32),
                 ("embed_dim_seg", i32), ("depth_seg", i32), ("num_heads_seg", i32),
-                ("n_hyp", i32), ("drop_path_rate", f32), ("max_batch", i32), ("precision", i32), ("rot_rep_dim", i32)]
+                ("n_hyp", i32), ("drop_path_rate", f32), ("max_batch", i32), ("precision", i32), ("rot_rep_dim", i32),
+                ("qk_scale_rot", f32), ("resid_scale_rot", f32), ("readout_mult_rot", f32),
+                ("qk_scale_seg", f32), ("resid_scale_seg", f32), ("readout_mult_seg", f32)]
 
 
 _SIGNATURES = {
@@ -44,6 +46,7 @@ _SIGNATURES = {
     "mp_aggregate": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, vp]),
     "mp_mpjpe_sum": (i32, [vp, vp, i64, vp, vp, i64, vp]),
     "mp_adam_step": (i32, [vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, f32, vp]),
+    "mp_adam_step_scaled": (i32, [vp, vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, f32, vp, vp, vp]),
     "mp_layernorm_fwd": (i32, [vp, vp, vp, f32, vp, vp, i32, i32, vp]),
     "mp_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, i64, vp]),
     "mp_linear_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -70,11 +70,36 @@ class FusedLiftingMixin:
             with torch.cuda.device(device):
                 self._engine = None
                 eng = LiftEngine(arch=self._arch, max_batch=max(B, self.max_batch_hint), precision=self.precision,
-                                 **self._engine_cfg)
+                                 **self._engine_cfg, **self._scale_cfg())
             self._engine = eng
             self._flat = None
         if self._flat is None or not self._views_intact():
             self._flatten(eng, device)
+
+    def _scale_cfg(self) -> dict:
+        """Attention / residual scales and MuReadout input multipliers of the two backbones as the engine takes them (0 = default):
+        explicit qk_scale arguments and the muP mode of the reference (mix_ste.py:243,330; mup.MuReadout), read off the modules."""
+        from ..mup_lite import MuReadout
+        out = {}
+        rot = getattr(self, "rotations_module", self)
+        for tag, mod in (("rot", rot), ("seg", getattr(self, "segments_module", None))):
+            if mod is None:
+                continue
+            blk = mod.STEblocks[0]
+            d = mod.embed_dim // mod.num_heads
+            out[f"qk_scale_{tag}"] = 0.0 if abs(blk.attn.scale - d ** -0.5) < 1e-12 else float(blk.attn.scale)
+            out[f"resid_scale_{tag}"] = 0.0 if blk.residual_scale == 1.0 else float(blk.residual_scale)
+            heads = [h.prediction_head for h in mod.head] if isinstance(mod.head, torch.nn.ModuleList) else [mod.head[1]]
+            mults = {h.input_multiplier() if isinstance(h, MuReadout) else 1.0 for h in heads}
+            if len(mults) != 1:
+                raise NotImplementedError("manipose_amd: hypothesis heads with different MuReadout multipliers")
+            if isinstance(mod.head, torch.nn.ModuleList):
+                for h in mod.head:
+                    if isinstance(h.score_head, MuReadout) and h.score_head.input_multiplier() != 1.0:
+                        raise NotImplementedError("manipose_amd: a score head with a width multiplier (its fan-in, the joint count, is not a width)")
+            m = mults.pop()
+            out[f"readout_mult_{tag}"] = 0.0 if m == 1.0 else float(m)
+        return out
 
     def _views_intact(self) -> bool:
         base = self._flat.data_ptr()
@@ -103,7 +128,7 @@ class FusedLiftingMixin:
         p = next(self.parameters())
         if p.device.type != "cuda":
             if self._flat is None or self._flat.device != p.device or not self._views_intact():
-                self._engine = LiftEngine(arch=self._arch, max_batch=0, precision=self.precision, **self._engine_cfg)
+                self._engine = LiftEngine(arch=self._arch, max_batch=0, precision=self.precision, **self._engine_cfg, **self._scale_cfg())
                 self._flatten(self._engine, p.device)
             return self._flat
         if self._flat is None or self._flat.device != p.device or not self._views_intact():

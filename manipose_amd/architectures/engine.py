@@ -18,7 +18,9 @@ class LiftEngine:
 
     def __init__(self, *, arch: str, num_frame: int, num_joints: int, num_bones: int, embed_dim_rot: int, depth_rot: int,
                  num_heads_rot: int, embed_dim_seg: int, depth_seg: int, num_heads_seg: int, n_hyp: int,
-                 drop_path_rate: float, max_batch: int, precision: str = "fp32", rot_rep_dim: int = 6):
+                 drop_path_rate: float, max_batch: int, precision: str = "fp32", rot_rep_dim: int = 6, qk_scale_rot: float = 0.0,
+                 resid_scale_rot: float = 0.0, readout_mult_rot: float = 0.0, qk_scale_seg: float = 0.0, resid_scale_seg: float = 0.0,
+                 readout_mult_seg: float = 0.0):
         self.lib = _lib.load()
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {list(PRECISIONS)}, got {precision}")
@@ -27,7 +29,9 @@ class LiftEngine:
                                     depth_rot=depth_rot, num_heads_rot=num_heads_rot, embed_dim_seg=embed_dim_seg,
                                     depth_seg=depth_seg, num_heads_seg=num_heads_seg, n_hyp=max(1, n_hyp),
                                     drop_path_rate=drop_path_rate, max_batch=max_batch,
-                                    precision=PRECISIONS[precision], rot_rep_dim=rot_rep_dim)
+                                    precision=PRECISIONS[precision], rot_rep_dim=rot_rep_dim, qk_scale_rot=qk_scale_rot,
+                                    resid_scale_rot=resid_scale_rot, readout_mult_rot=readout_mult_rot, qk_scale_seg=qk_scale_seg,
+                                    resid_scale_seg=resid_scale_seg, readout_mult_seg=readout_mult_seg)
         self.arch = arch
         self.K = max(1, n_hyp) if arch == "rmcl_manifold" else 1
         self.max_batch = max_batch

@@ -14,6 +14,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from ..mup_lite import MuReadout
 from ._fused import FusedLiftingMixin
 
 _ENGINE_ONLY = ("manipose_amd: {} holds parameters only; its arithmetic runs inside the fused HIP engine. Call the "
@@ -55,11 +56,12 @@ class Attention(nn.Module):
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0, comb=False,
                  vis=False, mup=False):
         super().__init__()
-        if mup or comb or qk_scale is not None or attn_drop != 0.0 or proj_drop != 0.0 or not qkv_bias:
-            raise NotImplementedError("manipose_amd: attention kernels implement the reference defaults (qkv_bias=True, "
-                                      "scale=head_dim**-0.5, comb=False, no dropout, mup=False)")
+        if comb or attn_drop != 0.0 or proj_drop != 0.0 or not qkv_bias:
+            raise NotImplementedError("manipose_amd: attention kernels implement the reference defaults (qkv_bias=True, comb=False, "
+                                      "no dropout)")
         self.num_heads = num_heads
-        self.scale = (dim // num_heads) ** -0.5
+        head_dim = dim // num_heads
+        self.scale = qk_scale or (1 / head_dim if mup else head_dim ** -0.5)          # mix_ste.py:243-244
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
@@ -82,7 +84,7 @@ class Block(nn.Module):
         self.norm1 = norm_layer(dim)
         self.attn = attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
                               proj_drop=drop, comb=comb, vis=vis, mup=mup)
-        self.residual_scale = 1.0
+        self.residual_scale = 1 / depth ** 0.5 if mup else 1.0                        # mix_ste.py:327-330 (muP across depth)
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
@@ -102,8 +104,6 @@ class MixSTE(FusedLiftingMixin, nn.Module):
                  mlp_ratio=2.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.2,
                  norm_layer=None, mup=False):
         super().__init__()
-        if mup:
-            raise NotImplementedError("manipose_amd: mu-parametrisation (model.mup=True) is outside the accelerated path")
         if mlp_ratio != 2.0 or norm_layer is not None or drop_rate != 0.0:
             raise NotImplementedError("manipose_amd: the engine is built for mlp_ratio=2, LayerNorm(eps=1e-6), drop_rate=0")
         norm_layer = partial(nn.LayerNorm, eps=1e-6)
@@ -118,13 +118,13 @@ class MixSTE(FusedLiftingMixin, nn.Module):
         dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth)]
         self.block_depth = depth
         common = dict(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
-                      drop=drop_rate, attn_drop=attn_drop_rate, norm_layer=norm_layer)
-        self.STEblocks = nn.ModuleList([Block(drop_path=dpr[i], **common) for i in range(depth)])
+                      drop=drop_rate, attn_drop=attn_drop_rate, norm_layer=norm_layer, mup=mup)
+        self.STEblocks = nn.ModuleList([Block(drop_path=dpr[i], depth=depth if mup else 0, **common) for i in range(depth)])
         self.TTEblocks = nn.ModuleList([Block(drop_path=dpr[i], currentdim=i + 1, depth=depth, **common)
                                         for i in range(depth)])
         self.Spatial_norm = norm_layer(embed_dim)
         self.Temporal_norm = norm_layer(embed_dim)
-        self.head = nn.Sequential(nn.LayerNorm(embed_dim), nn.Linear(embed_dim, out_dim))
+        self.head = nn.Sequential(nn.LayerNorm(embed_dim), (MuReadout if mup else nn.Linear)(embed_dim, out_dim))    # mix_ste.py:118-126
         self._standalone = in_chans == 2 and out_dim == 3 and num_joints == 17
         self._init_fused("mixste", dict(num_frame=num_frame, num_joints=num_joints, num_bones=16, embed_dim_rot=embed_dim, depth_rot=depth,
                                         num_heads_rot=num_heads, embed_dim_seg=128, depth_seg=1, num_heads_seg=8, n_hyp=1,

@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from .. import _lib
 from .manifold_mix_ste import ManifoldMixSTE
+from ..mup_lite import MuReadout
 from .mix_ste import MixSTE
 
 
@@ -18,11 +19,10 @@ class MCLHead(nn.Module):
 
     def __init__(self, embed_dim: int, out_dim: int, num_joints: int, mup: bool = False):
         super().__init__()
-        if mup:
-            raise NotImplementedError("manipose_amd: mup heads are outside the accelerated path")
         self.norm = nn.LayerNorm(embed_dim)
-        self.prediction_head = nn.Linear(embed_dim, out_dim + 1)
-        self.score_head = nn.Linear(num_joints, 1)
+        linear = MuReadout if mup else nn.Linear                                      # rmcl_manifold_mix_ste.py:278-289
+        self.prediction_head = linear(embed_dim, out_dim + 1)
+        self.score_head = linear(num_joints, 1)
 
 
 class RMCLRotMixSTE(MixSTE):

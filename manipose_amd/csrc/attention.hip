@@ -175,7 +175,12 @@ __global__ __launch_bounds__(WPB * 64) void attn_spatial_bwd_kernel(const TS* __
   }
 }
 
-static float qk_scale(int D) { return 1.0f / sqrtf((float)D); }   // head_dim ** -0.5, mix_ste.py:243-244
+// head_dim ** -0.5 (mix_ste.py:243-244) unless the model engine has set another scale for the launches it is about to issue on this
+// thread (muP: 1 / head_dim, mix_ste.py:243; or an explicit qk_scale): attn_scale_override(s > 0), reset with 0
+static thread_local float g_scale_override = 0.f;
+void attn_scale_override(float s) { g_scale_override = s; }
+float attn_qk_scale(int D) { return g_scale_override > 0.f ? g_scale_override : 1.0f / sqrtf((float)D); }
+static float qk_scale(int D) { return attn_qk_scale(D); }
 
 template <typename TS>
 static int spatial_fwd_t(const TS* qkv, TS* out, int B, int T, int J, int C, int H, hipStream_t st) {

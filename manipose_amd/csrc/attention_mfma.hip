@@ -611,12 +611,13 @@ __global__ __launch_bounds__(512) void attn_smfma_bwd_kernel(const bf16* __restr
   (void)pA;
 }
 
+float attn_qk_scale(int D);      // attention.hip: head_dim ** -0.5 or the engine's override (muP)
 bool attn_smfma_supported(int N, int D, int H) { return N >= 16 && N <= 32 && (D == 64 || D == 16) && H >= 1 && H <= 8; }
 
 int attn_smfma_fwd(const bf16* qkv, bf16* out, int B, int T, int J, int C, int H, hipStream_t st) {
   const int D = C / H;
   MP_CHECK(attn_smfma_supported(J, D, H) && C % 8 == 0, MP_ERR_ARG, "attn_smfma_fwd: J=%d D=%d H=%d unsupported", J, D, H);
-  const float scale = 1.0f / sqrtf((float)D);
+  const float scale = attn_qk_scale(D);
   const size_t lds = (size_t)J * (6 * C + 16);
   if (D == 64) {
     static bool attr_set = false;
@@ -635,7 +636,7 @@ int attn_smfma_fwd(const bf16* qkv, bf16* out, int B, int T, int J, int C, int H
 int attn_smfma_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, int B, int T, int J, int C, int H, hipStream_t st) {
   const int D = C / H;
   MP_CHECK(attn_smfma_supported(J, D, H) && C % 8 == 0, MP_ERR_ARG, "attn_smfma_bwd: J=%d D=%d H=%d unsupported", J, D, H);
-  const float scale = 1.0f / sqrtf((float)D);
+  const float scale = attn_qk_scale(D);
   const size_t lds = (size_t)J * (6 * C + 16) + (size_t)J * (2 * C + 16);
   if (D == 64) {
     static bool attr_set = false;
@@ -979,7 +980,7 @@ int attn_spatial_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf
     if (rc) return rc;
     return split_planes(scratch + 3 * M * C, out_hi, out_lo, M * C, st);
   }
-  const float scale = 1.0f / sqrtf((float)D);
+  const float scale = attn_qk_scale(D);
   const size_t lds = 2 * (size_t)J * (6 * C + 16);
   MP_CHECK(lds <= 160 * 1024, MP_ERR_ARG, "attn_spatial_fwd_x3: frame block of %zu bytes exceeds the LDS", lds);
   MP_CHECK((long)J * (6 * C / 16) <= 7L * H * 64, MP_ERR_ARG, "attn_spatial_fwd_x3: frame block too large for the register prefetch (J=%d C=%d H=%d)", J, C, H);
@@ -1038,7 +1039,7 @@ int attn_temporal_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, b
     if (rc) return rc;
     return split_planes(scratch + 3 * M * C, out_hi, out_lo, M * C, st);
   }
-  const float scale = 1.0f / sqrtf((float)D);
+  const float scale = attn_qk_scale(D);
   const int units = B * J * H;
   if (D == 64) return launch_tmfma_fwd_x3<64>(qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, st);
   return launch_tmfma_fwd_x3<16>(qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, st);
@@ -1067,7 +1068,7 @@ static int launch_tmfma_fwd(const bf16* qkv, bf16* out, float* lse, int units, i
 int attn_tmfma_fwd(const bf16* qkv, bf16* out, float* lse, int B, int T, int J, int C, int H, hipStream_t st) {
   const int D = C / H;
   MP_CHECK(attn_tmfma_supported(T, D) && C % 8 == 0, MP_ERR_ARG, "attn_tmfma_fwd: T=%d D=%d unsupported", T, D);
-  const float scale = 1.0f / sqrtf((float)D);
+  const float scale = attn_qk_scale(D);
   const int units = B * J * H;
   // (run-time tile count only: with a compile-time count the scheduler hoists across the whole score strip and spills)
   if (D == 64) return launch_tmfma_fwd<64, 0>(qkv, out, lse, units, T, J, C, H, scale, st);
@@ -1097,7 +1098,7 @@ int attn_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, const flo
                    hipStream_t st) {
   const int D = C / H;
   MP_CHECK(attn_tmfma_supported(T, D) && C % 8 == 0, MP_ERR_ARG, "attn_tmfma_bwd: T=%d D=%d unsupported", T, D);
-  const float scale = 1.0f / sqrtf((float)D);
+  const float scale = attn_qk_scale(D);
   const int units = B * J * H;
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("MANIPOSE_ATTN_DEBUG"); dbg = e ? atoi(e) : 0; }

@@ -67,6 +67,13 @@ int mp_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
                    (hipStream_t)stream);
 }
 
+int mp_adam_step_scaled(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, float grad_scale, const float* lr_mult, const float* wd_mult, void* stream) {
+  MP_CHECK(params && grads && exp_avg && exp_avg_sq && lr_mult && wd_mult && n > 0, MP_ERR_ARG, "mp_adam_step_scaled: bad argument");
+  return adam_step(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale, (hipStream_t)stream, lr_mult,
+                   wd_mult);
+}
+
 int mp_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* stats, int M, int C,
                      void* stream) {
   MP_CHECK(x && gamma && beta && y && stats, MP_ERR_ARG, "mp_layernorm_fwd: null pointer");

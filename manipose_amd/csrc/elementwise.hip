@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
                                                       const float* dskip, float* dx, bf16* __restrict__ dx_b16,
                                                       const float* __restrict__ mask, int mask_mode, int T, int J,
-                                                      float* __restrict__ partial, int M, int C) {
+                                                      float* __restrict__ partial, int M, int C, float rs) {
   __shared__ float red[4 * 2 * 256 * V];  // [wave][dgamma|dbeta][C <= 256 V]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
           o.y = rstd[r] * (d[i].y - s1 - xh[i].y * s2);
           o.z = rstd[r] * (d[i].z - s1 - xh[i].z * s2);
           o.w = rstd[r] * (d[i].w - s1 - xh[i].w * s2);
-          if (dskip != nullptr) { o.x += k[r][i].x; o.y += k[r][i].y; o.z += k[r][i].z; o.w += k[r][i].w; }
+          if (dskip != nullptr) { o.x += rs * k[r][i].x; o.y += rs * k[r][i].y; o.z += rs * k[r][i].z; o.w += rs * k[r][i].w; }
           st4(dx + (long)m * C + c, o);
           if (dx_b16 != nullptr)     // bf16 copy, pre-scaled by the consumer branch's DropPath mask: A operand of its GEMMs
             st4(dx_b16 + (long)m * C + c, make_float4(o.x * ms[r], o.y * ms[r], o.z * ms[r], o.w * ms[r]));
@@ -300,13 +300,13 @@ static bool param_stream(hipStream_t& st, hipStream_t st_param, hipEvent_t ev) {
 
 int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
            const float* mask, int mask_mode, int T, int J, float* dgamma, float* dbeta, int M, int C, float* scratch,
-           long scratch_floats, hipStream_t st, hipStream_t st_param, hipEvent_t ev) {
+           long scratch_floats, hipStream_t st, hipStream_t st_param, hipEvent_t ev, float rs) {
   MP_CHECK(C % 4 == 0 && C <= 1024, MP_ERR_ARG, "ln_bwd: C=%d unsupported", C);
   const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
   MP_CHECK(scratch_floats >= (long)grid * 2 * C, MP_ERR_ARG, "ln_bwd: scratch too small");
 #define MP_LN_BWD(TDY, V, R)                                                                                                             \
   hipLaunchKernelGGL((ln_bwd_kernel<TDY, V, R>), dim3(grid), dim3(256), 0, st, (const TDY*)dy, x, stats, gamma, dskip, dx, (bf16*)dx_b16, \
-                     mask, mask ? mask_mode : 0, T, J, scratch, M, C)
+                     mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs)
   if (C <= 512) { if (dy_bf16) MP_LN_BWD(bf16, 2, 2); else MP_LN_BWD(float, 2, 2); }
   else          { if (dy_bf16) MP_LN_BWD(bf16, 4, 1); else MP_LN_BWD(float, 4, 1); }
 #undef MP_LN_BWD
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy
                                                        const float* __restrict__ stats0, const float* __restrict__ gamma0,
                                                        const float* __restrict__ beta0, float* dx,
                                                        bf16* __restrict__ dx_b16, const float* __restrict__ mask, int mask_mode, int T,
-                                                       int J, float* __restrict__ partial, int M, int C) {
+                                                       int J, float* __restrict__ partial, int M, int C, float rs) {
   constexpr int V = 2;
   __shared__ float red[4 * 4 * 512];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -397,10 +397,10 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy
       t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < C) {
         const float4 k = kk[i], xv = xv0[i];
-        t[i].x = rstd1 * (d[i].x - s1 - xh[i].x * s2) + k.x;
-        t[i].y = rstd1 * (d[i].y - s1 - xh[i].y * s2) + k.y;
-        t[i].z = rstd1 * (d[i].z - s1 - xh[i].z * s2) + k.z;
-        t[i].w = rstd1 * (d[i].w - s1 - xh[i].w * s2) + k.w;
+        t[i].x = rstd1 * (d[i].x - s1 - xh[i].x * s2) + rs * k.x;
+        t[i].y = rstd1 * (d[i].y - s1 - xh[i].y * s2) + rs * k.y;
+        t[i].z = rstd1 * (d[i].z - s1 - xh[i].z * s2) + rs * k.z;
+        t[i].w = rstd1 * (d[i].w - s1 - xh[i].w * s2) + rs * k.w;
         xh[i] = make_float4((xv.x - mean0) * rstd0, (xv.y - mean0) * rstd0, (xv.z - mean0) * rstd0, (xv.w - mean0) * rstd0);
         acc[2][i].x += t[i].x * xh[i].x; acc[2][i].y += t[i].y * xh[i].y; acc[2][i].z += t[i].z * xh[i].z; acc[2][i].w += t[i].w * xh[i].w;
         acc[3][i].x += t[i].x; acc[3][i].y += t[i].y; acc[3][i].z += t[i].z; acc[3][i].w += t[i].w;
@@ -444,16 +444,16 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
             const float* x0, const float* stats0, const float* gamma0, const float* beta0, float* dx, void* dx_b16, const float* mask,
             int mask_mode, int T,
             int J, float* dgamma1, float* dbeta1, float* dgamma0, float* dbeta0, int M, int C, float* scratch, long scratch_floats,
-            hipStream_t st, hipStream_t st_param, hipEvent_t ev) {
+            hipStream_t st, hipStream_t st_param, hipEvent_t ev, float rs) {
   MP_CHECK(C % 4 == 0 && C <= 512, MP_ERR_ARG, "ln_bwd2: C=%d unsupported", C);
   const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
   MP_CHECK(scratch_floats >= (long)grid * 4 * C, MP_ERR_ARG, "ln_bwd2: scratch too small");
   if (dy_bf16)
     hipLaunchKernelGGL(ln_bwd2_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
-                       beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C);
+                       beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs);
   else
     hipLaunchKernelGGL(ln_bwd2_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
-                       beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C);
+                       beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs);
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dgamma1, dbeta1, dgamma0, dbeta0}, {0, C, 2 * C, 3 * C, 4 * C}, {1, 1, 1, 1}};
   if (!param_stream(st, st_param, ev)) return MP_ERR_HIP;
@@ -672,6 +672,21 @@ int tpos_grad(const float* g, float* dtpos, int B, int T, int J, int C, hipStrea
   return MP_OK;
 }
 
+__global__ void scale_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, float s, long n, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = accumulate ? dst[i] + s * src[i] : s * src[i];
+}
+int scale_copy(float* dst, const float* src, float s, long n, hipStream_t st) {
+  hipLaunchKernelGGL(scale_copy_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dst, src, s, n, 0);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+int axpy_scaled(float* dst, const float* src, float s, long n, hipStream_t st) {
+  hipLaunchKernelGGL(scale_copy_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dst, src, s, n, 1);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
 // out[m][:] = mask(m) * g[m][:]  (DropPath backward on a branch gradient)
 template <typename TO>
 __global__ void scale_rows_kernel(const float* __restrict__ g, const float* __restrict__ mask, int mode, TO* __restrict__ out,
@@ -699,37 +714,47 @@ int scale_rows(const float* g, const float* mask, int mask_mode, void* out, int 
 // ---------------------------------------------------------------------------------------------
 // Adam with L2 weight decay == torch.optim.Adam(lr, weight_decay) (main_h36m_lifting.py:234-238)
 // ---------------------------------------------------------------------------------------------
+// MULT: per-element learning-rate and weight-decay multipliers (mup.optim.MuAdam: matrix-like parameters train with lr / width_mult
+// and weight_decay * width_mult, main_h36m_lifting.py:227-232)
+template <bool MULT>
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float lr_bc1, float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd,
-                            float gscale) {
+                            float gscale, const float* __restrict__ lr_mult, const float* __restrict__ wd_mult) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i + 3 < n) {
     float4 pp = ld4(p + i), gg = ld4(g + i), mm = ld4(m + i), vv = ld4(v + i);
-    float* P = &pp.x; float* G = &gg.x; float* Mo = &mm.x; float* V = &vv.x;
+    float4 lm = make_float4(1.f, 1.f, 1.f, 1.f), wm = lm;
+    if (MULT) { lm = ld4(lr_mult + i); wm = ld4(wd_mult + i); }
+    float* P = &pp.x; float* G = &gg.x; float* Mo = &mm.x; float* V = &vv.x; float* LM = &lm.x; float* WM = &wm.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float gr = G[k] * gscale + wd * P[k];
+      const float gr = G[k] * gscale + (MULT ? wd * WM[k] : wd) * P[k];
       Mo[k] = beta1 * Mo[k] + (1.f - beta1) * gr;
       V[k] = beta2 * V[k] + (1.f - beta2) * gr * gr;
-      P[k] -= lr_bc1 * (Mo[k] / (sqrtf(V[k]) * inv_sqrt_bc2 + eps));
+      P[k] -= (MULT ? lr_bc1 * LM[k] : lr_bc1) * (Mo[k] / (sqrtf(V[k]) * inv_sqrt_bc2 + eps));
     }
     st4(p + i, pp); st4(m + i, mm); st4(v + i, vv);
   } else {
     for (; i < n; ++i) {
-      const float gr = g[i] * gscale + wd * p[i];
+      const float gr = g[i] * gscale + (MULT ? wd * wd_mult[i] : wd) * p[i];
       m[i] = beta1 * m[i] + (1.f - beta1) * gr;
       v[i] = beta2 * v[i] + (1.f - beta2) * gr * gr;
-      p[i] -= lr_bc1 * (m[i] / (sqrtf(v[i]) * inv_sqrt_bc2 + eps));
+      p[i] -= (MULT ? lr_bc1 * lr_mult[i] : lr_bc1) * (m[i] / (sqrtf(v[i]) * inv_sqrt_bc2 + eps));
     }
   }
 }
 
 int adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1, float beta2, float eps,
-              float weight_decay, float grad_scale, hipStream_t st) {
+              float weight_decay, float grad_scale, hipStream_t st, const float* lr_mult, const float* wd_mult) {
   MP_CHECK(step >= 1, MP_ERR_ARG, "adam_step: step must be >= 1");
+  MP_CHECK((lr_mult == nullptr) == (wd_mult == nullptr), MP_ERR_ARG, "adam_step: lr and weight-decay multipliers come together");
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  hipLaunchKernelGGL(adam_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1),
-                     (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale);
+  if (lr_mult != nullptr)
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1),
+                       (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale, lr_mult, wd_mult);
+  else
+  hipLaunchKernelGGL(adam_kernel<false>, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1),
+                     (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale, lr_mult, wd_mult);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

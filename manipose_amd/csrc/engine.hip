@@ -28,6 +28,8 @@ struct Module {
   bool is_rot;
   int N, C, H, depth;     // tokens per frame (17 joints / 16 bones), width, heads, depth
   int K, O;               // heads, out features per head
+  float qk_scale, rs, readout;   // attention softmax scale (0 = head_dim^-0.5), residual scale, MuReadout input multiplier (1 unless muP)
+  float *hw_eff, *hdw;    // readout != 1: the heads' weights times readout (forward / dx) and the scratch their gradient lands in
   int emb_w, emb_b, spos, tpos, sn_w, sn_b, tn_w, tn_b;
   std::vector<BlockP> bp; // order: STE0, TTE0, STE1, TTE1, ...
   int hg[8], hb[8], hw[8], hbias[8], sw[8], sb[8];
@@ -75,6 +77,7 @@ struct mp_model {
   hipEvent_t evE[2][4] = {}, evW[2][4] = {};
   bool wgrad_async = false;
   bool has_seg = true;                       // false for arch 2 (bare MixSTE): no segments module, no decoder
+  float cur_rs = 1.0f;                       // residual scale of the module whose kernels are being enqueued (Module::rs)
   // state of the last forward
   int B = 0;
   bool train = false;
@@ -180,6 +183,8 @@ static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int prec
     w.a1l = lo(M * C); w.qkvl = lo(M * 3 * C); w.aol = lo(M * C); w.a2l = lo(M * C); w.fl = lo(M * 2 * C);
   }
   md.x_final = bp.take(M * C);
+  md.hw_eff = md.readout != 1.0f ? bp.take((long)md.K * md.O * C) : nullptr;
+  md.hdw = md.readout != 1.0f ? bp.take((long)md.K * md.O * C) : nullptr;
   md.hstats = bp.take(M * 2);
   md.headout = bp.take((long)md.K * M * md.O);
   md.dheadout = bp.take((long)md.K * M * md.O);
@@ -306,7 +311,7 @@ static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* 
   if (m->cfg.precision == 0) {
     GemmF32Args g = {};
     g.A = (const float*)A; g.lda = K; g.B = P(m, fp, widx); g.ldb = K; g.C = (float*)Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
-    g.bias = P(m, fp, bidx); g.Z = (float*)Z; g.R = R; g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
+    g.bias = P(m, fp, bidx); g.Z = (float*)Z; g.R = R; g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J; g.rscale = m->cur_rs;
     RUNB(PC_GEMM_FWD, 2.0 * M * N * K, 4.0 * (M * K + (double)N * K + M * N * (1 + (epi == EPI_BIAS_RESID) + (epi == EPI_BIAS_GELU))),
          gemm_f32(0, 0, epi, g, st));
     return MP_OK;
@@ -314,7 +319,7 @@ static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* 
   GemmB16Args g = {};
   g.A = A; g.lda = K; g.B = m->wbf + m->params[widx].offset; g.ldb = K; g.C = Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
   g.bias = P(m, fp, bidx); g.Z = Z; g.R = R; g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
-  g.rstats = rstats; g.rgamma = rgamma; g.rbeta = rbeta;
+  g.rstats = rstats; g.rgamma = rgamma; g.rbeta = rbeta; g.rscale = m->cur_rs;
   if (m->cfg.precision == 2) {
     // split precision: planar hi/lo A and weights (both planes read), planar outputs (+ the plain-bf16 gelu'), fp32 residual in + out
     g.A_lo = A_lo; g.B_lo = m->wbf_lo + m->params[widx].offset; g.C_lo = C_lo;
@@ -375,7 +380,27 @@ static bool lazy_block_input(const mp_model* m, const Module& md, int l) {
   return m->cfg.precision >= 1 && l >= 2 && md.C <= 512;
 }
 
+static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hipStream_t st);
+static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg, int B, hipStream_t st);
+// the module's attention scale / residual scale apply to every launch of its backbone (attention launchers read the thread's override)
 static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStream_t st) {
+  attn_scale_override(md.qk_scale);
+  m->cur_rs = md.rs;
+  const int rc = backbone_fwd_impl(m, md, fp, B, st);
+  attn_scale_override(0.f);
+  m->cur_rs = 1.0f;
+  return rc;
+}
+static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int B, hipStream_t st) {
+  attn_scale_override(md.qk_scale);
+  m->cur_rs = md.rs;
+  const int rc = backbone_bwd_impl(m, md, fp, fg, B, st);
+  attn_scale_override(0.f);
+  m->cur_rs = 1.0f;
+  return rc;
+}
+
+static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hipStream_t st) {
   const int T = m->cfg.num_frame, N = md.N, C = md.C, H = md.H, L = 2 * md.depth;
   const int half = m->cfg.precision;          // LayerNorm output mode: 0 fp32, 1 bf16, 2 planar hi/lo bf16
   const bool x3 = m->cfg.precision == 2;
@@ -443,7 +468,7 @@ static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStre
 }
 
 // on entry m->g holds dL/d x_final; on exit m->g holds dL/d (embedding output)
-static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int B, hipStream_t st) {
+static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg, int B, hipStream_t st) {
   const int T = m->cfg.num_frame, N = md.N, C = md.C, H = md.H, L = 2 * md.depth;
   const long M = (long)B * T * N;
   const int half = m->cfg.precision >= 1;       // precision 2: the backward runs in bf16 on the hi planes
@@ -504,7 +529,7 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
     const float* mk1 = branch_mask(m, md, l, 0, B, m->train);
     float* lsc2 = ln_scratch();
     RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, m->g_b16, mk1, mode, T, N, G(m, fg, q.n2w),
-                         G(m, fg, q.n2b), (int)M, C, lsc2, ln_floats(lsc2), st, lsc2 == m->small ? nullptr : lst, lev));
+                         G(m, fg, q.n2b), (int)M, C, lsc2, ln_floats(lsc2), st, lsc2 == m->small ? nullptr : lst, lev, md.rs));
     // (e) attention branch: proj
     gb = half ? (const void*)m->g_b16 : (const void*)g;
     if (mk1 && !half) {
@@ -541,12 +566,12 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
       RUN(PC_LN, 0, ln_bwd2(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, wp.x_out, wp.stp, P(m, fp, pspatial ? md.sn_w : md.tn_w),
                             P(m, fp, pspatial ? md.sn_b : md.tn_b), g, m->g_b16, mkp, pspatial ? 1 : 2, T, N, G(m, fg, q.n1w), G(m, fg, q.n1b),
                             G(m, fg, pspatial ? md.sn_w : md.tn_w), G(m, fg, pspatial ? md.sn_b : md.tn_b), (int)M, C, lsc3,
-                            ln_floats(lsc3), st, lsc3 == m->small ? nullptr : lst, lev));
+                            ln_floats(lsc3), st, lsc3 == m->small ? nullptr : lst, lev, md.rs));
       post_done = true;
     } else {
       float* lsc4 = ln_scratch();
       RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, g, nullptr, nullptr, 0, T, N, G(m, fg, q.n1w),
-                           G(m, fg, q.n1b), (int)M, C, lsc4, ln_floats(lsc4), st, lsc4 == m->small ? nullptr : lst, lev));
+                           G(m, fg, q.n1b), (int)M, C, lsc4, ln_floats(lsc4), st, lsc4 == m->small ? nullptr : lst, lev, md.rs));
     }
   }
   if (wasync && have_prev) {    // the last block's fc1 / qkv weight gradients
@@ -559,15 +584,44 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
   return MP_OK;
 }
 
+// MuReadout (readout != 1): y = W (readout * x) + b is evaluated with the scaled copy W_eff = readout * W (refresh_head_weights, once per
+// forward); the kernels' weight gradient d W_eff lands in a zeroed scratch and readout * d W_eff is added to the gradient buffer afterwards
 static void head_params(const mp_model* m, const Module& md, const float* fp, HeadParams& hp) {
+  const long WC = (long)md.O * md.C;
   for (int k = 0; k < md.K; ++k) {
-    hp.gamma[k] = P(m, fp, md.hg[k]); hp.beta[k] = P(m, fp, md.hb[k]); hp.W[k] = P(m, fp, md.hw[k]); hp.b[k] = P(m, fp, md.hbias[k]);
+    hp.gamma[k] = P(m, fp, md.hg[k]); hp.beta[k] = P(m, fp, md.hb[k]); hp.b[k] = P(m, fp, md.hbias[k]);
+    hp.W[k] = md.hw_eff != nullptr ? md.hw_eff + k * WC : P(m, fp, md.hw[k]);
   }
 }
 static void head_grads(const mp_model* m, const Module& md, float* fg, HeadGrads& hg) {
+  const long WC = (long)md.O * md.C;
   for (int k = 0; k < md.K; ++k) {
-    hg.gamma[k] = G(m, fg, md.hg[k]); hg.beta[k] = G(m, fg, md.hb[k]); hg.W[k] = G(m, fg, md.hw[k]); hg.b[k] = G(m, fg, md.hbias[k]);
+    hg.gamma[k] = G(m, fg, md.hg[k]); hg.beta[k] = G(m, fg, md.hb[k]); hg.b[k] = G(m, fg, md.hbias[k]);
+    hg.W[k] = md.hdw != nullptr ? md.hdw + k * WC : G(m, fg, md.hw[k]);
   }
+}
+static int refresh_head_weights(mp_model* m, const Module& md, const float* fp, hipStream_t st) {
+  if (md.hw_eff == nullptr) return MP_OK;
+  const long WC = (long)md.O * md.C;
+  for (int k = 0; k < md.K; ++k) {
+    int rc = scale_copy(md.hw_eff + k * WC, P(m, fp, md.hw[k]), md.readout, WC, st);
+    if (rc) return rc;
+  }
+  return MP_OK;
+}
+static int zero_head_grad_scratch(const Module& md, hipStream_t st) {
+  if (md.hdw == nullptr) return MP_OK;
+  MP_HIP(hipMemsetAsync(md.hdw, 0, sizeof(float) * (size_t)md.K * md.O * md.C, st));
+  return MP_OK;
+}
+static int flush_head_grads(mp_model* m, const Module& md, float* fg, hipStream_t st) {
+  if (md.hdw == nullptr) return MP_OK;
+  const long WC = (long)md.O * md.C;
+  for (int k = 0; k < md.K; ++k) {
+    int rc = axpy_scaled(G(m, fg, md.hw[k]), md.hdw + k * WC, md.readout, WC, st);
+    if (rc) return rc;
+  }
+  return MP_OK;
 }
 
 }  // namespace mp
@@ -601,6 +655,12 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   m->seg.prefix = "segments_module."; m->seg.is_rot = false;
   m->seg.N = cfg->num_bones; m->seg.C = cfg->embed_dim_seg; m->seg.H = cfg->num_heads_seg; m->seg.depth = cfg->depth_seg;
   m->seg.K = 1; m->seg.O = 1;
+  m->rot.qk_scale = cfg->qk_scale_rot; m->rot.rs = cfg->resid_scale_rot != 0.f ? cfg->resid_scale_rot : 1.0f;
+  m->rot.readout = cfg->readout_mult_rot != 0.f ? cfg->readout_mult_rot : 1.0f;
+  m->seg.qk_scale = cfg->qk_scale_seg; m->seg.rs = cfg->resid_scale_seg != 0.f ? cfg->resid_scale_seg : 1.0f;
+  m->seg.readout = cfg->readout_mult_seg != 0.f ? cfg->readout_mult_seg : 1.0f;
+  MP_CHECK(m->rot.qk_scale >= 0.f && m->seg.qk_scale >= 0.f && m->rot.rs > 0.f && m->seg.rs > 0.f, MP_ERR_ARG,
+           "mp_model_create: attention / residual scales must be positive (0 = default)");
   build_module_params(m, m->rot);
   if (m->has_seg) build_module_params(m, m->seg);
   m->rot.mask_base = 0;
@@ -760,6 +820,8 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
   if (rc) return rc;
   HeadParams hp;
   head_params(m, m->rot, fp, hp);
+  rc = refresh_head_weights(m, m->rot, fp, st);
+  if (rc) return rc;
   RUN(PC_OTHER, 0, heads_fwd(m->rot.x_final, hp, K, m->rot.O, m->rot.headout, m->rot.hstats, (int)Mr, m->rot.C, st));
   if (m->cfg.arch == 0) {
     ScoreParams sp;
@@ -781,6 +843,8 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
     if (rc) return rc;
     HeadParams hs;
     head_params(m, m->seg, fp, hs);
+    rc = refresh_head_weights(m, m->seg, fp, st);
+    if (rc) return rc;
     RUN(PC_OTHER, 0, heads_fwd(m->seg.x_final, hs, 1, 1, m->seg.headout, m->seg.hstats, (int)Ms, m->seg.C, st));
     RUN(PC_OTHER, 0, bones_mean_fwd(m->seg.headout, m->lengths, B, T, S, st));
     MP_HIP(hipEventRecord(m->ev_join, m->st2));
@@ -803,6 +867,7 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   // parameter gradients of the heads / score heads are needed by nobody downstream: with the weight-gradient stream on they run there,
   // at the start of the backward where that stream is idle (own scratch, ordered behind the last writer of dheadout)
   hipStream_t pst = m->wgrad_async ? m->st3 : nullptr;
+  { int rz = zero_head_grad_scratch(m->rot, st); if (rz) return rz; }
   // decoder
   if (m->has_seg) RUN(PC_OTHER, 0, fk_decode_bwd(m->rot.headout, m->rot.O, m->cfg.rot_rep_dim, m->lengths, d_poses, m->rot.dheadout, m->dlen_pose, B, K, T, st));
   else MP_HIP(hipMemcpyAsync(m->rot.dheadout, d_poses, sizeof(float) * Mr * 3, hipMemcpyDeviceToDevice, st));
@@ -833,6 +898,7 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   head_grads(m, m->rot, fg, hg);
   RUN(PC_OTHER, 0, heads_bwd(m->rot.x_final, m->rot.hstats, hp, hg, K, m->rot.O, m->rot.dheadout, m->g, (int)Mr, m->rot.C,
                              pst ? m->hsmall : m->small, pst ? m->hsmall_floats : m->small_floats, st, pst));
+  { int rf = flush_head_grads(m, m->rot, fg, pst ? pst : st); if (rf) return rf; }
   int rc = backbone_bwd(m, m->rot, fp, fg, B, st);
   if (rc) return rc;
   RUN(PC_OTHER, 0, embed_bwd(m->g, m->x_in, G(m, fg, m->rot.emb_w), G(m, fg, m->rot.emb_b), G(m, fg, m->rot.spos), (int)Mr, m->rot.C, J,
@@ -847,8 +913,10 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     HeadGrads hgs;
     head_params(m, m->seg, fp, hs);
     head_grads(m, m->seg, fg, hgs);
+    { int rz = zero_head_grad_scratch(m->seg, st); if (rz) return rz; }
     RUN(PC_OTHER, 0, heads_bwd(m->seg.x_final, m->seg.hstats, hs, hgs, 1, 1, m->seg.dheadout, m->g, (int)Ms, m->seg.C, m->small,
                                m->small_floats, st));
+    { int rf = flush_head_grads(m, m->seg, fg, st); if (rf) return rf; }
     rc = backbone_bwd(m, m->seg, fp, fg, B, st);
     if (rc) return rc;
     RUN(PC_OTHER, 0, bones_embed_bwd(m->g, m->x_in, G(m, fg, m->seg.emb_w), G(m, fg, m->seg.emb_b), G(m, fg, m->seg.spos), B * T, J * 2,

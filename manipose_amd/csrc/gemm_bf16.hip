@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmB16Args g) {
       g.bias_slab[(long)blockIdx.z * g.M + m0 + tid] = bsum;
   }
   TC* Z = reinterpret_cast<TC*>(g.Z);
+  const float rsc = g.rscale != 0.f ? g.rscale : 1.0f;     // residual scale (muP: 1 / sqrt(depth))
   const int l15 = lane & 15, gq = lane >> 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmB16Args g) {
         st4(Z + o, d);
       } else if (EPI == EPI_BIAS_RESID) {
         const float4 r = ld4(g.R + o);
-        v = make_float4(r.x + dscale * v.x, r.y + dscale * v.y, r.z + dscale * v.z, r.w + dscale * v.w);
+        v = make_float4(r.x * rsc + dscale * v.x, r.y * rsc + dscale * v.y, r.z * rsc + dscale * v.z, r.w * rsc + dscale * v.w);
       } else if (EPI == EPI_DGELU) {
         const float4 z = ld4(Z + o);
         v = make_float4(v.x * z.x, v.y * z.y, v.z * z.z, v.w * z.w);      // Z holds gelu'(pre-activation)
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   }
   typename ZType<TC>::type* Z = reinterpret_cast<typename ZType<TC>::type*>(g.Z);
   const long lo_off = c_lo_off<TC>(g);
+  const float rsc = g.rscale != 0.f ? g.rscale : 1.0f;     // residual scale (muP: 1 / sqrt(depth))
   __syncthreads();                                   // every wave is done with the operand stages: reuse them
   float* img = reinterpret_cast<float*>(smem + wave * 16384);
   const int l15 = lane & 15, gq = lane >> 4;
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
           r = make_float4((r.x - mean) * rstd * rg4.x + rb4.x, (r.y - mean) * rstd * rg4.y + rb4.y, (r.z - mean) * rstd * rg4.z + rb4.z,
                           (r.w - mean) * rstd * rg4.w + rb4.w);
         }
-        v = make_float4(r.x + dscale * v.x, r.y + dscale * v.y, r.z + dscale * v.z, r.w + dscale * v.w);
+        v = make_float4(r.x * rsc + dscale * v.x, r.y * rsc + dscale * v.y, r.z * rsc + dscale * v.z, r.w * rsc + dscale * v.w);
       } else if (EPI == EPI_DGELU) {
         const float4 z = ld4(Z + o);
         v = make_float4(v.x * z.x, v.y * z.y, v.z * z.z, v.w * z.w);      // Z holds gelu'(pre-activation)
@@ -780,7 +782,8 @@ template <int TRA, int TRB, typename TC, int EPI, int SPLIT = 0>
 static int launch_glds(const GemmB16Args& g, int splits, hipStream_t st) {
   if constexpr (TRA == 0 && EPI != EPI_SLAB) {
     const int wgs = persist_workgroups();
-    if (wgs > 0 && splits == 1 && use_big_tile(g) && g.K >= 2 * GBK && g.K % GBK == 0 && (long)cdiv(g.N, 256) * cdiv(g.M, 256) >= (g_persist_min_tiles > 0 ? (long)g_persist_min_tiles : 2L * wgs) &&
+    // (a residual scale other than 1 - muP - is served by the tiled kernels only: the persistent residual epilogue sits at the 256-VGPR limit)
+    if (wgs > 0 && splits == 1 && (g.rscale == 0.f || g.rscale == 1.0f) && use_big_tile(g) && g.K >= 2 * GBK && g.K % GBK == 0 && (long)cdiv(g.N, 256) * cdiv(g.M, 256) >= (g_persist_min_tiles > 0 ? (long)g_persist_min_tiles : 2L * wgs) &&
         256L * g.lda * 2 < (1L << 31) && 64L * g.ldb * 2 < (1L << 31) && 256L * g.ldb * 2 < (1L << 31))
       return launch_persist<TRB, TC, EPI, SPLIT>(g, wgs, st);
   }

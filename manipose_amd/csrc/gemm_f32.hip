@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
           g.Z[o] = gelu_grad_f(v);      // Z keeps gelu'(z): all the backward needs from the pre-activation
           v = gelu_f(v);
         } else if (EPI == EPI_BIAS_RESID) {
-          v = g.R[o] + droppath_scale(g.mask, g.mask_mode, row, g.T, g.J) * v;
+          v = g.R[o] * (g.rscale != 0.f ? g.rscale : 1.0f) + droppath_scale(g.mask, g.mask_mode, row, g.T, g.J) * v;
         } else if (EPI == EPI_DGELU) {
           v *= g.Z[o];
         }

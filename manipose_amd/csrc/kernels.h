@@ -17,6 +17,7 @@ struct GemmF32Args {
   float* Z;            // EPI_BIAS_GELU: gelu'(pre-activation) (written); EPI_DGELU: the same (read)
   const float* R;      // EPI_BIAS_RESID: residual stream (read)
   const float* mask;   // EPI_BIAS_RESID: DropPath multipliers per sample, may be null
+  float rscale;        // EPI_BIAS_RESID: C = rscale * R + mask * (A B + bias); 0 means 1 (muP residual scale 1 / sqrt(depth), mix_ste.py:330)
   int mask_mode, T, J; // see droppath_scale()
   float* bias_slab;    // EPI_SLAB
   int k_per_split;     // EPI_SLAB
@@ -49,6 +50,7 @@ struct GemmB16Args {
   const void* A_lo;
   const void* B_lo;
   void* C_lo;
+  float rscale;        // residual epilogue: C = rscale * R + mask * (A B + bias); 0 means 1 (muP, mix_ste.py:330)
 };
 int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, hipStream_t st);
 // C = A B^T on planar hi/lo operands ("N","N" layouts: the forward Linear), three bf16 MFMA products per k-tile, fp32 accumulate.
@@ -78,13 +80,17 @@ struct LnFwdArgs {
 };
 int ln_fwd(const LnFwdArgs& a, int out_mode /* 0 fp32, 1 bf16, 2 planar bf16 hi/lo */, hipStream_t st);
 // dx = [dskip +] LN'(dy); partial param grads are reduced and ADDED into dgamma/dbeta.
+// dx = [rs * dskip +] LN'(dy) (rs: the block's residual scale, 1 unless muP)
 int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
            const float* mask, int mask_mode, int T, int J, float* dgamma, float* dbeta, int M, int C, float* scratch,
-           long scratch_floats, hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr);
+           long scratch_floats, hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr, float rs = 1.0f);
 int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, const float* gamma1, const float* dskip,
             const float* x0, const float* stats0, const float* gamma0, const float* beta0 /* non-null: x1 == LN0(x0) is recomputed */,
             float* dx, void* dx_b16, const float* mask, int mask_mode, int T, int J, float* dgamma1, float* dbeta1, float* dgamma0, float* dbeta0, int M, int C, float* scratch, long scratch_floats,
-            hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr);
+            hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr, float rs = 1.0f);
+// dst = s * src ; dst += s * src  (muP readout multiplier on the head weights / their gradients)
+int scale_copy(float* dst, const float* src, float s, long n, hipStream_t st);
+int axpy_scaled(float* dst, const float* src, float s, long n, hipStream_t st);
 
 int embed_fwd(const float* xin, const float* W, const float* b, const float* spos, float* out, int M, int C, int J,
               hipStream_t st);
@@ -97,12 +103,13 @@ int bones_embed_bwd(const float* g, const float* xin, float* dW, float* db, floa
 int tpos_grad(const float* g, float* dtpos, int B, int T, int J, int C, hipStream_t st);
 int scale_rows(const float* g, const float* mask, int mask_mode, void* out, int out_bf16, int M, int C, int T, int J, hipStream_t st);
 int adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1, float beta2, float eps,
-              float weight_decay, float grad_scale, hipStream_t st);
+              float weight_decay, float grad_scale, hipStream_t st, const float* lr_mult = nullptr, const float* wd_mult = nullptr);
 struct MaskDesc { int offset, count; float keep; };
 int droppath_masks(float* masks, const MaskDesc* descs, int ndesc, unsigned long long seed, unsigned long long step,
                    hipStream_t st);
 
 // ---------------------------------------------------------------- attention.hip
+void attn_scale_override(float s);   // softmax scale of the attention launches issued next on this thread (0 = head_dim ** -0.5)
 // qkv: [M][3C] (q | k | v, head-major inside each), out: [M][C]; token layout m = (b*T + t)*J + j
 int attn_spatial_fwd(const void* qkv, void* out, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st);
 int attn_spatial_bwd(const void* qkv, const void* dout, void* dqkv, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st);

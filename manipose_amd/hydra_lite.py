@@ -11,7 +11,11 @@ import yaml
 
 
 class Cfg(dict):
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, key):
+        try:
+            return self[key]
+        except KeyError:
+            raise AttributeError(key) from None
 
     @staticmethod
     def wrap(d):

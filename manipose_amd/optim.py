@@ -20,6 +20,19 @@ class FusedAdam:
         self.exp_avg: Optional[torch.Tensor] = None
         self.exp_avg_sq: Optional[torch.Tensor] = None
         self.param_groups = [{"lr": lr}]          # so torch lr schedulers' bookkeeping style code can read/modify lr
+        self.lr_mult: Optional[torch.Tensor] = None      # MuAdam: per-element lr / weight-decay multipliers in the flat layout
+        self.wd_mult: Optional[torch.Tensor] = None
+
+    def set_multipliers(self, mults) -> None:
+        """{state-dict key: (lr multiplier, weight-decay multiplier)} -> MuAdam-style training (mup_lite.mup_lr_multipliers)."""
+        m = self.model
+        flat = m.flat_parameters()
+        names = {id(p): n for n, p in m.named_parameters()}
+        self.lr_mult, self.wd_mult = torch.ones_like(flat), torch.ones_like(flat)
+        for (off, n), p in zip(m._slots, m._plist):
+            lm, wm = mults[names[id(p)]]
+            self.lr_mult[off:off + n] = lm
+            self.wd_mult[off:off + n] = wm
 
     def _flat_grad(self) -> torch.Tensor:
         m = self.model
@@ -44,6 +57,13 @@ class FusedAdam:
             self.exp_avg_sq = torch.zeros_like(flat)
         self.step_count += 1
         lr = self.param_groups[0]["lr"]
+        if self.lr_mult is not None:
+            if self.lr_mult.device != flat.device:
+                self.lr_mult, self.wd_mult = self.lr_mult.to(flat.device), self.wd_mult.to(flat.device)
+            _lib.check(lib.mp_adam_step_scaled(_lib.ptr(flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), flat.numel(),
+                                               self.step_count, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale,
+                                               _lib.ptr(self.lr_mult), _lib.ptr(self.wd_mult), _lib.stream_ptr()), "mp_adam_step_scaled")
+            return
         _lib.check(lib.mp_adam_step(_lib.ptr(flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
                                     flat.numel(), self.step_count, lr, self.betas[0], self.betas[1], self.eps,
                                     self.weight_decay, grad_scale, _lib.stream_ptr()), "mp_adam_step")

@@ -83,8 +83,9 @@ def mlp(x: Tensor, st: Dict[str, Tensor], pre: str) -> Tensor:
 
 
 def block(x: Tensor, st: Dict[str, Tensor], pre: str, num_heads: int,
-          mask_attn: Optional[Tensor] = None, mask_mlp: Optional[Tensor] = None) -> Tensor:
-    """Block.forward, mix_ste.py:352-368 with residual_scale = 1 (mup=False).
+          mask_attn: Optional[Tensor] = None, mask_mlp: Optional[Tensor] = None, scale: Optional[float] = None, rs: float = 1.0) -> Tensor:
+    """Block.forward, mix_ste.py:352-368; rs = residual_scale (:330: 1, or 1 / sqrt(depth) with mup), scale = the attention's
+    softmax scale (:243-244: head_dim ** -0.5, or 1 / head_dim with mup).
 
     ``mask_*`` are the DropPath multipliers of timm.models.layers.DropPath
     (third party, timm==0.9.16, not vendored in the reference; parity unpinned
@@ -93,20 +94,20 @@ def block(x: Tensor, st: Dict[str, Tensor], pre: str, num_heads: int,
     """
     C = x.shape[-1]
     a = attention(F.layer_norm(x, (C,), st[pre + "norm1.weight"], st[pre + "norm1.bias"], 1e-6),
-                  st, pre + "attn.", num_heads)
+                  st, pre + "attn.", num_heads, scale)
     if mask_attn is not None:
         a = a * mask_attn.view(-1, 1, 1)
-    x = x + a
+    x = x * rs + a
     m = mlp(F.layer_norm(x, (C,), st[pre + "norm2.weight"], st[pre + "norm2.bias"], 1e-6),
             st, pre + "mlp.")
     if mask_mlp is not None:
         m = m * mask_mlp.view(-1, 1, 1)
-    return x + m
+    return x * rs + m
 
 
 def mixste_backbone(x: Tensor, st: Dict[str, Tensor], pre: str, depth: int,
                     num_heads: int, masks: Optional[Dict[str, Tensor]] = None,
-                    embed: bool = True) -> Tensor:
+                    embed: bool = True, scale: Optional[float] = None, rs: float = 1.0) -> Tensor:
     """MixSTE.STE_forward / TTE_foward / ST_foward, mix_ste.py:128-173.
 
     x: (B, L, J, Cin) -> (B, L, J, C). ``masks`` maps
@@ -127,7 +128,7 @@ def mixste_backbone(x: Tensor, st: Dict[str, Tensor], pre: str, depth: int,
 
     def blk(z, name):
         return block(z, st, pre + name + ".", num_heads,
-                     masks.get(pre + name + ".attn"), masks.get(pre + name + ".mlp"))
+                     masks.get(pre + name + ".attn"), masks.get(pre + name + ".mlp"), scale, rs)
 
     # STE_forward :128-145
     x = x.reshape(B * L, J, -1)
@@ -156,24 +157,32 @@ def mixste_backbone(x: Tensor, st: Dict[str, Tensor], pre: str, depth: int,
     return x.contiguous()
 
 
-def mixste_forward(x: Tensor, st, pre: str, depth: int, num_heads: int, masks=None) -> Tensor:
-    """MixSTE.forward, mix_ste.py:175-191: backbone + head Sequential(LN eps 1e-5, Linear)."""
-    h = mixste_backbone(x, st, pre, depth, num_heads, masks)
+def mup_scales(embed_dim: int, num_heads: int, depth: int, readout: float = 1.0) -> dict:
+    """Scales of a MixSTE built with mup=True: attention 1 / head_dim (mix_ste.py:243), residual 1 / sqrt(depth) (:330), and the
+    input multiplier output_mult / width_mult of its mup.MuReadout head (:118-121; third party, mup==1.0.0: parity unpinned)."""
+    return dict(scale=1.0 / (embed_dim // num_heads), rs=depth ** -0.5, readout=readout)
+
+
+def mixste_forward(x: Tensor, st, pre: str, depth: int, num_heads: int, masks=None, scale=None, rs: float = 1.0, readout: float = 1.0) -> Tensor:
+    """MixSTE.forward, mix_ste.py:175-191: backbone + head Sequential(LN eps 1e-5, Linear | MuReadout)."""
+    h = mixste_backbone(x, st, pre, depth, num_heads, masks, scale=scale, rs=rs)
     C = h.shape[-1]
     h = F.layer_norm(h, (C,), st[pre + "head.0.weight"], st[pre + "head.0.bias"], 1e-5)
-    return F.linear(h, st[pre + "head.1.weight"], st[pre + "head.1.bias"])
+    return F.linear(h * readout, st[pre + "head.1.weight"], st[pre + "head.1.bias"])
 
 
 def rmcl_rot_forward(x: Tensor, st, pre: str, depth: int, num_heads: int, n_hyp: int,
-                     masks=None) -> Tuple[Tensor, Tensor]:
-    """RMCLRotMixSTE.forward (rmcl_manifold_mix_ste.py:239-264) with MCLHead.forward (:291-298)."""
+                     masks=None, readout: float = 1.0) -> Tuple[Tensor, Tensor]:
+    """RMCLRotMixSTE.forward (rmcl_manifold_mix_ste.py:239-264) with MCLHead.forward (:291-298).  The backbone is never built with mup
+    (:208-223 does not forward the flag); with mup the prediction heads are MuReadouts (input multiplier `readout`; the score head's
+    fan-in is the joint count, not a width: multiplier 1)."""
     h = mixste_backbone(x, st, pre, depth, num_heads, masks)
     C = h.shape[-1]
     preds, logits = [], []
     for k in range(n_hyp):
         hp = f"{pre}head.{k}."
         z = F.layer_norm(h, (C,), st[hp + "norm.weight"], st[hp + "norm.bias"], 1e-5)
-        z = F.linear(z, st[hp + "prediction_head.weight"], st[hp + "prediction_head.bias"])
+        z = F.linear(z * readout, st[hp + "prediction_head.weight"], st[hp + "prediction_head.bias"])
         preds.append(z[..., :-1])                                                  # (B, L, J, 6)
         logits.append(F.linear(z[..., -1], st[hp + "score_head.weight"], st[hp + "score_head.bias"]))
     hyp = torch.stack(preds, dim=1)                                                # (B, H, L, J, 6)
@@ -182,16 +191,16 @@ def rmcl_rot_forward(x: Tensor, st, pre: str, depth: int, num_heads: int, n_hyp:
 
 
 def bones_forward(x: Tensor, st, pre: str, depth: int, num_heads: int, num_bones: int,
-                  masks=None) -> Tensor:
+                  masks=None, scale=None, rs: float = 1.0, readout: float = 1.0) -> Tensor:
     """BonesMixSTE.forward, manifold_mix_ste.py:139-154. x (B,L,J,2) -> (B,S,1)."""
     B, L, _, _ = x.shape
     z = F.linear(x.reshape(B * L, -1), st[pre + "joints_to_segments_proj.weight"],
                  st[pre + "joints_to_segments_proj.bias"])
     z = z.reshape(B, L, num_bones, -1)
-    h = mixste_backbone(z, st, pre, depth, num_heads, masks, embed=False)
+    h = mixste_backbone(z, st, pre, depth, num_heads, masks, embed=False, scale=scale, rs=rs)
     C = h.shape[-1]
     h = F.layer_norm(h, (C,), st[pre + "head.0.weight"], st[pre + "head.0.bias"], 1e-5)
-    h = F.linear(h, st[pre + "head.1.weight"], st[pre + "head.1.bias"])            # (B, L, S, 1)
+    h = F.linear(h * readout, st[pre + "head.1.weight"], st[pre + "head.1.bias"])  # (B, L, S, 1)
     return h.mean(dim=1)
 
 
@@ -287,8 +296,11 @@ def rmcl_manifold_forward(x: Tensor, st, cfg: dict, masks=None) -> Tuple[Tensor,
     """
     B, L, J, _ = x.shape
     H = cfg["n_hyp"]
-    rot, scores = rmcl_rot_forward(x, st, "rotations_module.", cfg["depth_rot"], cfg["heads_rot"], H, masks)
-    bl = bones_forward(x, st, "segments_module.", cfg["depth_seg"], cfg["heads_seg"], cfg["num_bones"], masks)
+    # cfg["mup"] (optional) = {"rot": mup_scales(...), "seg": mup_scales(...)}: model.mup=True (only `readout` of "rot" applies here)
+    mup = cfg.get("mup") or {}
+    rot, scores = rmcl_rot_forward(x, st, "rotations_module.", cfg["depth_rot"], cfg["heads_rot"], H, masks,
+                                   readout=mup.get("rot", {}).get("readout", 1.0))
+    bl = bones_forward(x, st, "segments_module.", cfg["depth_seg"], cfg["heads_seg"], cfg["num_bones"], masks, **mup.get("seg", {}))
     poses = pose_decoder(rot.reshape(B * H * L, J, -1), bl)
     return poses.reshape(B, H, L, J, 3), scores
 
@@ -296,8 +308,9 @@ def rmcl_manifold_forward(x: Tensor, st, cfg: dict, masks=None) -> Tuple[Tensor,
 def manifold_forward(x: Tensor, st, cfg: dict, masks=None) -> Tensor:
     """ManifoldMixSTE.forward, manifold_mix_ste.py:75-88 (single hypothesis). -> (B,L,J,3)."""
     B, L, J, _ = x.shape
-    rot = mixste_forward(x, st, "rotations_module.", cfg["depth_rot"], cfg["heads_rot"], masks)
-    bl = bones_forward(x, st, "segments_module.", cfg["depth_seg"], cfg["heads_seg"], cfg["num_bones"], masks)
+    mup = cfg.get("mup") or {}
+    rot = mixste_forward(x, st, "rotations_module.", cfg["depth_rot"], cfg["heads_rot"], masks, **mup.get("rot", {}))
+    bl = bones_forward(x, st, "segments_module.", cfg["depth_seg"], cfg["heads_seg"], cfg["num_bones"], masks, **mup.get("seg", {}))
     return pose_decoder(rot.reshape(B * L, J, -1), bl).reshape(B, L, J, 3)
 
 

@@ -1445,3 +1445,68 @@ def test_custom_joint_weights_and_no_agg_segment_table_vs_oracle(lib):
         want = lg - lp if signed else (lg - lp).abs()
         assert got.shape == (B * T, 16)
         close(got, want, rtol=1e-5, atol=1e-6)
+
+
+# --------------------------------------------------------------------------------------------- muP mode (model.mup=True)
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("name", ["mup_manifold", "mup_rmcl"])
+def test_mup_mode_models_vs_reference_fixture(lib, name, precision):
+    """model.mup=True: attention scale 1 / head_dim, residual scale 1 / sqrt(depth) (the reference's own code, pinned by fixtures generated
+    from it) and MuReadout heads (input multiplier 1 / width_mult from base shapes; third-party formula) through the engine."""
+    from test_host_cpu import _mup_model
+    from manipose_amd.metrics import manifold_training_loss, mpjpe_error, rmcl_training_loss
+    fx = load_fixture(name)
+    model = _mup_model(fx)
+    model.precision = precision
+    model = model.cuda().eval()
+    X, y = dev(fx["X"]), dev(fx["y"])
+    if fx["cfg"]["n_hyp"]:
+        poses, scores = model(X)
+        total, _ = rmcl_training_loss(poses, scores, y)
+    else:
+        poses = model(X)
+        total, _ = manifold_training_loss(poses, y)
+    mp = mpjpe_error(poses, dev(fx["poses"]), "average").item()
+    print(f"\n[mup {name} {precision}] MPJPE vs reference {mp * 1e3:.5f} mm")
+    assert mp <= (MPJPE_TOL_M if precision != "bf16" else BF16_MPJPE_TOL_M)
+    total.backward()
+    if precision == "fp32":
+        close(poses, fx["poses"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(total.item(), float(fx["loss_total"]), rtol=1e-4)
+        _check_grads(model, fx)
+    else:
+        cs = {k: _cos(p.grad.cpu(), torch.from_numpy(fx["g::" + k])) for k, p in model.named_parameters()}
+        worst = min(cs.items(), key=lambda kv: kv[1])
+        assert worst[1] > 0.98, worst
+
+
+def test_mup_training_entry_and_muadam_step(lib, tmp_path, monkeypatch):
+    """hpe/main_h36m_lifting.py model.mup=true: base shapes (64 / 27 vs 128 / 81 as main_h36m_lifting.py:681-693), muP re-initialisation,
+    MuAdam multipliers in the fused Adam; one scaled Adam step against torch.optim.Adam with the same per-parameter groups."""
+    import os, sys
+    from manipose_amd.mup_lite import mup_lr_multipliers
+    from manipose_amd.optim import FusedAdam
+    from test_host_cpu import _mup_model
+    fx = load_fixture("mup_manifold")
+    model = _mup_model(fx).cuda()
+    mult = mup_lr_multipliers(model)
+    ref_params = {k: torch.from_numpy(fx["w::" + k]).clone().requires_grad_(True) for k in mult}
+    groups = [{"params": [ref_params[k]], "lr": 1e-3 * lm, "weight_decay": 1e-2 * wm} for k, (lm, wm) in mult.items()]
+    ref = torch.optim.Adam(groups, lr=1e-3, weight_decay=1e-2)
+    for k, p in model.named_parameters():
+        g = torch.from_numpy(fx["g::" + k])
+        p.grad = g.cuda()
+        ref_params[k].grad = g.clone()
+    opt = FusedAdam(model, lr=1e-3, weight_decay=1e-2)
+    opt.set_multipliers(mult)
+    opt.step()
+    ref.step()
+    for k, p in model.named_parameters():
+        close(p.detach(), ref_params[k].detach(), rtol=1e-5, atol=1e-7, msg=k)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hpe"))
+    from _entry import run
+    monkeypatch.chdir(tmp_path)
+    best = run(["model.mup=true", "train.epochs=1", "train.steps_per_epoch=2", "train.batch_size=2", "train.batch_size_test=2", "data.seq_len=27",
+                "model.channels=128", "model.layers=2", "model.nheads=4", "model.channels_seg=64", "model.layers_seg=1", "model.nheads_seg=4",
+                "multi_hyp.n_hyp=2", "data.synthetic_sequences=4", "run.test=false", "model.arch=manifold"])
+    assert np.isfinite(best)

@@ -295,7 +295,8 @@ def test_integration_doc_matches_the_header():
                 assert fl == structs["mp_model_config" if node.name == "ModelConfig" else "mp_loss_config"]
                 n_structs += 1
             if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id == "ModelConfig":
-                assert {k.arg for k in node.keywords} == set(structs["mp_model_config"])
+                kws = {k.arg for k in node.keywords}                       # unnamed fields are zero = their defaults
+                assert kws <= set(structs["mp_model_config"]) and {"arch", "num_frame", "max_batch", "precision", "rot_rep_dim"} <= kws
     assert n_argtypes >= 15 and n_calls >= 6 and n_structs == 2
 
 
@@ -462,3 +463,78 @@ def test_toy_entry_point_runs_the_readme_recipes(tmp_path, monkeypatch):
             toy_main.main(bad)
     with pytest.raises(ValueError):
         toy_main.main(["model.arch=transformer", "train.epochs=1"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# muP mode (model.mup=True): the reference's own muP code pinned by fixtures from the reference (oracle/gen_golden_mup.py); the third-party
+# mup package's parts (MuReadout multiplier, base shapes, MuAdam) restated in manipose_amd/mup_lite.py (parity unpinned)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _mup_oracle_cfg(fx):
+    c = fx["cfg"]
+    wm_rot, wm_seg = (float(v) for v in fx["width_mult"])
+    seg = orc.mup_scales(c["C_seg"], c["heads_seg"], c["depth_seg"], readout=1.0 / wm_seg)
+    if c["n_hyp"]:
+        rot = dict(readout=1.0 / wm_rot)                       # RMCLRotMixSTE: backbone without muP, MuReadout heads
+    else:
+        rot = orc.mup_scales(c["C_rot"], c["heads_rot"], c["depth_rot"], readout=1.0 / wm_rot)
+    return dict(orc.oracle_cfg(c), mup={"rot": rot, "seg": seg})
+
+
+@pytest.mark.parametrize("name", ["mup_manifold", "mup_rmcl"])
+def test_oracle_mup_mode_vs_reference_fixture(name):
+    fx = load_fixture(name)
+    st = {k: v.requires_grad_(True) for k, v in fixture_state(fx).items()}
+    X, y = torch.from_numpy(fx["X"]), torch.from_numpy(fx["y"])
+    cfg = _mup_oracle_cfg(fx)
+    if fx["cfg"]["n_hyp"]:
+        poses, scores = orc.rmcl_manifold_forward(X, st, cfg)
+        np.testing.assert_allclose(scores.detach().numpy(), fx["scores"], rtol=1e-5, atol=1e-6)
+        total, _ = orc.rmcl_training_loss(poses, scores, y)
+    else:
+        poses = orc.manifold_forward(X, st, cfg)
+        total, _ = orc.manifold_training_loss(poses, y)
+    np.testing.assert_allclose(poses.detach().numpy(), fx["poses"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(total.item(), float(fx["loss_total"]), rtol=1e-5)
+    total.backward()
+    for k, v in st.items():
+        want = fx["g::" + k]
+        np.testing.assert_allclose(v.grad.numpy(), want, rtol=2e-3, atol=1e-6 + 1e-4 * np.abs(want).max(), err_msg=k)
+
+
+def _mup_model(fx):
+    """The product's model with mup=True and the fixture's width multipliers, obtained the way the package derives them: base shapes from a
+    base and a delta model (widths rot 16 -> base, seg 4 -> base: multipliers 32/16 = 2 and 16/4 = 4)."""
+    from manipose_amd import ManifoldMixSTE, RMCLManifoldMixSTE, h36m_skeleton
+    from manipose_amd.mup_lite import make_base_shapes, set_base_shapes
+    c = fx["cfg"]
+
+    def build(C_rot, C_seg):
+        kw = dict(num_frame=c["T"], embed_dim_rot=C_rot, depth_rot=c["depth_rot"], num_heads_rot=c["heads_rot"], embed_dim_seg=C_seg,
+                  depth_seg=c["depth_seg"], num_heads_seg=c["heads_seg"], drop_path_rate=0.0, mup=True)
+        return RMCLManifoldMixSTE(h36m_skeleton(), n_hyp=c["n_hyp"], **kw) if c["n_hyp"] else ManifoldMixSTE(h36m_skeleton(), **kw)
+    model = build(c["C_rot"], c["C_seg"])
+    set_base_shapes(model, make_base_shapes(build(16, 4), build(64, 8)), rescale_params=False)
+    model.load_state_dict(fixture_state(fx), strict=True)
+    return model
+
+
+@pytest.mark.parametrize("name", ["mup_manifold", "mup_rmcl"])
+def test_mup_model_construction_matches_the_reference(name):
+    from manipose_amd.mup_lite import MuReadout, mup_lr_multipliers
+    fx = load_fixture(name)
+    model = _mup_model(fx)
+    sc = model._scale_cfg()
+    a_rot, a_seg = (float(v) for v in fx["attn_scales"])
+    r_rot, _, r_seg = (float(v) for v in fx["resid_scales"])
+    d_rot = fx["cfg"]["C_rot"] // fx["cfg"]["heads_rot"]
+    assert abs((sc["qk_scale_rot"] or d_rot ** -0.5) - a_rot) < 1e-7 and abs(sc["qk_scale_seg"] - a_seg) < 1e-7       # mix_ste.py:243
+    assert abs((sc["resid_scale_rot"] or 1.0) - r_rot) < 1e-7 and abs(sc["resid_scale_seg"] - r_seg) < 1e-7             # :330
+    assert abs(sc["readout_mult_rot"] - 0.5) < 1e-7 and abs(sc["readout_mult_seg"] - 0.25) < 1e-7                       # 1 / width_mult
+    got = sorted(n for n, m in model.named_modules() if isinstance(m, MuReadout))
+    assert got == sorted(str(n) for n in fx["readout_modules"])                                                        # which layers are MuReadouts
+    mult = mup_lr_multipliers(model)
+    assert mult["rotations_module.STEblocks.0.attn.qkv.weight"] == (0.5, 2.0)          # two width dimensions: lr / width_mult, wd * width_mult
+    assert mult["segments_module.TTEblocks.1.mlp.fc2.weight"] == (0.25, 4.0)
+    assert mult["rotations_module.Spatial_patch_to_embedding.weight"] == (1.0, 1.0) and mult["rotations_module.Spatial_norm.weight"] == (1.0, 1.0)
+    eng_cfg = model._engine_cfg
+    assert eng_cfg["embed_dim_rot"] == fx["cfg"]["C_rot"]
