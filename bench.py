@@ -32,7 +32,8 @@ PEAK_HBM_GBPS = 8000.0                                         # HBM3E spec peak
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction of
 # MI355X_MICROARCH.md section HBM, + WRITE_SIZE), see profiles/README.md; keyed by (precision, windows per GPU).
 # profiles/r01_final_bf16_B{79,64}_pmc_hbm_traffic.csv, last row: gemm_bf16_persist_kernel, all instantiations (2 x FETCH_SIZE + WRITE_SIZE)
-PMC_TRAFFIC_PER_LAUNCH = {("bf16", 79): 1493.9e6, ("bf16", 64): 1210.2e6}
+# profiles/r02_bf16x3_B79_pmc_hbm_traffic.csv: the same for the split-precision default
+PMC_TRAFFIC_PER_LAUNCH = {("bf16", 79): 1493.9e6, ("bf16", 64): 1210.2e6, ("bf16x3", 79): 1997.7e6}
 
 
 def host_cores():
