@@ -727,6 +727,9 @@ static int persist_workgroups() {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
     n = (cus / 8) * 8;
+    // MANIPOSE_GEMM_WGS: run the persistent GEMMs on fewer workgroups (= CUs), leaving the rest of the chip to kernels of other
+    // streams (a persistent workgroup takes a CU's whole LDS and register file); a multiple of 8 (one share per XCD)
+    if (const char* e = getenv("MANIPOSE_GEMM_WGS")) { const int w = atoi(e); if (w >= 8 && w <= n) n = (w / 8) * 8; }
   }
   if (g_persist_mode < 0) {
     const char* e = getenv("MANIPOSE_GEMM_PERSIST");

@@ -1074,7 +1074,7 @@ def test_rot4_bf16_engine_and_training_step(lib):
     assert np.isfinite(first) and np.isfinite(last) and last < first
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_config5_T81_K5_eval_mpjpe_pck_auc_vs_oracle(lib, precision):
     """BASELINE config #5 shape (MPI-INF-3DHP lifting: T=81, K=5, full width) through the evaluation path of the entry points
     (flip test-time augmentation batched into one forward, weighted-average / best-score / oracle aggregation, MPJPE in mm,
@@ -1105,12 +1105,12 @@ def test_config5_T81_K5_eval_mpjpe_pck_auc_vs_oracle(lib, precision):
                 "oracle_mpjpe": 1000 * orc.mpjpe_error(orac, y).item()}
         pck, auc = orc.keypoint_3d_pck_auc(1000 * agg.reshape(-1, 17, 3), 1000 * y.reshape(-1, 17, 3))
         pmp = 1000 * orc.p_mpjpe(agg.reshape(-1, 17, 3), y.reshape(-1, 17, 3)).item()
-    tol_mm = 0.1 if precision == "fp32" else 10.0                   # north star: 0.1 mm; bf16: the documented drift bound
+    tol_mm = 0.1 if precision != "bf16" else 10.0                   # north star: 0.1 mm (fp32 and the split precision); bf16: the documented drift bound
     for k, v in want.items():
         assert abs(res[k] - v) <= tol_mm, (k, res[k], v)
     a = res["analytics"]
     assert abs(a["mpjpe"] - want["mpjpe"]) <= tol_mm and abs(a["p_mpjpe"] - pmp) <= tol_mm
-    tol_pct = 0.2 if precision == "fp32" else 5.0
+    tol_pct = 0.2 if precision != "bf16" else 5.0
     assert abs(a["pck"] - pck.item()) <= tol_pct and abs(a["auc"] - auc.item()) <= tol_pct, (a["pck"], pck.item(), a["auc"], auc.item())
     assert 1.0 < a["pck"] < 99.0
     print(f"T=81 K=5 {precision}: MPJPE {res['mpjpe']:.3f} mm (oracle {want['mpjpe']:.3f}), PCK {a['pck']:.2f} ({pck.item():.2f}), AUC {a['auc']:.2f} ({auc.item():.2f})")

@@ -1,4 +1,4 @@
-"""Shape sweep of the whole model against the CPU oracle (checker only): unusual window lengths / widths / batch sizes, both precisions,
+"""Shape sweep of the whole model against the CPU oracle (checker only): unusual window lengths / widths / batch sizes, all three precisions,
 forward + fused loss + backward.  python tools/shape_fuzz.py [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,7 +26,7 @@ for T, C, H, B, K in cases:
         op = orc.manifold_forward(X, req, orc.oracle_cfg(cfg))
         ot, _ = orc.manifold_training_loss(op, y)
     ot.backward()
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16x3", "bf16"):
         model = RMCLManifoldMixSTE(n_hyp=K, **kw) if K > 0 else ManifoldMixSTE(**kw)
         model.load_state_dict(st, strict=True)
         model.precision = prec
@@ -44,9 +44,13 @@ for T, C, H, B, K in cases:
         wk = max(errs, key=errs.get)
         gerr = errs[wk]
         cos = min(torch.nn.functional.cosine_similarity(p.grad.cpu().reshape(-1), req[k].grad.reshape(-1), dim=0).item()
-                  for k, p in model.named_parameters())
-        ok = (mp <= 1e-4 and gerr <= 5e-3 and abs(tot.item() - ot.item()) <= 1e-4 * abs(ot.item())) if prec == "fp32" else \
-             (mp <= 5e-2 and np.isfinite(gerr) and abs(tot.item() - ot.item()) <= 5e-2 * abs(ot.item()))
+                  for k, p in model.named_parameters() if req[k].grad.abs().max() > 0)       # (K = 1: the score head has no gradient)
+        if prec == "fp32":
+            ok = mp <= 1e-4 and gerr <= 5e-3 and abs(tot.item() - ot.item()) <= 1e-4 * abs(ot.item())
+        elif prec == "bf16x3":        # forward inside the north-star bound on every shape; bf16 backward
+            ok = mp <= 1e-4 and np.isfinite(gerr) and cos > 0.97 and abs(tot.item() - ot.item()) <= 1e-3 * abs(ot.item())
+        else:
+            ok = mp <= 5e-2 and np.isfinite(gerr) and abs(tot.item() - ot.item()) <= 5e-2 * abs(ot.item())
         worst = max(worst, mp if prec == "fp32" else 0.0)
         print(f"T={T:3d} C={C:3d} H={H} B={B} K={K} {prec}: MPJPE {mp:.2e} m, loss {tot.item():.5f} vs {ot.item():.5f}, worst grad rel {gerr:.2e} ({wk}), min cosine {cos:.4f}  {'ok' if ok else 'FAIL'}",
               flush=True)
