@@ -199,7 +199,7 @@ int mp_model_forward(mp_model* m, const float* flat_params, const float* x, int 
 int mp_model_backward(mp_model* m, const float* flat_params, float* flat_grads, const float* d_poses, const float* d_scores,
                       void* stream);
 /* intermediate outputs of the last forward (device pointers owned by the model): 0 = head output
- * (K, B*T*17, O), 1 = segment lengths (B, 16) */
+ * (K, B*T*17, O), 1 = segment lengths (B, 16), 2 = the DropPath multipliers of the last train-mode forward (layout: mp_model_mask_info) */
 int mp_model_peek(const mp_model* m, int which, const float** ptr, int64_t* numel);
 /* copy `numel` floats of intermediate `which` into dst (device) on `stream` */
 int mp_model_peek_copy(const mp_model* m, int which, float* dst, int64_t numel, void* stream);

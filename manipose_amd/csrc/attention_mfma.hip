@@ -964,7 +964,9 @@ static int num_cus() {
 bool attn_tmfma_supported(int T, int D);
 bool attn_x3_needs_scratch(int temporal, int T, int J, int C, int H) {
   const int D = C / H;
-  return temporal ? !(attn_tmfma_supported(T, D) && C % 8 == 0) : !(attn_smfma_supported(J, D, H) && C % 8 == 0);
+  if (temporal) return !(attn_tmfma_supported(T, D) && C % 8 == 0);
+  // spatial: the frame's two planes must fit the LDS and the register prefetch (7 x 16 B per thread and plane)
+  return !(attn_smfma_supported(J, D, H) && C % 8 == 0 && 2L * J * (6 * C + 16) <= 160 * 1024 && (long)J * (6 * C / 16) <= 7L * H * 64);
 }
 
 int attn_spatial_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* scratch, int B, int T, int J, int C, int H,

@@ -938,6 +938,7 @@ int mp_model_peek(const mp_model* m, int which, const float** ptr, int64_t* nume
   const long Mr = (long)m->B * m->cfg.num_frame * m->cfg.num_joints;
   if (which == 0) { *ptr = m->rot.headout; *numel = (long)m->rot.K * Mr * m->rot.O; return MP_OK; }
   if (which == 1 && m->has_seg) { *ptr = m->lengths; *numel = (long)m->B * m->cfg.num_bones; return MP_OK; }
+  if (which == 2 && m->train) { *ptr = m->maskbuf; *numel = mp_model_mask_floats(m, m->B); return MP_OK; }   // DropPath multipliers of the last train-mode forward
   MP_CHECK(false, MP_ERR_ARG, "mp_model_peek: which=%d", which);
 }
 

@@ -333,6 +333,33 @@ def test_droppath_engine_rng_statistics(lib):
     layout = model._engine.mask_layout(X.shape[0])
     assert [n for n, *_ in layout][:2] == ["rotations_module.STEblocks.0.attn", "rotations_module.STEblocks.0.mlp"]
     assert abs(layout[4][3] - 0.5) < 1e-6 and layout[0][3] == 1.0      # linspace(0, .5, 2) -> keep 1.0, 0.5
+    # the masks the engine drew (timm DropPath semantics, mix_ste.py:8,334-336: Bernoulli(keep) / keep per sample of dim 0): values, empirical
+    # keep frequency, a pure function of (seed, step), independent across steps
+    fx2 = load_fixture("rmcl_tiny")
+    big = _build(fx2, drop_path_rate=0.4).train()
+    Xb = dev(np.tile(fx2["X"], (128, 1, 1, 1)))
+    B = Xb.shape[0]
+    with torch.no_grad():
+        big._seed, big._step_counter = 7, 0
+        big(Xb)
+        m1 = big._engine.peek(2).clone()
+        big(Xb)
+        m2 = big._engine.peek(2).clone()
+        big._step_counter = 0
+        big(Xb)
+        m1_again = big._engine.peek(2).clone()
+    assert torch.equal(m1, m1_again) and not torch.equal(m1, m2)
+    for name, off, cnt, keep in big._engine.mask_layout(B):
+        seg = m1[off:off + cnt]
+        if keep >= 1.0:
+            assert bool((seg == 1).all()), name
+            continue
+        vals = torch.unique(seg)
+        assert set(vals.tolist()) <= {0.0, float(np.float32(1.0 / keep))}, (name, vals)                 # 0 or 1 / keep
+        freq = (seg > 0).float().mean().item()
+        sigma = (keep * (1 - keep) / cnt) ** 0.5
+        assert abs(freq - keep) < 5 * sigma + 1e-3, (name, freq, keep, cnt)                              # empirical keep frequency
+        assert abs(seg.mean().item() - 1.0) < 5 * sigma / keep + 1e-2                                    # E[mask] = 1: the 1 / keep scaling
 
 
 def test_full_size_model_T243_K5_vs_oracle_and_manifold_property(lib):
