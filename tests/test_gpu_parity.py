@@ -1537,3 +1537,21 @@ def test_mup_training_entry_and_muadam_step(lib, tmp_path, monkeypatch):
                 "model.channels=128", "model.layers=2", "model.nheads=4", "model.channels_seg=64", "model.layers_seg=1", "model.nheads_seg=4",
                 "multi_hyp.n_hyp=2", "data.synthetic_sequences=4", "run.test=false", "model.arch=manifold"])
     assert np.isfinite(best)
+
+
+def test_deep_bones_net_draws_more_than_48_droppath_branches(lib):
+    """4 (layers + layers_seg) DropPath branches: 56 with layers=8, layers_seg=6 (the mask kernel takes 48 descriptors per launch)."""
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    torch.manual_seed(3)
+    model = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=9, embed_dim_rot=32, depth_rot=8, num_heads_rot=4, embed_dim_seg=16, depth_seg=6,
+                               num_heads_seg=4, n_hyp=2, drop_path_rate=0.3).cuda().train()
+    X = torch.randn(4, 9, 17, 2, device="cuda")
+    with torch.no_grad():
+        poses, scores = model(X)
+        masks = model._engine.peek(2)
+    layout = model._engine.mask_layout(4)
+    assert len(layout) == 56 and torch.isfinite(poses).all()
+    for name, off, cnt, keep in layout[-4:]:                       # the last branches (beyond descriptor 48) were drawn, not left at zero
+        seg = masks[off:off + cnt]
+        assert set(torch.unique(seg).tolist()) <= {0.0, float(np.float32(1.0 / keep))} and cnt > 0, name
+    assert bool((masks[layout[52][1]:layout[55][1] + layout[55][2]] > 0).any())
