@@ -211,7 +211,9 @@ def main():
         with torch.no_grad():
             p, sc = mdl.eval()(X_par.cuda())
         d = (p - oracle_out["poses"].cuda()).norm(dim=-1)
-        return {"mpjpe_m": d.mean().item(), "max_joint_err_m": d.max().item(),
+        # mean = MPJPE, the north-star metric; the tail is a handful of joints behind near-degenerate 6-D frames (two nearly colinear
+        # 3-vectors: the Gram-Schmidt step divides by |a x b|), where ANY operand rounding is amplified
+        return {"mpjpe_m": d.mean().item(), "p999_joint_err_m": torch.quantile(d.flatten().float(), 0.999).item(), "max_joint_err_m": d.max().item(),
                 "score_max_abs_diff": (sc - oracle_out["scores"].cuda()).abs().max().item()}
 
     model = model.cuda()
