@@ -1,4 +1,4 @@
-"""Longer bf16 training run on a fixed synthetic batch (memorisation): the loss must fall steadily and stay finite.
+"""Longer training run in all three precisions on a fixed synthetic batch (memorisation): the loss must fall steadily and stay finite.
 python tools/train_sanity.py [steps] [batch] [lr]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -40,7 +40,7 @@ with torch.no_grad():
     y = teacher(X)[0][:, 0].contiguous()
 del teacher
 torch.cuda.empty_cache()
-hists = {p: run(p, X, y) for p in ("fp32", "bf16")}
+hists = {p: run(p, X, y) for p in ("fp32", "bf16x3", "bf16")}
 for p, hist in hists.items():
     assert all(torch.isfinite(torch.tensor(hist))), f"{p}: non-finite loss"
     assert hist[-1] < 0.6 * hist[0], (p, hist[0], hist[-1])
