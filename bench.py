@@ -343,7 +343,11 @@ def main():
                                "flops_per_launch": k["flops"] / max(1, k["launches"]),
                                "bytes_per_launch": k["bytes"] / max(1, k["launches"]),
                                "intensity_flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
-                               "mfma_tflops": tflops, "mfma_frac": tflops / peak_tf, "hbm_gbps": gbps, "hbm_frac": gbps / peak_bw}
+                               "mfma_tflops": tflops, "mfma_frac": tflops / peak_tf, "hbm_gbps": gbps, "hbm_frac": gbps / peak_bw,
+                               # flops of the mathematical products only (2 M N K per GEMM: the split forward issues three matrix-core
+                               # products per product and `achieved` counts what is issued)
+                               "model_flops_per_launch": k["model_flops"] / max(1, k["launches"]),
+                               "model_tflops": k["model_flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0}
             tot = sum(v["ms"] for v in prof.values())
             out["kernel_classes"] = {n: {"ms_per_step": v["ms"] / args.steps, "share": v["ms"] / tot if tot else 0.0,
                                          "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}

@@ -212,7 +212,9 @@ int mp_model_peek_copy(const mp_model* m, int which, float* dst, int64_t numel, 
  * once) per class since the last reset and resets. */
 #define MP_PROF_CLASSES 7
 int mp_prof_enable(mp_model* m, int on);
-int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops, double* bytes /* nullable: algorithmic bytes, GEMM classes */);
+int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops, double* bytes /* nullable: algorithmic bytes, GEMM classes */,
+                    double* model_flops /* nullable: 2 M N K of the mathematical products; `flops` counts the matrix-core work issued, 3x that for the
+                                         * split-precision forward */);
 
 /* GPU-resident PoseSequenceGenerator (hpe/mh_so3_hpe/data/generators.py:44-219) + PoseFlip
  * (hpe/mh_so3_hpe/augmentations/transforms.py:7-28, functional.py:7-31): cuts B windows of T frames out of pose sequences stored

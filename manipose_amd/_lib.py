@@ -83,7 +83,7 @@ _SIGNATURES = {
     "mp_pose_metrics": (i32, [vp, C.POINTER(i64), vp, C.POINTER(i64), vp, i32, i32, i32, f32, f32, f32, f32, i32, i32, vp, vp, vp, i64, vp]),
     "mp_set_option": (i32, [C.c_char_p, i32]),
     "mp_prof_enable": (i32, [vp, i32]),
-    "mp_prof_collect": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mp_prof_collect": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 PROF_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "attention", "layernorm", "other", "gemm_persist")   # last: subset of the first two
 

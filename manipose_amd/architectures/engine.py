@@ -107,6 +107,6 @@ class LiftEngine:
 
     def prof_collect(self) -> Dict[str, Dict[str, float]]:
         n = len(_lib.PROF_CLASSES)
-        ms, cnt, fl, by = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)()
-        _lib.check(self.lib.mp_prof_collect(self.handle, ms, cnt, fl, by), "mp_prof_collect")
-        return {name: {"ms": ms[i], "launches": int(cnt[i]), "flops": fl[i], "bytes": by[i]} for i, name in enumerate(_lib.PROF_CLASSES)}
+        ms, cnt, fl, by, mf = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        _lib.check(self.lib.mp_prof_collect(self.handle, ms, cnt, fl, by, mf), "mp_prof_collect")
+        return {name: {"ms": ms[i], "launches": int(cnt[i]), "flops": fl[i], "bytes": by[i], "model_flops": mf[i]} for i, name in enumerate(_lib.PROF_CLASSES)}

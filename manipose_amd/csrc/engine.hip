@@ -86,7 +86,7 @@ struct mp_model {
   bool prof = false;
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_cls;
-  std::vector<double> ev_flops, ev_bytes;
+  std::vector<double> ev_flops, ev_bytes, ev_mflops;   // issued matrix-core flops, algorithmic bytes, flops of the mathematical product (2 M N K)
   std::vector<char> ev_tag;              // 1: the launch ran gemm_bf16_persist_kernel
   size_t ev_used = 0;
 };
@@ -266,12 +266,13 @@ struct ProfScope {
   mp_model* m;
   hipStream_t st;
   bool on;
-  ProfScope(mp_model* mm, hipStream_t s, int cls, double flops, double bytes = 0.0) : m(mm), st(s), on(false) {
+  ProfScope(mp_model* mm, hipStream_t s, int cls, double flops, double bytes = 0.0, double mflops = -1.0) : m(mm), st(s), on(false) {
     if (m->prof && m->ev_used + 2 <= m->ev.size()) {
       on = true;
       m->ev_cls.push_back(cls);
       m->ev_flops.push_back(flops);
       m->ev_bytes.push_back(bytes);
+      m->ev_mflops.push_back(mflops >= 0.0 ? mflops : flops);
       (void)gemm_bf16_take_last_persist();
       (void)hipEventRecord(m->ev[m->ev_used], st);
     }
@@ -324,7 +325,11 @@ static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* 
     // split precision: planar hi/lo A and weights (both planes read), planar outputs (+ the plain-bf16 gelu'), fp32 residual in + out
     g.A_lo = A_lo; g.B_lo = m->wbf_lo + m->params[widx].offset; g.C_lo = C_lo;
     const double ob = epi == EPI_BIAS_RESID ? 8.0 * M * N : 4.0 * M * N + (epi == EPI_BIAS_GELU ? 2.0 * M * N : 0.0);
-    RUNB(PC_GEMM_FWD, 6.0 * M * N * K, 4.0 * (M * K + (double)N * K) + ob, gemm_bf16x3(g, epi == EPI_BIAS_RESID ? 1 : 0, epi, st));
+    {
+      ProfScope ps__(m, st, PC_GEMM_FWD, 6.0 * M * N * K, 4.0 * (M * K + (double)N * K) + ob, 2.0 * M * N * K);   // three products issued per product of the model
+      int rc__ = gemm_bf16x3(g, epi == EPI_BIAS_RESID ? 1 : 0, epi, st);
+      if (rc__) return rc__;
+    }
     return MP_OK;
   }
   // bf16 A and weights; output bf16 (+ a second bf16 output gelu') or, for the residual epilogue, fp32 in + fp32 out
@@ -963,13 +968,14 @@ int mp_prof_enable(mp_model* m, int on) {
   m->ev_cls.clear();
   m->ev_flops.clear();
   m->ev_bytes.clear();
+  m->ev_mflops.clear();
   m->ev_tag.clear();
   return MP_OK;
 }
 
-int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops, double* bytes) {
+int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops, double* bytes, double* model_flops) {
   MP_CHECK(m && ms && launches && flops, MP_ERR_ARG, "mp_prof_collect: null argument");
-  for (int c = 0; c < MP_PROF_CLASSES; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; if (bytes) bytes[c] = 0; }
+  for (int c = 0; c < MP_PROF_CLASSES; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; if (bytes) bytes[c] = 0; if (model_flops) model_flops[c] = 0; }
   for (size_t i = 0; i < m->ev_cls.size() && 2 * i + 1 < m->ev_used; ++i) {
     MP_HIP(hipEventSynchronize(m->ev[2 * i + 1]));
     float t = 0.f;
@@ -979,17 +985,20 @@ int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops, d
     launches[c] += 1;
     flops[c] += m->ev_flops[i];
     if (bytes) bytes[c] += m->ev_bytes[i];
+    if (model_flops) model_flops[c] += m->ev_mflops[i];
     if (i < m->ev_tag.size() && m->ev_tag[i]) {         // class 6: the launches of classes 0/1 that ran gemm_bf16_persist_kernel
       ms[6] += t;
       launches[6] += 1;
       flops[6] += m->ev_flops[i];
       if (bytes) bytes[6] += m->ev_bytes[i];
+      if (model_flops) model_flops[6] += m->ev_mflops[i];
     }
   }
   m->ev_used = 0;
   m->ev_cls.clear();
   m->ev_flops.clear();
   m->ev_bytes.clear();
+  m->ev_mflops.clear();
   m->ev_tag.clear();
   return MP_OK;
 }
