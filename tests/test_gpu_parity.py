@@ -1555,3 +1555,35 @@ def test_deep_bones_net_draws_more_than_48_droppath_branches(lib):
         seg = masks[off:off + cnt]
         assert set(torch.unique(seg).tolist()) <= {0.0, float(np.float32(1.0 / keep))} and cnt > 0, name
     assert bool((masks[layout[52][1]:layout[55][1] + layout[55][2]] > 0).any())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_config2_T27_K1_single_hypothesis_full_width_vs_oracle(lib, precision):
+    """BASELINE config #2: H36M lifting T=27 J=17 K=1 (ManifoldMixSTE) at FULL width (C=512, depth 8; bones net C=128, depth 2), B=3, against
+    the fp32 CPU oracle: poses inside the north-star bound in fp32 and in the split precision, loss, parameter gradients."""
+    from manipose_amd import ManifoldMixSTE, h36m_skeleton
+    from manipose_amd.metrics import manifold_training_loss, mpjpe_error
+    cfg = dict(orc.FULL_CFG, T=27, n_hyp=0)
+    st_ = orc.make_state(cfg, seed=11)
+    model = ManifoldMixSTE(h36m_skeleton(), num_frame=27, drop_path_rate=0.0)
+    model.load_state_dict(st_, strict=True)
+    model.precision = precision
+    model = model.cuda().eval()
+    X, y = orc.synthetic_batch(3, 27, seed=12)
+    pred = model(X.cuda())
+    req = {k: v.clone().requires_grad_(True) for k, v in st_.items()}
+    o_pred = orc.manifold_forward(X, req, orc.oracle_cfg(cfg))
+    mp = mpjpe_error(pred, o_pred.detach().cuda(), "average").item()
+    print(f"\n[config #2 T=27 K=1 {precision}] MPJPE vs oracle {mp * 1e3:.5f} mm")
+    assert mp <= MPJPE_TOL_M and pred.shape == (3, 27, 17, 3) and bool((pred[..., 0, :] == 0).all())
+    total, _ = manifold_training_loss(pred, y.cuda())
+    o_total, _ = orc.manifold_training_loss(o_pred, y)
+    np.testing.assert_allclose(total.item(), o_total.item(), rtol=1e-4 if precision == "fp32" else 1e-3)
+    total.backward()
+    o_total.backward()
+    if precision == "fp32":
+        bad = [(k, ((p.grad.cpu() - req[k].grad).abs().max() / (req[k].grad.abs().max() + 1e-12)).item()) for k, p in model.named_parameters()]
+        assert max(e for _, e in bad) <= 5e-3, sorted(bad, key=lambda t: -t[1])[:3]
+    else:
+        cs = [_cos(p.grad.cpu(), req[k].grad) for k, p in model.named_parameters() if req[k].grad.abs().max() > 0]
+        assert min(cs) > 0.98, min(cs)
