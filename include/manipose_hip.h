@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 3
+#define MP_ABI_VERSION 4
 
 int mp_abi_version(void);
 const char* mp_last_error(void);
@@ -139,6 +139,20 @@ int mp_linear_fwd_bf16x3(const void* x_hi, const void* x_lo, const void* W_hi, c
  * shape (spatial: 16 <= J <= 32 tokens, head dim 64 or 16, <= 8 heads; temporal: T <= 256, head dim 64 or 16); NULL otherwise. */
 int mp_attention_fwd_bf16x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, float* scratch, int temporal,
                             int B, int T, int J, int C, int H, void* stream);
+
+/* K output heads, head k = LayerNorm(C, eps 1e-5) -> Linear(C, O)  (MCLHead stack, rmcl_manifold_mix_ste.py:291-298; MixSTE.head,
+ * mix_ste.py:123-126), all fp32.  Packed parameters: gamma, beta [K][C]; W [K][O][C]; b [K][O].  out [K][M][O]; stats [M][2] (mean, rstd
+ * of x, shared by the heads) and fold (mp_heads_fold_floats(C) floats: the LayerNorm affine folded into the weights) are written by the
+ * forward and, with out, read by the backward.  impl 0 = the engine's choice (fp32 matrix cores when K*O >= 16 and C is 128 or 512, row kernels
+ * otherwise), 1 = row kernels, 2 = matrix cores (MP_ERR_ARG when the shape is not covered).
+ * Backward: dx [M][C] is overwritten; dgamma, dbeta, dW, db are ACCUMULATED into.  scratch: mp_heads_bwd_scratch_floats(K, O, C). */
+int64_t mp_heads_fold_floats(int C);
+int64_t mp_heads_bwd_scratch_floats(int K, int O, int C);
+int mp_heads_fwd(const float* x, const float* gamma, const float* beta, const float* W, const float* b, int K, int O, float* out, float* stats,
+                 float* fold, int M, int C, int impl, void* stream);
+int mp_heads_bwd(const float* x, const float* stats, const float* fold, const float* out, const float* gamma, const float* beta, const float* W,
+                 const float* b, const float* d_out, float* dx, float* dgamma, float* dbeta, float* dW, float* db, int K, int O, int M, int C, int impl,
+                 float* scratch, int64_t scratch_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Model engine: RMCLManifoldMixSTE / ManifoldMixSTE forward + backward as one native launch sequence

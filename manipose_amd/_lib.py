@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MANIPOSE_HIP_LIB") or os.path.join(_HERE, "libmanipos
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "manipose_hip.h")
 
 _lib: Optional[C.CDLL] = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 vp, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
@@ -58,6 +58,10 @@ _SIGNATURES = {
     "mp_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mp_attention_fwd_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mp_attention_bwd_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mp_heads_fold_floats": (i64, [i32]),
+    "mp_heads_bwd_scratch_floats": (i64, [i32, i32, i32]),
+    "mp_heads_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]),
+    "mp_heads_bwd": (i32, [vp] * 14 + [i32, i32, i32, i32, i32, vp, i64, vp]),
     "mp_split_bf16": (i32, [vp, vp, vp, i64, vp]),
     "mp_linear_fwd_bf16x3": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mp_attention_fwd_bf16x3": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -179,6 +179,41 @@ int mp_attention_fwd_bf16x3(const void* qkv_hi, const void* qkv_lo, void* out_hi
                                         (hipStream_t)stream);
 }
 
+static int heads_pick(int impl, int K, int O, int C, const char* who, bool* mfma) {
+  MP_CHECK(impl >= 0 && impl <= 2, MP_ERR_ARG, "%s: impl %d", who, impl);
+  MP_CHECK(K >= 1 && K <= 8 && O >= 1, MP_ERR_ARG, "%s: K=%d O=%d unsupported", who, K, O);
+  *mfma = impl == 2 || (impl == 0 && heads_use_mfma(K, O, C));
+  MP_CHECK(!*mfma || heads_mfma_supported(K, O, C), MP_ERR_ARG, "%s: K=%d O=%d C=%d not covered by the matrix-core heads", who, K, O, C);
+  return MP_OK;
+}
+int64_t mp_heads_fold_floats(int C) { return heads_fold_floats(C); }
+int64_t mp_heads_bwd_scratch_floats(int K, int O, int C) { return 512L * K * ((long)O * C + O + 2 * C) + 256L * heads_fold_floats(C); }
+int mp_heads_fwd(const float* x, const float* gamma, const float* beta, const float* W, const float* b, int K, int O, float* out, float* stats,
+                 float* fold, int M, int C, int impl, void* stream) {
+  MP_CHECK(x && gamma && beta && W && b && out && stats && fold && M > 0, MP_ERR_ARG, "mp_heads_fwd: bad argument");
+  bool mfma = false;
+  if (int rc = heads_pick(impl, K, O, C, "mp_heads_fwd", &mfma)) return rc;
+  HeadParams p = {};
+  for (int k = 0; k < K; ++k) { p.gamma[k] = gamma + (long)k * C; p.beta[k] = beta + (long)k * C; p.W[k] = W + (long)k * O * C; p.b[k] = b + (long)k * O; }
+  return mfma ? heads_fwd_mfma(x, p, K, O, out, stats, M, C, fold, (hipStream_t)stream) : heads_fwd(x, p, K, O, out, stats, M, C, (hipStream_t)stream);
+}
+int mp_heads_bwd(const float* x, const float* stats, const float* fold, const float* out, const float* gamma, const float* beta, const float* W,
+                 const float* b, const float* d_out, float* dx, float* dgamma, float* dbeta, float* dW, float* db, int K, int O, int M, int C, int impl,
+                 float* scratch, int64_t scratch_floats, void* stream) {
+  MP_CHECK(x && stats && fold && out && gamma && beta && W && b && d_out && dx && dgamma && dbeta && dW && db && scratch && M > 0, MP_ERR_ARG,
+           "mp_heads_bwd: bad argument");
+  bool mfma = false;
+  if (int rc = heads_pick(impl, K, O, C, "mp_heads_bwd", &mfma)) return rc;
+  HeadParams p = {};
+  HeadGrads g = {};
+  for (int k = 0; k < K; ++k) {
+    p.gamma[k] = gamma + (long)k * C; p.beta[k] = beta + (long)k * C; p.W[k] = W + (long)k * O * C; p.b[k] = b + (long)k * O;
+    g.gamma[k] = dgamma + (long)k * C; g.beta[k] = dbeta + (long)k * C; g.W[k] = dW + (long)k * O * C; g.b[k] = db + (long)k * O;
+  }
+  return mfma ? heads_bwd_mfma(x, stats, fold, out, p, g, K, O, d_out, dx, M, C, scratch, scratch_floats, (hipStream_t)stream, nullptr)
+              : heads_bwd(x, stats, p, g, K, O, d_out, dx, M, C, scratch, scratch_floats, (hipStream_t)stream);
+}
+
 int mp_gather_windows(const float* poses_2d, const float* poses_3d, const int64_t* seq_offset, int S, const int32_t* win_seq,
                       const int32_t* win_start, const uint8_t* win_flip, const int32_t* mirror, const float* mask2d, const float* noise2d,
                       int B, int T, int J, float* X, float* y, void* stream) {

@@ -34,7 +34,7 @@ struct Module {
   std::vector<BlockP> bp; // order: STE0, TTE0, STE1, TTE1, ...
   int hg[8], hb[8], hw[8], hbias[8], sw[8], sb[8];
   std::vector<BlockWS> ws;
-  float *x_final, *hstats, *headout, *dheadout;
+  float *x_final, *hstats, *hfold, *headout, *dheadout;
   std::vector<MaskBranch> masks;   // 2 per block: attn, mlp
   int mask_base;                   // index of this module's first branch in the global list
 };
@@ -186,6 +186,7 @@ static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int prec
   md.hw_eff = md.readout != 1.0f ? bp.take((long)md.K * md.O * C) : nullptr;
   md.hdw = md.readout != 1.0f ? bp.take((long)md.K * md.O * C) : nullptr;
   md.hstats = bp.take(M * 2);
+  md.hfold = bp.take(heads_fold_floats(C));
   md.headout = bp.take((long)md.K * M * md.O);
   md.dheadout = bp.take((long)md.K * M * md.O);
 }
@@ -196,7 +197,7 @@ static long small_scratch_floats(const mp_model* m) {
   for (const Module* md : mods) s = max(s, 512L * md->K * ((long)md->O * md->C + md->O + 2 * md->C));   // heads_bwd
   s = max(s, 128L * (3 + m->rot.N) * m->rot.C);                                   // embed_bwd
   s = max(s, 33L * m->seg.N * m->seg.C * 35);                                     // bones_embed_bwd
-  s = max(s, 8L * m->cfg.max_batch * m->cfg.num_frame + 64);                       // scores_bwd dlogit / loss partials
+  s = max(s, scores_bwd_scratch_floats(8, m->cfg.max_batch, m->cfg.num_frame) + 64);  // scores_bwd dlogit + partials / loss partials
   return s + 1024;
 }
 
@@ -249,7 +250,7 @@ static void carve_all(mp_model* m, Bump& bp) {
   m->dscore_zero = bp.take((long)Bm * m->rot.K * T);
   m->hsmall_floats = 512L * m->rot.K * ((long)m->rot.O * m->rot.C + m->rot.O + 2 * m->rot.C) + 1024;
   m->hsmall = bp.take(m->hsmall_floats);
-  m->sc_dlogit = bp.take((long)Bm * m->rot.K * T + 64);
+  m->sc_dlogit = bp.take(scores_bwd_scratch_floats(m->rot.K, Bm, T) + 64);
   m->lnpart_slice = 1024L * 4 * m->rot.C;                  // LNB_GRID rows x up to 4 C partial sums (ln_bwd2)
   m->lnpart_n = 3 * 2 * m->rot.depth + 2;                  // at most three LayerNorm backwards per block
   m->lnpart = bp.take(m->lnpart_slice * m->lnpart_n);
@@ -827,7 +828,10 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
   head_params(m, m->rot, fp, hp);
   rc = refresh_head_weights(m, m->rot, fp, st);
   if (rc) return rc;
-  RUN(PC_OTHER, 0, heads_fwd(m->rot.x_final, hp, K, m->rot.O, m->rot.headout, m->rot.hstats, (int)Mr, m->rot.C, st));
+  if (heads_use_mfma(K, m->rot.O, m->rot.C))
+    RUN(PC_OTHER, 0, heads_fwd_mfma(m->rot.x_final, hp, K, m->rot.O, m->rot.headout, m->rot.hstats, (int)Mr, m->rot.C, m->rot.hfold, st));
+  else
+    RUN(PC_OTHER, 0, heads_fwd(m->rot.x_final, hp, K, m->rot.O, m->rot.headout, m->rot.hstats, (int)Mr, m->rot.C, st));
   if (m->cfg.arch == 0) {
     ScoreParams sp;
     for (int k = 0; k < K; ++k) { sp.w[k] = P(m, fp, m->rot.sw[k]); sp.b[k] = P(m, fp, m->rot.sb[k]); }
@@ -850,7 +854,10 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
     head_params(m, m->seg, fp, hs);
     rc = refresh_head_weights(m, m->seg, fp, st);
     if (rc) return rc;
-    RUN(PC_OTHER, 0, heads_fwd(m->seg.x_final, hs, 1, 1, m->seg.headout, m->seg.hstats, (int)Ms, m->seg.C, st));
+    if (heads_use_mfma(1, 1, m->seg.C))
+      RUN(PC_OTHER, 0, heads_fwd_mfma(m->seg.x_final, hs, 1, 1, m->seg.headout, m->seg.hstats, (int)Ms, m->seg.C, m->seg.hfold, st));
+    else
+      RUN(PC_OTHER, 0, heads_fwd(m->seg.x_final, hs, 1, 1, m->seg.headout, m->seg.hstats, (int)Ms, m->seg.C, st));
     RUN(PC_OTHER, 0, bones_mean_fwd(m->seg.headout, m->lengths, B, T, S, st));
     MP_HIP(hipEventRecord(m->ev_join, m->st2));
     st = main_st;
@@ -887,7 +894,7 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     float* sc = m->tmpC;    // (B,K,T) scratch, free at this point of the backward
     RUN(PC_OTHER, 0, scores_fwd(m->rot.headout, sp, K, m->rot.O, sc, B, T, J, st));
     RUN(PC_OTHER, 0, scores_bwd(m->rot.headout, sc, d_scores ? d_scores : m->dscore_zero, sp, sg, K, m->rot.O, m->rot.dheadout, B, T, J,
-                                pst ? m->sc_dlogit : m->small, pst ? (long)K * B * T : m->small_floats, st, pst, pst ? m->ev_heads : nullptr));
+                                pst ? m->sc_dlogit : m->small, pst ? scores_bwd_scratch_floats(K, B, T) : m->small_floats, st, pst, pst ? m->ev_heads : nullptr));
   } else if (pst) {
     MP_HIP(hipEventRecord(m->ev_heads, st));             // dheadout is final: the head parameter gradients may start on the other stream
     MP_HIP(hipStreamWaitEvent(pst, m->ev_heads, 0));
@@ -901,8 +908,12 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   HeadGrads hg;
   head_params(m, m->rot, fp, hp);
   head_grads(m, m->rot, fg, hg);
-  RUN(PC_OTHER, 0, heads_bwd(m->rot.x_final, m->rot.hstats, hp, hg, K, m->rot.O, m->rot.dheadout, m->g, (int)Mr, m->rot.C,
-                             pst ? m->hsmall : m->small, pst ? m->hsmall_floats : m->small_floats, st, pst));
+  if (heads_use_mfma(K, m->rot.O, m->rot.C))
+    RUN(PC_OTHER, 0, heads_bwd_mfma(m->rot.x_final, m->rot.hstats, m->rot.hfold, m->rot.headout, hp, hg, K, m->rot.O, m->rot.dheadout, m->g, (int)Mr, m->rot.C,
+                                    pst ? m->hsmall : m->small, pst ? m->hsmall_floats : m->small_floats, st, pst));
+  else
+    RUN(PC_OTHER, 0, heads_bwd(m->rot.x_final, m->rot.hstats, hp, hg, K, m->rot.O, m->rot.dheadout, m->g, (int)Mr, m->rot.C,
+                               pst ? m->hsmall : m->small, pst ? m->hsmall_floats : m->small_floats, st, pst));
   { int rf = flush_head_grads(m, m->rot, fg, pst ? pst : st); if (rf) return rf; }
   int rc = backbone_bwd(m, m->rot, fp, fg, B, st);
   if (rc) return rc;
@@ -919,8 +930,12 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     head_params(m, m->seg, fp, hs);
     head_grads(m, m->seg, fg, hgs);
     { int rz = zero_head_grad_scratch(m->seg, st); if (rz) return rz; }
-    RUN(PC_OTHER, 0, heads_bwd(m->seg.x_final, m->seg.hstats, hs, hgs, 1, 1, m->seg.dheadout, m->g, (int)Ms, m->seg.C, m->small,
-                               m->small_floats, st));
+    if (heads_use_mfma(1, 1, m->seg.C))
+      RUN(PC_OTHER, 0, heads_bwd_mfma(m->seg.x_final, m->seg.hstats, m->seg.hfold, m->seg.headout, hs, hgs, 1, 1, m->seg.dheadout, m->g, (int)Ms,
+                                      m->seg.C, m->small, m->small_floats, st, nullptr));
+    else
+      RUN(PC_OTHER, 0, heads_bwd(m->seg.x_final, m->seg.hstats, hs, hgs, 1, 1, m->seg.dheadout, m->g, (int)Ms, m->seg.C, m->small,
+                                 m->small_floats, st));
     { int rf = flush_head_grads(m, m->seg, fg, st); if (rf) return rf; }
     rc = backbone_bwd(m, m->seg, fp, fg, B, st);
     if (rc) return rc;

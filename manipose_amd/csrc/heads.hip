@@ -368,40 +368,56 @@ __global__ void scores_bwd_kernel(const float* __restrict__ scores, const float*
   }
 }
 
-// grid K, block 256: dw_k[j] += sum_f dlogit[k][f] * emb[k][f][j]; db_k += sum_f dlogit[k][f]   (J <= 32)
+// dw_k[j] += sum_f dlogit[k][f] * emb[k][f][j]; db_k += sum_f dlogit[k][f]   (J <= 32).  Two launches: grid (SP_BLOCKS, K) sums frame
+// slices into partial[k][block][33] (a thread owns whole frames: the J score channels of a frame are one 4 J O-byte span), then one block
+// per head adds the partials in a fixed order into the gradients.
+constexpr int SP_BLOCKS = 96;
+
 __global__ __launch_bounds__(256) void scores_param_kernel(const float* __restrict__ headout, const float* __restrict__ dlogit,
-                                                            ScoreGrads g, int K, int O, int B, int T, int J) {
-  __shared__ float red[256];
-  const int k = blockIdx.x;
+                                                            float* __restrict__ partial, int O, int B, int T, int J) {
+  __shared__ float red[4][33];
+  const int k = blockIdx.y;
   const long M = (long)B * T * J;
   const int F = B * T;
-  for (int j = 0; j <= J; ++j) {   // j == J -> bias
-    float s = 0.f;
-    for (int f = threadIdx.x; f < F; f += 256) {
-      const float dl = dlogit[(long)k * F + f];
-      s += (j < J) ? dl * headout[((long)k * M + (long)f * J + j) * O + (O - 1)] : dl;
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      if (j < J) g.w[k][j] += red[0];
-      else g.b[k][0] += red[0];
-    }
-    __syncthreads();
+  float s[33];
+#pragma unroll
+  for (int j = 0; j < 33; ++j) s[j] = 0.f;
+  for (int f = blockIdx.x * 256 + threadIdx.x; f < F; f += SP_BLOCKS * 256) {
+    const float dl = dlogit[(long)k * F + f];
+    const float* e = headout + ((long)k * M + (long)f * J) * O + (O - 1);
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (j < J) s[j] += dl * e[(long)j * O];
+    s[32] += dl;
   }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 33; ++j) {
+    const float v = wave_sum(s[j]);
+    if (lane == 0) red[w][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 33) partial[((long)k * SP_BLOCKS + blockIdx.x) * 33 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(64) void scores_param_fin_kernel(const float* __restrict__ partial, ScoreGrads g, int J) {
+  const int k = blockIdx.x, j = threadIdx.x;
+  if (j > 32 || (j >= J && j != 32)) return;
+  float a = 0.f;
+  for (int b = 0; b < SP_BLOCKS; ++b) a += partial[((long)k * SP_BLOCKS + b) * 33 + j];
+  if (j < J) g.w[k][j] += a;
+  else g.b[k][0] += a;
 }
 
 // ev / st_param: when given, the parameter kernel runs on st_param after `ev` (recorded here on `st` behind the kernel that fills
 // `scratch` and the score channel of dheadout); the caller owns `scratch` until it is done
+long scores_bwd_scratch_floats(int K, int B, int T) { return (long)K * B * T + (long)K * SP_BLOCKS * 33; }
+
 int scores_bwd(const float* headout, const float* scores, const float* dscores, const ScoreParams& p, const ScoreGrads& gp, int K,
                int O, float* dheadout, int B, int T, int J, float* scratch, long scratch_floats, hipStream_t st, hipStream_t st_param,
                hipEvent_t ev) {
   MP_CHECK(K >= 1 && K <= 8 && J <= 32, MP_ERR_ARG, "scores_bwd: K=%d J=%d unsupported", K, J);
-  MP_CHECK(scratch_floats >= (long)K * B * T, MP_ERR_ARG, "scores_bwd: scratch too small");
+  MP_CHECK(scratch_floats >= scores_bwd_scratch_floats(K, B, T), MP_ERR_ARG, "scores_bwd: scratch too small");
   hipLaunchKernelGGL(scores_bwd_kernel, dim3(cdiv(B * T, 128)), dim3(128), 0, st, scores, dscores, p, K, O, dheadout, scratch, B, T,
                      J);
   MP_LAUNCH_CHECK();
@@ -410,7 +426,10 @@ int scores_bwd(const float* headout, const float* scores, const float* dscores, 
     MP_HIP(hipStreamWaitEvent(st_param, ev, 0));
     st = st_param;
   }
-  hipLaunchKernelGGL(scores_param_kernel, dim3(K), dim3(256), 0, st, headout, scratch, gp, K, O, B, T, J);
+  float* partial = scratch + (long)K * B * T;
+  hipLaunchKernelGGL(scores_param_kernel, dim3(SP_BLOCKS, K), dim3(256), 0, st, headout, scratch, partial, O, B, T, J);
+  MP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scores_param_fin_kernel, dim3(K), dim3(64), 0, st, partial, gp, J);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

@@ -131,12 +131,21 @@ int split_planes(const float* in, bf16* hi, bf16* lo, long n, hipStream_t st);
 struct HeadParams { const float* gamma[8]; const float* beta[8]; const float* W[8]; const float* b[8]; };
 struct HeadGrads { float* gamma[8]; float* beta[8]; float* W[8]; float* b[8]; };
 int heads_fwd(const float* x, const HeadParams& p, int K, int O, float* out, float* stats, int M, int C, hipStream_t st);
+bool heads_mfma_supported(int K, int O, int C);
+// heads on the fp32 matrix cores (heads_mfma.hip), same results as heads_fwd / heads_bwd.  fold: heads_fold_floats(C) floats owned by the
+// module, written by the forward and read by the same step's backward, which also reads the forward's head outputs (`out`).
+inline long heads_fold_floats(int C) { return 48L * C + 48; }
+bool heads_use_mfma(int K, int O, int C);   // the engine's choice: K O >= 16 outputs and a covered width; MANIPOSE_HEADS_MFMA=0 keeps the row kernels
+int heads_fwd_mfma(const float* x, const HeadParams& p, int K, int O, float* out, float* stats, int M, int C, float* fold, hipStream_t st);
+int heads_bwd_mfma(const float* x, const float* stats, const float* fold, const float* out, const HeadParams& p, const HeadGrads& gp, int K, int O,
+                   const float* dout, float* dx, int M, int C, float* scratch, long scratch_floats, hipStream_t st, hipStream_t st_param);
 int heads_bwd(const float* x, const float* stats, const HeadParams& p, const HeadGrads& gp, int K, int O, const float* dout,
               float* dx, int M, int C, float* scratch, long scratch_floats, hipStream_t st, hipStream_t st_param = nullptr);
 // score head: logit[b,k,t] = sum_j ws_k[j] * headout[k][(b,t,j)][O-1] + bs_k ; scores = softmax_k
 struct ScoreParams { const float* w[8]; const float* b[8]; };
 struct ScoreGrads { float* w[8]; float* b[8]; };
 int scores_fwd(const float* headout, const ScoreParams& p, int K, int O, float* scores, int B, int T, int J, hipStream_t st);
+long scores_bwd_scratch_floats(int K, int B, int T);   // dlogit [K][B T] + the parameter-gradient partials
 int scores_bwd(const float* headout, const float* scores, const float* dscores, const ScoreParams& p, const ScoreGrads& gp,
                int K, int O, float* dheadout, int B, int T, int J, float* scratch, long scratch_floats, hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr);
 int bones_mean_fwd(const float* headout, float* lengths, int B, int T, int S, hipStream_t st);

@@ -153,6 +153,52 @@ def test_layernorm_forward_backward(lib, M, C):
     close(db, br.grad, rtol=1e-4, atol=1e-4)
 
 
+# K output heads = K x [LayerNorm(C, eps 1e-5) -> Linear(C, O)] (MCLHead stack, rmcl_manifold_mix_ste.py:291-298; MixSTE.head,
+# mix_ste.py:123-126) against torch autograd on the CPU, for the row kernels (impl 1) and the fp32 matrix-core kernels (impl 2):
+# ragged token counts (not a multiple of the 16-token MFMA tile, fewer tokens than one tile), both widths, 1..48 output columns.
+@pytest.mark.parametrize("impl,K,O,C,M", [(1, 5, 7, 512, 1003), (2, 5, 7, 512, 1003), (2, 5, 7, 512, 7), (2, 1, 3, 512, 17 * 9 + 1), (2, 3, 7, 128, 77),
+                                          (2, 6, 8, 128, 4131), (1, 1, 1, 128, 333), (2, 1, 1, 128, 333), (2, 2, 7, 512, 100), (2, 4, 7, 128, 1601),
+                                          (2, 8, 5, 512, 2 * 243 * 17), (0, 5, 7, 512, 243 * 17), (0, 1, 1, 128, 243 * 16)])
+def test_output_heads_forward_backward(lib, impl, K, O, C, M):
+    from manipose_amd import _lib
+    g = torch.Generator().manual_seed(7 * M + K + O + C)
+    x = 1.5 * torch.randn(M, C, generator=g) + 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(K, C, generator=g), 0.1 * torch.randn(K, C, generator=g)
+    W, b = torch.randn(K, O, C, generator=g) / C ** 0.5, 0.1 * torch.randn(K, O, generator=g)
+    dout = torch.randn(K, M, O, generator=g)
+    ref = [t.clone().requires_grad_(True) for t in (x, gamma, beta, W, b)]
+    y_ref = torch.stack([torch.nn.functional.linear(torch.nn.functional.layer_norm(ref[0], (C,), ref[1][k], ref[2][k], 1e-5), ref[3][k], ref[4][k])
+                         for k in range(K)])
+    (y_ref * dout).sum().backward()
+    xd, gd, bd, Wd, bbd, dd = (t.cuda() for t in (x, gamma, beta, W, b, dout))
+    out, stats = torch.empty(K, M, O, device="cuda"), torch.empty(M, 2, device="cuda")
+    fold = torch.zeros(lib.mp_heads_fold_floats(C), device="cuda")
+    _lib.check(lib.mp_heads_fwd(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), Wd.data_ptr(), bbd.data_ptr(), K, O, out.data_ptr(), stats.data_ptr(),
+                                fold.data_ptr(), M, C, impl, st()))
+    close(out, y_ref, rtol=1e-5, atol=5e-6)
+    close(stats[:, 0], x.mean(1), rtol=1e-5, atol=1e-6)
+    dx = torch.full((M, C), float("nan"), device="cuda")
+    seed = [0.5 * torch.randn(t.shape, generator=g) for t in (gamma, beta, W, b)]       # parameter gradients are accumulated into
+    grads = [t.cuda() for t in seed]
+    scratch = torch.empty(lib.mp_heads_bwd_scratch_floats(K, O, C), device="cuda")
+    _lib.check(lib.mp_heads_bwd(xd.data_ptr(), stats.data_ptr(), fold.data_ptr(), out.data_ptr(), gd.data_ptr(), bd.data_ptr(), Wd.data_ptr(),
+                                bbd.data_ptr(), dd.data_ptr(), dx.data_ptr(), *[t.data_ptr() for t in grads], K, O, M, C, impl,
+                                scratch.data_ptr(), scratch.numel(), st()))
+    close(dx, ref[0].grad, rtol=1e-4, atol=2e-5)
+    tol = 2e-4 * max(1.0, (M / 1000) ** 0.5)
+    for got, s0, r in zip(grads, seed, ref[1:]):
+        close(got, s0 + r.grad, rtol=1e-4, atol=tol)
+
+
+def test_output_heads_reject_uncovered_shapes(lib):
+    from manipose_amd import _lib
+    t = torch.zeros(4096, device="cuda")
+    for K, O, C in ((5, 7, 256), (7, 7, 512), (1, 9, 512)):        # width without a matrix-core instance; 49 > 48 columns; 9 outputs per head
+        rc = lib.mp_heads_fwd(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), K, O, t.data_ptr(), t.data_ptr(), t.data_ptr(), 4, C, 2, st())
+        assert rc != 0 and b"matrix-core" in lib.mp_last_error(), (K, O, C, rc)
+    assert lib.mp_heads_fwd(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 5, 7, t.data_ptr(), t.data_ptr(), t.data_ptr(), 4, 512, 3, st()) != 0
+
+
 @pytest.mark.parametrize("M,N,K", [(306, 96, 32), (130, 48, 16), (4131, 1536, 512), (1000, 512, 1024)])
 def test_linear_forward_epilogues_and_backward(lib, M, N, K):
     from manipose_amd import _lib
