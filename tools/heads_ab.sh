@@ -1,3 +1,7 @@
+#!/bin/bash
+# Output-heads A/B on one box: the model-level GPU tests that exercise the heads, then the default bench under rocprofv3 with the row
+# kernels (MANIPOSE_HEADS_MFMA=0) and with the matrix-core kernels (=1); prints ms/step and the heads / scores kernel lines of each run.
+# Usage (from the repo root, on the GPU box): bash tools/heads_ab.sh
 set -e
 mkdir -p gpurun_out
 timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "heads or rmcl or manifold or full_size or mix_ste or train or grad or mup or config" > gpurun_out/heads_tests.log 2>&1 || { tail -n 30 gpurun_out/heads_tests.log; exit 1; }
