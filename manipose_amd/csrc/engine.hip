@@ -688,7 +688,17 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   real.base = m->arena;
   carve_all(m, real);
   use_scratch(m, 0);
-  if (hipStreamCreateWithFlags(&m->st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+  // MANIPOSE_SIDE_PRIORITY: queue priority of the side streams relative to the caller's stream (probe; default 0 = same priority).
+  // digit 1 = bones-net stream, digit 2 = weight-gradient stream: 0 normal, 1 low, 2 high  (e.g. 11 = both low)
+  auto side_stream = [](hipStream_t* st, int which) {
+    const char* e = getenv("MANIPOSE_SIDE_PRIORITY");
+    const int v = e ? atoi(e) : 0, mode = which == 0 ? v % 10 : (v / 10) % 10;
+    if (mode == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, mode == 1 ? least : greatest);
+  };
+  if (side_stream(&m->st2, 0) != hipSuccess || hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {
     set_error("mp_model_create: could not create the side stream / events");
     (void)hipFree(m->arena);
@@ -698,7 +708,7 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   {
     const char* ev = getenv("MANIPOSE_WGRAD_STREAM");
     m->wgrad_async = !(ev && atoi(ev) == 0);
-    bool ok = hipStreamCreateWithFlags(&m->st3, hipStreamNonBlocking) == hipSuccess;
+    bool ok = side_stream(&m->st3, 1) == hipSuccess;
     for (int a = 0; a < 2 && ok; ++a)
       for (int b = 0; b < 4 && ok; ++b)
         ok = hipEventCreateWithFlags(&m->evE[a][b], hipEventDisableTiming) == hipSuccess &&
