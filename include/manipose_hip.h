@@ -143,7 +143,7 @@ int mp_attention_fwd_bf16x3(const void* qkv_hi, const void* qkv_lo, void* out_hi
 /* K output heads, head k = LayerNorm(C, eps 1e-5) -> Linear(C, O)  (MCLHead stack, rmcl_manifold_mix_ste.py:291-298; MixSTE.head,
  * mix_ste.py:123-126), all fp32.  Packed parameters: gamma, beta [K][C]; W [K][O][C]; b [K][O].  out [K][M][O]; stats [M][2] (mean, rstd
  * of x, shared by the heads) and fold (mp_heads_fold_floats(C) floats: the LayerNorm affine folded into the weights) are written by the
- * forward and, with out, read by the backward.  impl 0 = the engine's choice (fp32 matrix cores when K*O >= 16 and C is 128 or 512, row kernels
+ * forward and, with out, read by the backward.  impl 0 = the engine's choice (fp32 matrix cores when C is 128, 256 or 512 and K*O <= 48, row kernels
  * otherwise), 1 = row kernels, 2 = matrix cores (MP_ERR_ARG when the shape is not covered).
  * Backward: dx [M][C] is overwritten; dgamma, dbeta, dW, db are ACCUMULATED into.  scratch: mp_heads_bwd_scratch_floats(K, O, C). */
 int64_t mp_heads_fold_floats(int C);

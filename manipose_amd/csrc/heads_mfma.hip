@@ -125,7 +125,7 @@ static int hm_grid(int M) {
   return max(1, min(cdiv(M, 64), cus));
 }
 
-bool heads_mfma_supported(int K, int O, int C) { return K >= 1 && O >= 1 && O <= 8 && K * O <= HM_NPAD && (C == 512 || C == 128); }
+bool heads_mfma_supported(int K, int O, int C) { return K >= 1 && O >= 1 && O <= 8 && K * O <= HM_NPAD && (C == 512 || C == 256 || C == 128); }
 // MANIPOSE_HEADS_MFMA: 0 = row kernels everywhere, 1 (default) = matrix cores wherever covered (a 16-wide tile for the bones head's single
 // output wastes most of the MFMA, but the kernel is bound by reading x either way), 2 = matrix cores only from 16 outputs up
 bool heads_use_mfma(int K, int O, int C) {
@@ -151,8 +151,9 @@ int heads_fwd_mfma(const float* x, const HeadParams& p, int K, int O, float* out
     }                                                                                                                                            \
     hipLaunchKernelGGL((heads_fwd_mfma_kernel<NS_, NT_>), dim3(hm_grid(M / 2 + 1)), dim3(HM_FWD_THREADS), lds, st, x, G, c0, K, O, out, stats, M);              \
   } while (0)
-  if (C == 512) { if (NT == 3) MP_HM_FWD(32, 3); else if (NT == 2) MP_HM_FWD(32, 2); else MP_HM_FWD(32, 1); }
-  else          { if (NT == 3) MP_HM_FWD(8, 3); else if (NT == 2) MP_HM_FWD(8, 2); else MP_HM_FWD(8, 1); }
+  if (C == 512)      { if (NT == 3) MP_HM_FWD(32, 3); else if (NT == 2) MP_HM_FWD(32, 2); else MP_HM_FWD(32, 1); }
+  else if (C == 256) { if (NT == 3) MP_HM_FWD(16, 3); else if (NT == 2) MP_HM_FWD(16, 2); else MP_HM_FWD(16, 1); }
+  else               { if (NT == 3) MP_HM_FWD(8, 3); else if (NT == 2) MP_HM_FWD(8, 2); else MP_HM_FWD(8, 1); }
 #undef MP_HM_FWD
   MP_LAUNCH_CHECK();
   return MP_OK;
@@ -412,8 +413,9 @@ int heads_bwd_mfma(const float* x, const float* stats, const float* fold, const 
                        out, dx, M);                                                                                                              \
   } while (0)
   const int NQ4 = cdiv(K * O, 16);
-  if (C == 512) { if (NQ4 == 3) MP_HM_DX(32, 3); else if (NQ4 == 2) MP_HM_DX(32, 2); else MP_HM_DX(32, 1); }
-  else          { if (NQ4 == 3) MP_HM_DX(8, 3); else if (NQ4 == 2) MP_HM_DX(8, 2); else MP_HM_DX(8, 1); }
+  if (C == 512)      { if (NQ4 == 3) MP_HM_DX(32, 3); else if (NQ4 == 2) MP_HM_DX(32, 2); else MP_HM_DX(32, 1); }
+  else if (C == 256) { if (NQ4 == 3) MP_HM_DX(16, 3); else if (NQ4 == 2) MP_HM_DX(16, 2); else MP_HM_DX(16, 1); }
+  else               { if (NQ4 == 3) MP_HM_DX(8, 3); else if (NQ4 == 2) MP_HM_DX(8, 2); else MP_HM_DX(8, 1); }
 #undef MP_HM_DX
   MP_LAUNCH_CHECK();
   if (st_param != nullptr) st = st_param;

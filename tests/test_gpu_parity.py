@@ -158,7 +158,7 @@ def test_layernorm_forward_backward(lib, M, C):
 # ragged token counts (not a multiple of the 16-token MFMA tile, fewer tokens than one tile), both widths, 1..48 output columns.
 @pytest.mark.parametrize("impl,K,O,C,M", [(1, 5, 7, 512, 1003), (2, 5, 7, 512, 1003), (2, 5, 7, 512, 7), (2, 1, 3, 512, 17 * 9 + 1), (2, 3, 7, 128, 77),
                                           (2, 6, 8, 128, 4131), (1, 1, 1, 128, 333), (2, 1, 1, 128, 333), (2, 2, 7, 512, 100), (2, 4, 7, 128, 1601),
-                                          (2, 8, 5, 512, 2 * 243 * 17), (0, 5, 7, 512, 243 * 17), (0, 1, 1, 128, 243 * 16)])
+                                          (2, 8, 5, 512, 2 * 243 * 17), (0, 5, 7, 512, 243 * 17), (0, 1, 1, 128, 243 * 16), (2, 5, 7, 256, 1500), (0, 1, 3, 256, 999)])
 def test_output_heads_forward_backward(lib, impl, K, O, C, M):
     from manipose_amd import _lib
     g = torch.Generator().manual_seed(7 * M + K + O + C)
@@ -193,7 +193,7 @@ def test_output_heads_forward_backward(lib, impl, K, O, C, M):
 def test_output_heads_reject_uncovered_shapes(lib):
     from manipose_amd import _lib
     t = torch.zeros(4096, device="cuda")
-    for K, O, C in ((5, 7, 256), (7, 7, 512), (1, 9, 512)):        # width without a matrix-core instance; 49 > 48 columns; 9 outputs per head
+    for K, O, C in ((5, 7, 384), (7, 7, 512), (1, 9, 512)):        # width without a matrix-core instance; 49 > 48 columns; 9 outputs per head
         rc = lib.mp_heads_fwd(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), K, O, t.data_ptr(), t.data_ptr(), t.data_ptr(), 4, C, 2, st())
         assert rc != 0 and b"matrix-core" in lib.mp_last_error(), (K, O, C, rc)
     assert lib.mp_heads_fwd(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 5, 7, t.data_ptr(), t.data_ptr(), t.data_ptr(), 4, 512, 3, st()) != 0
