@@ -278,7 +278,7 @@ __device__ __forceinline__ bf16x8_t read_frag2(const char* __restrict__ S, int o
 
 // One k-tile (GBK = 64) of MFMAs for a wave's (BT/2) x 64 sub-tile, fragment reads software-pipelined: the ds_reads of
 // step s+1 are issued before the 8 MFMAs of step s.
-template <int TRA, int TRB, int BT>
+template <int TRA, int TRB, int BT, int ABL = 0>
 __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const char* __restrict__ Bs, f32x4 (&acc)[BT / 32][4], int wr, int wc,
                                           int lane) {
   constexpr int MI = BT / 32;
@@ -288,16 +288,21 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
   for (int j = 0; j < 4; ++j) b_cur[j] = read_frag2<TRB, BT>(Bs, wc * 64 + j * 16, 0, lane);
   a_cur[0] = read_frag2<TRA, BT>(As, wr * (BT / 2), 0, lane);
   a_cur[1] = read_frag2<TRA, BT>(As, wr * (BT / 2) + 16, 0, lane);
+  // ABL (timing ablation, results wrong): 1 = the B fragments are read once per call instead of once per 32 reduction indices,
+  // 2 = the A fragments are read once per call
 #pragma unroll
   for (int step = 0; step < NSTEP; ++step) {
     const int ip = step % HS;
     if (step + 1 < NSTEP) {
       const int nks = (step + 1) / HS, nip = (step + 1) % HS;
-      a_nxt[0] = read_frag2<TRA, BT>(As, wr * (BT / 2) + (2 * nip) * 16, nks, lane);
-      a_nxt[1] = read_frag2<TRA, BT>(As, wr * (BT / 2) + (2 * nip + 1) * 16, nks, lane);
+      if (ABL & 2) { a_nxt[0] = a_cur[1]; a_nxt[1] = a_cur[0]; }
+      else {
+        a_nxt[0] = read_frag2<TRA, BT>(As, wr * (BT / 2) + (2 * nip) * 16, nks, lane);
+        a_nxt[1] = read_frag2<TRA, BT>(As, wr * (BT / 2) + (2 * nip + 1) * 16, nks, lane);
+      }
       if (nip == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b_nxt[j] = read_frag2<TRB, BT>(Bs, wc * 64 + j * 16, nks, lane);
+        for (int j = 0; j < 4; ++j) b_nxt[j] = (ABL & 1) ? b_cur[(j + 1) & 3] : read_frag2<TRB, BT>(Bs, wc * 64 + j * 16, nks, lane);
       }
     }
 #pragma unroll
@@ -306,7 +311,7 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
     for (int j = 0; j < 4; ++j) acc[2 * ip + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[j], a_cur[1], acc[2 * ip + 1][j], 0, 0, 0);
     // pin the order "next step's LDS reads, then this step's 8 MFMAs" (hipcc otherwise sinks the reads behind the MFMAs
     // and exposes their latency before every group)
-    if (step + 1 < NSTEP) {
+    if (ABL == 0 && step + 1 < NSTEP) {
       if ((step + 1) % HS == 0) {            // A and B fragments of the next k-step
         if (TRA && TRB) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
         else if (TRB) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
@@ -317,7 +322,7 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
         else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    if (ABL == 0) __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
     if (step + 1 < NSTEP) {
       a_cur[0] = a_nxt[0];
       a_cur[1] = a_nxt[1];
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
             __builtin_amdgcn_global_load_lds((gptr)(g.bias + n0 + wc * 64 + lane), (lptr)img, 4, 0, 0);
           }
         }
-        mma_stage<0, TRB, BT>(As, Bs, acc, wr, wc, lane);               // term 0: A_lo B_hi, 1: A_hi B_hi, 2: A_hi B_lo
+        mma_stage<0, TRB, BT, (SPLIT >> 1)>(As, Bs, acc, wr, wc, lane);  // term 0: A_lo B_hi, 1: A_hi B_hi, 2: A_hi B_lo
         if (++term == 3) { term = 0; ++kt; }
       }
       (void)stage;
@@ -878,6 +883,15 @@ int gemm_bf16x3(GemmB16Args g, int c_f32, int epi, hipStream_t st) {
            "gemm_bf16x3: K and the leading dimensions must be multiples of 8, N of 4 (M=%d N=%d K=%d)", g.M, g.N, g.K);
   MP_CHECK(g.A_lo && g.B_lo && (c_f32 || g.C_lo), MP_ERR_ARG, "gemm_bf16x3: lo plane missing");
   g.k_per_split = ((g.K + GBK - 1) / GBK) * GBK;
+  {
+    static const int abl = [] { const char* e = getenv("MANIPOSE_GEMM_ABL"); return e ? atoi(e) : 0; }();     // timing ablation of the fragment reads
+    if (abl && !c_f32 && epi == EPI_BIAS) {
+      const int wgs = persist_workgroups();
+      if (abl == 1) return launch_persist<0, bf16p, EPI_BIAS, 3>(g, wgs, st);
+      if (abl == 2) return launch_persist<0, bf16p, EPI_BIAS, 5>(g, wgs, st);
+      return launch_persist<0, bf16p, EPI_BIAS, 7>(g, wgs, st);
+    }
+  }
   if (!c_f32 && epi == EPI_BIAS) return launch_glds<0, 0, bf16p, EPI_BIAS, 1>(g, 1, st);
   if (!c_f32 && epi == EPI_BIAS_GELU) return launch_glds<0, 0, bf16p, EPI_BIAS_GELU, 1>(g, 1, st);
   if (c_f32 && epi == EPI_BIAS) return launch_glds<0, 0, float, EPI_BIAS, 1>(g, 1, st);
