@@ -647,23 +647,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       char* const B1 = smem + STAGE + OPB;
       // one loop body for the three steps (a single copy of the MFMA stage: three inlined copies spill at the 256-VGPR limit); the
       // buffers of a step are wave-uniform selects
+      // DMA schedule: step 0 requests A_hi[kt] (used by step 1), step 1 requests B_lo[kt] (step 2) and then - A0 is free as soon as step 0
+      // is over - A_lo of the NEXT k-tile / tile (used two steps later), step 2 requests the next B_hi (one step later).  Step 2 waits with
+      // vmcnt(4): requests retire in order, so B_lo has landed while the four A_lo requests issued behind it may still be in flight -
+      // one of the two tiles the next step 0 needs has two steps to arrive instead of one.
+      bool early = false;
       for (int kt = 0, term = 0; kt < nk;) {
         if (kt == 0 && term == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only: (A_lo, B_hi) of this tile were waited for before the previous epilogue
+        else if (term == 2 && early) __builtin_amdgcn_s_waitcnt(0x0074);             // vmcnt(4) lgkmcnt(0)
         else __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
         const char* As = term == 0 ? A0 : A1;
         const char* Bs = term == 2 ? B1 : B0;
+        const bool last = kt + 1 == nk;
         if (term == 0) {
           persist_dma(A1, a_base(m0, kt), aoff, wave);                    // A_hi[kt]
         } else if (term == 1) {
           persist_dma(B1, b_base(n0, kt) + b_lo, boff, wave);             // B_lo[kt]
-        } else {
-          const bool last = kt + 1 == nk;
-          if (!last || has_next) {
+          early = !last || has_next;
+          if (early) {
             if (last) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
-            persist_dma(A0, a_base(last ? m0n : m0, last ? 0 : kt + 1) + a_lo, aoff, wave);      // A_lo, B_hi of the next k-tile / tile
-            persist_dma(B0, b_base(last ? n0n : n0, last ? 0 : kt + 1), boff, wave);
+            persist_dma(A0, a_base(last ? m0n : m0, last ? 0 : kt + 1) + a_lo, aoff, wave);      // A_lo of the next k-tile / tile
           }
+        } else {
+          if (!last || has_next) persist_dma(B0, b_base(last ? n0n : n0, last ? 0 : kt + 1), boff, wave);   // B_hi of the next k-tile / tile
           if (last && has_bias) {
             typedef __attribute__((address_space(3))) void* lptr;
             typedef const __attribute__((address_space(1))) void* gptr;
