@@ -884,7 +884,7 @@ int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, 
 }
 
 int gemm_bf16x3(GemmB16Args g, int c_f32, int epi, hipStream_t st) {
-  g.debug = 0;
+  { const char* e = getenv("MANIPOSE_GEMM_DEBUG"); g.debug = e ? (atoi(e) & 4) : 0; }   // timing ablation: 4 = no epilogue (the only bit the split loop looks at)
   MP_CHECK(g.M > 0 && g.N > 0 && g.K > 0, MP_ERR_ARG, "gemm_bf16x3: empty problem");
   MP_CHECK(g.K % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.N % 4 == 0 && g.ldc % 4 == 0, MP_ERR_ARG,
            "gemm_bf16x3: K and the leading dimensions must be multiples of 8, N of 4 (M=%d N=%d K=%d)", g.M, g.N, g.K);
