@@ -1,12 +1,16 @@
 #!/bin/bash
-# Build libmanipose_hip.so for gfx950 (MI355X) in-tree.  Usage: manipose_amd/csrc/build.sh [-j N]
+# Build libmanipose_hip.so for gfx950 (MI355X) in-tree.  Usage: manipose_amd/csrc/build.sh
+# MP_DIAG=1: the diagnostics build (-DMP_GEMM_DIAG: per-tile time stamps / start stagger in the persistent GEMMs) -> libmanipose_hip_diag.so,
+# loaded through MANIPOSE_HIP_LIB by tools/gemm_stamps.py; never the product library.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../libmanipose_hip.so"
 OBJ="$HERE/_obj"
+EXTRA=""
+if [ "${MP_DIAG:-0}" = "1" ]; then OUT="$HERE/../libmanipose_hip_diag.so"; OBJ="$HERE/_obj_diag"; EXTRA="-DMP_GEMM_DIAG"; fi
 mkdir -p "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $EXTRA"
 pids=()
 for f in "$HERE"/*.hip; do
   o="$OBJ/$(basename "${f%.hip}").o"

@@ -628,6 +628,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   typename ZType<TC>::type* const Z = reinterpret_cast<typename ZType<TC>::type*>(g.Z);
   float* const img = reinterpret_cast<float*>(smem + 2 * STAGE + wave * 4096);
   const bool has_bias = EPI != EPI_DGELU && g.bias != nullptr;
+#ifdef MP_GEMM_DIAG                                          // diagnostics build (MP_DIAG=1 build.sh -> libmanipose_hip_diag.so, tools/gemm_stamps.py)
+  int tile_no = 0;
+  if (g.stagger > 0) {                                      // start the workgroups of an XCD in four phase groups
+    const int phase = (blockIdx.x >> 3) & 3;
+    if (phase) {
+      const long long t0 = wall_clock64(), dt = (long long)phase * g.stagger;
+      while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+#endif
 
   while (true) {
     const int idn = id + gridDim.x;
@@ -709,6 +719,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
     landed = true;
 
     // ---- epilogue, 16 rows of the wave's 128 x 64 sub-tile per pass through the wave-private image ----
+#ifdef MP_GEMM_DIAG
+    if (g.stamps != nullptr && tid == 0 && tile_no < 64) g.stamps[((long)blockIdx.x * 64 + tile_no) * 2] = wall_clock64();
+#endif
     if (!(g.debug & 4)) {
       // the lane indices pass through an opaque move so that the epilogue's address arithmetic is redone per tile instead of
       // being hoisted out of the tile loop, where it would sit in ~20 VGPRs across the main loop (the kernel runs at the
@@ -721,6 +734,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       if (m0 + BT <= g.M) persist_epilogue<TC, EPI, true>(g, acc, img, m0 + wr * 128, col, bias4, C, Z, e15, eq);
       else persist_epilogue<TC, EPI, false>(g, acc, img, m0 + wr * 128, col, bias4, C, Z, e15, eq);
     }
+#ifdef MP_GEMM_DIAG
+    if (g.stamps != nullptr && tid == 0 && tile_no < 64) g.stamps[((long)blockIdx.x * 64 + tile_no) * 2 + 1] = wall_clock64();
+    ++tile_no;
+#endif
     if (!has_next) break;
     id = idn; m0 = m0n; n0 = n0n;
   }
@@ -755,8 +772,18 @@ static thread_local int g_last_persist = 0;
 int gemm_bf16_take_last_persist() { const int v = g_last_persist; g_last_persist = 0; return v; }
 
 template <int TRB, typename TC, int EPI, int SPLIT = 0>
-static int launch_persist(const GemmB16Args& g, int wgs, hipStream_t st) {
+static int launch_persist(const GemmB16Args& g_in, int wgs, hipStream_t st) {
   g_last_persist = 1;
+  GemmB16Args g = g_in;
+  g.stamps = nullptr; g.stagger = 0;
+#ifdef MP_GEMM_DIAG
+  {
+    static long long* const stamps = [] { const char* e = getenv("MANIPOSE_GEMM_STAMPS"); return e ? (long long*)strtoull(e, nullptr, 0) : (long long*)nullptr; }();
+    g.stamps = stamps;
+    static const int stagger = [] { const char* e = getenv("MANIPOSE_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+    g.stagger = stagger;
+  }
+#endif
   constexpr size_t lds = 2 * 2 * 256 * 128 + 8 * 4096;     // two operand stages + the epilogue images = 160 KiB
   static bool attr_set = false;
   if (!attr_set) {

@@ -46,6 +46,8 @@ struct GemmB16Args {
   float* bias_slab;
   int k_per_split;
   int debug;           // timing-ablation bits (MANIPOSE_GEMM_DEBUG), 0 in production
+  int stagger;         // diagnostics (MANIPOSE_GEMM_STAGGER): start delay per phase group of the persistent kernels, clock ticks
+  long long* stamps;   // diagnostics (MANIPOSE_GEMM_STAMPS=<device address>): persistent kernels record [workgroup][tile < 64][epilogue start, end] in 10 ns ticks
   // split precision (gemm_bf16x3): lo planes of A, B and (planar outputs) C; A / B / C are the hi planes (common.h: bf16p)
   const void* A_lo;
   const void* B_lo;
