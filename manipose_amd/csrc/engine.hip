@@ -195,7 +195,7 @@ static long small_scratch_floats(const mp_model* m) {
   long s = 1024L * 4 * 1024;                                                       // ln_bwd / ln_bwd2 partials (LNB_GRID rows)
   const Module* mods[2] = {&m->rot, &m->seg};
   for (const Module* md : mods) s = max(s, 512L * md->K * ((long)md->O * md->C + md->O + 2 * md->C));   // heads_bwd
-  s = max(s, 128L * (3 + m->rot.N) * m->rot.C);                                   // embed_bwd
+  s = max(s, embed_bwd_scratch_floats(m->rot.C, m->rot.N));                       // embed_bwd
   s = max(s, 33L * m->seg.N * m->seg.C * 35);                                     // bones_embed_bwd
   s = max(s, scores_bwd_scratch_floats(8, m->cfg.max_batch, m->cfg.num_frame) + 64);  // scores_bwd dlogit + partials / loss partials
   return s + 1024;

@@ -96,6 +96,7 @@ int axpy_scaled(float* dst, const float* src, float s, long n, hipStream_t st);
 
 int embed_fwd(const float* xin, const float* W, const float* b, const float* spos, float* out, int M, int C, int J,
               hipStream_t st);
+long embed_bwd_scratch_floats(int C, int J);
 int embed_bwd(const float* g, const float* xin, float* dW, float* db, float* dspos, int M, int C, int J, float* scratch,
               long scratch_floats, hipStream_t st);
 int bones_embed_fwd(const float* xin, const float* W, const float* b, const float* spos, float* out, int BT, int IN, int O,
