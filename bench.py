@@ -10,8 +10,12 @@ relays its output.
 Prints ONE JSON line on rank 0 with
   `roofline`      dominant kernel = gemm_bf16_persist_kernel, the forward + dgrad Linear GEMMs; HIP events inside the engine on the
                   stream each launch goes to;
-  `parity`        MPJPE of the TIMED precision against the fp32 CPU oracle at full size (T=243 K=5, B=1, the bench's own weights),
-                  measured in this run, with the north-star bound 1e-4 m (the oracle forward runs in a CPU child process);
+  `parity`        MPJPE of the TIMED precision against the fp32 CPU oracle at full size (T=243 K=5, the bench's own weights), measured in
+                  this run AT THE TIMED BATCH: the parity windows are embedded in a full B-window eval forward, so the kernels that are
+                  timed (the persistent split-precision GEMMs incl. the recomputed-LayerNorm residual epilogue) are the ones checked;
+                  the same windows as a stand-alone small batch are reported next to it (`mpjpe_m_small_batch`); bound 1e-4 m
+                  (north star); the oracle forward runs in a CPU child process; at N>1 every rank checks its own replica;
+  `rccl`          (N>1) backend name and the sum of a ones tensor all-reduced over the process group = the ranks RCCL really joined;
   `other_precisions`  (N=1) poses/s and the same parity figure of the other two precisions, a few steps each;
   `cpu_baseline`  oracle/manipose_ref.py timed on the host cores (rank 0, N=1 only).
 Default precision: "bf16x3" (split bf16 hi/lo operands, three matrix-core products per product, fp32 accumulate) - the fastest
@@ -29,11 +33,19 @@ sys.path.insert(0, ROOT)
 TRAIN_GFLOP_PER_POSE = {243: 3.705, 81: 3.562, 27: 3.513}      # SURVEY.md 8d (3 x forward GEMM+attention FLOPs)
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}                  # MI355X_MICROARCH.md: dense matrix peaks
 PEAK_HBM_GBPS = 8000.0                                         # HBM3E spec peak (measured copy peak on this pool: ~5.5-6.3 TB/s)
-# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction of
-# MI355X_MICROARCH.md section HBM, + WRITE_SIZE), see profiles/README.md; keyed by (precision, windows per GPU).
-# profiles/r01_final_bf16_B{79,64}_pmc_hbm_traffic.csv, last row: gemm_bf16_persist_kernel, all instantiations (2 x FETCH_SIZE + WRITE_SIZE)
-# profiles/r02_bf16x3_B79_pmc_hbm_traffic.csv: the same for the split-precision default
-PMC_TRAFFIC_PER_LAUNCH = {("bf16", 79): 1493.9e6, ("bf16", 64): 1210.2e6, ("bf16x3", 79): 1997.7e6}
+
+
+def pmc_traffic_per_launch(precision, batch):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (2 x FETCH_SIZE per the gfx950 correction of
+    MI355X_MICROARCH.md section HBM, + WRITE_SIZE): profiles/pmc_traffic.json, written by tools/refresh_profiles.sh together with the
+    <tag>_pmc_hbm_traffic.csv whose last row it repeats (one source, so the two cannot diverge).  None when that configuration
+    was never profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(f"{precision}:{batch}", {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
 
 
 def host_cores():
@@ -103,6 +115,7 @@ def free_port():
 
 
 PARITY_BOUND_M = 1e-4          # BASELINE.json north_star: outputs within 1e-4 on MPJPE
+PARITY_WINDOWS = 3             # parity windows per run (oracle forward on the host: ~1 s each), spread over the timed batch
 EXTRA_BATCH = {"fp32": 16, "bf16": 79, "bf16x3": 79}
 
 
@@ -162,14 +175,19 @@ def main():
         return mdl
 
     model = build_model(args.precision, args.batch)
-    cpu_json, oracle_out, X_par = None, None, None
+    cpu_json, oracle_out = None, None
+    # parity windows: the same on every rank (own generator), placed at the start, middle and end of the timed batch
+    gp = torch.Generator().manual_seed(4242)
+    npar = min(PARITY_WINDOWS, args.batch)
+    X_par = (0.3 * torch.randn(npar, args.frames, 17, 2, generator=gp)).clamp(-1, 1)
+
+    def spread(nb):          # rows of an nb-window batch that carry the parity windows: first, middle, last
+        return [min(nb - 1, (i * (nb - 1)) // max(1, npar - 1)) for i in range(npar)]
     want_cpu = world == 1 and args.gpus == 1 and not args.no_cpu_baseline
     if rank == 0 and (want_cpu or not args.no_parity):
         io_dir = tempfile.mkdtemp(prefix="manipose_bench_")
         child = [sys.executable, os.path.abspath(__file__), "--frames", str(args.frames), "--hyp", str(args.hyp)]
         if not args.no_parity:
-            gp = torch.Generator().manual_seed(4242)
-            X_par = (0.3 * torch.randn(1, args.frames, 17, 2, generator=gp)).clamp(-1, 1)
             torch.save({"state": {k: v.detach().clone() for k, v in model.state_dict().items()}, "X": X_par, "T": args.frames, "K": args.hyp},
                        os.path.join(io_dir, "parity_in.pt"))
             child += ["--parity-io", io_dir]
@@ -204,38 +222,75 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
-    def parity_of(mdl):
-        """MPJPE (m) of mdl's eval-mode forward on the parity window against the oracle's poses; None without the oracle output."""
-        if oracle_out is None:
-            return None
-        with torch.no_grad():
-            p, sc = mdl.eval()(X_par.cuda())
-        d = (p - oracle_out["poses"].cuda()).norm(dim=-1)
-        # mean = MPJPE, the north-star metric; the tail is a handful of joints behind near-degenerate 6-D frames (two nearly colinear
-        # 3-vectors: the Gram-Schmidt step divides by |a x b|), where ANY operand rounding is amplified
-        return {"mpjpe_m": d.mean().item(), "p999_joint_err_m": torch.quantile(d.flatten().float(), 0.999).item(), "max_joint_err_m": d.max().item(),
-                "score_max_abs_diff": (sc - oracle_out["scores"].cuda()).abs().max().item()}
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
+    # every rank starts from rank 0's weights (one broadcast of the flat buffer) and - for the parity block - holds rank 0's oracle output
+    rccl = None
+    have_oracle = torch.tensor([1 if oracle_out is not None else 0], device="cuda", dtype=torch.int32)
     model = model.cuda()
-    parity = parity_of(model) if rank == 0 else None          # on the initial weights, before any optimisation step
-    model = model.train()
-    trainer = LiftingTrainer(model, lr=4e-5, weight_decay=1e-6, seed=42)
+    if world > 1:
+        from manipose_amd.distributed import broadcast_parameters
+        model._ensure_engine(args.batch, torch.device("cuda", local))
+        broadcast_parameters(model._flat)
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)                  # every rank contributes 1: the sum is the number of ranks the backend really joined
+        rccl = {"backend": dist.get_backend(), "ranks": int(round(ones.item())), "world_size": world,
+                "device": torch.cuda.get_device_name(local)}
+        dist.broadcast(have_oracle, src=0)
+        if have_oracle.item():
+            K = args.hyp
+            op = oracle_out["poses"].cuda() if rank == 0 else torch.empty(npar, K, args.frames, 17, 3, device="cuda")
+            osc = oracle_out["scores"].cuda() if rank == 0 else torch.empty(npar, K, args.frames, 1, device="cuda")
+            dist.broadcast(op, src=0)
+            dist.broadcast(osc, src=0)
+            oracle_out = {"poses": op, "scores": osc}
+    elif oracle_out is not None:
+        oracle_out = {k: v.cuda() for k, v in oracle_out.items()}
+
     B, T = args.batch, args.frames
     g = torch.Generator(device="cuda").manual_seed(42 + rank)
     X = (0.3 * torch.randn(B, T, 17, 2, device="cuda", generator=g)).clamp(-1, 1)
     y = 0.3 * torch.randn(B, T, 17, 3, device="cuda", generator=g)
     y[:, :, 0] = 0
 
+    def parity_of(mdl, Xfull):
+        """MPJPE (m) of mdl's eval-mode forward against the oracle's poses on the parity windows, measured twice: with the windows embedded
+        in the full batch Xfull at its first, middle and last row (the shapes - and therefore the kernels - of the timed steps) and as a
+        small stand-alone batch.  None without the oracle output."""
+        if oracle_out is None or Xfull.shape[0] < npar:
+            return None
+        idx = spread(Xfull.shape[0])
+        Xe = Xfull.clone()
+        Xe[idx] = X_par.cuda()
+        with torch.no_grad():
+            pf, sf = mdl.eval()(Xe)
+            pf, sf = pf[idx].clone(), sf[idx].clone()
+            p1, _ = mdl(X_par.cuda())
+        d = (pf - oracle_out["poses"]).norm(dim=-1)
+        d1 = (p1 - oracle_out["poses"]).norm(dim=-1)
+        # mean = MPJPE, the north-star metric; the tail is a handful of joints behind near-degenerate 6-D frames (two nearly colinear
+        # 3-vectors: the Gram-Schmidt step divides by |a x b|), where ANY operand rounding is amplified
+        return {"mpjpe_m": d.mean().item(), "mpjpe_m_small_batch": d1.mean().item(), "batch": int(Xfull.shape[0]), "windows_checked": npar, "rows_in_batch": idx,
+                "p999_joint_err_m": torch.quantile(d.flatten().float(), 0.999).item(), "max_joint_err_m": d.max().item(),
+                "score_max_abs_diff": (sf - oracle_out["scores"]).abs().max().item()}
+
+    parity = parity_of(model, X)               # on the initial weights, before any optimisation step; every rank checks its own replica
+    if world > 1 and parity is not None:
+        worst = torch.tensor([parity["mpjpe_m"]], device="cuda", dtype=torch.float64)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        parity["mpjpe_m_worst_rank"] = worst.item()
+        parity["ranks_checked"] = world
+    model = model.train()
+    trainer = LiftingTrainer(model, lr=4e-5, weight_decay=1e-6, seed=42)
+
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def log(msg):
-        if rank == 0:
-            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
-
-    log(f"model built, B={B} T={T} precision={args.precision}")
+    log(f"model built, B={B} T={T} precision={args.precision}" + (f", parity at B={B}: {parity['mpjpe_m']:.2e} m" if parity else ""))
     for i in range(args.warmup):
         terms = trainer.train_step(X, y)
         if i == 0:
@@ -274,10 +329,10 @@ def main():
             try:
                 Bx = EXTRA_BATCH[prec]
                 mx = build_model(prec, Bx).cuda()
-                par = parity_of(mx)
-                tx = LiftingTrainer(mx.train(), lr=4e-5, weight_decay=1e-6, seed=42)
                 Xx = X[:Bx] if Bx <= B else X.repeat((Bx + B - 1) // B, 1, 1, 1)[:Bx]
                 yx = y[:Bx] if Bx <= B else y.repeat((Bx + B - 1) // B, 1, 1, 1)[:Bx]
+                par = parity_of(mx, Xx)
+                tx = LiftingTrainer(mx.train(), lr=4e-5, weight_decay=1e-6, seed=42)
                 nst = 5 if prec != "fp32" else 3
                 tx.train_step(Xx, yx)
                 torch.cuda.synchronize()
@@ -306,9 +361,15 @@ def main():
                           "seq_len": T, "parallelism": f"dp{world}", "precision": args.precision, "drop_path_rate": 0.1},
                "loss": loss, "model_tflops": poses_per_s * gf / 1e3}
         if parity is not None:
-            out["parity"] = dict(parity, precision=args.precision, bound_m=PARITY_BOUND_M, within_bound=parity["mpjpe_m"] <= PARITY_BOUND_M,
-                                 sample=f"T={T} K={args.hyp} B=1 eval-mode forward on the bench model's initial weights (seed 42) vs the fp32 CPU "
-                                        f"oracle (oracle/manipose_ref.py) run in a CPU child process of this job")
+            worst = max(parity["mpjpe_m"], parity["mpjpe_m_small_batch"], parity.get("mpjpe_m_worst_rank", 0.0))
+            out["parity"] = dict(parity, precision=args.precision, bound_m=PARITY_BOUND_M, within_bound=worst <= PARITY_BOUND_M,
+                                 sample=f"T={T} K={args.hyp}: {npar} parity windows embedded in an eval-mode forward of the TIMED batch "
+                                        f"(B={B} windows: the persistent split-precision GEMMs and their recomputed-LayerNorm residual epilogue "
+                                        f"run, as in the timed steps) on the bench model's initial weights (seed 42), and the same windows as a "
+                                        f"stand-alone B={npar} batch (mpjpe_m_small_batch), vs the fp32 CPU oracle "
+                                        f"(oracle/manipose_ref.py) run in a CPU child process of this job")
+        if rccl is not None:
+            out["rccl"] = rccl
         if other:
             out["other_precisions"] = other
         if prof is not None:
@@ -319,35 +380,36 @@ def main():
                 k = sub
                 kname = ("gemm_bf16_persist_kernel (forward + dgrad Linear GEMMs: persistent, direct-to-LDS 256x256x64 tiles, "
                          "v_mfma_f32_16x16x32_bf16; all instantiations" +
-                         ("; the split-precision forward instantiations read planar hi/lo operands and issue 3 products per k-tile: "
-                          "flops = issued matrix-core flops (6 M N K), bytes = both planes)" if args.precision == "bf16x3" else ")"))
+                         ("; the split-precision forward instantiations read planar hi/lo operands and issue 3 products per k-tile; "
+                          "flops = 2 M N K, bytes = both planes)" if args.precision == "bf16x3" else ")"))
             else:
                 k = prof["gemm_fwd"]
                 kname = ("gemm_bf16_glds_kernel (forward Linear GEMMs)" if args.precision != "fp32"
                          else "gemm_f32_kernel<AL=0,BL=0,*> (forward Linear GEMMs, v_mfma_f32_32x32x2_f32)")
-            # Which roof?  Arithmetic intensity of the average launch (algorithmic FLOPs / algorithmic bytes: operands read once,
-            # outputs written once) against the ridge peak_flops / peak_bw of the dtype.  Below the ridge the launch is HBM-bound
-            # by the roofline model and `achieved` is algorithmic bytes / time; the MFMA view is reported next to it.
-            tflops = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
-            gbps = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+            # Roofline of the dominant kernel on ALGORITHMIC work: flops = 2 M N K of the mathematical products, bytes = every
+            # operand read once + every output written once.  SURVEY 8d classes the Linear GEMMs as MFMA-bound (weights reused across all
+            # tokens), so `achieved` / `frac` are model flops / time against the dense bf16 matrix peak; the split-precision forward ISSUES
+            # three bf16 products per product, reported separately as `mfma_issue_*` (its effective roof for fp32-grade products is
+            # peak / 3), and the bandwidth view of the same launches as `hbm_*`.
+            sec = k["ms"] * 1e-3
+            issued_tflops = k["flops"] / sec / 1e12 if sec > 0 else 0.0
+            model_tflops = k["model_flops"] / sec / 1e12 if sec > 0 else 0.0
+            gbps = k["bytes"] / sec / 1e9 if sec > 0 else 0.0
             peak_tf, peak_bw = PEAK_TFLOPS[args.precision], PEAK_HBM_GBPS
-            intensity = k["flops"] / k["bytes"] if k["bytes"] > 0 else float("inf")
-            ridge = peak_tf * 1e12 / (peak_bw * 1e9)
-            hbm_bound = intensity < ridge
-            out["roofline"] = {"bound": "hbm" if hbm_bound else "mfma", "kernel": kname,
-                               "achieved": gbps if hbm_bound else tflops, "peak": peak_bw if hbm_bound else peak_tf,
-                               "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                               "frac": (gbps / peak_bw) if hbm_bound else (tflops / peak_tf),
-                               "traffic": PMC_TRAFFIC_PER_LAUNCH.get((args.precision, B)),
-                               "avg_launch_ms": k["ms"] / max(1, k["launches"]), "launches": k["launches"],
-                               "flops_per_launch": k["flops"] / max(1, k["launches"]),
-                               "bytes_per_launch": k["bytes"] / max(1, k["launches"]),
-                               "intensity_flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
-                               "mfma_tflops": tflops, "mfma_frac": tflops / peak_tf, "hbm_gbps": gbps, "hbm_frac": gbps / peak_bw,
-                               # flops of the mathematical products only (2 M N K per GEMM: the split forward issues three matrix-core
-                               # products per product and `achieved` counts what is issued)
-                               "model_flops_per_launch": k["model_flops"] / max(1, k["launches"]),
-                               "model_tflops": k["model_flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0}
+            nl = max(1, k["launches"])
+            out["roofline"] = {"bound": "mfma", "kernel": kname,
+                               "achieved": model_tflops, "peak": peak_tf, "unit": "TFLOP/s", "frac": model_tflops / peak_tf,
+                               "traffic": pmc_traffic_per_launch(args.precision, B),
+                               "avg_launch_ms": k["ms"] / nl, "launches": k["launches"],
+                               "flops_per_launch": k["model_flops"] / nl, "bytes_per_launch": k["bytes"] / nl,
+                               "intensity_flop_per_byte": k["model_flops"] / k["bytes"] if k["bytes"] > 0 else None,
+                               "ridge_flop_per_byte": peak_tf * 1e12 / (peak_bw * 1e9),
+                               "hbm_gbps": gbps, "hbm_frac": gbps / peak_bw,
+                               "mfma_issue_tflops": issued_tflops, "mfma_issue_frac": issued_tflops / peak_tf,
+                               "issued_flops_per_launch": k["flops"] / nl,
+                               "note": ("flops = 2 M N K per GEMM (SURVEY 8d). bf16x3: the forward launches issue 3 bf16 matrix-core products per "
+                                        "product (6 M N K, mfma_issue_*), so fp32-grade products have an effective roof of peak / 3 in the forward; "
+                                        "dgrad launches are plain bf16." if args.precision == "bf16x3" else "flops = 2 M N K per GEMM (SURVEY 8d)")}
             tot = sum(v["ms"] for v in prof.values())
             out["kernel_classes"] = {n: {"ms_per_step": v["ms"] / args.steps, "share": v["ms"] / tot if tot else 0.0,
                                          "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 4
+#define MP_ABI_VERSION 5
 
 int mp_abi_version(void);
 const char* mp_last_error(void);
@@ -135,6 +135,17 @@ int mp_split_bf16(const float* src, void* hi, void* lo, int64_t n, void* stream)
  * plain bf16; 2: y = r + (x W^T + b) in fp32 (y_lo unused). */
 int mp_linear_fwd_bf16x3(const void* x_hi, const void* x_lo, const void* W_hi, const void* W_lo, const float* b, void* y, void* y_lo,
                          void* z, const float* r, int M, int N, int K, int epilogue, void* stream);
+/* The residual Linear of a Block from the third block on (architectures/mix_ste.py:352-368 inside ST_foward :157-173): the block input is
+ * the shared post-norm of the previous block's output, x = LayerNorm(r_in) (Spatial_norm / Temporal_norm, eps folded into rstats), which
+ * the engine never materialises - the epilogue recomputes it from r_in and its row statistics while adding the branch:
+ *   y[m][n] = (r_in[m][n] - mean[m]) * rstd[m] * rgamma[n] + rbeta[n] + mask(m) * (x W^T + b)[m][n]        (fp32, N columns)
+ * rstats: (M, 2) = (mean, rstd) per row; mask: DropPath multipliers per sample or NULL (mask_mode 1: sample = m / J, a spatial block's
+ * (b, t); 2: sample = b * J + m % J, a temporal block's (b, j), with b = m / (T J)); r_in and y may not alias.  This is the same
+ * kernel path mp_model_forward takes in precision 2 (persistent split-precision GEMM when the problem has >= 2 tiles per CU or
+ * "gemm_persist_min_tiles" says so). */
+int mp_linear_fwd_bf16x3_lnres(const void* x_hi, const void* x_lo, const void* W_hi, const void* W_lo, const float* b, float* y,
+                               const float* r_in, const float* rstats, const float* rgamma, const float* rbeta, const float* mask, int mask_mode,
+                               int T, int J, int M, int N, int K, void* stream);
 /* attention core on a planar fused qkv buffer, planar output.  scratch: 4*M*C floats, needed only where no MFMA kernel covers the
  * shape (spatial: 16 <= J <= 32 tokens, head dim 64 or 16, <= 8 heads; temporal: T <= 256, head dim 64 or 16); NULL otherwise. */
 int mp_attention_fwd_bf16x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, float* scratch, int temporal,

@@ -286,7 +286,9 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
   __syncthreads();
   const int ntile = NTC ? NTC : (T + 15) >> 4;
   bf16* dq_base = dqkv + ((long)b * T * J + j) * 3 * C + h * D;
+#ifdef MP_GEMM_DIAG
   if (debug & 1) return;                                 // timing ablation: staging only
+#endif
   const float scale2 = scale * 1.4426950408889634f;    // p = 2^(s scale log2 e - lse log2 e)
   ImgRd<D> Qr, Kr, Vr, Gr;
   Qr.init(Qs, lane);
@@ -339,7 +341,9 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
       for (int db = 0; db < DB; ++db) store4(dq_base + (long)tq * rs3 + 16 * db + 4 * g, dq[db], scale);
     }
   }
+#ifdef MP_GEMM_DIAG
   if (debug & 2) return;                                 // timing ablation: no dK/dV pass
+#endif
 
   // ---- pass B: dK, dV (scores in the [query][key] orientation) ----
   for (int kt = wave; kt < ntile; kt += nw) {
@@ -1102,8 +1106,12 @@ int attn_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, const flo
   MP_CHECK(attn_tmfma_supported(T, D) && C % 8 == 0, MP_ERR_ARG, "attn_tmfma_bwd: T=%d D=%d unsupported", T, D);
   const float scale = attn_qk_scale(D);
   const int units = B * J * H;
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("MANIPOSE_ATTN_DEBUG"); dbg = e ? atoi(e) : 0; }
+  // timing ablations (1 staging only, 2 no dK/dV pass: results wrong by design) exist in the diagnostics build only
+#ifdef MP_GEMM_DIAG
+  static const int dbg = [] { const char* e = getenv("MANIPOSE_ATTN_DEBUG"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int dbg = 0;
+#endif
   const bool full = T > 240;
   if (D == 64) return full ? launch_tmfma_bwd<64, 16>(qkv, out, dout, lse, dqkv, units, T, J, C, H, scale, dbg, st)
                            : launch_tmfma_bwd<64, 0>(qkv, out, dout, lse, dqkv, units, T, J, C, H, scale, dbg, st);

@@ -170,6 +170,19 @@ int mp_linear_fwd_bf16x3(const void* x_hi, const void* x_lo, const void* W_hi, c
   const int epi = epilogue == 0 ? EPI_BIAS : (epilogue == 1 ? EPI_BIAS_GELU : EPI_BIAS_RESID);
   return gemm_bf16x3(g, epilogue == 2, epi, (hipStream_t)stream);
 }
+int mp_linear_fwd_bf16x3_lnres(const void* x_hi, const void* x_lo, const void* W_hi, const void* W_lo, const float* b, float* y,
+                               const float* r_in, const float* rstats, const float* rgamma, const float* rbeta, const float* mask, int mask_mode,
+                               int T, int J, int M, int N, int K, void* stream) {
+  MP_CHECK(x_hi && x_lo && W_hi && W_lo && y && r_in && rstats && rgamma && rbeta, MP_ERR_ARG, "mp_linear_fwd_bf16x3_lnres: null argument");
+  MP_CHECK(mask == nullptr || ((mask_mode == 1 || mask_mode == 2) && T > 0 && J > 0 && M % (T * J) == 0), MP_ERR_ARG,
+           "mp_linear_fwd_bf16x3_lnres: a DropPath mask needs mask_mode 1 or 2 and M a multiple of T*J");
+  MP_CHECK(y != r_in, MP_ERR_ARG, "mp_linear_fwd_bf16x3_lnres: y and r_in may not alias");
+  GemmB16Args g = {};
+  g.A = x_hi; g.A_lo = x_lo; g.lda = K; g.B = W_hi; g.B_lo = W_lo; g.ldb = K; g.C = y; g.ldc = N; g.M = M; g.N = N; g.K = K;
+  g.bias = b; g.R = r_in; g.rstats = rstats; g.rgamma = rgamma; g.rbeta = rbeta;
+  g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
+  return gemm_bf16x3(g, 1, EPI_BIAS_RESID, (hipStream_t)stream);
+}
 int mp_attention_fwd_bf16x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, float* scratch, int temporal,
                             int B, int T, int J, int C, int H, void* stream) {
   MP_CHECK(qkv_hi && qkv_lo && out_hi && out_lo && (!temporal || lse), MP_ERR_ARG, "mp_attention_fwd_bf16x3: null pointer");

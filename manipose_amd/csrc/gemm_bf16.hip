@@ -19,6 +19,15 @@
 
 namespace mp {
 
+// Timing ablations (skip the MFMA stage / the operand DMA / the epilogue: results wrong by design) exist only in the diagnostics build
+// (MP_DIAG=1 build.sh -> libmanipose_hip_diag.so); in the product library the bits are a compile-time zero and no environment
+// variable can switch them on.
+#ifdef MP_GEMM_DIAG
+#define MP_DBG(g, bit) ((g).debug & (bit))
+#else
+#define MP_DBG(g, bit) 0
+#endif
+
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short bf16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -412,13 +421,13 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
     __syncthreads();   // (vmcnt(0) + barrier): tile k0 has landed for every wave; nobody still reads the other stage
     const char* As = smem + stage * STAGE;
     const char* Bs = As + OPB;
-    if (k0 + GBK < kend && !(g.debug & 2)) {
+    if (k0 + GBK < kend && !MP_DBG(g, 2)) {
       char* nx = smem + (stage ^ 1) * STAGE;
       if (b_first) glds_tile<TRB, BT, NW>(nx + OPB, B, g.ldb, n0, k0 + GBK, g.N, kend, lane, wave);
       glds_tile<TRA, BT, NW>(nx, A, g.lda, m0, k0 + GBK, g.M, kend, lane, wave);
       if (!b_first) glds_tile<TRB, BT, NW>(nx + OPB, B, g.ldb, n0, k0 + GBK, g.N, kend, lane, wave);
     }
-    if (g.debug & 1) continue;
+    if (MP_DBG(g, 1)) continue;
     if (EPI == EPI_SLAB && TRA == 1) {
       if (tn == 0 && tid < BT) {
         const int oc = tid >> 3, wi = tid & 7;
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   }
   }
 
-  if ((g.debug & 4) && acc[0][0][0] != 12345.678f) return;
+  if (MP_DBG(g, 4) && acc[0][0][0] != 12345.678f) return;
   // ---- epilogue through LDS: the accumulators (transposed-tile layout: lane = row, 4 consecutive columns per register
   // group) are written to a wave-private 64 x 64 fp32 image (16-byte chunks XOR-swizzled by the row) and read back row-major,
   // so bias / residual / pre-activation loads and the output stores are full 128/256-byte lines, 16 lanes per row. ----
@@ -702,7 +711,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       const char* Bs = As + OPB;
       char* nx = smem + (stage ^ 1) * STAGE;
       const bool last = ks + 1 == nk;
-      if (!(g.debug & 2) && (!last || has_next)) {
+      if (!MP_DBG(g, 2) && (!last || has_next)) {
         if (last) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
         persist_dma(nx, a_base(last ? m0n : m0, last ? 0 : ks + 1), aoff, wave);
         persist_dma(nx + OPB, b_base(last ? n0n : n0, last ? 0 : ks + 1), boff, wave);
@@ -712,7 +721,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
         typedef const __attribute__((address_space(1))) void* gptr;
         __builtin_amdgcn_global_load_lds((gptr)(g.bias + n0 + wc * 64 + lane), (lptr)img, 4, 0, 0);
       }
-      if (!(g.debug & 1)) mma_stage<0, TRB, BT>(As, Bs, acc, wr, wc, lane);
+      if (!MP_DBG(g, 1)) mma_stage<0, TRB, BT>(As, Bs, acc, wr, wc, lane);
     }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): the next tile's first k-tile (issued one k-tile ago)
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
 #ifdef MP_GEMM_DIAG
     if (g.stamps != nullptr && tid == 0 && tile_no < 64) g.stamps[((long)blockIdx.x * 64 + tile_no) * 2] = wall_clock64();
 #endif
-    if (!(g.debug & 4)) {
+    if (!MP_DBG(g, 4)) {
       // the lane indices pass through an opaque move so that the epilogue's address arithmetic is redone per tile instead of
       // being hoisted out of the tile loop, where it would sit in ~20 VGPRs across the main loop (the kernel runs at the
       // 256-VGPR limit of two waves per SIMD)
@@ -889,7 +898,10 @@ static int launch_b16(const GemmB16Args& g, int splits, hipStream_t st) {
 
 // C[M,N] = A(i,r) B(r,j): a_f32/c_f32 select fp32 instead of bf16 storage; a_tr/b_tr select the "T" layouts.
 int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, hipStream_t st) {
-  { const char* e = getenv("MANIPOSE_GEMM_DEBUG"); g.debug = e ? atoi(e) : 0; }   // timing ablations only (1 no MFMA, 2 no DMA, 4 no epilogue)
+  g.debug = 0;
+#ifdef MP_GEMM_DIAG
+  { static const int dbg = [] { const char* e = getenv("MANIPOSE_GEMM_DEBUG"); return e ? atoi(e) : 0; }(); g.debug = dbg; }   // timing ablations (1 no MFMA, 2 no DMA, 4 no epilogue)
+#endif
   MP_CHECK(g.M > 0 && g.N > 0 && g.K > 0, MP_ERR_ARG, "gemm_bf16: empty problem");
   MP_CHECK((a_tr ? g.M : g.K) % 8 == 0 && (b_tr ? g.N : g.K) % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.N % 4 == 0 &&
                g.ldc % 4 == 0, MP_ERR_ARG,
@@ -911,14 +923,18 @@ int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, 
 }
 
 int gemm_bf16x3(GemmB16Args g, int c_f32, int epi, hipStream_t st) {
-  { const char* e = getenv("MANIPOSE_GEMM_DEBUG"); g.debug = e ? (atoi(e) & 4) : 0; }   // timing ablation: 4 = no epilogue (the only bit the split loop looks at)
+  g.debug = 0;
+#ifdef MP_GEMM_DIAG
+  { static const int dbg = [] { const char* e = getenv("MANIPOSE_GEMM_DEBUG"); return e ? (atoi(e) & 4) : 0; }(); g.debug = dbg; }   // timing ablation: 4 = no epilogue (the only bit the split loop looks at)
+#endif
   MP_CHECK(g.M > 0 && g.N > 0 && g.K > 0, MP_ERR_ARG, "gemm_bf16x3: empty problem");
   MP_CHECK(g.K % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.N % 4 == 0 && g.ldc % 4 == 0, MP_ERR_ARG,
            "gemm_bf16x3: K and the leading dimensions must be multiples of 8, N of 4 (M=%d N=%d K=%d)", g.M, g.N, g.K);
   MP_CHECK(g.A_lo && g.B_lo && (c_f32 || g.C_lo), MP_ERR_ARG, "gemm_bf16x3: lo plane missing");
   g.k_per_split = ((g.K + GBK - 1) / GBK) * GBK;
+#ifdef MP_GEMM_DIAG
   {
-    static const int abl = [] { const char* e = getenv("MANIPOSE_GEMM_ABL"); return e ? atoi(e) : 0; }();     // timing ablation of the fragment reads
+    static const int abl = [] { const char* e = getenv("MANIPOSE_GEMM_ABL"); return e ? atoi(e) : 0; }();     // timing ablation of the fragment reads (extra kernel instantiations)
     if (abl && !c_f32 && epi == EPI_BIAS) {
       const int wgs = persist_workgroups();
       if (abl == 1) return launch_persist<0, bf16p, EPI_BIAS, 3>(g, wgs, st);
@@ -926,6 +942,7 @@ int gemm_bf16x3(GemmB16Args g, int c_f32, int epi, hipStream_t st) {
       return launch_persist<0, bf16p, EPI_BIAS, 7>(g, wgs, st);
     }
   }
+#endif
   if (!c_f32 && epi == EPI_BIAS) return launch_glds<0, 0, bf16p, EPI_BIAS, 1>(g, 1, st);
   if (!c_f32 && epi == EPI_BIAS_GELU) return launch_glds<0, 0, bf16p, EPI_BIAS_GELU, 1>(g, 1, st);
   if (c_f32 && epi == EPI_BIAS) return launch_glds<0, 0, float, EPI_BIAS, 1>(g, 1, st);

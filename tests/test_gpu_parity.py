@@ -952,24 +952,38 @@ def test_rccl_backend_single_rank_collectives_on_the_flat_gradient_buffer(lib):
         "assert float(g.sum().item()) == 2.0 * g.numel()\n"
         "dist.destroy_process_group()\n"
         "print('rccl ok', dist.is_nccl_available())\n")
-    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    # bounded wait with our own kill: a child stuck inside the RCCL bootstrap does not always die on subprocess.run's timeout, and
-    # a hang here would take the rest of the suite with it
+    # an ephemeral rendezvous port (other tests of this session start torch.distributed.run children; a fixed port can meet a
+    # listener that has not gone away yet); NCCL_DEBUG=INFO so that a failure carries RCCL's own account of where it stopped.
+    # HSA_ENABLE_IPC_MODE_LEGACY=0 is the pool's contract for multi-process GPU work (the host driver only supports dmabuf IPC; without it
+    # RCCL's hipIpcGetMemHandle fails): already exported on the box, repeated so the child has it whatever the caller's environment.
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="INFO")
+    # bounded wait with our own kill of the child's process group (a child stuck inside the RCCL bootstrap does not always die on
+    # subprocess.run's timeout and would take the rest of the suite with it).  A child that does not finish is a FAILURE of this test,
+    # reported with the tail of its output - the one RCCL check of the suite must not turn into a skip when it matters.
     import signal, tempfile, time
     with tempfile.TemporaryFile("w+") as out, tempfile.TemporaryFile("w+") as err:
         p = subprocess.Popen([sys.executable, "-c", code], stdout=out, stderr=err, text=True, env=env, cwd=root, start_new_session=True)
         t0 = time.time()
         while p.poll() is None and time.time() - t0 < 180:
             time.sleep(0.5)
-        if p.poll() is None:
+        timed_out = p.poll() is None
+        if timed_out:
             os.killpg(p.pid, signal.SIGKILL)
             t1 = time.time()
             while p.poll() is None and time.time() - t1 < 15:
                 time.sleep(0.5)
-            err.seek(0)
-            pytest.skip("the single-rank RCCL process did not finish within 180 s on this box (killed): " + err.read()[-500:])
         out.seek(0); err.seek(0)
         so, se = out.read(), err.read()
+    log_dir = os.path.join(root, "gpurun_out")
+    if os.path.isdir(log_dir):                 # keep RCCL's log of this run next to the other GPU-side logs
+        with open(os.path.join(log_dir, "rccl_single_rank.log"), "w") as f:
+            f.write(so + "\n--- stderr ---\n" + se)
+    assert not timed_out, "the single-rank RCCL process did not finish within 180 s (killed); its output:\n" + so[-500:] + "\n" + se[-3000:]
     assert p.returncode == 0 and "rccl ok True" in so, (so[-500:], se[-2000:])
 
 
@@ -1431,7 +1445,7 @@ def test_bf16x3_model_meets_the_parity_bound_on_the_reference_fixtures(lib, name
     cs = {k: _cos(p.grad.cpu(), torch.from_numpy(fx["g::" + k])) for k, p in model.named_parameters()}
     worst = min(cs.items(), key=lambda kv: kv[1])
     print(f"[bf16x3 drift] {name}: worst gradient cosine {worst[1]:.5f} at {worst[0]}")
-    assert worst[1] > 0.98, worst
+    assert worst[1] > 0.9995, worst            # measured 0.99998 - 0.99999 (bf16 backward on the hi planes)
 
 
 def test_bf16x3_full_size_model_meets_the_parity_bound(lib):
@@ -1467,8 +1481,10 @@ def test_bf16x3_full_size_model_meets_the_parity_bound(lib):
     cs = {k: _cos(p.grad.cpu(), req[k].grad) for k, p in model.named_parameters()}
     worst = min(cs.items(), key=lambda kv: kv[1])
     mean = sum(cs.values()) / len(cs)
-    print(f"[bf16x3 drift] full size: gradient cosine mean {mean:.5f}, worst {worst[1]:.5f} at {worst[0]}")
-    assert worst[1] > 0.9 and mean > 0.99, (worst, mean)
+    wc, wck, _, wm, wmk = _grad_report(model.named_parameters(), {k: v.grad for k, v in req.items()})
+    print(f"[bf16x3 drift] full size: gradient cosine mean {mean:.6f}, worst {worst[1]:.6f} at {worst[0]}; worst max-norm error {wm:.2e} at {wmk}")
+    assert worst[1] > 0.9999 and mean > 0.99999, (worst, mean)      # measured: worst 0.99999, mean 1.00000
+    assert wm < 5e-2, (wm, wmk)
     par = torch.tensor(orc.H36M_PARENTS[1:], device="cuda")
     seg = (poses[..., 1:, :] - poses[..., par, :]).norm(dim=-1)
     lens = model._engine.peek(1).view(1, 1, 1, 16).abs()
@@ -1496,6 +1512,199 @@ def test_bf16x3_training_step_and_droppath(lib):
     X, y = dev(fx["X"]), dev(fx["y"])
     losses = [float(tr.train_step(X, y).sum().item()) for _ in range(8)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def _grad_report(named_params, ref_grads):
+    """(worst cosine, its key, mean cosine, worst max-norm error relative to the reference gradient's max-norm, its key)."""
+    cs, mx = {}, {}
+    for k, p in named_params:
+        g, r = p.grad.detach().cpu().double(), ref_grads[k].double()
+        cs[k] = _cos(g, r)
+        mx[k] = float((g - r).abs().max() / (r.abs().max() + 1e-30))
+    wc = min(cs.items(), key=lambda kv: kv[1])
+    wm = max(mx.items(), key=lambda kv: kv[1])
+    return wc[1], wc[0], sum(cs.values()) / len(cs), wm[1], wm[0]
+
+
+@pytest.mark.parametrize("M,N,K,mode,T,J", [(66096, 512, 512, 1, 243, 17), (66096, 512, 1024, 2, 243, 17), (2754, 256, 256, 2, 27, 17), (2592, 128, 128, 1, 27, 16),
+                                            (2754, 512, 512, 0, 27, 17)])
+def test_bf16x3_residual_linear_with_recomputed_layernorm(lib, M, N, K, mode, T, J):
+    """The residual Linear of a block from the third on (mix_ste.py:352-368 inside ST_foward :157-173) as the engine runs it in the split
+    precision: y = LayerNorm(r_in) + DropPath-mask * (x W^T + b) with the LayerNorm recomputed in the GEMM epilogue from r_in and its row
+    statistics - through mp_linear_fwd_bf16x3_lnres against the same expression in fp64.  Both the persistent kernel (forced from one
+    tile up: the kernel the benchmark times) and the tiled kernels (256- and 128-wide tiles) are checked."""
+    from manipose_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K + mode)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r_in = torch.randn(M, N, generator=g) * 2.0 + 0.3
+    gamma, beta = 1.0 + 0.2 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    mean = r_in.mean(1)
+    rstd = (r_in.var(1, unbiased=False) + 1e-6).rsqrt()
+    stats = torch.stack([mean, rstd], 1).contiguous()
+    ns = {0: 0, 1: M // J, 2: (M // (T * J)) * J}[mode]
+    mask = ((torch.rand(ns, generator=g) > 0.3).float() / 0.7) if mode else None
+    rows = torch.arange(M)
+    mrow = torch.ones(M) if mode == 0 else (mask[rows // J] if mode == 1 else mask[(rows // (T * J)) * J + rows % J])
+    want = ((r_in.double() - mean.double()[:, None]) * rstd.double()[:, None] * gamma.double() + beta.double()
+            + mrow.double()[:, None] * (x.double() @ W.double().t() + b.double()))
+    scale = float(want.abs().max())
+    xd, Wd = x.cuda(), W.cuda()
+    xh, xl, Wh, Wl = (torch.empty(t.shape, device="cuda", dtype=torch.bfloat16) for t in (x, x, W, W))
+    _lib.check(lib.mp_split_bf16(xd.data_ptr(), xh.data_ptr(), xl.data_ptr(), xd.numel(), st()))
+    _lib.check(lib.mp_split_bf16(Wd.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), Wd.numel(), st()))
+    bd, rd, sd, gd, be = b.cuda(), r_in.cuda(), stats.cuda(), gamma.cuda(), beta.cuda()
+    md = mask.cuda() if mask is not None else None
+    for min_tiles in (1, 1 << 30):                   # persistent kernel forced / tiled kernels only
+        _lib.check(lib.mp_set_option(b"gemm_persist_min_tiles", min_tiles))
+        try:
+            y = torch.full((M, N), float("nan"), device="cuda")
+            _lib.check(lib.mp_linear_fwd_bf16x3_lnres(xh.data_ptr(), xl.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), bd.data_ptr(), y.data_ptr(), rd.data_ptr(),
+                                                      sd.data_ptr(), gd.data_ptr(), be.data_ptr(), md.data_ptr() if md is not None else None, mode, T, J,
+                                                      M, N, K, st()), "mp_linear_fwd_bf16x3_lnres")
+        finally:
+            _lib.check(lib.mp_set_option(b"gemm_persist_min_tiles", 0))
+        err = (y.cpu().double() - want).abs().max().item() / scale
+        assert err < 4e-5, (min_tiles, err)                                     # bf16 operands: ~4e-3
+    with pytest.raises(RuntimeError):                # y may not alias r_in
+        _lib.check(lib.mp_linear_fwd_bf16x3_lnres(xh.data_ptr(), xl.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), bd.data_ptr(), rd.data_ptr(), rd.data_ptr(),
+                                                  sd.data_ptr(), gd.data_ptr(), be.data_ptr(), None, 0, T, J, M, N, K, st()), "alias")
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_bf16x3_persistent_kernels_inside_the_model_vs_oracle(lib, train):
+    """The kernels the benchmark times - gemm_bf16_persist_kernel<.., SPLIT=1> with the bias, GELU and (recomputed-LayerNorm) residual
+    epilogues, which the default rule only selects from 512 output tiles up - forced on (one tile is enough) inside a model wide and deep
+    enough for them (C = 256, depth 3: the lazy block input / recomputed residual runs from the third block on), eval mode and train mode
+    with injected DropPath masks, against the CPU ORACLE (not against the tiled kernels): MPJPE within the north-star bound, scores,
+    loss, every parameter gradient.  The engine's own launch accounting proves the persistent kernel ran."""
+    from manipose_amd import RMCLManifoldMixSTE, _lib, h36m_skeleton
+    from manipose_amd.metrics import mpjpe_error, rmcl_training_loss
+    cfg = dict(T=27, J=17, num_bones=16, C_rot=256, depth_rot=3, heads_rot=4, C_seg=256, depth_seg=2, heads_seg=4, n_hyp=3)
+    B, rate = 6, 0.3
+    st_ = orc.make_state(cfg, seed=21)
+    X, y = orc.synthetic_batch(B, cfg["T"], seed=9)
+    _lib.check(lib.mp_set_option(b"gemm_persist_min_tiles", 1))
+    try:
+        model = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=cfg["T"], embed_dim_rot=256, depth_rot=3, num_heads_rot=4, embed_dim_seg=256,
+                                   depth_seg=2, num_heads_seg=4, n_hyp=3, drop_path_rate=rate if train else 0.0)
+        model.load_state_dict(st_, strict=True)
+        model.precision = "bf16x3"
+        model = model.cuda()
+        model = model.train() if train else model.eval()
+        model._ensure_engine(B, torch.device("cuda"))
+        masks = None
+        if train:
+            gen = torch.Generator().manual_seed(11)
+            masks = {name: (torch.rand(cnt, generator=gen) < keep).float() / keep for name, _, cnt, keep in model._engine.mask_layout(B) if keep < 1.0}
+            model.set_droppath_masks({k: v.cuda() for k, v in masks.items()})
+        model._engine.prof_enable(True)
+        poses, scores = model(X.cuda())
+        total, _ = rmcl_training_loss(poses, scores, y.cuda())
+        total.backward()
+        prof = model._engine.prof_collect()
+        model._engine.prof_enable(False)
+    finally:
+        _lib.check(lib.mp_set_option(b"gemm_persist_min_tiles", 0))
+    # 4 Linear layers x 2 blocks x depth, both backbones, forward; the dgrad launches of the backward on top
+    n_fwd = 4 * 2 * (cfg["depth_rot"] + cfg["depth_seg"])
+    assert prof["gemm_persist"]["launches"] >= n_fwd, prof["gemm_persist"]
+    req = {k: v.clone().requires_grad_(True) for k, v in st_.items()}
+    o_poses, o_scores = orc.rmcl_manifold_forward(X, req, orc.oracle_cfg(cfg), masks=masks)
+    o_total, _ = orc.rmcl_training_loss(o_poses, o_scores, y)
+    o_total.backward()
+    mp = mpjpe_error(poses, o_poses.detach().cuda(), "average").item()
+    wc, wck, mean, wm, wmk = _grad_report(model.named_parameters(), {k: v.grad for k, v in req.items()})
+    print(f"\n[bf16x3 persistent] train={train}: MPJPE vs oracle {mp * 1e3:.5f} mm, loss {total.item():.6f} vs {o_total.item():.6f}, gradient cosine "
+          f"mean {mean:.6f} worst {wc:.6f} ({wck}), worst max-norm error {wm:.2e} ({wmk}), persistent launches {prof['gemm_persist']['launches']}")
+    assert mp <= MPJPE_TOL_M
+    close(scores, o_scores.detach(), rtol=1e-3, atol=1e-5)
+    assert abs(total.item() - o_total.item()) <= 1e-3 * abs(o_total.item())
+    assert wc > 0.999 and mean > 0.9999, (wc, wck, mean)
+    assert wm < 5e-2, (wm, wmk)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_ten_training_steps_follow_the_oracle_trajectory(lib, precision):
+    """The loop of train() (hpe/main_h36m_lifting.py:294-311) for ten optimisation steps - engine forward, fused loss, engine backward,
+    fused Adam with the reference's lr / weight decay - against the oracle's own ten steps (autograd + orc.adam_step) from the same
+    weights on the same batch, DropPath off: the loss of every step and, at the end, the two models' outputs on the batch (the
+    north star's "MPJPE within 0.1 mm of the reference on identical synthetic batches" after training, not only at initialisation)."""
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    from manipose_amd.metrics import mpjpe_error
+    from manipose_amd.training import LiftingTrainer
+    cfg = dict(T=27, J=17, num_bones=16, C_rot=128, depth_rot=3, heads_rot=8, C_seg=64, depth_seg=2, heads_seg=4, n_hyp=3)
+    B, steps, lr, wd = 4, 10, 4e-5, 1e-6
+    st_ = orc.make_state(cfg, seed=5)
+    X, y = orc.synthetic_batch(B, cfg["T"], seed=13)
+    model = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=cfg["T"], embed_dim_rot=128, depth_rot=3, num_heads_rot=8, embed_dim_seg=64,
+                               depth_seg=2, num_heads_seg=4, n_hyp=3, drop_path_rate=0.0)
+    model.load_state_dict(st_, strict=True)
+    model.precision = precision
+    model = model.cuda().train()
+    tr = LiftingTrainer(model, lr=lr, weight_decay=wd, seed=1)
+    Xd, yd = X.cuda(), y.cuda()
+    got = [float(tr.train_step(Xd, yd).sum().item()) for _ in range(steps)]
+    w = {k: v.clone().requires_grad_(True) for k, v in st_.items()}
+    m1 = {k: torch.zeros_like(v) for k, v in st_.items()}
+    m2 = {k: torch.zeros_like(v) for k, v in st_.items()}
+    want = []
+    for i in range(steps):
+        poses, scores = orc.rmcl_manifold_forward(X, w, orc.oracle_cfg(cfg))
+        total, _ = orc.rmcl_training_loss(poses, scores, y)
+        for v in w.values():
+            v.grad = None
+        total.backward()
+        want.append(float(total.item()))
+        with torch.no_grad():
+            for k in w:
+                pk, m1[k], m2[k] = orc.adam_step(w[k], w[k].grad, m1[k], m2[k], i + 1, lr=lr, weight_decay=wd)
+                w[k].copy_(pk)
+    rel = max(abs(a - b) / abs(b) for a, b in zip(got, want))
+    with torch.no_grad():
+        o_poses, o_scores = orc.rmcl_manifold_forward(X, w, orc.oracle_cfg(cfg))
+        p, s = model.eval()(Xd)
+    mp = mpjpe_error(p, o_poses.cuda(), "average").item()
+    dw = max(float((dict(model.named_parameters())[k].detach().cpu() - w[k].detach()).abs().max()) for k in w)
+    print(f"\n[trajectory] {precision}: worst per-step loss deviation {rel:.2e}, MPJPE of the two trained models {mp * 1e3:.5f} mm, "
+          f"largest weight difference {dw:.2e} (an Adam step moves a weight by up to lr = {lr:g})")
+    assert want[-1] < want[0]
+    assert rel <= (1e-4 if precision == "fp32" else 1e-3), (got, want)
+    assert mp <= MPJPE_TOL_M
+    close(s, o_scores, rtol=2e-3, atol=2e-5)
+
+
+def test_product_library_ignores_the_timing_ablation_switches(lib):
+    """MANIPOSE_GEMM_DEBUG / MANIPOSE_GEMM_ABL / MANIPOSE_ATTN_DEBUG switch wrong-by-design timing ablations on in the DIAGNOSTICS build
+    only (MP_DIAG=1 build.sh); with all of them set, a child process using the product library must still produce the oracle's numbers."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'oracle')!r})\n"
+        "import manipose_ref as orc\n"
+        "from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton\n"
+        "cfg = dict(T=27, J=17, num_bones=16, C_rot=256, depth_rot=2, heads_rot=4, C_seg=128, depth_seg=1, heads_seg=8, n_hyp=2)\n"
+        "st = orc.make_state(cfg, seed=2)\n"
+        "for prec in ('bf16x3', 'bf16'):\n"
+        "    m = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=27, embed_dim_rot=256, depth_rot=2, num_heads_rot=4, embed_dim_seg=128, depth_seg=1,\n"
+        "                           num_heads_seg=8, n_hyp=2, drop_path_rate=0.0)\n"
+        "    m.load_state_dict(st, strict=True); m.precision = prec; m = m.cuda().eval()\n"
+        "    X, y = orc.synthetic_batch(4, 27, seed=3)\n"
+        "    p, s = m(X.cuda())\n"
+        "    (p.square().sum() + s.square().sum()).backward()\n"
+        "    g = torch.cat([q.grad.reshape(-1) for q in m.parameters()])\n"
+        "    with torch.no_grad():\n"
+        "        op, _ = orc.rmcl_manifold_forward(X, st, orc.oracle_cfg(cfg))\n"
+        "    print(prec, float((p.detach().cpu() - op).norm(dim=-1).mean()), bool(torch.isfinite(g).all()), float(g.abs().sum()))\n")
+    env = dict(os.environ, MANIPOSE_GEMM_DEBUG="7", MANIPOSE_GEMM_ABL="3", MANIPOSE_ATTN_DEBUG="3")
+    env.pop("MANIPOSE_HIP_LIB", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = {l.split()[0]: l.split()[1:] for l in r.stdout.splitlines() if l.startswith("bf16")}
+    assert float(rows["bf16x3"][0]) <= MPJPE_TOL_M and float(rows["bf16"][0]) <= 8e-3, rows
+    assert rows["bf16x3"][1] == "True" and rows["bf16"][1] == "True" and float(rows["bf16x3"][2]) > 0, rows
 
 
 def test_custom_joint_weights_and_no_agg_segment_table_vs_oracle(lib):
@@ -1648,4 +1857,5 @@ def test_config2_T27_K1_single_hypothesis_full_width_vs_oracle(lib, precision):
         assert max(e for _, e in bad) <= 5e-3, sorted(bad, key=lambda t: -t[1])[:3]
     else:
         cs = [_cos(p.grad.cpu(), req[k].grad) for k, p in model.named_parameters() if req[k].grad.abs().max() > 0]
-        assert min(cs) > 0.98, min(cs)
+        print(f"\n[bf16x3 drift] config #2: worst gradient cosine {min(cs):.6f}")
+        assert min(cs) > 0.9995, min(cs)

@@ -4,9 +4,10 @@
 #   <tag>_bench_under_rocprof.json    the bench JSON line printed in that run (its roofline.avg_launch_ms must agree with the stats)
 #   <tag>_stream_timeline.txt         tools/stream_timeline.py over the kernel trace of that run
 #   <tag>_pmc_hbm_traffic.csv         per-kernel FETCH_SIZE / WRITE_SIZE averages from two separate --pmc passes
+#   pmc_traffic.json                  profiles/pmc_traffic.json with this configuration's entry replaced by the last row of that csv
 # The files are written under gpurun_out/ (merged back by gpurun); copy them into profiles/ afterwards.
 set -eu
-TAG="${1:-r02_bf16x3_B79}"
+TAG="${1:-r03_bf16x3_B79}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/profiles_new; rm -rf "$O"; mkdir -p "$O"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-extra > "$O/stats.log" 2>&1
@@ -40,6 +41,12 @@ with open(f"{O}/{TAG}_pmc_hbm_traffic.csv", "w") as fh:
         N = sum(n for n, _, _ in tp); F = sum(n * f for n, f, _ in tp) / N; W = sum(n * w for n, _, w in tp) / N
         fh.write(f"\"gemm_bf16_persist_kernel (all instantiations)\",{N},{F:.1f},{W:.1f},{(2 * F + W) * 1024 / 1e6:.1f}\n")
         print("persist kernel HBM MB/launch:", (2 * F + W) * 1024 / 1e6)
+        # profiles/pmc_traffic.json is what bench.py reads for roofline.traffic: same number, same run (copy it into profiles/ with the csv)
+        import json
+        line = json.loads(open(f"{O}/{TAG}_bench_under_rocprof.json").read().strip().splitlines()[-1])
+        tj = json.load(open("profiles/pmc_traffic.json"))
+        tj[f"{line['dtype']}:{line['config']['windows_per_gpu']}"] = {"bytes_per_launch": round((2 * F + W) * 1024, 0), "source": f"profiles/{TAG}_pmc_hbm_traffic.csv"}
+        json.dump(tj, open(f"{O}/pmc_traffic.json", "w"), indent=1)
 st = list(csv.DictReader(open(f"{O}/{TAG}_kernel_stats.csv")))
 tp = [(float(r["TotalDurationNs"]), int(r["Calls"])) for r in st if "persist_kernel" in r["Name"]]
 if tp:
