@@ -244,19 +244,21 @@ def run(argv, extra_defaults=None):
     dev = torch.device("cuda", local)
     torch.manual_seed(cfg.run.seed)
     model = instantiate_model(cfg)
-    if cfg.run.checkpoint_model:
-        ck = torch.load(cfg.run.checkpoint_model, map_location="cpu")
-        model.load_state_dict(ck["model_pos"] if "model_pos" in ck else ck)
     mup_mults = None
-    if cfg.model.mup:                          # create_model / set_mup_base_shapes (main_h36m_lifting.py:673-708) + re-initialisation (:762-764)
+    if cfg.model.mup:                          # create_model / set_mup_base_shapes (main_h36m_lifting.py:673-708): BEFORE any checkpoint is loaded,
+        # as in the reference - set_base_shapes rescales the freshly initialised MuReadout weights by sqrt(width_mult), which must never
+        # touch weights that come from a checkpoint
         from manipose_amd.mup_lite import make_base_shapes, mu_init_params, mup_lr_multipliers, set_base_shapes
         small, big = copy.deepcopy(cfg), copy.deepcopy(cfg)
         small["model"]["channels"], small["model"]["channels_seg"], small["data"]["seq_len"] = 64, 64, 27
         big["model"]["channels"], big["model"]["channels_seg"], big["data"]["seq_len"] = 128, 128, 81
         set_base_shapes(model, make_base_shapes(instantiate_model(Cfg.wrap(small)), instantiate_model(Cfg.wrap(big))))
-        if not cfg.run.checkpoint_model:
-            mu_init_params(model)
         mup_mults = mup_lr_multipliers(model)
+    if cfg.run.checkpoint_model:               # main_h36m_lifting.py:754-760: checkpoint weights are used untouched
+        ck = torch.load(cfg.run.checkpoint_model, map_location="cpu")
+        model.load_state_dict(ck["model_pos"] if "model_pos" in ck else ck)
+    elif cfg.model.mup:                        # :761-764: re-initialisation according to muP only without a checkpoint
+        mu_init_params(model)
     model.max_batch_hint = max(cfg.train.batch_size, 2 * cfg.train.batch_size_test)      # x2: flip-TTA batches the mirrored copy
     model = model.to(dev)
     if cfg.train.get("lat_sym_regularization", 0) > 0:

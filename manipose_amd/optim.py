@@ -92,23 +92,48 @@ class FusedAdam:
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        """Accepts torch.optim.Adam's layout (a reference checkpoint, or one written by state_dict() above) and the flat layout
-        {"step", "exp_avg", "exp_avg_sq"} this class wrote before."""
+        """Accepts torch.optim.Adam's layout (a reference checkpoint, or one written by state_dict() above), the several-group layout
+        mup.optim.MuAdam writes (a reference params*.pth of a model.mup run; the third-party package is absent offline, its published
+        grouping is restated: parity unpinned for that part) and the flat layout {"step", "exp_avg", "exp_avg_sq"} this class wrote before."""
         m = self.model
         flat = m.flat_parameters()
         if "param_groups" in sd:
-            g = sd["param_groups"][0]
-            self.param_groups[0]["lr"] = g.get("lr", self.lr)
+            groups = sd["param_groups"]
             params = list(m.parameters())
-            if len(g["params"]) != len(params):
-                raise ValueError(f"optimizer state has {len(g['params'])} parameters, the model {len(params)}")
+            if len(groups) == 1:
+                order = params                                         # torch.optim.Adam: index i = i-th entry of model.parameters()
+                self.param_groups[0]["lr"] = groups[0].get("lr", self.lr)
+            else:
+                # mup.optim.MuAdam (mup 1.0.0, the reference's optimizer under model.mup: main_h36m_lifting.py:227-232) splits the one
+                # group into one group per width multiplier of the matrix-like parameters (two infinite dimensions; lr / width_mult,
+                # weight_decay * width_mult; in first-seen order) followed by one group of everything else; the state indices run
+                # through the groups in that order.  Rebuild the same order from the model's infshapes (mup_lite.set_base_shapes).
+                if any(getattr(p, "infshape", None) is None for p in params):
+                    raise ValueError("optimizer state with several param groups (MuAdam) needs a model with base shapes: build it with "
+                                     "model.mup=true / mup_lite.set_base_shapes first")
+                matrix, vector = {}, []
+                for p in params:
+                    if p.infshape.ninf() == 2:
+                        matrix.setdefault(p.infshape.width_mult(), []).append(p)
+                    else:
+                        vector.append(p)
+                mine = list(matrix.values()) + [vector]
+                if [len(g["params"]) for g in groups] != [len(g) for g in mine]:
+                    raise ValueError(f"MuAdam optimizer state has groups of {[len(g['params']) for g in groups]} parameters, the model's base "
+                                     f"shapes give {[len(g) for g in mine]}")
+                order = [p for g in mine for p in g]
+                self.param_groups[0]["lr"] = groups[-1].get("lr", self.lr)       # the vector-like group trains at the base learning rate
+            n_sd = sum(len(g["params"]) for g in groups)
+            if n_sd != len(params):
+                raise ValueError(f"optimizer state has {n_sd} parameters, the model {len(params)}")
+            ids = [pid for g in groups for pid in g["params"]]
             slot = {id(p): s for s, p in zip(m._slots, m._plist)}
             self.exp_avg, self.exp_avg_sq, self.step_count = torch.zeros_like(flat), torch.zeros_like(flat), 0
-            for i, pid in enumerate(g["params"]):
+            for i, pid in enumerate(ids):
                 st = sd["state"].get(pid)
                 if st is None:
                     continue
-                off, n = slot[id(params[i])]
+                off, n = slot[id(order[i])]
                 if st["exp_avg"].numel() != n:
                     raise ValueError(f"optimizer state of parameter {i} has {st['exp_avg'].numel()} elements, expected {n}")
                 self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1).to(flat.device, torch.float32))

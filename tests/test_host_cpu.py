@@ -354,6 +354,94 @@ def test_fused_adam_state_dict_is_interchangeable_with_torch_adam():
     assert opt.step_count == 7 and opt.param_groups[0]["lr"] == 1e-3
 
 
+def test_fused_adam_loads_a_muadam_state_with_several_param_groups():
+    """A params*.pth of a model.mup run of the reference is written by mup.optim.MuAdam: one param group per width multiplier of the
+    matrix-like parameters (lr / width_mult, weight_decay * width_mult) followed by the vector-like group, state indices running through
+    the groups.  The same grouping built here with torch.optim.Adam stands in for the absent package (parity unpinned for its part)."""
+    from manipose_amd.optim import FusedAdam
+    fx = load_fixture("mup_rmcl")
+    m = _mup_model(fx)
+    matrix, vector = {}, []
+    for p in m.parameters():
+        (matrix.setdefault(p.infshape.width_mult(), []) if p.infshape.ninf() == 2 else vector).append(p)
+    assert len(matrix) == 2 and vector                                  # rot (x2) and seg (x4) width multipliers
+    groups = [{"params": ps, "lr": 4e-5 / wm, "weight_decay": 1e-6 * wm} for wm, ps in matrix.items()] + [{"params": vector, "lr": 4e-5, "weight_decay": 1e-6}]
+    ref = torch.optim.Adam(groups)
+    g = torch.Generator().manual_seed(1)
+    for p in m.parameters():
+        p.grad = torch.randn(p.shape, generator=g)
+    ref.step(); ref.step(); ref.step()
+    sd = ref.state_dict()
+    assert len(sd["param_groups"]) == 3
+    opt = FusedAdam(m, lr=1.0)
+    opt.load_state_dict(sd)
+    assert opt.step_count == 3 and opt.param_groups[0]["lr"] == 4e-5
+    lay = {n: (o, k) for n, o, k in m.flat_layout()}
+    name_of = {id(p): n for n, p in m.named_parameters()}
+    order = [p for grp in groups for p in grp["params"]]
+    for i, p in enumerate(order):
+        o, k = lay[name_of[id(p)]]
+        assert torch.equal(opt.exp_avg[o:o + k], sd["state"][i]["exp_avg"].reshape(-1)), name_of[id(p)]
+        assert torch.equal(opt.exp_avg_sq[o:o + k], sd["state"][i]["exp_avg_sq"].reshape(-1)), name_of[id(p)]
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    plain = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=9, embed_dim_rot=32, depth_rot=1, num_heads_rot=4, embed_dim_seg=16, depth_seg=1, num_heads_seg=4, n_hyp=2)
+    with pytest.raises(ValueError, match="base shapes"):
+        FusedAdam(plain).load_state_dict(sd)
+
+
+def test_mup_checkpoint_is_loaded_after_the_base_shapes_and_used_untouched(tmp_path, monkeypatch):
+    """create_model / set_mup_base_shapes run BEFORE load_state_dict in the reference (main_h36m_lifting.py:673-708, :754-764): the
+    rescaling of freshly initialised MuReadout weights by sqrt(width_mult) must never touch checkpoint weights, and mu_init_params only
+    runs without a checkpoint.  The entry point's model-construction part is driven up to the first device call."""
+    sys.path.insert(0, os.path.join(ROOT, "hpe"))
+    import _entry
+    import manipose_amd.mup_lite as ml
+    overrides = ["model.mup=true", "model.channels=128", "model.channels_seg=64", "model.layers=1", "model.layers_seg=1", "data.seq_len=9",
+                 "multi_hyp.n_hyp=2", "run.seed=3"]
+    cfg = _entry.load_config(overrides, None)
+    torch.manual_seed(3)
+    src = _entry.instantiate_model(cfg)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.uniform_(-0.5, 0.5)
+    want = {k: v.clone() for k, v in src.state_dict().items()}
+    ck = tmp_path / "mup_model.pth"
+    torch.save({"model_pos": want}, ck)
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_to(self, *a, **k):                 # first device call of run(): capture the model as constructed, then leave
+        seen["state"] = {k_: v.detach().clone() for k_, v in self.state_dict().items()}
+        seen["infshapes"] = all(getattr(p, "infshape", None) is not None for p in self.parameters())
+        raise Stop()
+    calls = []
+    real_init = ml.mu_init_params
+    monkeypatch.setattr(ml, "mu_init_params", lambda mdl: (calls.append(1), real_init(mdl)))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch.nn.Module, "to", fake_to)
+    with pytest.raises(Stop):
+        _entry.run(overrides + [f"run.checkpoint_model={ck}"])
+    assert seen["infshapes"] and not calls
+    assert all(torch.equal(seen["state"][k], want[k]) for k in want), [k for k in want if not torch.equal(seen["state"][k], want[k])][:3]
+    with pytest.raises(Stop):                   # without a checkpoint: muP re-initialisation runs (once)
+        _entry.run(overrides)
+    assert calls == [1]
+
+
+def test_product_library_has_no_timing_ablation_switches():
+    """The wrong-by-design timing ablations (MANIPOSE_GEMM_DEBUG / MANIPOSE_GEMM_ABL / MANIPOSE_ATTN_DEBUG and the extra kernel
+    instantiations behind them) are compiled into the diagnostics build only (MP_DIAG=1 build.sh): the product library does not even
+    contain the variable names, so no environment can switch them on."""
+    from manipose_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"MANIPOSE_GEMM_DEBUG", b"MANIPOSE_GEMM_ABL", b"MANIPOSE_ATTN_DEBUG", b"MANIPOSE_GEMM_STAMPS", b"MANIPOSE_GEMM_STAGGER"):
+        assert name not in blob, name
+    assert b"MANIPOSE_GEMM_PERSIST" in blob      # (the scan does see environment names: the documented tuning knobs are there)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # toy experiment (BASELINE config #1: 1-D -> 2-D circle-manifold MLPs on the CPU) against vectors produced by the reference's own
 # toy_experiment package (oracle/gen_golden_toy.py -> tests/golden/toy.npz)
