@@ -224,7 +224,10 @@ int mp_model_forward(mp_model* m, const float* flat_params, const float* x, int 
 int mp_model_backward(mp_model* m, const float* flat_params, float* flat_grads, const float* d_poses, const float* d_scores,
                       void* stream);
 /* intermediate outputs of the last forward (device pointers owned by the model): 0 = head output
- * (K, B*T*17, O), 1 = segment lengths (B, 16), 2 = the DropPath multipliers of the last train-mode forward (layout: mp_model_mask_info) */
+ * (K, B*T*17, O), 1 = segment lengths (B, 16), 2 = the DropPath multipliers of the last train-mode forward (layout: mp_model_mask_info);
+ * the fp32 residual stream block by block (blocks in execution order STE0, TTE0, STE1, ...; (B*T*N, C) each): 100 + 2 l = after the
+ * attention branch of block l of the rotations net, 101 + 2 l = after its MLP branch, 99 = its embedding output; 300 + 2 l, 301 + 2 l,
+ * 299 the same for the segments net */
 int mp_model_peek(const mp_model* m, int which, const float** ptr, int64_t* numel);
 /* copy `numel` floats of intermediate `which` into dst (device) on `stream` */
 int mp_model_peek_copy(const mp_model* m, int which, float* dst, int64_t numel, void* stream);
@@ -306,7 +309,8 @@ int mp_procrustes_errors(const float* pred, const float* gt, const uint8_t* mask
 
 /* test / tuning hooks (no reference counterpart): "gemm_small_tile" (1 = 128x128 GEMM tiles everywhere),
  * "gemm_persist_min_tiles" (output-tile count from which the persistent GEMM kernels are used; 0 = default),
- * "gemm_persist_mode" (0 tiled kernels only, 1 = default: persistent kernel where it applies). */
+ * "gemm_persist_mode" (0 tiled kernels only, 1 = default: persistent kernel where it applies), "side_streams" (0 = the bones net is
+ * enqueued on the caller's stream instead of the engine's side stream; 1 = default). */
 int mp_set_option(const char* name, int value);
 
 #ifdef __cplusplus

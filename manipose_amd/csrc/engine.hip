@@ -11,6 +11,10 @@
 
 namespace mp {
 
+// debugging hook (mp_set_option("side_streams", 0)): enqueue the bones net on the caller's stream instead of the engine's side stream
+static int g_side_streams = 1;
+void engine_side_streams(int on) { g_side_streams = on; }
+
 const char* last_error();
 long wgrad_f32_slab_floats(int Mtok, int Nout, int Kin);
 
@@ -825,8 +829,9 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
   if (m->cfg.precision == 1) RUN(PC_OTHER, 0, cast_to_bf16(fp, m->wbf, m->flat_size, st));
   if (m->cfg.precision == 2) RUN(PC_OTHER, 0, cast_to_bf16x2(fp, m->wbf, m->wbf_lo, m->flat_size, st));
   // fork: the side stream may start once the masks / bf16 weights above are in place
+  const hipStream_t side = g_side_streams ? m->st2 : st;
   MP_HIP(hipEventRecord(m->ev_fork, st));
-  MP_HIP(hipStreamWaitEvent(m->st2, m->ev_fork, 0));
+  MP_HIP(hipStreamWaitEvent(side, m->ev_fork, 0));
   use_scratch(m, 0);
   // rotations backbone (mix_ste.py:128-173)
   const long Mr = (long)B * T * J, Ms = (long)B * T * S;
@@ -854,7 +859,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
   // bones net (manifold_mix_ste.py:139-154) on the side stream, concurrently with the rotations net enqueued above
   {
     hipStream_t main_st = st;
-    st = m->st2;
+    st = side;
     use_scratch(m, 1);
     RUN(PC_OTHER, 0, bones_embed_fwd(x, P(m, fp, m->seg.emb_w), P(m, fp, m->seg.emb_b), P(m, fp, m->seg.spos), m->seg.ws[0].x_in,
                                      B * T, J * 2, S * m->seg.C, st));
@@ -869,7 +874,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
     else
       RUN(PC_OTHER, 0, heads_fwd(m->seg.x_final, hs, 1, 1, m->seg.headout, m->seg.hstats, (int)Ms, m->seg.C, st));
     RUN(PC_OTHER, 0, bones_mean_fwd(m->seg.headout, m->lengths, B, T, S, st));
-    MP_HIP(hipEventRecord(m->ev_join, m->st2));
+    MP_HIP(hipEventRecord(m->ev_join, side));
     st = main_st;
     use_scratch(m, 0);
     MP_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
@@ -910,8 +915,9 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     MP_HIP(hipStreamWaitEvent(pst, m->ev_heads, 0));
   }
   // fork: the bones-net backward only needs the per-pose length gradients of the decoder backward
+  const hipStream_t side = g_side_streams ? m->st2 : st;
   MP_HIP(hipEventRecord(m->ev_fork, st));
-  MP_HIP(hipStreamWaitEvent(m->st2, m->ev_fork, 0));
+  MP_HIP(hipStreamWaitEvent(side, m->ev_fork, 0));
   use_scratch(m, 0);
   // rotations module
   HeadParams hp;
@@ -932,7 +938,7 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   // segments module, on the side stream with its own scratch set
   if (m->has_seg) {
     hipStream_t main_st = st;
-    st = m->st2;
+    st = side;
     use_scratch(m, 1);
     RUN(PC_OTHER, 0, bones_mean_bwd(m->dlen_pose, K * T, nullptr, m->seg.dheadout, B, T, S, st));
     HeadParams hs;
@@ -951,7 +957,7 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     if (rc) return rc;
     RUN(PC_OTHER, 0, bones_embed_bwd(m->g, m->x_in, G(m, fg, m->seg.emb_w), G(m, fg, m->seg.emb_b), G(m, fg, m->seg.spos), B * T, J * 2,
                                      S * m->seg.C, m->small, m->small_floats, st));
-    MP_HIP(hipEventRecord(m->ev_join, m->st2));
+    MP_HIP(hipEventRecord(m->ev_join, side));
     st = main_st;
     use_scratch(m, 0);
     MP_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
@@ -969,6 +975,21 @@ int mp_model_peek(const mp_model* m, int which, const float** ptr, int64_t* nume
   if (which == 0) { *ptr = m->rot.headout; *numel = (long)m->rot.K * Mr * m->rot.O; return MP_OK; }
   if (which == 1 && m->has_seg) { *ptr = m->lengths; *numel = (long)m->B * m->cfg.num_bones; return MP_OK; }
   if (which == 2 && m->train) { *ptr = m->maskbuf; *numel = mp_model_mask_floats(m, m->B); return MP_OK; }   // DropPath multipliers of the last train-mode forward
+  // fp32 residual stream of the backbones, block by block (bisecting a discrepancy to a layer): 100 + 2 l = after the attention branch of
+  // block l of the rotations net (x_mid), 101 + 2 l = after its MLP branch (x_out); 300 + ... the same for the segments net;
+  // 99 / 299 = the embedding output when it is materialised.  Blocks in execution order STE0, TTE0, STE1, ...
+  if (which >= 99 && which < 500) {
+    const bool seg = which >= 299;
+    MP_CHECK(!seg || m->has_seg, MP_ERR_ARG, "mp_model_peek: no segments net");
+    const Module& md = seg ? m->seg : m->rot;
+    const long M = (long)m->B * m->cfg.num_frame * md.N;
+    const int k = which - (seg ? 300 : 100);
+    if (k == -1) { *ptr = md.ws[0].x_in; *numel = M * md.C; return MP_OK; }
+    MP_CHECK(k >= 0 && k / 2 < (int)md.ws.size(), MP_ERR_ARG, "mp_model_peek: block %d of %d", k / 2, (int)md.ws.size());
+    *ptr = (k & 1) ? md.ws[k / 2].x_out : md.ws[k / 2].x_mid;
+    *numel = M * md.C;
+    return MP_OK;
+  }
   MP_CHECK(false, MP_ERR_ARG, "mp_model_peek: which=%d", which);
 }
 

@@ -473,6 +473,10 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
         *reinterpret_cast<f32x4*>(img + lr * 64 + ch * 4) = acc[hp * 4 + ii][j];
       }
     }
+    // row statistics of the 64 rows of this pass, one row per lane (a single coalesced load), handed out by shuffles below
+    float2 rs_lane = make_float2(0.f, 1.f);
+    if (EPI == EPI_BIAS_RESID && g.rstats != nullptr)
+      rs_lane = *reinterpret_cast<const float2*>(g.rstats + 2 * (long)min(m0 + wr * (BT / 2) + hp * 64 + lane, g.M - 1));
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
       const int lr = it * 4 + gq;
@@ -488,7 +492,14 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
         const float dscale = dp.scale(row);
         float4 r = ld4(g.R + o);
         if (g.rstats != nullptr) {               // the residual is LayerNorm(R), recomputed (ln_fwd stage-1 expression)
-          const float mean = g.rstats[2 * (long)row], rstd = g.rstats[2 * (long)row + 1];
+          // (mean, rstd) of this row out of the wave's prefetched statistics.  NOT a per-row float2 load consumed on the spot: that
+          // form compiled to `global_load_dwordx2 v[n:n+1]; s_waitcnt vmcnt(0); ... v_pk_mul_f32 .., v[n:n+1] op_sel:[0,1]` (the low
+          // lane of the packed multiply takes the pair's HIGH register), and on gfx950 its low-lane results came out wrong for lanes
+          // 48-63 in ~1e-4 of the rows - run-to-run different, caught by tools/gemm_determinism.py in round 3 (an empty asm that only
+          // forces the two values into separate registers made it disappear).  The shuffle delivers them in separate registers,
+          // long after the load; the asm keeps the compiler from re-pairing them.
+          float mean = __shfl(rs_lane.x, lr, 64), rstd = __shfl(rs_lane.y, lr, 64);
+          asm volatile("" : "+v"(mean), "+v"(rstd));
           r = make_float4((r.x - mean) * rstd * rg4.x + rb4.x, (r.y - mean) * rstd * rg4.y + rb4.y, (r.z - mean) * rstd * rg4.z + rb4.z,
                           (r.w - mean) * rstd * rg4.w + rb4.w);
         }

@@ -65,6 +65,7 @@ int cast_to_bf16(const float* src, bf16* dst, long n, hipStream_t st);
 void gemm_bf16_force_small_tile(bool on);          // test hooks (mp_set_option)
 void gemm_bf16_persist_min_tiles(int n);
 void gemm_bf16_persist_mode(int mode);
+void engine_side_streams(int on);                 // engine.hip: 0 = the bones net runs on the caller's stream (debugging)
 int gemm_bf16_take_last_persist();                  // 1 if this thread's last gemm_bf16() ran the persistent kernel (and clears it)
 
 // ---------------------------------------------------------------- elementwise.hip
