@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     for (int r = 0; r < R; ++r) {
       const int m = m0 + r * nwaves;
       if (m < M) {
-        mean[r] = stats[2 * (long)m];
-        rstd[r] = stats[2 * (long)m + 1];
+        mean[r] = lone(stats[2 * (long)m]);
+        rstd[r] = lone(stats[2 * (long)m + 1]);
         ms[r] = (dx_b16 != nullptr) ? droppath_scale(mask, mask_mode, __builtin_amdgcn_readfirstlane(m), T, J) : 1.0f;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
@@ -349,8 +349,8 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy
     float4 xh[V], d[V], t[V];
     float s1 = 0.f, s2 = 0.f;
     // every input of the row is requested up front (the second norm's operands used to be loaded behind the first reduction)
-    const float mean1 = stats1[2 * (long)m], rstd1 = stats1[2 * (long)m + 1];
-    const float mean0 = stats0[2 * (long)m], rstd0 = stats0[2 * (long)m + 1];
+    const float mean1 = lone(stats1[2 * (long)m]), rstd1 = lone(stats1[2 * (long)m + 1]);
+    const float mean0 = lone(stats0[2 * (long)m]), rstd0 = lone(stats0[2 * (long)m + 1]);
     const float ms = (dx_b16 != nullptr) ? droppath_scale(mask, mask_mode, __builtin_amdgcn_readfirstlane(m), T, J) : 1.0f;
     float4 xv1[V], gy[V], kk[V], xv0[V];
 #pragma unroll
@@ -471,7 +471,7 @@ __global__ void embed_fwd_kernel(const float* __restrict__ xin, const float* __r
   const int c4 = C / 4;
   if (i >= (long)M * c4) return;
   const int m = (int)(i / c4), c = (int)(i % c4) * 4;
-  const float x0 = xin[2 * (long)m], x1 = xin[2 * (long)m + 1];
+  const float x0 = lone(xin[2 * (long)m]), x1 = lone(xin[2 * (long)m + 1]);
   const float4 w01 = ld4(W + 2 * c), w23 = ld4(W + 2 * c + 4);   // W[c][0..1] interleaved
   const float4 bb = ld4(b + c), p = ld4(spos + (long)(m % J) * C + c);
   float4 o;
@@ -544,10 +544,12 @@ __global__ __launch_bounds__(256) void embed_bwd4_kernel(const float* __restrict
     const float* gr = g + (long)f * JT * C + (ok ? c : 0);
 #pragma unroll
     for (int j = 0; j < JT; ++j) v[j] = ld4(gr + (long)j * C);
+#pragma unroll
+    for (int j = 0; j < JT; ++j) v[j] = lone4(v[j]);  // each component is splat over (w0, w1) below: common.h, lone()
     const float* xr = xin + (long)f * JT * 2;         // wave-uniform
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
-      const float x0 = xr[2 * j], x1 = xr[2 * j + 1];
+      const float x0 = lone(xr[2 * j]), x1 = lone(xr[2 * j + 1]);
       w0.x += v[j].x * x0; w0.y += v[j].y * x0; w0.z += v[j].z * x0; w0.w += v[j].w * x0;
       w1.x += v[j].x * x1; w1.y += v[j].y * x1; w1.z += v[j].z * x1; w1.w += v[j].w * x1;
       bs.x += v[j].x; bs.y += v[j].y; bs.z += v[j].z; bs.w += v[j].w;
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(256) void bones_embed_fwd_kernel(const float* __res
 #pragma unroll
   for (int f = 0; f < BE_FRAMES; ++f) acc[f] = base;
   for (int i = 0; i < BE_IN; ++i) {
-    const float w = W[(long)o * BE_IN + i];
+    const float w = lone(W[(long)o * BE_IN + i]);
 #pragma unroll
     for (int f = 0; f < BE_FRAMES; ++f) acc[f] += w * xs[f * BE_IN + i];
   }

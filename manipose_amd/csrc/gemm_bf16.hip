@@ -482,6 +482,10 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
       const int lr = it * 4 + gq;
       const int row = m0 + wr * (BT / 2) + hp * 64 + lr;
       float4 v = *reinterpret_cast<const float4*>(img + lr * 64 + ((l15 ^ (lr & 15)) << 2));
+      // (mean, rstd) of this row out of the wave's prefetched statistics - shuffled while every lane is still active (the source lane
+      // of a row can belong to a lane group whose own row lies past M in the last tile)
+      float mean = 0.f, rstd = 1.f;
+      if (EPI == EPI_BIAS_RESID) { mean = __shfl(rs_lane.x, lr, 64); rstd = __shfl(rs_lane.y, lr, 64); }
       if (row >= g.M || col >= g.N) continue;
       const long o = (long)row * g.ldc + col;
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
@@ -496,10 +500,9 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
           // form compiled to `global_load_dwordx2 v[n:n+1]; s_waitcnt vmcnt(0); ... v_pk_mul_f32 .., v[n:n+1] op_sel:[0,1]` (the low
           // lane of the packed multiply takes the pair's HIGH register), and on gfx950 its low-lane results came out wrong for lanes
           // 48-63 in ~1e-4 of the rows - run-to-run different, caught by tools/gemm_determinism.py in round 3 (an empty asm that only
-          // forces the two values into separate registers made it disappear).  The shuffle delivers them in separate registers,
-          // long after the load; the asm keeps the compiler from re-pairing them.
-          float mean = __shfl(rs_lane.x, lr, 64), rstd = __shfl(rs_lane.y, lr, 64);
-          asm volatile("" : "+v"(mean), "+v"(rstd));
+          // forces the two values into separate registers made it disappear).  The shuffle above delivers them long after the
+          // load; lone() (common.h) puts each into a VALU-written register of its own.
+          mean = lone(mean); rstd = lone(rstd);
           r = make_float4((r.x - mean) * rstd * rg4.x + rb4.x, (r.y - mean) * rstd * rg4.y + rb4.y, (r.z - mean) * rstd * rg4.z + rb4.z,
                           (r.w - mean) * rstd * rg4.w + rb4.w);
         }
@@ -588,7 +591,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
     for (int it = 0; it < 4; ++it) {
       in[it] = in_nxt[it]; ds[it] = ds_nxt[it];
       if (EPI == EPI_BIAS_RESID && resid_ln) {     // ln_fwd stage-1 expression
-        const float mean = rs_nxt[it].x, rstd = rs_nxt[it].y;
+        const float mean = lone(rs_nxt[it].x), rstd = lone(rs_nxt[it].y);      // common.h: loaded pair, splat over packed lanes
         in[it] = make_float4((in[it].x - mean) * rstd * rg4.x + rb4.x, (in[it].y - mean) * rstd * rg4.y + rb4.y,
                              (in[it].z - mean) * rstd * rg4.z + rb4.z, (in[it].w - mean) * rstd * rg4.w + rb4.w);
       }

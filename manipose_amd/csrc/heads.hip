@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
       for (int i = 0; i < HV; ++i) {
         const int c = lane * 4 + 256 * i;
         if (c < C) {
-          const float4 g = ld4(p.gamma[k] + c), b = ld4(p.beta[k] + c);
+          const float4 g = lone4(ld4(p.gamma[k] + c)), b = lone4(ld4(p.beta[k] + c));      // splat over the HR rows: common.h, lone()
 #pragma unroll
           for (int r = 0; r < HR; ++r)
             y[r][i] = make_float4(xh[r][i].x * g.x + b.x, xh[r][i].y * g.y + b.y, xh[r][i].z * g.z + b.z, xh[r][i].w * g.w + b.w);
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
         for (int i = 0; i < HV; ++i) {
           const int c = lane * 4 + 256 * i;
           if (c < C) {
-            const float4 w = ld4(p.W[k] + (long)o * C + c);
+            const float4 w = lone4(ld4(p.W[k] + (long)o * C + c));
 #pragma unroll
             for (int r = 0; r < HR; ++r) s[r] += dot4(y[r][i], w);
           }
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256) void heads_bwd_dx_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < HR; ++r) {
       const int m = min(m0 + r, M - 1);
-      float mean = stats[2 * (long)m];
-      rstd[r] = stats[2 * (long)m + 1];
+      float mean = lone(stats[2 * (long)m]);
+      rstd[r] = lone(stats[2 * (long)m + 1]);
       head_row_xhat(x + (long)m * C, lane, C, 1e-5f, true, mean, rstd[r], xh[r]);
 #pragma unroll
       for (int i = 0; i < HV; ++i) d[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -222,14 +222,14 @@ __global__ __launch_bounds__(512) void heads_bwd_param_kernel(const float* __res
   for (int o = 0; o < O; ++o) db[o] = 0.f;
   for (int m0 = wave; m0 < M; m0 += nwaves) {
     const int m = __builtin_amdgcn_readfirstlane(m0);
-    float mean = stats[2 * (long)m], rstd = stats[2 * (long)m + 1];
+    float mean = lone(stats[2 * (long)m]), rstd = lone(stats[2 * (long)m + 1]);
     float4 xh[HV], dy[HV];
     head_row_xhat(x + (long)m * C, lane, C, 1e-5f, true, mean, rstd, xh);
 #pragma unroll
     for (int i = 0; i < HV; ++i) dy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int o = 0; o < O; ++o) {
-      const float g = dout[((long)k * M + m) * O + o];
+      const float g = lone(dout[((long)k * M + m) * O + o]);
       db[o] += g;
 #pragma unroll
       for (int i = 0; i < HV; ++i) {

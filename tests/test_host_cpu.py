@@ -431,6 +431,18 @@ def test_mup_checkpoint_is_loaded_after_the_base_shapes_and_used_untouched(tmp_p
     assert calls == [1]
 
 
+def test_generated_code_has_no_packed_op_reading_a_freshly_loaded_high_register():
+    """Audit of the gfx950 assembly of every kernel source for the hazard described in csrc/common.h (lone()): a packed fp32 op whose low
+    lane takes the high register of a pair that a vector-memory load wrote.  Round 3 traced run-to-run different results (2 mm on the
+    segment lengths at the benchmark's batch, non-reproducible gradients) to exactly that pattern; tools/scan_pk_opsel.py compiles the
+    sources with hipcc (cross-compilation, no GPU needed) and must find none."""
+    import shutil, subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scan_pk_opsel.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "0 suspicious packed ops" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
 def test_product_library_has_no_timing_ablation_switches():
     """The wrong-by-design timing ablations (MANIPOSE_GEMM_DEBUG / MANIPOSE_GEMM_ABL / MANIPOSE_ATTN_DEBUG and the extra kernel
     instantiations behind them) are compiled into the diagnostics build only (MP_DIAG=1 build.sh): the product library does not even

@@ -48,8 +48,16 @@ def rep(tag, a, b):
 
 
 p_small, _, h_small, l_small = run(Xp, 1)
+p_small2, _, h_small2, l_small2 = run(Xp, 1)
+rep("poses  stand-alone B=3, first forward of the process vs second", p_small, p_small2)
+print("   head outputs identical: %.4f, lengths identical: %.4f" % ((h_small == h_small2).float().mean().item(), (l_small == l_small2).float().mean().item()))
 ref = run(X, 0, 0)            # tiled kernels, one stream
-rep("poses  B=%d tiled / one stream vs stand-alone B=3" % B, ref[0][idx], p_small)
+rep("poses  B=%d tiled / one stream vs stand-alone B=3 (first)" % B, ref[0][idx], p_small)
+rep("poses  B=%d tiled / one stream vs stand-alone B=3 (second)" % B, ref[0][idx], p_small2)
+p_small3, _, h_small3, l_small3 = run(Xp, 1)
+rep("poses  stand-alone B=3 after the big batch vs second", p_small3, p_small2)
+hb = ref[2].view(5, B, 243 * 17, -1)[:, idx]
+print("   head outputs of the big tiled run vs stand-alone (second): max %.3e; lengths max %.3e" % ((hb - h_small2.view(5, 3, 243 * 17, -1)).abs().max().item(), (ref[3].view(B, 16)[idx] - l_small2.view(3, 16)).abs().max().item()))
 for mode, side in ((0, 0), (0, 1), (1, 0), (1, 1), (1, 1), (1, 1)):
     o = run(X, mode, side)
     d = (o[0] - ref[0]).norm(dim=-1)

@@ -1,0 +1,75 @@
+"""Build-time audit for a gfx950 hazard found in round 3: a packed fp32 VALU op (v_pk_mul/add/fma_f32) whose LOW lane reads the HIGH
+register of a VGPR pair (op_sel bit = 1 for that source) produced wrong low-lane results for lanes 48-63, rarely and run-to-run
+different, when that register had just been written by a vector-memory load (global_load_dwordx2 of a (mean, rstd) pair).  Forcing the
+two loaded values through an empty asm (common.h: unpair) makes the compiler copy / re-materialise them and the pattern disappears.
+This script compiles every csrc/*.hip to gfx950 assembly and lists the packed ops whose op_sel'd source register was last written by a
+vector-memory load (linear scan per kernel).  Exit status 1 if any is found.      python tools/scan_pk_opsel.py [file.s ...]"""
+import glob, os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PK = re.compile(r'^\s*v_pk_(mul|add|fma)_f32\s+(.*)$')
+DST = re.compile(r'^\s*([a-z_0-9]+)\s+(v\[\d+:\d+\]|v\d+)(?=[\s,]|$)')
+
+
+def regs(tok):
+    m = re.match(r'v\[(\d+):(\d+)\]', tok)
+    if m:
+        return list(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r'v(\d+)$', tok)
+    return [int(m.group(1))] if m else []
+
+
+def scan(path):
+    hits, kernel, last = {}, "?", {}
+    for line in open(path):
+        if line.startswith("_Z") and ":" in line:
+            kernel, last = line.split(":")[0], {}
+            continue
+        code = line.split(";")[0]
+        m = PK.match(code)
+        if m:
+            body = m.group(2)
+            sel = re.search(r'op_sel:\[([01,]+)\]', body)
+            ops = [o.strip() for o in re.split(r',\s*(?![^\[]*\])', re.sub(r'\s+(op_sel|op_sel_hi|neg_lo|neg_hi|clamp).*$', '', body))]
+            if sel:
+                bits = sel.group(1).split(",")
+                for k, b in enumerate(bits):
+                    if b == "1" and k + 1 < len(ops):
+                        r = regs(ops[k + 1])
+                        if len(r) == 2 and last.get(r[1]) == "vmem":
+                            hits.setdefault(kernel, []).append(code.strip())
+        d = DST.match(code)
+        if d:
+            mnem = d.group(1)
+            kind = "vmem" if re.match(r'(global|buffer|flat|scratch)_load', mnem) else ("lds" if mnem.startswith("ds_") else "valu")
+            if re.match(r'(global|buffer|flat|scratch)_(store|atomic)', mnem) or mnem.startswith("ds_write") or mnem.startswith("ds_store"):
+                continue
+            for r in regs(d.group(2)):
+                last[r] = kind
+    return hits
+
+
+def main():
+    files = sys.argv[1:]
+    tmp = None
+    if not files:
+        tmp = tempfile.mkdtemp(prefix="pkscan_")
+        procs = []
+        for src in sorted(glob.glob(os.path.join(ROOT, "manipose_amd", "csrc", "*.hip"))):
+            out = os.path.join(tmp, os.path.basename(src)[:-4] + ".s")
+            procs.append((out, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+                                                stderr=subprocess.DEVNULL)))
+        for out, p in procs:
+            if p.wait() == 0:
+                files.append(out)
+    total = 0
+    for f in files:
+        for k, v in scan(f).items():
+            total += len(v)
+            print(f"{os.path.basename(f)}: {k[:100]}: {len(v)} packed ops read the high half of a freshly loaded pair in their low lane, e.g. {v[0][:110]}")
+    print(f"{total} suspicious packed ops in {len(files)} files")
+    sys.exit(1 if total else 0)
+
+
+if __name__ == "__main__":
+    main()
