@@ -10,7 +10,7 @@ EXTRA=""
 if [ "${MP_DIAG:-0}" = "1" ]; then OUT="$HERE/../libmanipose_hip_diag.so"; OBJ="$HERE/_obj_diag"; EXTRA="-DMP_GEMM_DIAG"; fi
 mkdir -p "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $EXTRA"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-slp-vectorize -Wall -Wno-unused-function $EXTRA"
 pids=()
 for f in "$HERE"/*.hip; do
   o="$OBJ/$(basename "${f%.hip}").o"

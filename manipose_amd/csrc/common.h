@@ -92,14 +92,17 @@ __device__ __forceinline__ float4 ld4(const bf16p* p, long lo_off) {
 }
 
 // ---- gfx950 hazard guard ------------------------------------------------------------------------
-// Found in round 3 (tools/gemm_determinism.py, tools/step_determinism.py): when a packed fp32 op (v_pk_mul/add/fma_f32) takes, for its
-// LOW lane, the HIGH register of a VGPR pair (op_sel bit set on that source) and that register was written by a vector-memory load
-// shortly before (typically a (mean, rstd) pair fetched with global_load_dwordx2 and splat over both lanes), the low-lane result came out
-// wrong for lanes 48-63 in ~1e-4 of the rows - different in every run, more often with other streams busy.  s_waitcnt vmcnt was in place;
-// forcing the loaded values through an empty asm (separate registers, the compiler copies with v_mov) removes the pattern and with it the
-// errors.  Every scalar that was loaded from memory and is multiplied into a vector goes through lone() - an explicit v_mov into a
-// register of its own, so that whatever the packed op selects was written by the VALU, not by the memory pipeline;
-// tools/scan_pk_opsel.py audits the generated code for the pattern (a CPU test runs it).
+// Found in round 3 (tools/gemm_determinism.py, tools/step_determinism.py, tools/batch_invariance.py): a packed fp32 op
+// (v_pk_mul/add/fma_f32) that takes, for its LOW lane, the HIGH register of a VGPR pair (op_sel bit set on that source - what the
+// compiler emits to splat the odd element of a register pair over both lanes) gave wrong low-lane results for lanes 48-63 in ~1e-4 of the
+// rows: different in every run, more often with other streams busy, with every s_waitcnt in place and also when the register had been
+// written by the VALU.  Seen in two places: the tiled GEMM's recomputed-LayerNorm residual epilogue ((mean, rstd) pair: 2 mm errors on
+// the segment lengths at the benchmark's batch) and the LayerNorm backward (non-reproducible gradients).  Such ops only come out of the
+// SLP vectoriser pairing scalar code, so the library is built with -fno-slp-vectorize (build.sh): the explicitly vector-typed packed
+// math (GELU, softmax, accumulator scaling) stays and never needs that operand form; the step time did not change.
+// tools/scan_pk_opsel.py audits the generated code of every kernel for the operand form (a CPU test runs it), and the reproducibility
+// tests in tests/test_gpu_parity.py hold two identical training steps to identical bits.
+// lone(): additionally gives a memory-loaded scalar that is multiplied into several values a VALU-written register of its own.
 __device__ __forceinline__ float lone(float v) {
   float r;
   asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));

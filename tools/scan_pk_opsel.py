@@ -1,9 +1,9 @@
-"""Build-time audit for a gfx950 hazard found in round 3: a packed fp32 VALU op (v_pk_mul/add/fma_f32) whose LOW lane reads the HIGH
-register of a VGPR pair (op_sel bit = 1 for that source) produced wrong low-lane results for lanes 48-63, rarely and run-to-run
-different, when that register had just been written by a vector-memory load (global_load_dwordx2 of a (mean, rstd) pair).  Forcing the
-two loaded values through an empty asm (common.h: unpair) makes the compiler copy / re-materialise them and the pattern disappears.
-This script compiles every csrc/*.hip to gfx950 assembly and lists the packed ops whose op_sel'd source register was last written by a
-vector-memory load (linear scan per kernel).  Exit status 1 if any is found.      python tools/scan_pk_opsel.py [file.s ...]"""
+"""Build-time audit for a gfx950 hazard found in round 3 (csrc/common.h, "gfx950 hazard guard"): a packed fp32 VALU op
+(v_pk_mul/add/fma_f32) whose LOW lane reads the HIGH register of a VGPR pair (op_sel bit = 1 on that source) produced wrong low-lane
+results for lanes 48-63, rarely and differently in every run.  The SLP vectoriser is the only producer of that operand form in this
+code base, so the library is built with -fno-slp-vectorize; this script compiles every csrc/*.hip to gfx950 assembly with the flags of
+build.sh and lists every packed fp32 op that still has the form (and, as a second class, those whose selected register was last
+written by a vector-memory load).  Exit status 1 if any is found.      python tools/scan_pk_opsel.py [file.s ...]"""
 import glob, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,8 +36,8 @@ def scan(path):
                 for k, b in enumerate(bits):
                     if b == "1" and k + 1 < len(ops):
                         r = regs(ops[k + 1])
-                        if len(r) == 2 and last.get(r[1]) == "vmem":
-                            hits.setdefault(kernel, []).append(code.strip())
+                        if len(r) == 2:
+                            hits.setdefault(kernel, []).append(("[after a memory load] " if last.get(r[1]) == "vmem" else "") + code.strip())
         d = DST.match(code)
         if d:
             mnem = d.group(1)
@@ -49,6 +49,13 @@ def scan(path):
     return hits
 
 
+def build_flags():
+    """the code-generation flags of csrc/build.sh that are not in the fixed command line below (e.g. -fno-slp-vectorize)"""
+    text = open(os.path.join(ROOT, "manipose_amd", "csrc", "build.sh")).read()
+    m = re.search(r'FLAGS="([^"]*)"', text)
+    return [f for f in (m.group(1).split() if m else []) if f.startswith("-f") and f != "-fPIC"]
+
+
 def main():
     files = sys.argv[1:]
     tmp = None
@@ -57,7 +64,7 @@ def main():
         procs = []
         for src in sorted(glob.glob(os.path.join(ROOT, "manipose_amd", "csrc", "*.hip"))):
             out = os.path.join(tmp, os.path.basename(src)[:-4] + ".s")
-            procs.append((out, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+            procs.append((out, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + build_flags() + ["-S", "--cuda-device-only", "-o", out, src],
                                                 stderr=subprocess.DEVNULL)))
         for out, p in procs:
             if p.wait() == 0:
@@ -66,7 +73,7 @@ def main():
     for f in files:
         for k, v in scan(f).items():
             total += len(v)
-            print(f"{os.path.basename(f)}: {k[:100]}: {len(v)} packed ops read the high half of a freshly loaded pair in their low lane, e.g. {v[0][:110]}")
+            print(f"{os.path.basename(f)}: {k[:100]}: {len(v)} packed fp32 ops take the high register of a pair for their low lane, e.g. {v[0][:130]}")
     print(f"{total} suspicious packed ops in {len(files)} files")
     sys.exit(1 if total else 0)
 
