@@ -310,7 +310,8 @@ int mp_procrustes_errors(const float* pred, const float* gt, const uint8_t* mask
 /* test / tuning hooks (no reference counterpart): "gemm_small_tile" (1 = 128x128 GEMM tiles everywhere),
  * "gemm_persist_min_tiles" (output-tile count from which the persistent GEMM kernels are used; 0 = default),
  * "gemm_persist_mode" (0 tiled kernels only, 1 = default: persistent kernel where it applies), "side_streams" (0 = the bones net is
- * enqueued on the caller's stream instead of the engine's side stream; 1 = default). */
+ * enqueued on the caller's stream instead of the engine's side stream; 1 = default), "attn_two_phase" (0 = the one-strip-at-a-time
+ * split-precision temporal attention forward for every shape; 1 = default: the two-phase kernel for head dim 64 and T > 128). */
 int mp_set_option(const char* name, int value);
 
 #ifdef __cplusplus

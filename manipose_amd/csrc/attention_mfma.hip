@@ -691,8 +691,16 @@ __device__ __forceinline__ int img_off(int img, int img_bytes) { return img * im
 template <int D>
 __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __restrict__ qkv_hi, const bf16* __restrict__ qkv_lo,
                                                                  bf16* __restrict__ out_hi, bf16* __restrict__ out_lo,
-                                                                 float* __restrict__ lse, int nunits, int T, int J, int C, int H, float scale) {
+                                                                 float* __restrict__ lse, int nunits, int T, int J, int C, int H, float scale, int debug) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
+  // timing ablations, diagnostics build only (results wrong by design): 1 = images staged for the first unit only, 2 = one K / V fragment
+  // read per strip instead of one per tile (no LDS traffic), 4 = no softmax arithmetic, 8 = no matrix-core work, 16 = no output stores,
+  // 32 = no Q loads
+#ifdef MP_GEMM_DIAG
+#define MP_ADBG(bit) (debug & (bit))
+#else
+#define MP_ADBG(bit) 0
+#endif
   constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB, CH = ACfg<D>::CH, PER = 4;
   const int rows = (T + 31) & ~31, nw = (int)(blockDim.x >> 6), nthreads = (int)blockDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __re
       for (int ks = 0; ks < KS; ++ks) {
         const int d0 = 32 * ks + 8 * g;
         bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bool ok = tq < T && d0 < D;
+        const bool ok = tq < T && d0 < D && !MP_ADBG(32);
         qn_h[sidx][ks] = ok ? *reinterpret_cast<const bf16x8_t*>(qh + (long)tq * rs3 + d0) : z;
         qn_l[sidx][ks] = ok ? *reinterpret_cast<const bf16x8_t*>(ql + (long)tq * rs3 + d0) : z;
       }
@@ -759,12 +767,14 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __re
   if (unit >= nunits) return;
   fetch_q(unit);
   fetch(unit);
+  bool first_unit = true;
   while (true) {
     __syncthreads();                       // every wave is done with the previous unit's images
-    commit();
+    if (!MP_ADBG(1) || first_unit) commit();
     __syncthreads();
     const int next = unit + gridDim.x;
-    if (next < nunits) fetch(next);        // in flight during the compute below
+    if (next < nunits && !MP_ADBG(1)) fetch(next);        // in flight during the compute below
+    first_unit = false;
     bool q_fetched = false;                // the next unit's Q fragments are requested once this wave's last score strip is done
     const int h = unit % H, bj = unit / H, j = bj % J, b = bj / J;
 #pragma unroll
@@ -780,7 +790,9 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __re
         if (kt < ntile) {
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8_t kh = Khr.rows(ks, kt * 16), kl = Khr.rows(ks, kt * 16, dlo);
+            const int krow = MP_ADBG(2) ? 0 : kt * 16;
+            const bf16x8_t kh = Khr.rows(ks, krow), kl = Khr.rows(ks, krow, dlo);
+            if (MP_ADBG(8)) { acc[0] += __builtin_bit_cast(float, (int)kh[0] + (int)kl[1]); continue; }
             MP_MFMA3(acc, kh, kl, qn_h[sidx][ks], qn_l[sidx][ks]);
           }
           acc *= scale2;
@@ -800,6 +812,7 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __re
       float sum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NTILE; ++kt) {
+        if (MP_ADBG(4)) { sum += s[kt][0]; continue; }
         if (kt < ntile) {
           const f32x4 t = s[kt] - mx;
           f32x4 e;
@@ -822,12 +835,14 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __re
           pack_acc_x2(s[2 * kp], s[2 * kp + 1], bph, bpl);
 #pragma unroll
           for (int db = 0; db < DB; ++db) {
-            const bf16x8_t vh = Vhr.cols(db, kp * 32), vl = Vhr.cols(db, kp * 32, dlo);
+            const int vrow = MP_ADBG(2) ? 0 : kp * 32;
+            const bf16x8_t vh = Vhr.cols(db, vrow), vl = Vhr.cols(db, vrow, dlo);
+            if (MP_ADBG(8)) { o[db][0] += __builtin_bit_cast(float, (int)vh[0] + (int)vl[1] + (int)bph[0] + (int)bpl[0]); continue; }
             MP_MFMA3(o[db], vh, vl, bph, bpl);
           }
         }
       }
-      if (tq < T) {
+      if (tq < T && !(MP_ADBG(16) && sum != 12345.f)) {
         const float inv = 1.0f / sum;
         const long oo = ((long)(b * T + tq) * J + j) * C + h * D;
 #pragma unroll
@@ -840,6 +855,192 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __re
     unit = next;
   }
 }
+
+// Two-phase form of the split-precision temporal forward for head dim 64 and windows of more than 128 frames (the benchmark's shape).
+// The LDS holds region A = (K_hi, K_lo) and region B = (V_hi, V_lo); a unit is computed as
+//   phase 1: scores + softmax of BOTH 16-query strips of a wave from region A   (meanwhile: V of this unit arrives in region B)
+//   phase 2: O = P V of both strips from region B                              (meanwhile: K of the next unit arrives in region A)
+// with the images fetched by direct-to-LDS DMA (global_load_lds_dwordx4; the XOR swizzle of stage_rows applied to the source address),
+// so no register is spent on prefetching and the scores of both strips can stay live: every K / V fragment read from LDS now serves two
+// strips (half the LDS fragment traffic of the one-strip-at-a-time kernel above), the staging of a unit is hidden behind the other
+// phase, and the output tile is transposed through a wave-private LDS buffer so that every store instruction writes whole 128-byte
+// rows (the accumulator layout gave 32-byte pieces of 16 rows that lie J*C*2 bytes apart).
+__device__ __forceinline__ void tm_dma_region(char* __restrict__ region, const bf16* __restrict__ p_hi, const bf16* __restrict__ p_lo, long rs3, int T,
+                                              int rows, int lane, int wave, int nw) {
+  typedef __attribute__((address_space(3))) void* lptr;
+  typedef const __attribute__((address_space(1))) void* gptr;
+  const int per_img = rows >> 3;                     // DMA instructions per image: 8 rows (1 KiB) each
+  for (int n = wave; n < 2 * per_img; n += nw) {     // wave-uniform instruction index
+    const int img = n >= per_img, q = n - img * per_img;
+    const int r = q * 8 + (lane >> 3), c = (lane & 7) ^ (r & 7);
+    const bf16* src = (img ? p_lo : p_hi) + (long)min(r, T - 1) * rs3 + c * 8;      // frames past T repeat the last frame (finite; their
+    __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(region + n * 1024), 16, 0, 0);   // probabilities are exactly 0)
+  }
+}
+
+__global__ __launch_bounds__(512) void attn_tmfma_fwd_x3p_kernel(const bf16* __restrict__ qkv_hi, const bf16* __restrict__ qkv_lo,
+                                                                  bf16* __restrict__ out_hi, bf16* __restrict__ out_lo,
+                                                                  float* __restrict__ lse, int nunits, int T, int J, int C, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int D = 64, ROWB = 128, KS = 2, DB = 4, NW = 8, OPITCH = 144;
+  const int rows = (T + 31) & ~31;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long rs3 = (long)J * 3 * C;
+  const int ntile = (T + 15) >> 4;
+  const int img_bytes = rows * ROWB;
+  char* const regA = sm;                              // K_hi | K_lo
+  char* const regB = sm + 2 * img_bytes;              // V_hi | V_lo
+  char* const obuf = sm + 4 * img_bytes + wave * (16 * OPITCH);
+  ImgRd<D> Khr, Vhr;
+  Khr.init(regA, lane);
+  Vhr.init(regB, lane);
+  const int dlo = __builtin_amdgcn_readfirstlane(img_bytes);
+  const float scale2 = scale * 1.4426950408889634f;
+  auto unit_base = [&](int unit) -> long {
+    const int h = unit % H, bj = unit / H, j = bj % J, b = bj / J;
+    return ((long)b * T * J + j) * 3 * C + h * D;
+  };
+  bf16x8_t qh[2][KS], ql[2][KS];
+  auto fetch_q = [&](int unit) {
+    const long qoff = unit_base(unit);
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const int tq = min((wave + sidx * NW) * 16 + l15, T - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        qh[sidx][ks] = *reinterpret_cast<const bf16x8_t*>(qkv_hi + qoff + (long)tq * rs3 + 32 * ks + 8 * g);
+        ql[sidx][ks] = *reinterpret_cast<const bf16x8_t*>(qkv_lo + qoff + (long)tq * rs3 + 32 * ks + 8 * g);
+      }
+    }
+  };
+  int unit = blockIdx.x;
+  if (unit >= nunits) return;
+  {
+    const long qoff = unit_base(unit);
+    tm_dma_region(regA, qkv_hi + qoff + C, qkv_lo + qoff + C, rs3, T, rows, lane, wave, NW);
+  }
+  fetch_q(unit);
+  const bool two = wave + NW < ntile;                 // this wave's second strip exists
+  while (true) {
+    const long qoff = unit_base(unit);
+    const int h = unit % H, bj = unit / H, j = bj % J, b = bj / J;
+    // K(unit) has landed for every wave; nobody reads region B (V of the previous unit) any more
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    tm_dma_region(regB, qkv_hi + qoff + 2 * C, qkv_lo + qoff + 2 * C, rs3, T, rows, lane, wave, NW);
+    // ---- phase 1: scores of both strips (every K fragment serves both), exact softmax ----
+    f32x4 s[2][NTILE];
+    float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int kt = 0; kt < NTILE; ++kt) {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+      if (kt < ntile) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8_t kh = Khr.rows(ks, kt * 16), kl = Khr.rows(ks, kt * 16, dlo);
+          MP_MFMA3(a0, kh, kl, qh[0][ks], ql[0][ks]);
+          MP_MFMA3(a1, kh, kl, qh[1][ks], ql[1][ks]);
+        }
+        a0 *= scale2;
+        a1 *= scale2;
+        if (kt == ntile - 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kt * 16 + 4 * g + r >= T) { a0[r] = -INFINITY; a1[r] = -INFINITY; }
+        }
+        mx[0] = fmaxf(fmaxf(mx[0], fmaxf(a0[0], a0[1])), fmaxf(a0[2], a0[3]));
+        mx[1] = fmaxf(fmaxf(mx[1], fmaxf(a1[0], a1[1])), fmaxf(a1[2], a1[3]));
+      } else {
+        a0 = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        a1 = a0;
+      }
+      s[0][kt] = a0;
+      s[1][kt] = a1;
+    }
+    float sum[2];
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      mx[sidx] = group_max(mx[sidx]);
+      float sm_ = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NTILE; ++kt) {
+        if (kt < ntile) {
+          const f32x4 t = s[sidx][kt] - mx[sidx];
+          f32x4 e;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+          s[sidx][kt] = e;
+          sm_ += (e[0] + e[1]) + (e[2] + e[3]);
+        } else {
+          s[sidx][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      sum[sidx] = group_sum(sm_);
+    }
+    // V(unit) has landed for every wave; nobody reads region A (K of this unit) any more
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    const int next = unit + gridDim.x;
+    if (next < nunits) {
+      const long noff = unit_base(next);
+      tm_dma_region(regA, qkv_hi + noff + C, qkv_lo + noff + C, rs3, T, rows, lane, wave, NW);
+      fetch_q(next);
+    }
+    // ---- phase 2: O = P V of both strips (every V fragment serves both) ----
+    f32x4 o[2][DB];
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+      for (int db = 0; db < DB; ++db) o[sidx][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kp = 0; kp < NTILE / 2; ++kp) {
+      if (2 * kp < ntile) {
+        bf16x8_t p0h, p0l, p1h, p1l;
+        pack_acc_x2(s[0][2 * kp], s[0][2 * kp + 1], p0h, p0l);
+        pack_acc_x2(s[1][2 * kp], s[1][2 * kp + 1], p1h, p1l);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          const bf16x8_t vh = Vhr.cols(db, kp * 32), vl = Vhr.cols(db, kp * 32, dlo);
+          MP_MFMA3(o[0][db], vh, vl, p0h, p0l);
+          MP_MFMA3(o[1][db], vh, vl, p1h, p1l);
+        }
+      }
+    }
+    // ---- output: per strip and plane, the 16 x 64 tile goes through the wave-private buffer and leaves as whole 128-byte rows ----
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      if (sidx == 1 && !two) break;
+      const int qt = wave + sidx * NW;
+      const float inv = 1.0f / sum[sidx];
+      uint2 hv[DB], lv[DB];
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        split_bf16x2(o[sidx][db][0] * inv, o[sidx][db][1] * inv, hv[db].x, lv[db].x);
+        split_bf16x2(o[sidx][db][2] * inv, o[sidx][db][3] * inv, hv[db].y, lv[db].y);
+      }
+#pragma unroll
+      for (int plane = 0; plane < 2; ++plane) {
+#pragma unroll
+        for (int db = 0; db < DB; ++db) *reinterpret_cast<uint2*>(obuf + l15 * OPITCH + 32 * db + 8 * g) = plane ? lv[db] : hv[db];
+        bf16* const dst = plane ? out_lo : out_hi;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int row = pass * 8 + (lane >> 3), tq = qt * 16 + row;
+          const uint4 v = *reinterpret_cast<const uint4*>(obuf + row * OPITCH + (lane & 7) * 16);
+          if (tq < T) *reinterpret_cast<uint4*>(dst + ((long)(b * T + tq) * J + j) * C + h * D + (lane & 7) * 8) = v;
+        }
+      }
+      const int tq = qt * 16 + l15;
+      if (g == 0 && tq < T) lse[(long)unit * T + tq] = (mx[sidx] + __log2f(sum[sidx])) * 0.6931471805599453f;
+    }
+    if (next >= nunits) break;
+    unit = next;
+  }
+}
+
+static int g_attn_two_phase = 1;           // mp_set_option("attn_two_phase", 0): the one-strip-at-a-time kernel for every shape (A/B timing, tests)
+void attn_two_phase(int on) { g_attn_two_phase = on; }
 
 // spatial: workgroup per frame, wave per head; the frame's hi and lo qkv blocks (2 x N x 6C bytes, contiguous in HBM) are both staged.
 // Persistent with register prefetch of the next frame's blocks like the temporal kernel (105 KiB of LDS at C = 512: one workgroup per CU).
@@ -1027,7 +1228,12 @@ static int launch_tmfma_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out
   }
   const int per_cu = (int)max((size_t)1, min((size_t)4, (size_t)(160 * 1024) / lds));
   const int grid = min(units, num_cus() * per_cu);
-  hipLaunchKernelGGL((attn_tmfma_fwd_x3_kernel<D>), dim3(grid), dim3(64 * waves), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale);
+#ifdef MP_GEMM_DIAG
+  static const int dbg = [] { const char* e = getenv("MANIPOSE_ATTN_DEBUG"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int dbg = 0;
+#endif
+  hipLaunchKernelGGL((attn_tmfma_fwd_x3_kernel<D>), dim3(grid), dim3(64 * waves), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, dbg);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -1047,6 +1253,19 @@ int attn_temporal_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, b
   }
   const float scale = attn_qk_scale(D);
   const int units = B * J * H;
+  if (D == 64 && T > 128 && g_attn_two_phase && (C * 2) % 128 == 0 && (3L * C * 2) % 16 == 0) {
+    const int rows = (T + 31) & ~31;
+    const size_t lds = 4 * (size_t)rows * 128 + 8 * 16 * 144;
+    static bool attr_set = false;
+    if (!attr_set) {
+      MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * 128 + 8 * 16 * 144)));
+      attr_set = true;
+    }
+    const int grid = min(units, num_cus());
+    hipLaunchKernelGGL(attn_tmfma_fwd_x3p_kernel, dim3(grid), dim3(512), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale);
+    MP_LAUNCH_CHECK();
+    return MP_OK;
+  }
   if (D == 64) return launch_tmfma_fwd_x3<64>(qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, st);
   return launch_tmfma_fwd_x3<16>(qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, st);
 }

@@ -279,6 +279,7 @@ int mp_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_persist_min_tiles")) { gemm_bf16_persist_min_tiles(value); return MP_OK; }
   if (!strcmp(name, "gemm_persist_mode")) { gemm_bf16_persist_mode(value); return MP_OK; }
   if (!strcmp(name, "side_streams")) { engine_side_streams(value); return MP_OK; }
+  if (!strcmp(name, "attn_two_phase")) { attn_two_phase(value); return MP_OK; }
   MP_CHECK(false, MP_ERR_ARG, "mp_set_option: unknown option '%s'", name);
 }
 

@@ -127,6 +127,7 @@ int attn_spatial_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf
                         hipStream_t st);
 int attn_temporal_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* lse, float* scratch, int B, int T, int J,
                          int C, int H, hipStream_t st);
+void attn_two_phase(int on);        // 0 = one-strip-at-a-time split-precision temporal forward for every shape (mp_set_option)
 int join_planes(const bf16* hi, const bf16* lo, float* out, long n, hipStream_t st);
 int split_planes(const float* in, bf16* hi, bf16* lo, long n, hipStream_t st);
 

@@ -1403,7 +1403,8 @@ def test_bf16x3_linear_forward_epilogues(lib, M, N, K):
 
 
 @pytest.mark.parametrize("temporal,B,T,J,C,H", [(1, 2, 243, 3, 128, 2), (1, 1, 81, 17, 512, 8), (1, 2, 27, 16, 128, 8), (1, 1, 256, 2, 64, 1),
-                                                (1, 1, 17, 2, 32, 2), (1, 1, 300, 2, 128, 2), (1, 1, 100, 2, 64, 4),
+                                                (1, 1, 17, 2, 32, 2), (1, 1, 300, 2, 128, 2), (1, 1, 100, 2, 64, 4), (1, 3, 243, 17, 512, 8),
+                                                (1, 2, 129, 5, 64, 1), (1, 40, 200, 3, 128, 2), (1, 1, 145, 2, 64, 1),
                                                 (0, 1, 9, 17, 128, 2), (0, 2, 5, 17, 512, 8), (0, 1, 7, 16, 128, 8), (0, 1, 3, 17, 64, 4)])
 def test_bf16x3_attention_forward(lib, temporal, B, T, J, C, H):
     """Split-precision attention forward (MFMA kernels with hi/lo images; fp32 route for the other shapes) against the fp32 formula
@@ -1423,6 +1424,19 @@ def test_bf16x3_attention_forward(lib, temporal, B, T, J, C, H):
                                            temporal, B, T, J, C, H, st()))
     err = (_join(oh, ol).cpu() - ref).abs().max().item() / float(ref.abs().max())
     assert err < 1e-4, err                                                     # bf16 kernels: ~1e-2
+    if temporal and C // H == 64 and 128 < T <= 256:
+        # this shape runs the two-phase kernel (K / V regions fetched by direct-to-LDS DMA, two strips per fragment read): the
+        # one-strip-at-a-time kernel computes the same products in the same order: same log-sum-exp and hi plane bit for bit, lo plane up to
+        # the contraction of (o * 1/sum - hi) into one fused multiply-add
+        o2h, o2l, lse2 = torch.zeros_like(oh), torch.zeros_like(ol), torch.zeros_like(lse)
+        _lib.check(lib.mp_set_option(b"attn_two_phase", 0))
+        try:
+            _lib.check(lib.mp_attention_fwd_bf16x3(qh.data_ptr(), ql.data_ptr(), o2h.data_ptr(), o2l.data_ptr(), lse2.data_ptr(), scratch.data_ptr(),
+                                                   temporal, B, T, J, C, H, st()))
+        finally:
+            _lib.check(lib.mp_set_option(b"attn_two_phase", 1))
+        assert torch.equal(oh, o2h) and torch.equal(lse, lse2)
+        assert (_join(oh, ol) - _join(o2h, o2l)).abs().max().item() <= 1e-5 * float(ref.abs().max())      # one ulp of a lo plane
 
 
 @pytest.mark.parametrize("name", ["rmcl_tiny", "rmcl_small"])
