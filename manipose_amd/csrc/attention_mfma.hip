@@ -866,14 +866,14 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __re
 // phase, and the output tile is transposed through a wave-private LDS buffer so that every store instruction writes whole 128-byte
 // rows (the accumulator layout gave 32-byte pieces of 16 rows that lie J*C*2 bytes apart).
 __device__ __forceinline__ void tm_dma_region(char* __restrict__ region, const bf16* __restrict__ p_hi, const bf16* __restrict__ p_lo, long rs3, int T,
-                                              int rows, int lane, int wave, int nw) {
+                                              int rows, int lane, int wave, int nw, long rs_second = 0) {
   typedef __attribute__((address_space(3))) void* lptr;
   typedef const __attribute__((address_space(1))) void* gptr;
   const int per_img = rows >> 3;                     // DMA instructions per image: 8 rows (1 KiB) each
   for (int n = wave; n < 2 * per_img; n += nw) {     // wave-uniform instruction index
     const int img = n >= per_img, q = n - img * per_img;
     const int r = q * 8 + (lane >> 3), c = (lane & 7) ^ (r & 7);
-    const bf16* src = (img ? p_lo : p_hi) + (long)min(r, T - 1) * rs3 + c * 8;      // frames past T repeat the last frame (finite; their
+    const bf16* src = (img ? p_lo : p_hi) + (long)min(r, T - 1) * ((img && rs_second) ? rs_second : rs3) + c * 8;   // frames past T repeat the last frame (finite; their
     __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(region + n * 1024), 16, 0, 0);   // probabilities are exactly 0)
   }
 }
@@ -1039,6 +1039,12 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3p_kernel(const bf16* __r
   }
 }
 
+// (A two-phase form of the bf16 temporal BACKWARD - (K, V) and (Q, dO) regions by DMA behind the other pass, eight waves with two strips
+// each so that every LDS fragment serves both - was built and measured in round 3: bit-compatible, half the LDS fragment traffic, and no
+// faster: 1100-1130 us against 1123 us isolated at the benchmark's batch, 178.9 against 177.7 ms per step.  The SQ counters of both
+// forms show why: waves parked on s_waitcnt / barriers 45 % of their cycles, issue stalls 32 %, LDS busy 3 %, matrix cores 27 % - the
+// kernel waits for its 128-byte rows, which lie J * 3C * 2 bytes apart in the token-major qkv layout (2.4 TB/s effective for every
+// temporal kernel, where the spatial kernels - whole contiguous frames - reach 5 TB/s).  Not kept.)
 static int g_attn_two_phase = 1;           // mp_set_option("attn_two_phase", 0): the one-strip-at-a-time kernel for every shape (A/B timing, tests)
 void attn_two_phase(int on) { g_attn_two_phase = on; }
 
@@ -1253,7 +1259,7 @@ int attn_temporal_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, b
   }
   const float scale = attn_qk_scale(D);
   const int units = B * J * H;
-  if (D == 64 && T > 128 && g_attn_two_phase && (C * 2) % 128 == 0 && (3L * C * 2) % 16 == 0) {
+  if (D == 64 && T > 128 && (g_attn_two_phase & 1) && (C * 2) % 128 == 0 && (3L * C * 2) % 16 == 0) {
     const int rows = (T + 31) & ~31;
     const size_t lds = 4 * (size_t)rows * 128 + 8 * 16 * 144;
     static bool attr_set = false;

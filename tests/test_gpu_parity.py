@@ -543,6 +543,7 @@ def test_bf16_precision_model_drift_vs_reference(lib, name):
 @pytest.mark.parametrize("temporal,B,T,J,C,H", [(1, 2, 243, 3, 128, 2), (1, 1, 81, 17, 512, 8), (1, 2, 27, 16, 128, 8),
                                                 (1, 1, 256, 2, 64, 1), (1, 1, 17, 2, 32, 2), (1, 1, 300, 2, 128, 2),
                                                 (1, 2, 81, 3, 128, 8), (1, 1, 100, 2, 64, 4), (1, 1, 128, 2, 128, 2), (1, 3, 200, 2, 32, 2),
+                                                (1, 3, 243, 17, 512, 8), (1, 30, 241, 3, 128, 2), (1, 2, 250, 2, 64, 1),
                                                 (0, 1, 9, 17, 128, 2), (0, 2, 5, 17, 512, 8), (0, 1, 7, 16, 128, 8),
                                                 (0, 1, 3, 17, 64, 4)])
 def test_bf16_attention_forward_backward(lib, temporal, B, T, J, C, H):
