@@ -428,7 +428,7 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
       if (!b_first) glds_tile<TRB, BT, NW>(nx + OPB, B, g.ldb, n0, k0 + GBK, g.N, kend, lane, wave);
     }
     if (MP_DBG(g, 1)) continue;
-    if (EPI == EPI_SLAB && TRA == 1) {
+    if (EPI == EPI_SLAB && TRA == 1 && !MP_DBG(g, 8)) {
       if (tn == 0 && tid < BT) {
         const int oc = tid >> 3, wi = tid & 7;
         for (int r = 0; r < GBK; ++r)
@@ -914,7 +914,7 @@ static int launch_b16(const GemmB16Args& g, int splits, hipStream_t st) {
 int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, hipStream_t st) {
   g.debug = 0;
 #ifdef MP_GEMM_DIAG
-  { static const int dbg = [] { const char* e = getenv("MANIPOSE_GEMM_DEBUG"); return e ? atoi(e) : 0; }(); g.debug = dbg; }   // timing ablations (1 no MFMA, 2 no DMA, 4 no epilogue)
+  { static const int dbg = [] { const char* e = getenv("MANIPOSE_GEMM_DEBUG"); return e ? atoi(e) : 0; }(); g.debug = dbg; }   // timing ablations (1 no MFMA, 2 no DMA, 4 no epilogue, 8 no bias-gradient column sums in the weight-gradient kernel)
 #endif
   MP_CHECK(g.M > 0 && g.N > 0 && g.K > 0, MP_ERR_ARG, "gemm_bf16: empty problem");
   MP_CHECK((a_tr ? g.M : g.K) % 8 == 0 && (b_tr ? g.N : g.K) % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.N % 4 == 0 &&
