@@ -653,6 +653,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   const bool has_bias = EPI != EPI_DGELU && g.bias != nullptr;
 #ifdef MP_GEMM_DIAG                                          // diagnostics build (MP_DIAG=1 build.sh -> libmanipose_hip_diag.so, tools/gemm_stamps.py)
   int tile_no = 0;
+  // per-wave shader-clock totals of the main loop: cycles parked on s_waitcnt (operand DMA), on the barrier behind it, and in the MFMA stage
+  unsigned long long dg_wait = 0, dg_bar = 0, dg_mma = 0, dg_epi = 0;
   if (g.stagger > 0) {                                      // start the workgroups of an XCD in four phase groups
     const int phase = (blockIdx.x >> 3) & 3;
     if (phase) {
@@ -686,10 +688,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       // one of the two tiles the next step 0 needs has two steps to arrive instead of one.
       bool early = false;
       for (int kt = 0, term = 0; kt < nk;) {
+#ifdef MP_GEMM_DIAG
+        const unsigned long long tk0 = __builtin_readcyclecounter();
+#endif
         if (kt == 0 && term == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only: (A_lo, B_hi) of this tile were waited for before the previous epilogue
         else if (term == 2 && early) __builtin_amdgcn_s_waitcnt(0x0074);             // vmcnt(4) lgkmcnt(0)
         else __builtin_amdgcn_s_waitcnt(0x0070);
+#ifdef MP_GEMM_DIAG
+        const unsigned long long tk1 = __builtin_readcyclecounter();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef MP_GEMM_DIAG
+        const unsigned long long tk2 = __builtin_readcyclecounter();
+        dg_wait += tk1 - tk0; dg_bar += tk2 - tk1;
+#endif
         const char* As = term == 0 ? A0 : A1;
         const char* Bs = term == 2 ? B1 : B0;
         const bool last = kt + 1 == nk;
@@ -711,6 +723,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
           }
         }
         mma_stage<0, TRB, BT, (SPLIT >> 1)>(As, Bs, acc, wr, wc, lane);  // term 0: A_lo B_hi, 1: A_hi B_hi, 2: A_hi B_lo
+#ifdef MP_GEMM_DIAG
+        dg_mma += __builtin_readcyclecounter() - tk2;
+#endif
         if (++term == 3) { term = 0; ++kt; }
       }
       (void)stage;
@@ -718,9 +733,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
     for (int ks = 0; ks < nk; ++ks, stage ^= 1) {
       // k-tile ks has landed for every wave and nobody still reads the other stage.  On a tile's first k-tile the DMA was
       // waited for before the previous epilogue: do not wait for that epilogue's stores here, they drain under this k-tile.
+#ifdef MP_GEMM_DIAG
+      const unsigned long long tk0 = __builtin_readcyclecounter();
+#endif
       if (ks == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only
       else __builtin_amdgcn_s_waitcnt(0x0070);                        // vmcnt(0) lgkmcnt(0)
+#ifdef MP_GEMM_DIAG
+      const unsigned long long tk1 = __builtin_readcyclecounter();
+#endif
       __builtin_amdgcn_s_barrier();
+#ifdef MP_GEMM_DIAG
+      const unsigned long long tk2 = __builtin_readcyclecounter();
+      dg_wait += tk1 - tk0; dg_bar += tk2 - tk1;
+#endif
       const char* As = smem + stage * STAGE;
       const char* Bs = As + OPB;
       char* nx = smem + (stage ^ 1) * STAGE;
@@ -736,6 +761,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
         __builtin_amdgcn_global_load_lds((gptr)(g.bias + n0 + wc * 64 + lane), (lptr)img, 4, 0, 0);
       }
       if (!MP_DBG(g, 1)) mma_stage<0, TRB, BT>(As, Bs, acc, wr, wc, lane);
+#ifdef MP_GEMM_DIAG
+      dg_mma += __builtin_readcyclecounter() - tk2;
+#endif
     }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): the next tile's first k-tile (issued one k-tile ago)
@@ -744,6 +772,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
     // ---- epilogue, 16 rows of the wave's 128 x 64 sub-tile per pass through the wave-private image ----
 #ifdef MP_GEMM_DIAG
     if (g.stamps != nullptr && tid == 0 && tile_no < 64) g.stamps[((long)blockIdx.x * 64 + tile_no) * 2] = wall_clock64();
+    const unsigned long long te0 = __builtin_readcyclecounter();
 #endif
     if (!MP_DBG(g, 4)) {
       // the lane indices pass through an opaque move so that the epilogue's address arithmetic is redone per tile instead of
@@ -758,8 +787,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       else persist_epilogue<TC, EPI, false>(g, acc, img, m0 + wr * 128, col, bias4, C, Z, e15, eq);
     }
 #ifdef MP_GEMM_DIAG
+    dg_epi += __builtin_readcyclecounter() - te0;
     if (g.stamps != nullptr && tid == 0 && tile_no < 64) g.stamps[((long)blockIdx.x * 64 + tile_no) * 2 + 1] = wall_clock64();
     ++tile_no;
+    if (!has_next && g.stamps != nullptr && lane == 0) {      // per-wave totals behind the per-tile stamps: [workgroup][wave][wait, barrier, mma, epilogue]
+      long long* o = g.stamps + 256 * 64 * 2 + ((long)blockIdx.x * 8 + wave) * 4;
+      o[0] = (long long)dg_wait; o[1] = (long long)dg_bar; o[2] = (long long)dg_mma; o[3] = (long long)dg_epi;
+    }
 #endif
     if (!has_next) break;
     id = idn; m0 = m0n; n0 = n0n;

@@ -6,7 +6,7 @@ from manipose_amd import _lib
 lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
 if os.environ.get("ATTN2P") == "0":
     _lib.check(lib.mp_set_option(b"attn_two_phase", 0))
-B, T, J, C, H = int(os.environ.get("B", "32")), int(os.environ.get("T", "243")), 17, 512, 8
+B, T, J, C, H = int(os.environ.get("B", "32")), int(os.environ.get("T", "243")), int(os.environ.get("J", "17")), 512, 8
 M = B * T * J
 qkv = torch.randn(M, 3 * C, device="cuda").bfloat16(); dout = torch.randn(M, C, device="cuda").bfloat16()
 out = torch.empty(M, C, device="cuda", dtype=torch.bfloat16); dq = torch.empty(M, 3 * C, device="cuda", dtype=torch.bfloat16)

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 diag = os.path.join(ROOT, "manipose_amd", "libmanipose_hip_diag.so")
 assert os.path.exists(diag), "build the diagnostics library first: MP_DIAG=1 bash manipose_amd/csrc/build.sh"
 os.environ["MANIPOSE_HIP_LIB"] = diag
-stamps = torch.zeros(256 * 64 * 2, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(256 * 64 * 2 + 256 * 8 * 4, dtype=torch.int64, device="cuda")
 os.environ["MANIPOSE_GEMM_STAMPS"] = hex(stamps.data_ptr())
 from manipose_amd import _lib
 lib = _lib.load()
@@ -29,7 +29,8 @@ def run():
         _lib.check(lib.mp_linear_fwd_bf16(xh.data_ptr(), Wh.data_ptr(), b.data_ptr(), yh.data_ptr(), None, None, M, N, K, 0, st))
 for _ in range(3): run()
 torch.cuda.synchronize(); stamps.zero_(); run(); torch.cuda.synchronize()
-s = stamps.view(256, 64, 2).cpu()
+s = stamps[:256 * 64 * 2].view(256, 64, 2).cpu()
+cyc = stamps[256 * 64 * 2:].view(256, 8, 4).cpu().double()
 t0 = int(s[s > 0].min())
 tiles = int((s[:, :, 1] > 0).all(0).sum())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -51,3 +52,11 @@ T = float(end.max())
 ts = torch.arange(0, T, 0.5, dtype=torch.float64)
 busy = ((start.reshape(-1, 1) <= ts) & (end.reshape(-1, 1) > ts)).sum(0)
 print(f"workgroups inside an epilogue at a time: mean {busy.double().mean():.1f}, max {int(busy.max())}; fraction of the launch with > 128 of them in it: {(busy > 128).double().mean():.2f}, with none: {(busy == 0).double().mean():.2f}")
+
+# shader-clock totals per wave over the launch: where the main loop's cycles go
+tot = cyc.sum(-1, keepdim=True)
+fr = (cyc / tot).mean((0, 1))
+print(f"per-wave cycle split over the launch (mean of 256 x 8 waves): parked on s_waitcnt (operand DMA) {fr[0]:.3f}, on the barrier {fr[1]:.3f}, MFMA stage {fr[2]:.3f}, "
+      f"epilogue {fr[3]:.3f}; cycles per wave {tot.mean():.0f}")
+w = cyc / tot
+print("  by wave index (wait / barrier / mma / epilogue): " + "  ".join(f"w{i}: {w[:, i, 0].mean():.2f}/{w[:, i, 1].mean():.2f}/{w[:, i, 2].mean():.2f}/{w[:, i, 3].mean():.2f}" for i in range(8)))
