@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("MANIPOSE_PRECISION", "bf16x3"), choices=["bf16", "bf16x3", "fp32"],
                     help="bf16x3 (default) = split bf16 hi/lo operands, 3 matrix-core products per product: inside the 1e-4 m parity bound; "
                          "bf16 = plain bf16 matrix cores (fp32 accumulate/residual/softmax), ~3 mm drift; fp32 = fp32 matrix cores")
+    ap.add_argument("--grad-buckets", action="store_true",
+                    help="N > 1: overlap the gradient exchange with the backward (one all-reduce per layer of the rotations net on a communication "
+                         "stream) instead of one all-reduce of the flat buffer behind it; off by default (never measured on a multi-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity measurement (profiling passes)")
@@ -286,7 +289,7 @@ def main():
         parity["mpjpe_m_worst_rank"] = worst.item()
         parity["ranks_checked"] = world
     model = model.train()
-    trainer = LiftingTrainer(model, lr=4e-5, weight_decay=1e-6, seed=42)
+    trainer = LiftingTrainer(model, lr=4e-5, weight_decay=1e-6, seed=42, grad_buckets=args.grad_buckets)
 
     def barrier():
         if world > 1:
@@ -361,7 +364,9 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                "config": {"workload": f"H36M lifting T={T} J=17 K={args.hyp} ManiPose full (C=512, depth 8), train step "
                                       f"fwd+WTA loss+bwd+allreduce+Adam", "windows_per_gpu": B, "global_batch": world * B,
-                          "seq_len": T, "parallelism": f"dp{world}", "precision": args.precision, "drop_path_rate": 0.1},
+                          "seq_len": T, "parallelism": f"dp{world}", "precision": args.precision, "drop_path_rate": 0.1,
+                          "gradient_exchange": ("none" if world == 1 else ("8 layer buckets overlapped with the backward + remainder" if args.grad_buckets
+                                                                          else "one all-reduce of the flat buffer (137.8 MB) behind the backward"))},
                "loss": loss, "model_tflops": poses_per_s * gf / 1e3}
         if parity is not None:
             worst = max(parity["mpjpe_m"], parity["mpjpe_m_small_batch"], parity.get("mpjpe_m_worst_rank", 0.0))

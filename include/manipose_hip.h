@@ -223,6 +223,16 @@ int mp_model_forward(mp_model* m, const float* flat_params, const float* x, int 
  * ACCUMULATED into flat_grads (zero it first for a fresh gradient). */
 int mp_model_backward(mp_model* m, const float* flat_params, float* flat_grads, const float* d_poses, const float* d_scores,
                       void* stream);
+/* Gradient buckets for overlapping the data-parallel exchange with the backward (the reference has no counterpart: it wraps the
+ * model in nn.DataParallel, hpe/main_h36m_lifting.py:749-751).  Bucket i = the parameter gradients of layer i of the rotations net
+ * (STEblocks.i and TTEblocks.i: one contiguous range [offset, offset + numel) of the flat gradient buffer, ~25 MB at full width).  The
+ * backward finishes them from the last layer down; mp_model_grad_bucket_wait makes `stream` wait (device side, the host does not block)
+ * until bucket `index` of the LAST mp_model_backward is final, so a collective enqueued on that stream afterwards runs while the rest of
+ * the backward is still computing.  Everything outside the buckets (embeddings, shared norms, heads, the segments net) is final when the
+ * stream mp_model_backward was given has passed the call. */
+int mp_model_grad_bucket_count(const mp_model* m);
+int mp_model_grad_bucket_info(const mp_model* m, int index, int64_t* offset, int64_t* numel);
+int mp_model_grad_bucket_wait(mp_model* m, int index, void* stream);
 /* intermediate outputs of the last forward (device pointers owned by the model): 0 = head output
  * (K, B*T*17, O), 1 = segment lengths (B, 16), 2 = the DropPath multipliers of the last train-mode forward (layout: mp_model_mask_info);
  * the fp32 residual stream block by block (blocks in execution order STE0, TTE0, STE1, ...; (B*T*N, C) each): 100 + 2 l = after the

@@ -77,6 +77,9 @@ _SIGNATURES = {
     "mp_model_mask_floats": (i64, [vp, i32]),
     "mp_model_forward": (i32, [vp, vp, vp, i32, vp, vp, i32, vp, u64, u64, vp]),
     "mp_model_backward": (i32, [vp, vp, vp, vp, vp, vp]),
+    "mp_model_grad_bucket_count": (i32, [vp]),
+    "mp_model_grad_bucket_info": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
+    "mp_model_grad_bucket_wait": (i32, [vp, i32, vp]),
     "mp_model_peek": (i32, [vp, i32, C.POINTER(vp), C.POINTER(i64)]),
     "mp_model_peek_copy": (i32, [vp, i32, vp, i64, vp]),
     "mp_gather_windows": (i32, [vp, vp, vp, i32, vp, vp, vp, C.POINTER(i32), vp, vp, i32, i32, i32, vp, vp, vp]),

@@ -102,6 +102,19 @@ class LiftEngine:
                    "mp_model_peek_copy")
         return out
 
+    def grad_buckets(self) -> List[Tuple[int, int]]:
+        """[(offset, numel)] of the gradient buckets (one per layer of the rotations net) in the flat gradient buffer."""
+        off, n = C.c_int64(), C.c_int64()
+        out = []
+        for i in range(self.lib.mp_model_grad_bucket_count(self.handle)):
+            _lib.check(self.lib.mp_model_grad_bucket_info(self.handle, i, C.byref(off), C.byref(n)), "mp_model_grad_bucket_info")
+            out.append((int(off.value), int(n.value)))
+        return out
+
+    def grad_bucket_wait(self, index: int, stream: "torch.cuda.Stream") -> None:
+        """Make `stream` wait (on the device) until bucket `index` of the last backward is final."""
+        _lib.check(self.lib.mp_model_grad_bucket_wait(self.handle, index, stream.cuda_stream), "mp_model_grad_bucket_wait")
+
     def prof_enable(self, on: bool = True) -> None:
         _lib.check(self.lib.mp_prof_enable(self.handle, int(on)), "mp_prof_enable")
 

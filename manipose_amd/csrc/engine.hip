@@ -69,7 +69,9 @@ struct mp_model {
   struct ScratchSet { float *g, *tmpC, *tmpMask, *delta, *slab, *small; bf16* g_b16; void *tmp2C, *tmp3C; long slab_floats, small_floats; };
   ScratchSet sets[2];
   hipStream_t st2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_heads = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_heads = nullptr, ev_sync = nullptr;
+  std::vector<hipEvent_t> ev_bucket;        // one per MixSTE layer of the rotations net: its (STE_i, TTE_i) parameter gradients of the last backward are final
+  bool buckets_recorded = false;
   float *hsmall = nullptr, *sc_dlogit = nullptr;   // scratch of the head / score parameter-gradient kernels when they run on the wgrad stream
   long hsmall_floats = 0;
   float* lnpart = nullptr;                   // one partial-sum slice per LayerNorm backward of the rotations net (reduced on the wgrad stream)
@@ -583,6 +585,16 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
       RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, g, nullptr, nullptr, 0, T, N, G(m, fg, q.n1w),
                            G(m, fg, q.n1b), (int)M, C, lsc4, ln_floats(lsc4), st, lsc4 == m->small ? nullptr : lst, lev, md.rs));
     }
+    // gradient bucket of layer i = l / 2 (STE_i and TTE_i: one contiguous range of the flat buffer): everything that writes it has been
+    // enqueued - the weight-gradient stream first waits for the main stream's position, then carries the event
+    if (md.is_rot && (l % 2 == 0) && (size_t)(l / 2) < m->ev_bucket.size()) {
+      if (sw != st) {
+        MP_HIP(hipEventRecord(m->ev_sync, st));
+        MP_HIP(hipStreamWaitEvent(sw, m->ev_sync, 0));
+      }
+      MP_HIP(hipEventRecord(m->ev_bucket[l / 2], sw));
+      m->buckets_recorded = true;
+    }
   }
   if (wasync && have_prev) {    // the last block's fc1 / qkv weight gradients
     WAIT_W(par ^ 1, 1);
@@ -718,6 +730,9 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
         ok = hipEventCreateWithFlags(&m->evE[a][b], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&m->evW[a][b], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&m->ev_heads, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&m->ev_sync, hipEventDisableTiming) == hipSuccess;
+    m->ev_bucket.assign((size_t)m->rot.depth, nullptr);
+    for (auto& e : m->ev_bucket) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
       set_error("mp_model_create: could not create the wgrad stream / events");
       (void)hipFree(m->arena);
@@ -749,6 +764,8 @@ void mp_model_destroy(mp_model* m) {
   if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
   if (m->ev_join) (void)hipEventDestroy(m->ev_join);
   if (m->ev_heads) (void)hipEventDestroy(m->ev_heads);
+  if (m->ev_sync) (void)hipEventDestroy(m->ev_sync);
+  for (auto& e : m->ev_bucket) if (e) (void)hipEventDestroy(e);
   if (m->arena) (void)hipFree(m->arena);
   delete m;
 }
@@ -966,6 +983,27 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     MP_HIP(hipEventRecord(m->ev_heads, pst));
     MP_HIP(hipStreamWaitEvent(st, m->ev_heads, 0));
   }
+  return MP_OK;
+}
+
+int mp_model_grad_bucket_count(const mp_model* m) { return m ? m->rot.depth : 0; }
+
+int mp_model_grad_bucket_info(const mp_model* m, int index, int64_t* offset, int64_t* numel) {
+  MP_CHECK(m && index >= 0 && index < m->rot.depth, MP_ERR_ARG, "mp_model_grad_bucket_info: bad index %d", index);
+  // layer i of the rotations net = blocks 2 i (STE_i) and 2 i + 1 (TTE_i): norm1.weight of the first ... fc2.bias of the second
+  const BlockP& a = m->rot.bp[2 * index];
+  const BlockP& b = m->rot.bp[2 * index + 1];
+  const ParamDesc& first = m->params[a.n1w];
+  const ParamDesc& last = m->params[b.f2b];
+  if (offset) *offset = first.offset;
+  if (numel) *numel = last.offset + (last.numel + 63) / 64 * 64 - first.offset;
+  return MP_OK;
+}
+
+int mp_model_grad_bucket_wait(mp_model* m, int index, void* stream) {
+  MP_CHECK(m && index >= 0 && index < (int)m->ev_bucket.size(), MP_ERR_ARG, "mp_model_grad_bucket_wait: bad index %d", index);
+  MP_CHECK(m->buckets_recorded, MP_ERR_STATE, "mp_model_grad_bucket_wait: no backward has been run");
+  MP_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev_bucket[index], 0));
   return MP_OK;
 }
 

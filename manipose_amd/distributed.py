@@ -51,3 +51,31 @@ def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, group=None) ->
     """Make every rank start from rank `src`'s weights (one broadcast of the flat parameter buffer)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat_params, src=src, group=group)
+
+
+def allreduce_gradients_bucketed(flat_grads: torch.Tensor, engine, comm_stream: "torch.cuda.Stream", group=None) -> None:
+    """The same exchange overlapped with the backward (~25 MB buckets): call right after `engine.backward(...)` has been
+    ENQUEUED.  Bucket i (layer i of the rotations net, finished by the backward from the last layer down) is all-reduced on `comm_stream`
+    as soon as the device has produced it - `engine.grad_bucket_wait` is a device-side wait, the host never blocks - and everything outside
+    the buckets (embeddings, shared norms, heads, the segments net) once the whole backward is done.  On return the CURRENT stream waits for
+    `comm_stream`, so the optimizer step enqueued next sees the reduced gradients.  Same result, bit for bit, as `allreduce_gradients`."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    cur = torch.cuda.current_stream()
+    buckets = engine.grad_buckets()
+    works = []
+    with torch.cuda.stream(comm_stream):
+        for i in reversed(range(len(buckets))):                      # the backward finishes the last layer first
+            off, n = buckets[i]
+            engine.grad_bucket_wait(i, comm_stream)
+            works.append(dist.all_reduce(flat_grads[off:off + n], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        comm_stream.wait_stream(cur)                                 # the rest is final when the backward's own stream has passed the call
+        lo = min(off for off, _ in buckets) if buckets else flat_grads.numel()
+        hi = max(off + n for off, n in buckets) if buckets else flat_grads.numel()
+        if lo > 0:
+            works.append(dist.all_reduce(flat_grads[:lo], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        if hi < flat_grads.numel():
+            works.append(dist.all_reduce(flat_grads[hi:], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        for w in works:
+            w.wait()                                                 # stream-ordered for RCCL (no host block); gloo completes the copy-back
+    cur.wait_stream(comm_stream)

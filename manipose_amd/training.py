@@ -13,14 +13,14 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .distributed import allreduce_gradients
+from .distributed import allreduce_gradients, allreduce_gradients_bucketed
 from .optim import FusedAdam
 
 
 class LiftingTrainer:
     def __init__(self, model, lr: float = 4e-5, weight_decay: float = 1e-6, w_loss: bool = True, vel_loss: float = 2.0,
                  smooth_reg: float = 0.5, rmcl_score_reg: float = 0.1, seed: int = 42, process_group=None,
-                 sq_loss: bool = False, rigid_seg_reg: float = 0.0):
+                 sq_loss: bool = False, rigid_seg_reg: float = 0.0, grad_buckets: bool = False):
         self.model = model
         self.lib = _lib.load()
         self.opt = FusedAdam(model, lr=lr, weight_decay=weight_decay)
@@ -31,6 +31,12 @@ class LiftingTrainer:
             raise NotImplementedError("train.rigid_seg_reg > 0 with the multi-hypothesis model: the reference's term permutes a 4-D "
                                       "(B, L, J, 3) prediction and fails on (B, H, L, J, 3) hypotheses")
         self.step_no = 0
+        # grad_buckets: overlap the gradient exchange with the backward, one all-reduce per layer of the rotations net (~25 MB) on a
+        # communication stream as the backward finishes it, instead of one 138 MB all-reduce behind it.  Off by default: the single
+        # collective is ~1 ms of a ~175 ms step, and no multi-GPU box was available to measure whether RCCL kernels resident during the
+        # backward cost the persistent GEMMs more than the overlap saves.
+        self.grad_buckets = bool(grad_buckets)
+        self._comm_stream = None
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         # every rank draws its own DropPath masks (the reference draws independent per-sample masks over the whole batch)
@@ -83,7 +89,12 @@ class LiftingTrainer:
         if self.world > 1:
             # one collective per step over the single flat gradient buffer (137.8 MB fp32 at full size); RCCL picks the
             # all-links algorithm over the xGMI mesh.  Averaging is folded into the Adam kernel (grad_scale).
-            allreduce_gradients(self.flat_grads, self.pg)
+            if self.grad_buckets:
+                if self._comm_stream is None:
+                    self._comm_stream = torch.cuda.Stream()
+                allreduce_gradients_bucketed(self.flat_grads, eng, self._comm_stream, self.pg)
+            else:
+                allreduce_gradients(self.flat_grads, self.pg)
         self.opt.step(self.flat_grads, grad_scale=1.0 / self.world)
         return bf["terms"]
 

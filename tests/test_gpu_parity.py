@@ -933,6 +933,58 @@ def test_bench_two_rank_path_rehearsal_on_one_gpu(lib):
     assert d["dtype"] == "bf16x3" and d["parity"]["within_bound"] and d["parity"]["mpjpe_m"] <= 1e-4, d.get("parity")
 
 
+def test_bucketed_gradient_exchange_equals_the_single_all_reduce(lib):
+    """LiftingTrainer(grad_buckets=True): one all-reduce per layer of the rotations net on a communication stream, each behind a
+    device-side wait for that layer's gradients of the running backward (mp_model_grad_bucket_wait), the rest behind the whole backward
+    - against the single all-reduce of the flat buffer.  Two ranks on this GPU with gloo carrying the collectives (a one-GPU box cannot
+    host two RCCL ranks): after three training steps on different per-rank batches every rank must hold the same parameter BITS in both
+    modes, and the two ranks must agree with each other."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton\n"
+        "from manipose_amd.distributed import broadcast_parameters\n"
+        "from manipose_amd.training import LiftingTrainer\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('gloo')\n"
+        "rank = dist.get_rank()\n"
+        "outs = []\n"
+        "for buckets in (False, True):\n"
+        "    torch.manual_seed(3)\n"
+        "    m = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=27, embed_dim_rot=128, depth_rot=3, num_heads_rot=8, embed_dim_seg=64, depth_seg=2,\n"
+        "                           num_heads_seg=4, n_hyp=3, drop_path_rate=0.1)\n"
+        "    m.precision = 'bf16x3'\n"
+        "    m = m.cuda().train()\n"
+        "    broadcast_parameters(m.flat_parameters())\n"
+        "    tr = LiftingTrainer(m, lr=1e-3, weight_decay=1e-6, seed=5, grad_buckets=buckets)\n"
+        "    g = torch.Generator(device='cuda').manual_seed(10 + rank)\n"
+        "    X = (0.3 * torch.randn(4, 27, 17, 2, device='cuda', generator=g)).clamp(-1, 1)\n"
+        "    y = 0.3 * torch.randn(4, 27, 17, 3, device='cuda', generator=g)\n"
+        "    for _ in range(3):\n"
+        "        tr.train_step(X, y)\n"
+        "    torch.cuda.synchronize()\n"
+        "    outs.append(m.flat_parameters().clone())\n"
+        "same_modes = bool(torch.equal(outs[0], outs[1]))\n"
+        "other = outs[1].clone()\n"
+        "dist.broadcast(other, src=0)\n"
+        "print('rank', rank, 'modes_equal', same_modes, 'ranks_equal', bool(torch.equal(other, outs[1])), 'finite', bool(torch.isfinite(outs[1]).all()), flush=True)\n"
+        "dist.destroy_process_group()\n")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    script = os.path.join(root, "gpurun_out", "_bucket_ranks.py") if os.path.isdir(os.path.join(root, "gpurun_out")) else os.path.join("/tmp", "_bucket_ranks.py")
+    with open(script, "w") as f:
+        f.write(code)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        script], capture_output=True, text=True, timeout=400, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("rank ")]
+    assert len(lines) == 2 and all("modes_equal True ranks_equal True finite True" in l for l in lines), r.stdout[-1000:]
+
+
 def test_rccl_backend_single_rank_collectives_on_the_flat_gradient_buffer(lib):
     """backend="nccl" (= RCCL) on this GPU with world size 1: init with device_id, broadcast of the flat parameter buffer, SUM
     all-reduce of a flat gradient buffer of the real size, barrier, destroy - the calls training.py / distributed.py make per step."""

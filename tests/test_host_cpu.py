@@ -431,6 +431,29 @@ def test_mup_checkpoint_is_loaded_after_the_base_shapes_and_used_untouched(tmp_p
     assert calls == [1]
 
 
+def test_gradient_buckets_cover_the_layers_of_the_rotations_net():
+    """mp_model_grad_bucket_info: bucket i is exactly the contiguous flat-buffer range of STEblocks.i and TTEblocks.i (24 tensors), the
+    buckets are disjoint and everything else (embeddings, positional tables, shared norms, heads, segments net) lies outside them."""
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    m = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=27, embed_dim_rot=64, depth_rot=3, num_heads_rot=4, embed_dim_seg=32, depth_seg=2,
+                           num_heads_seg=4, n_hyp=2)
+    m.flat_parameters()
+    buckets = m._engine.grad_buckets()
+    assert len(buckets) == 3
+    inside = [[] for _ in buckets]
+    for name, off, n in m.flat_layout():
+        hit = [i for i, (bo, bn) in enumerate(buckets) if bo <= off and off + n <= bo + bn]
+        part = [i for i, (bo, bn) in enumerate(buckets) if off < bo + bn and off + n > bo]
+        assert hit == part, (name, hit, part)                    # never straddles a bucket boundary
+        if hit:
+            inside[hit[0]].append(name)
+    for i, names in enumerate(inside):
+        want = {n for n, _, _ in m.flat_layout() if n.startswith(f"rotations_module.STEblocks.{i}.") or n.startswith(f"rotations_module.TTEblocks.{i}.")}
+        assert set(names) == want and len(want) == 24, (i, sorted(set(names) ^ want)[:4])
+    ends = [bo + bn for bo, bn in buckets]
+    assert all(buckets[i + 1][0] >= ends[i] for i in range(len(buckets) - 1))
+
+
 def test_generated_code_has_no_packed_op_reading_a_freshly_loaded_high_register():
     """Audit of the gfx950 assembly of every kernel source for the hazard described in csrc/common.h (lone()): a packed fp32 op whose low
     lane takes the high register of a pair that a vector-memory load wrote.  Round 3 traced run-to-run different results (2 mm on the
