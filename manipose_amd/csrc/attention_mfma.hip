@@ -866,14 +866,14 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __re
 // phase, and the output tile is transposed through a wave-private LDS buffer so that every store instruction writes whole 128-byte
 // rows (the accumulator layout gave 32-byte pieces of 16 rows that lie J*C*2 bytes apart).
 __device__ __forceinline__ void tm_dma_region(char* __restrict__ region, const bf16* __restrict__ p_hi, const bf16* __restrict__ p_lo, long rs3, int T,
-                                              int rows, int lane, int wave, int nw, long rs_second = 0) {
+                                              int rows, int lane, int wave, int nw) {
   typedef __attribute__((address_space(3))) void* lptr;
   typedef const __attribute__((address_space(1))) void* gptr;
   const int per_img = rows >> 3;                     // DMA instructions per image: 8 rows (1 KiB) each
   for (int n = wave; n < 2 * per_img; n += nw) {     // wave-uniform instruction index
     const int img = n >= per_img, q = n - img * per_img;
     const int r = q * 8 + (lane >> 3), c = (lane & 7) ^ (r & 7);
-    const bf16* src = (img ? p_lo : p_hi) + (long)min(r, T - 1) * ((img && rs_second) ? rs_second : rs3) + c * 8;   // frames past T repeat the last frame (finite; their
+    const bf16* src = (img ? p_lo : p_hi) + (long)min(r, T - 1) * rs3 + c * 8;      // frames past T repeat the last frame (finite; their
     __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(region + n * 1024), 16, 0, 0);   // probabilities are exactly 0)
   }
 }

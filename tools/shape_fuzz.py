@@ -10,7 +10,9 @@ from manipose_amd.metrics import manifold_training_loss, mpjpe_error, rmcl_train
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 cases = [(2, 32, 4, 1, 3), (3, 64, 8, 5, 5), (17, 32, 4, 2, 1), (64, 64, 4, 1, 2), (100, 128, 8, 3, 4), (243, 64, 8, 2, 5), (256, 32, 4, 1, 3),
-         (300, 64, 4, 2, 2), (81, 128, 8, 7, 0), (27, 256, 8, 2, 0)]
+         (300, 64, 4, 2, 2), (81, 128, 8, 7, 0), (27, 256, 8, 2, 0),
+         # head dim 64 with 128 < T <= 256: the two-phase split-precision temporal attention forward; ragged last GEMM tiles
+         (200, 256, 4, 2, 3), (255, 128, 2, 3, 2), (130, 64, 1, 1, 2), (243, 512, 8, 1, 2), (241, 128, 2, 5, 1)]
 worst = 0.0
 for T, C, H, B, K in cases:
     cfg = dict(T=T, J=17, num_bones=16, C_rot=C, depth_rot=2, heads_rot=H, C_seg=32, depth_seg=1, heads_seg=4, n_hyp=K)
