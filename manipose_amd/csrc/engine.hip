@@ -697,6 +697,7 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   hipError_t e = hipMalloc((void**)&m->arena, m->arena_bytes);
   if (e != hipSuccess) {
     set_error("mp_model_create: hipMalloc(%zu bytes) failed: %s", m->arena_bytes, hipGetErrorString(e));
+    (void)hipGetLastError();            // the refusal is reported through the return code: do not leave it as the thread's sticky HIP error
     delete m;
     return MP_ERR_HIP;
   }

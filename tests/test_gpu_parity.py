@@ -1869,6 +1869,34 @@ def test_training_step_is_bitwise_reproducible_and_batch_invariant(lib):
     assert d_alone.mean().item() < 2e-5 and d_plain.mean().item() < 2e-5, (d_alone.mean().item(), d_plain.mean().item())
 
 
+def test_workspace_larger_than_the_device_memory_is_refused_cleanly(lib):
+    """The activation arena is sized for max_batch windows (1.57 GiB per window at full width in the split precision: 124 GiB at the
+    benchmark's 79).  A batch whose arena cannot be allocated must come back as an error of mp_model_create - code 2, a message naming the
+    size - and leave the device usable; it must not crash or half-initialise a model."""
+    import ctypes as C
+    from manipose_amd import RMCLManifoldMixSTE, _lib, h36m_skeleton
+    cfg = _lib.ModelConfig(arch=0, num_frame=243, num_joints=17, num_bones=16, embed_dim_rot=512, depth_rot=8, num_heads_rot=8, embed_dim_seg=128,
+                           depth_seg=2, num_heads_seg=8, n_hyp=5, drop_path_rate=0.1, max_batch=400, precision=2, rot_rep_dim=6)
+    h = C.c_void_p()
+    rc = lib.mp_model_create(C.byref(cfg), C.byref(h))
+    assert rc == 2 and not h.value, rc
+    msg = lib.mp_last_error().decode()
+    assert "hipMalloc" in msg and "bytes" in msg, msg
+    need = int(msg.split("hipMalloc(")[1].split(" bytes")[0])
+    assert need > torch.cuda.get_device_properties(0).total_memory                 # it was refused for the right reason
+    # the Python mirror turns it into a RuntimeError, and the device still works afterwards
+    model = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=243, n_hyp=5)
+    model.precision = "bf16x3"
+    model.max_batch_hint = 400
+    with pytest.raises(RuntimeError, match="hipMalloc"):
+        model.cuda()(torch.zeros(400, 243, 17, 2, device="cuda"))
+    del model
+    small = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=27, embed_dim_rot=64, depth_rot=1, num_heads_rot=4, embed_dim_seg=32, depth_seg=1, num_heads_seg=4,
+                               n_hyp=2).cuda().eval()
+    p, _ = small(torch.zeros(2, 27, 17, 2, device="cuda"))
+    assert torch.isfinite(p).all()
+
+
 def test_product_library_ignores_the_timing_ablation_switches(lib):
     """MANIPOSE_GEMM_DEBUG / MANIPOSE_GEMM_ABL / MANIPOSE_ATTN_DEBUG switch wrong-by-design timing ablations on in the DIAGNOSTICS build
     only (MP_DIAG=1 build.sh); with all of them set, a child process using the product library must still produce the oracle's numbers."""
