@@ -302,6 +302,13 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
 #pragma unroll
   for (int step = 0; step < NSTEP; ++step) {
     const int ip = step % HS;
+    // Pinned order per group of 8 MFMAs: first MFMA (hipcc puts its s_waitcnt lgkmcnt(0) for this group's fragments in front of it), then the
+    // LDS reads of the next group, then the other 7 MFMAs, which cover the reads' latency.  Left to itself (or with sched_group_barrier
+    // hints) hipcc issues most reads directly in front of an s_waitcnt lgkmcnt(0) and their first use - a dozen exposed LDS round trips per
+    // k-tile and wave; and with the reads ahead of the group it still waits with lgkmcnt(0), i.e. for the reads it has just issued.
+    __builtin_amdgcn_sched_barrier(0);
+    acc[2 * ip][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[0], a_cur[0], acc[2 * ip][0], 0, 0, 0);   // C^T tile
+    __builtin_amdgcn_sched_barrier(0);
     if (step + 1 < NSTEP) {
       const int nks = (step + 1) / HS, nip = (step + 1) % HS;
       if (ABL & 2) { a_nxt[0] = a_cur[1]; a_nxt[1] = a_cur[0]; }
@@ -314,24 +321,12 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
         for (int j = 0; j < 4; ++j) b_nxt[j] = (ABL & 1) ? b_cur[(j + 1) & 3] : read_frag2<TRB, BT>(Bs, wc * 64 + j * 16, nks, lane);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[2 * ip][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[j], a_cur[0], acc[2 * ip][j], 0, 0, 0);   // C^T tile
+    for (int j = 1; j < 4; ++j) acc[2 * ip][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[j], a_cur[0], acc[2 * ip][j], 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[2 * ip + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[j], a_cur[1], acc[2 * ip + 1][j], 0, 0, 0);
-    // pin the order "next step's LDS reads, then this step's 8 MFMAs" (hipcc otherwise sinks the reads behind the MFMAs
-    // and exposes their latency before every group)
-    if (ABL == 0 && step + 1 < NSTEP) {
-      if ((step + 1) % HS == 0) {            // A and B fragments of the next k-step
-        if (TRA && TRB) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-        else if (TRB) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
-        else if (TRA) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        else __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-      } else {
-        if (TRA) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      }
-    }
-    if (ABL == 0) __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    __builtin_amdgcn_sched_barrier(0);
     if (step + 1 < NSTEP) {
       a_cur[0] = a_nxt[0];
       a_cur[1] = a_nxt[1];
@@ -341,6 +336,30 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
       }
     }
   }
+}
+
+// Per-lane byte offsets of the 4 DMA instructions a wave issues per operand and k-tile, relative to the (wave-uniform)
+// address of the tile's first element of that k-tile; the same source swizzles as glds_tile.  Rows past the end of the
+// matrix are clamped to its last row (their products are never stored), so no lane needs a different base.
+template <int TR>
+__device__ __forceinline__ void persist_offsets(unsigned (&off)[4], long ld, int out0, int OUT, int lane, int wave) {
+#pragma unroll
+  for (int n4 = 0; n4 < 4; ++n4) {
+    const int c = 64 * (wave * 4 + n4) + lane;
+    if (TR == 0) {
+      const int row = c >> 3, kg = (c & 7) ^ (row & 7);
+      off[n4] = (unsigned)(min(row, OUT - 1 - out0) * (int)ld * 2 + kg * 16);
+    } else {
+      const int rr = c >> 5, oc = (c & 31) ^ t_swz(rr);      // OUT % 256 == 0 (launcher): every chunk is in range
+      off[n4] = (unsigned)(rr * (int)ld * 2 + oc * 16);
+    }
+  }
+}
+__device__ __forceinline__ void persist_dma(char* __restrict__ S, const char* __restrict__ base, const unsigned (&off)[4], int wave) {
+  typedef __attribute__((address_space(3))) void* lptr;
+  typedef const __attribute__((address_space(1))) void* gptr;
+#pragma unroll
+  for (int n4 = 0; n4 < 4; ++n4) __builtin_amdgcn_global_load_lds((gptr)(base + off[n4]), (lptr)(S + (wave * 4 + n4) * 1024), 16, 0, 0);
 }
 
 // BT x BT output tile (BT = 128: 4 waves, 256: 8 waves); waves laid out 2 x (BT/64); each wave (BT/2) x 64.
@@ -417,15 +436,34 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
     }
     (void)stage;
   } else {
+  // Weight-gradient shape (both operands read transposed, 256 x 256 tile): when the tile lies inside both matrices, a k-tile that lies inside
+  // the split's range is fetched from a wave-uniform base + per-lane 32-bit offsets computed once (the general glds_tile spends ~100
+  // VALU instructions per wave and k-tile, a dozen of them 64-bit multiplies, on addresses and bounds ahead of the MFMA stage)
+  constexpr bool FASTDMA = BT == 256 && TRA == 1 && TRB == 1;
+  unsigned aoff[4] = {0, 0, 0, 0}, boff[4] = {0, 0, 0, 0};
+  bool fast_tile = false;
+  if constexpr (FASTDMA) {
+    fast_tile = m0 + BT <= g.M && n0 + BT <= g.N && (long)GBK * max(g.lda, g.ldb) * 2 + 512 < (1L << 31);
+    persist_offsets<1>(aoff, g.lda, 0, BT, lane, wave);
+    persist_offsets<1>(boff, g.ldb, 0, BT, lane, wave);
+  }
   for (int k0 = kbeg; k0 < kend; k0 += GBK, stage ^= 1) {
     __syncthreads();   // (vmcnt(0) + barrier): tile k0 has landed for every wave; nobody still reads the other stage
     const char* As = smem + stage * STAGE;
     const char* Bs = As + OPB;
     if (k0 + GBK < kend && !MP_DBG(g, 2)) {
       char* nx = smem + (stage ^ 1) * STAGE;
-      if (b_first) glds_tile<TRB, BT, NW>(nx + OPB, B, g.ldb, n0, k0 + GBK, g.N, kend, lane, wave);
-      glds_tile<TRA, BT, NW>(nx, A, g.lda, m0, k0 + GBK, g.M, kend, lane, wave);
-      if (!b_first) glds_tile<TRB, BT, NW>(nx + OPB, B, g.ldb, n0, k0 + GBK, g.N, kend, lane, wave);
+      if (FASTDMA && fast_tile && k0 + 2 * GBK <= kend) {
+        const char* const ab = reinterpret_cast<const char*>(A) + ((long)(k0 + GBK) * g.lda + m0) * 2;
+        const char* const bb = reinterpret_cast<const char*>(B) + ((long)(k0 + GBK) * g.ldb + n0) * 2;
+        if (b_first) persist_dma(nx + OPB, bb, boff, wave);
+        persist_dma(nx, ab, aoff, wave);
+        if (!b_first) persist_dma(nx + OPB, bb, boff, wave);
+      } else {
+        if (b_first) glds_tile<TRB, BT, NW>(nx + OPB, B, g.ldb, n0, k0 + GBK, g.N, kend, lane, wave);
+        glds_tile<TRA, BT, NW>(nx, A, g.lda, m0, k0 + GBK, g.M, kend, lane, wave);
+        if (!b_first) glds_tile<TRB, BT, NW>(nx + OPB, B, g.ldb, n0, k0 + GBK, g.N, kend, lane, wave);
+      }
     }
     if (MP_DBG(g, 1)) continue;
     if (EPI == EPI_SLAB && TRA == 1 && !MP_DBG(g, 8)) {
@@ -526,30 +564,6 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
 // Tile order: workgroup w runs on XCD w & 7 (round-robin dispatch); in every round each XCD owns G/8 consecutive
 // row-major tiles, i.e. a few complete tile rows: the A rows are shared through that XCD's L2, the weights stay in it.
 // =================================================================================================================
-// Per-lane byte offsets of the 4 DMA instructions a wave issues per operand and k-tile, relative to the (wave-uniform)
-// address of the tile's first element of that k-tile; the same source swizzles as glds_tile.  Rows past the end of the
-// matrix are clamped to its last row (their products are never stored), so no lane needs a different base.
-template <int TR>
-__device__ __forceinline__ void persist_offsets(unsigned (&off)[4], long ld, int out0, int OUT, int lane, int wave) {
-#pragma unroll
-  for (int n4 = 0; n4 < 4; ++n4) {
-    const int c = 64 * (wave * 4 + n4) + lane;
-    if (TR == 0) {
-      const int row = c >> 3, kg = (c & 7) ^ (row & 7);
-      off[n4] = (unsigned)(min(row, OUT - 1 - out0) * (int)ld * 2 + kg * 16);
-    } else {
-      const int rr = c >> 5, oc = (c & 31) ^ t_swz(rr);      // OUT % 256 == 0 (launcher): every chunk is in range
-      off[n4] = (unsigned)(rr * (int)ld * 2 + oc * 16);
-    }
-  }
-}
-__device__ __forceinline__ void persist_dma(char* __restrict__ S, const char* __restrict__ base, const unsigned (&off)[4], int wave) {
-  typedef __attribute__((address_space(3))) void* lptr;
-  typedef const __attribute__((address_space(1))) void* gptr;
-#pragma unroll
-  for (int n4 = 0; n4 < 4; ++n4) __builtin_amdgcn_global_load_lds((gptr)(base + off[n4]), (lptr)(S + (wave * 4 + n4) * 1024), 16, 0, 0);
-}
-
 // Epilogue of one wave's 128 x 64 sub-tile: 16 rows per pass are written to the wave-private image in the accumulator layout
 // (lane = row, 4 consecutive columns; 16-byte chunks XOR-swizzled by the row) and read back row-major, so residual / gelu'
 // loads and the stores are full lines, 16 lanes per row.  FULL = the tile has no rows past M: no predicates, and the

@@ -1,7 +1,7 @@
 """Where the persistent GEMM's workgroups are in time: every workgroup stamps the start and end of each tile's epilogue (MANIPOSE_GEMM_STAMPS,
 10 ns ticks of the constant clock).  Prints, for one launch of the split-precision qkv shape, the epilogue durations and how the epilogues of
 the 256 workgroups line up (all at once = a chip-wide burst of stores, or spread over the tile time).  Needs the diagnostics build of the
-library (MP_DIAG=1 bash manipose_amd/csrc/build.sh).   [MANIPOSE_GEMM_STAGGER=ticks] python tools/gemm_stamps.py [x3|bf16]"""
+library (MP_DIAG=1 bash manipose_amd/csrc/build.sh).   [MANIPOSE_GEMM_STAGGER=ticks] python tools/gemm_stamps.py [x3|bf16|dgrad [N K]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,14 +16,22 @@ lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
 mode = sys.argv[1] if len(sys.argv) > 1 else "x3"
 M, N, K = 326349, 1536, 512
+if len(sys.argv) > 3: N, K = int(sys.argv[2]), int(sys.argv[3])      # dgrad: N = reduction (dy columns), K = dx columns
 x = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") / K ** 0.5
 xh, xl = torch.empty_like(x, dtype=torch.bfloat16), torch.empty_like(x, dtype=torch.bfloat16)
 Wh, Wl = torch.empty_like(W, dtype=torch.bfloat16), torch.empty_like(W, dtype=torch.bfloat16)
 lib.mp_split_bf16(x.data_ptr(), xh.data_ptr(), xl.data_ptr(), x.numel(), st); lib.mp_split_bf16(W.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), W.numel(), st)
 b = torch.randn(N, device="cuda")
 yh, yl = torch.empty(M, N, device="cuda", dtype=torch.bfloat16), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+if mode == "dgrad":
+    # (the call also runs the weight-gradient GEMM, which is not a persistent kernel and writes no stamps: the "launch us" line includes it)
+    dy = torch.randn(M, N, device="cuda").bfloat16(); dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+    dW, db = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+    slab = torch.empty(int(lib.mp_linear_bwd_slab_floats(N, K)), device="cuda")
 def run():
-    if mode == "x3":
+    if mode == "dgrad":
+        _lib.check(lib.mp_linear_bwd_bf16(dy.data_ptr(), 0, xh.data_ptr(), Wh.data_ptr(), dx.data_ptr(), 0, dW.data_ptr(), db.data_ptr(), M, N, K, slab.data_ptr(), slab.numel(), st))
+    elif mode == "x3":
         _lib.check(lib.mp_linear_fwd_bf16x3(xh.data_ptr(), xl.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), b.data_ptr(), yh.data_ptr(), yl.data_ptr(), None, None, M, N, K, 0, st))
     else:
         _lib.check(lib.mp_linear_fwd_bf16(xh.data_ptr(), Wh.data_ptr(), b.data_ptr(), yh.data_ptr(), None, None, M, N, K, 0, st))
