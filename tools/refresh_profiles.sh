@@ -3,6 +3,7 @@
 #   <tag>_kernel_stats.csv            rocprofv3 --kernel-trace --stats of the default bench command
 #   <tag>_bench_under_rocprof.json    the bench JSON line printed in that run (its roofline.avg_launch_ms must agree with the stats)
 #   <tag>_stream_timeline.txt         tools/stream_timeline.py over the kernel trace of that run
+#   <tag>_main_queue_gaps.txt         tools/gap_list.py over the same trace (idle gaps of the main queue and the kernels around them)
 #   <tag>_pmc_hbm_traffic.csv         per-kernel FETCH_SIZE / WRITE_SIZE averages from two separate --pmc passes
 #   pmc_traffic.json                  profiles/pmc_traffic.json with this configuration's entry replaced by the last row of that csv
 # The files are written under gpurun_out/ (merged back by gpurun); copy them into profiles/ afterwards.
@@ -14,6 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python ben
 find "$O/stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$O/${TAG}_kernel_stats.csv"
 grep "^{" "$O/stats.log" > "$O/${TAG}_bench_under_rocprof.json"
 find "$O/stats" -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/stream_timeline.py {} > "$O/${TAG}_stream_timeline.txt"
+find "$O/stats" -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/gap_list.py {} 40 > "$O/${TAG}_main_queue_gaps.txt"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_$c" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra --no-prof > "$O/pmc_$c.log" 2>&1
   find "$O/pmc_$c" -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} "$O/pmc_$c.csv"
