@@ -25,6 +25,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int TP = 256;            // padded frames
 constexpr int NTILE = TP / 16;
 
+// Single-lane fp32 arithmetic for the softmax that is interleaved with MFMAs: written component by component so that it does not
+// compile to v_pk_*_f32 (a packed fp32 instruction beside the matrix cores costs ~20 cycles more than the two plain ones it replaces:
+// MI355X_MICROARCH.md, "price of one filler beside MFMAs").  Plain C, not inline asm: hipcc inserts the wait states an MFMA result needs
+// before a VALU instruction reads it only for instructions it knows (an asm v_fma_f32 on an accumulator read stale data).
+__device__ __forceinline__ float sfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float sadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float smul(float a, float b) { return a * b; }
+__device__ __forceinline__ float ssub(float a, float b) { return a - b; }
+
 template <int D> struct ACfg {
   // LDS bytes per frame row.  Head dim 64: exactly 128 B, the 16-byte chunk index XOR-swizzled by (frame & 7) - conflict-free for
   // both the row reads (ds_read_b128) and the transpose reads (ds_read_b64_tr_b16); a 16-byte pad (144 B rows) made both of them
@@ -185,7 +194,8 @@ __global__ __launch_bounds__(512, 4) void attn_tmfma_fwd_kernel(const bf16* __re
       if (kt < ntile) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kr.rows(ks, kt * 16), bq[ks], acc, 0, 0, 0);
-        acc *= scale2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = smul(acc[r], scale2);
         if (kt == ntile - 1) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -202,10 +212,9 @@ __global__ __launch_bounds__(512, 4) void attn_tmfma_fwd_kernel(const bf16* __re
 #pragma unroll
     for (int kt = 0; kt < NTILE; ++kt) {
       if (kt < ntile) {
-        const f32x4 t = s[kt] - mx;
         f32x4 e;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(ssub(s[kt][r], mx));
         s[kt] = e;
         sum += (e[0] + e[1]) + (e[2] + e[3]);
       } else {
@@ -321,16 +330,18 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
           sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kr.rows(ks, kt * 16), bq[ks], sc, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vr.rows(ks, kt * 16), bg[ks], dp, 0, 0, 0);
         }
-        const f32x4 t = sc * scale2 + nL;
+        // component by component (fmaf / add / mul on single floats): the vector forms compile to v_pk_*_f32, which cost ~20 cycles
+        // each beside MFMAs on this chip (MI355X_MICROARCH: packed fp32 next to the matrix cores)
         f32x4 e;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(sfma(sc[r], scale2, nL));
         if (kt >= ntile - 1) {                         // key padding exists in the last tile only (and in the tile past an odd count)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (kt * 16 + 4 * g + r >= T) e[r] = 0.f;
         }
-        ds[hf] = e * (dp + ndl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[hf][r] = smul(e[r], sadd(dp[r], ndl));
       }
       const bf16x8_t bd = pack_acc(ds[0], ds[1]);
 #pragma unroll
@@ -371,12 +382,12 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
         }
         // rows of this orientation are queries (4 consecutive per lane group); -lse = -inf on padding -> p = 0
         const f32x4 nL = *reinterpret_cast<const f32x4*>(Ls + qt * 16 + 4 * g), ndl = *reinterpret_cast<const f32x4*>(Dl + qt * 16 + 4 * g);
-        const f32x4 t = sc * scale2 + nL;
         f32x4 e;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(sfma(sc[r], scale2, nL[r]));
         p2[hf] = e;
-        d2[hf] = e * (dp + ndl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d2[hf][r] = smul(e[r], sadd(dp[r], ndl[r]));
       }
       const bf16x8_t bp = pack_acc(p2[0], p2[1]), bd = pack_acc(d2[0], d2[1]);
 #pragma unroll
@@ -795,7 +806,8 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __re
             if (MP_ADBG(8)) { acc[0] += __builtin_bit_cast(float, (int)kh[0] + (int)kl[1]); continue; }
             MP_MFMA3(acc, kh, kl, qn_h[sidx][ks], qn_l[sidx][ks]);
           }
-          acc *= scale2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = smul(acc[r], scale2);
           if (kt == ntile - 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -814,10 +826,9 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __re
       for (int kt = 0; kt < NTILE; ++kt) {
         if (MP_ADBG(4)) { sum += s[kt][0]; continue; }
         if (kt < ntile) {
-          const f32x4 t = s[kt] - mx;
           f32x4 e;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+          for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(ssub(s[kt][r], mx));
           s[kt] = e;
           sum += (e[0] + e[1]) + (e[2] + e[3]);
         } else {
@@ -942,8 +953,8 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3p_kernel(const bf16* __r
           MP_MFMA3(a0, kh, kl, qh[0][ks], ql[0][ks]);
           MP_MFMA3(a1, kh, kl, qh[1][ks], ql[1][ks]);
         }
-        a0 *= scale2;
-        a1 *= scale2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a0[r] = smul(a0[r], scale2); a1[r] = smul(a1[r], scale2); }      // not a0 *= scale2: see sfma()
         if (kt == ntile - 1) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -966,10 +977,9 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3p_kernel(const bf16* __r
 #pragma unroll
       for (int kt = 0; kt < NTILE; ++kt) {
         if (kt < ntile) {
-          const f32x4 t = s[sidx][kt] - mx[sidx];
           f32x4 e;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+          for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(ssub(s[sidx][kt][r], mx[sidx]));
           s[sidx][kt] = e;
           sm_ += (e[0] + e[1]) + (e[2] + e[3]);
         } else {
