@@ -180,6 +180,9 @@ def main():
     if os.environ.get("MANIPOSE_ATTN_TWO_PHASE"):       # A/B timing of the two-phase temporal attention kernels (bit 0 forward, bit 1 backward)
         from manipose_amd import _lib as _l
         _l.check(_l.load().mp_set_option(b"attn_two_phase", int(os.environ["MANIPOSE_ATTN_TWO_PHASE"])))
+    if os.environ.get("MANIPOSE_SIDE_STREAMS"):         # 0: every kernel on one queue (isolated kernel durations under rocprofv3; a profiling aid)
+        from manipose_amd import _lib as _l
+        _l.check(_l.load().mp_set_option(b"side_streams", int(os.environ["MANIPOSE_SIDE_STREAMS"])))
     model = build_model(args.precision, args.batch)
     cpu_json, oracle_out = None, None
     # parity windows: the same on every rank (own generator), placed at the start, middle and end of the timed batch
