@@ -50,10 +50,19 @@ def scan(path):
 
 
 def build_flags():
-    """the code-generation flags of csrc/build.sh that are not in the fixed command line below (e.g. -fno-slp-vectorize)"""
+    """the code-generation flags of csrc/build.sh that are not in the fixed command line below (e.g. -fno-slp-vectorize, -Xclang -target-feature -Xclang -packed-fp32-ops)"""
     text = open(os.path.join(ROOT, "manipose_amd", "csrc", "build.sh")).read()
     m = re.search(r'FLAGS="([^"]*)"', text)
-    return [f for f in (m.group(1).split() if m else []) if f.startswith("-f") and f != "-fPIC"]
+    toks, out, i = (m.group(1).split() if m else []), [], 0
+    while i < len(toks):
+        if toks[i] == "-Xclang" and i + 1 < len(toks):          # -Xclang <arg> pairs (e.g. -target-feature -packed-fp32-ops)
+            out += toks[i:i + 2]
+            i += 2
+            continue
+        if toks[i].startswith("-f") and toks[i] != "-fPIC":
+            out.append(toks[i])
+        i += 1
+    return out
 
 
 def main():
