@@ -398,6 +398,11 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
+  f32x4 accb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};     // 256-wide tiles: bias-gradient column sums of this wave's 32 output rows
+  // the bias gradient of a (row tile, split) is summed by the first bias_parts column tiles, k-tile kt by column tile kt % bias_parts, each
+  // into a slab row of its own (reduce_slabs_b16_kernel adds them): every workgroup of the launch then carries the same extra work
+  const int bias_parts = (BT == 256 && g.bias_parts > 1) ? g.bias_parts : 1;
+  const bool bias_here = tn < bias_parts && g.bias_slab != nullptr;
 
   // neighbouring tiles issue their two operand loads in opposite order: workgroups that share a panel then ask for it at different
   // moments of the k-tile instead of all at once (measured on the weight-gradient shapes: 3-18 % fewer fabric reads, same isolated time)
@@ -466,12 +471,24 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
       }
     }
     if (MP_DBG(g, 1)) continue;
-    if (EPI == EPI_SLAB && TRA == 1 && !MP_DBG(g, 8)) {
+    if (EPI == EPI_SLAB && TRA == 1 && BT != 256 && !MP_DBG(g, 8)) {      // 128-wide tiles: column sums from the LDS image
       if (tn == 0 && tid < BT) {
         const int oc = tid >> 3, wi = tid & 7;
         for (int r = 0; r < GBK; ++r)
           bsum += __uint_as_float((unsigned)(*reinterpret_cast<const unsigned short*>(As + r * (BT * 2) + ((oc ^ t_swz(r)) << 4) + wi * 2)) << 16);
       }
+    }
+    if (EPI == EPI_SLAB && TRA == 1 && BT == 256 && bias_here && ((k0 - kbeg) / GBK) % bias_parts == tn && !MP_DBG(g, 8)) {
+      // 256-wide tiles: the bias gradient (column sums of the A operand over the reduction) on the matrix cores - ones x fragment, four
+      // MFMAs and four fragment reads per wave and k-tile (wave w owns the output rows 32 w .. 32 w + 31 of the tile); the element-wise
+      // LDS walk above cost 13 % of the kernel at this tile size
+      union { unsigned u[4]; bf16x8_t v; } ones;
+      ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3F803F80u;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int ks = 0; ks < GBK / 32; ++ks)
+          accb[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, read_frag2<1, BT>(As, (2 * wave + f) * 16, ks, lane), accb[f], 0, 0, 0);
     }
     mma_stage<TRA, TRB, BT>(As, Bs, acc, wr, wc, lane);
   }
@@ -484,7 +501,15 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   TC* C = reinterpret_cast<TC*>(g.C);
   if (EPI == EPI_SLAB) {
     C += (long)tz * g.M * g.ldc;
-    if (TRA == 1 && tn == 0 && tid < BT && m0 + tid < g.M && g.bias_slab != nullptr)
+    if (BT == 256) {
+      if (TRA == 1 && bias_here) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {          // every column of the 16 x 16 result holds the sums; lane = output row
+          const int row = m0 + (2 * wave + f) * 16 + (lane & 15);
+          if (lane < 16 && row < g.M) g.bias_slab[((long)tz * bias_parts + tn) * g.M + row] = accb[f][0];
+        }
+      }
+    } else if (TRA == 1 && tn == 0 && tid < BT && m0 + tid < g.M && g.bias_slab != nullptr)
       g.bias_slab[(long)tz * g.M + m0 + tid] = bsum;
   }
   typename ZType<TC>::type* Z = reinterpret_cast<typename ZType<TC>::type*>(g.Z);
@@ -909,7 +934,7 @@ static int launch_glds(const GemmB16Args& g, int splits, hipStream_t st) {
 // outputs, 21-64 slabs deep).
 constexpr int RS_OUT = 64;
 __global__ __launch_bounds__(256) void reduce_slabs_b16_kernel(const float* __restrict__ slabW, float* __restrict__ dW, long nW4,
-                                                               const float* __restrict__ slabB, float* __restrict__ db, long nB4, int S) {
+                                                               const float* __restrict__ slabB, float* __restrict__ db, long nB4, int S, int SB) {
   __shared__ float4 part[3][RS_OUT];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   long i = (long)blockIdx.x * RS_OUT + lane;
@@ -920,7 +945,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_b16_kernel(const float* __re
   if (i >= nW4) {
     i -= nW4;
     live = i < nB4;
-    slab = slabB; out = db; n4 = nB4;
+    slab = slabB; out = db; n4 = nB4; S = SB;
   }
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (live) {
@@ -1034,12 +1059,22 @@ int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, i
   MP_CHECK(slab_floats >= per * splits, MP_ERR_ARG, "wgrad_bf16: slab too small (%ld < %ld)", slab_floats, per * splits);
   g.C = slab; g.ldc = Kin;
   g.bias_slab = (db != nullptr) ? slab + (long)splits * Nout * Kin : nullptr;
+  // 256-wide tiles: spread the bias-gradient sums over the column tiles of a row tile when the slab has room for their extra rows
+  int bparts = 1;
+  if (db != nullptr && !dy_f32 && use_big_tile(g)) {
+    const int tn = cdiv(Kin, 256);
+    if (tn > 1 && slab_floats >= ((long)Nout * Kin + (long)Nout * tn) * splits) bparts = tn;
+  }
+  g.bias_parts = bparts;
+#ifdef MP_GEMM_DIAG
+  { static const int dbg = [] { const char* e = getenv("MANIPOSE_GEMM_DEBUG"); return e ? atoi(e) : 0; }(); g.debug = dbg; }   // timing ablations: 1 no MFMA, 2 no DMA, 8 no bias column sums
+#endif
   g.k_per_split = kper;
   int rc = dy_f32 ? launch_b16<float, 1, bf16, 1, float, EPI_SLAB>(g, splits, st)
                   : launch_glds<1, 1, float, EPI_SLAB>(g, splits, st);
   if (rc) return rc;
   const long nW4 = (long)Nout * Kin / 4, nB4 = db != nullptr ? Nout / 4 : 0;        // Nout, Kin are multiples of 8
-  hipLaunchKernelGGL(reduce_slabs_b16_kernel, dim3(cdiv(nW4, (long)RS_OUT) + cdiv(nB4, (long)RS_OUT)), dim3(256), 0, st, slab, dW, nW4, g.bias_slab, db, nB4, splits);
+  hipLaunchKernelGGL(reduce_slabs_b16_kernel, dim3(cdiv(nW4, (long)RS_OUT) + cdiv(nB4, (long)RS_OUT)), dim3(256), 0, st, slab, dW, nW4, g.bias_slab, db, nB4, splits, splits * bparts);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

@@ -44,6 +44,7 @@ struct GemmB16Args {
   const float* mask;
   int mask_mode, T, J;
   float* bias_slab;
+  int bias_parts;      // weight-gradient kernel, 256-wide tiles: the column tiles 0 .. bias_parts-1 of a row tile share its bias-gradient sums by k-tile (0 = 1)
   int k_per_split;
   int debug;           // timing-ablation bits (MANIPOSE_GEMM_DEBUG), 0 in production
   int stagger;         // diagnostics (MANIPOSE_GEMM_STAGGER): start delay per phase group of the persistent kernels, clock ticks
