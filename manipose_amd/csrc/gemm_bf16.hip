@@ -362,10 +362,39 @@ __device__ __forceinline__ void persist_dma(char* __restrict__ S, const char* __
   for (int n4 = 0; n4 < 4; ++n4) __builtin_amdgcn_global_load_lds((gptr)(base + off[n4]), (lptr)(S + (wave * 4 + n4) * 1024), 16, 0, 0);
 }
 
+// The same with an UNEVEN split of a tile's 32 DMA pieces over the waves (weight-gradient kernel): the waves of group 0 (0-3) take P0 pieces
+// each, those of group 1 (4-7) 8 - P0.  Measured, not derived: group 0 - the older wave of every SIMD - with ONE piece per operand and group 1
+// with seven is 3 % faster than the even split on the weight-gradient shapes; the same split does nothing for the persistent kernels.
+template <int TR, int NP>
+__device__ __forceinline__ void uneven_offsets(unsigned (&off)[NP], long ld, int lane, int first) {
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = 64 * (first + i) + lane;
+    if (TR == 0) {
+      const int row = c >> 3, kg = (c & 7) ^ (row & 7);
+      off[i] = (unsigned)(row * (int)ld * 2 + kg * 16);
+    } else {
+      const int rr = c >> 5, oc = (c & 31) ^ t_swz(rr);
+      off[i] = (unsigned)(rr * (int)ld * 2 + oc * 16);
+    }
+  }
+}
+template <int NP>
+__device__ __forceinline__ void uneven_dma(char* __restrict__ S, const char* __restrict__ base, const unsigned (&off)[NP], int first, int np) {
+  typedef __attribute__((address_space(3))) void* lptr;
+  typedef const __attribute__((address_space(1))) void* gptr;
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+    if (i < np) __builtin_amdgcn_global_load_lds((gptr)(base + off[i]), (lptr)(S + (first + i) * 1024), 16, 0, 0);
+}
+
 // BT x BT output tile (BT = 128: 4 waves, 256: 8 waves); waves laid out 2 x (BT/64); each wave (BT/2) x 64.
 // SPLIT = 1 (split precision, common.h): A and B are the hi planes of planar operands; every 64-wide k-tile is multiplied three
 // times - (A_lo, B_hi), (A_hi, B_hi), (A_hi, B_lo) - into the same fp32 accumulators: three main-loop steps per k-tile over four
 // fetched operand tiles (see the loop).
+#ifndef WG_P0
+#define WG_P0 1      // measured on the four weight-gradient shapes of a block: 4 (even) 1485 us, 2: 1470, 1: 1444, 0: 1680; 6: 1535
+#endif
 template <int TRA, int TRB, typename TC, int EPI, int BT, int SPLIT = 0>
 __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -445,12 +474,14 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   // the split's range is fetched from a wave-uniform base + per-lane 32-bit offsets computed once (the general glds_tile spends ~100
   // VALU instructions per wave and k-tile, a dozen of them 64-bit multiplies, on addresses and bounds ahead of the MFMA stage)
   constexpr bool FASTDMA = BT == 256 && TRA == 1 && TRB == 1;
-  unsigned aoff[4] = {0, 0, 0, 0}, boff[4] = {0, 0, 0, 0};
+  constexpr int P0 = WG_P0, PMAX = P0 > 8 - P0 ? P0 : 8 - P0;
+  unsigned aoff[PMAX], boff[PMAX];
   bool fast_tile = false;
+  const int np = wave < 4 ? P0 : 8 - P0, first = wave < 4 ? wave * P0 : 4 * P0 + (wave - 4) * (8 - P0);
   if constexpr (FASTDMA) {
     fast_tile = m0 + BT <= g.M && n0 + BT <= g.N && (long)GBK * max(g.lda, g.ldb) * 2 + 512 < (1L << 31);
-    persist_offsets<1>(aoff, g.lda, 0, BT, lane, wave);
-    persist_offsets<1>(boff, g.ldb, 0, BT, lane, wave);
+    uneven_offsets<1, PMAX>(aoff, g.lda, lane, first);
+    uneven_offsets<1, PMAX>(boff, g.ldb, lane, first);
   }
   for (int k0 = kbeg; k0 < kend; k0 += GBK, stage ^= 1) {
     __syncthreads();   // (vmcnt(0) + barrier): tile k0 has landed for every wave; nobody still reads the other stage
@@ -461,9 +492,9 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
       if (FASTDMA && fast_tile && k0 + 2 * GBK <= kend) {
         const char* const ab = reinterpret_cast<const char*>(A) + ((long)(k0 + GBK) * g.lda + m0) * 2;
         const char* const bb = reinterpret_cast<const char*>(B) + ((long)(k0 + GBK) * g.ldb + n0) * 2;
-        if (b_first) persist_dma(nx + OPB, bb, boff, wave);
-        persist_dma(nx, ab, aoff, wave);
-        if (!b_first) persist_dma(nx + OPB, bb, boff, wave);
+        if (b_first) uneven_dma<PMAX>(nx + OPB, bb, boff, first, np);
+        uneven_dma<PMAX>(nx, ab, aoff, first, np);
+        if (!b_first) uneven_dma<PMAX>(nx + OPB, bb, boff, first, np);
       } else {
         if (b_first) glds_tile<TRB, BT, NW>(nx + OPB, B, g.ldb, n0, k0 + GBK, g.N, kend, lane, wave);
         glds_tile<TRA, BT, NW>(nx, A, g.lda, m0, k0 + GBK, g.M, kend, lane, wave);
