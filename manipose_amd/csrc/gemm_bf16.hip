@@ -689,6 +689,33 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
   }
 }
 
+// bf16 output, no bias / residual / activation (the dgrad GEMMs): the accumulators are rounded to bf16 BEFORE the transposition, so the
+// wave-private image is 16 rows x 128 bytes per pass (half the LDS traffic of the fp32 image) and every lane leaves with 16 bytes per
+// store instruction (two dwordx4 per pass instead of four dwordx2).  Same values: the rounding is that of st4(bf16*).
+// Image: row r, 8-byte chunk q (= 4 columns) at r * 128 + ((q ^ (r & 14)) << 3) - conflict-free for the 8-byte writes (lane = row, one
+// chunk per instruction) and for the 16-byte row-major reads (an aligned pair of chunks stays a pair).
+template <bool FULL>
+__device__ __forceinline__ void persist_epilogue_bf16_packed(const GemmB16Args& g, const f32x4 (&acc)[8][4], char* __restrict__ img, int row0, int col0,
+                                                             bf16* __restrict__ C, int l15, int gq, int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint2 v;
+      v.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+      v.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+      *reinterpret_cast<uint2*>(img + l15 * 128 + (((4 * j + gq) ^ (l15 & 14)) << 3)) = v;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int r = it * 8 + (lane >> 3), c16 = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(img + r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4));
+      const int row = row0 + i * 16 + r;
+      if (FULL || row < g.M) *reinterpret_cast<uint4*>(C + (long)row * g.ldc + col0 + 8 * c16) = v;
+    }
+  }
+}
+
 // SPLIT: see gemm_bf16_glds_kernel (three steps per k-tile, the DMA source planes rotate)
 template <int TRB, typename TC, int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, int tiles_n, int ntiles) {
@@ -853,8 +880,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       const int col = n0 + wc * 64 + 4 * e15;               // < N: N % 256 == 0
       float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (has_bias) bias4 = *reinterpret_cast<const float4*>(img + 4 * e15);
-      if (m0 + BT <= g.M) persist_epilogue<TC, EPI, true>(g, acc, img, m0 + wr * 128, col, bias4, C, Z, e15, eq);
-      else persist_epilogue<TC, EPI, false>(g, acc, img, m0 + wr * 128, col, bias4, C, Z, e15, eq);
+      bool done = false;
+      if constexpr (sizeof(TC) == 2 && EPI == EPI_BIAS && SPLIT == 0) {      // plain bf16 output (bf16p is the planar tag: SPLIT kernels only)
+        if (!has_bias) {
+          int el = lane;
+          asm volatile("" : "+v"(el));
+          if (m0 + BT <= g.M) persist_epilogue_bf16_packed<true>(g, acc, reinterpret_cast<char*>(img), m0 + wr * 128, n0 + wc * 64, reinterpret_cast<bf16*>(C), e15, eq, el);
+          else persist_epilogue_bf16_packed<false>(g, acc, reinterpret_cast<char*>(img), m0 + wr * 128, n0 + wc * 64, reinterpret_cast<bf16*>(C), e15, eq, el);
+          done = true;
+        }
+      }
+      if (!done) {
+        if (m0 + BT <= g.M) persist_epilogue<TC, EPI, true>(g, acc, img, m0 + wr * 128, col, bias4, C, Z, e15, eq);
+        else persist_epilogue<TC, EPI, false>(g, acc, img, m0 + wr * 128, col, bias4, C, Z, e15, eq);
+      }
     }
 #ifdef MP_GEMM_DIAG
     dg_epi += __builtin_readcyclecounter() - te0;
