@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from manipose_amd import _lib
 lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
-if os.environ.get("ATTN2P") == "0":
-    _lib.check(lib.mp_set_option(b"attn_two_phase", 0))
+if os.environ.get("ATTN2P") is not None:         # bit 0: two-phase split-precision forward, bit 1: two-image backward
+    _lib.check(lib.mp_set_option(b"attn_two_phase", int(os.environ["ATTN2P"])))
 B, T, J, C, H = int(os.environ.get("B", "32")), int(os.environ.get("T", "243")), int(os.environ.get("J", "17")), 512, 8
 M = B * T * J
 qkv = torch.randn(M, 3 * C, device="cuda").bfloat16(); dout = torch.randn(M, C, device="cuda").bfloat16()
