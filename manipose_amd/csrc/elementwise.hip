@@ -320,11 +320,16 @@ int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, cons
   return MP_OK;
 }
 
+#ifndef LNB2_R
+#define LNB2_R 2
+#endif
 // Fused pair of LayerNorm backwards across a block boundary (precision-independent, C <= 512):
 //   t  = dskip + LN1'(dy1; x1, stats1, gamma1)        (norm1 of block l+1, plus the residual skip gradient)
 //   dx = LN0'(t; x0, stats0, gamma0)                  (shared post-norm behind block l)
 // saving one fp32 write + read of the gradient stream per block.  Partials: [dgamma1 | dbeta1 | dgamma0 | dbeta0].
-template <typename TDY>
+// R rows in flight per wave: every load of the R rows is issued before the first row is reduced (one row per wave left ~60 KB in flight per
+// CU and the kernel at 4.2 TB/s of its 16 B per element, against 5.8 TB/s for ln_bwd_kernel with its two rows).
+template <typename TDY, int R>
 __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy1, const float* __restrict__ x1,
                                                        const float* __restrict__ stats1, const float* __restrict__ gamma1,
                                                        const float* dskip, const float* __restrict__ x0,
@@ -345,82 +350,89 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy
     for (int k = 0; k < 4; ++k) acc[k][i] = make_float4(0.f, 0.f, 0.f, 0.f);
     g1[i] = (c < C) ? ld4(gamma1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     g0[i] = (c < C) ? ld4(gamma0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    b0[i] = (c < C && beta0 != nullptr) ? ld4(beta0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    b0[i] = (c < C) ? ld4(beta0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int m = wave; m < M; m += nwaves) {
-    float4 xh[V], d[V], t[V];
-    float s1 = 0.f, s2 = 0.f;
-    // every input of the row is requested up front (the second norm's operands used to be loaded behind the first reduction)
-    const float mean1 = lone(stats1[2 * (long)m]), rstd1 = lone(stats1[2 * (long)m + 1]);
-    const float mean0 = lone(stats0[2 * (long)m]), rstd0 = lone(stats0[2 * (long)m + 1]);
-    const float ms = (dx_b16 != nullptr) ? droppath_scale(mask, mask_mode, __builtin_amdgcn_readfirstlane(m), T, J) : 1.0f;
-    float4 xv1[V], gy[V], kk[V], xv0[V];
+  for (int m0 = wave; m0 < M; m0 += R * nwaves) {
+    // every input of the R rows is requested up front
+    float mean1[R], rstd1[R], mean0[R], rstd0[R], ms[R];
+    float4 gy[R][V], kk[R][V], xv0[R][V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const int c = lane * 4 + 256 * i;
-      if (c < C) {
-        gy[i] = ld4(dy1 + (long)m * C + c);
-        kk[i] = ld4(dskip + (long)m * C + c);
-        xv0[i] = ld4(x0 + (long)m * C + c);
-        if (beta0 == nullptr) xv1[i] = ld4(x1 + (long)m * C + c);
+    for (int r = 0; r < R; ++r) {
+      const int m = m0 + r * nwaves;
+      if (m < M) {
+        mean1[r] = lone(stats1[2 * (long)m]); rstd1[r] = lone(stats1[2 * (long)m + 1]);
+        mean0[r] = lone(stats0[2 * (long)m]); rstd0[r] = lone(stats0[2 * (long)m + 1]);
+        ms[r] = (dx_b16 != nullptr) ? droppath_scale(mask, mask_mode, __builtin_amdgcn_readfirstlane(m), T, J) : 1.0f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const int c = lane * 4 + 256 * i;
+          if (c < C) {
+            gy[r][i] = ld4(dy1 + (long)m * C + c);
+            kk[r][i] = ld4(dskip + (long)m * C + c);
+            xv0[r][i] = ld4(x0 + (long)m * C + c);
+          }
+        }
       }
     }
-    if (beta0 != nullptr) {
-      // x1 is the post-norm output of x0 (no positional table behind the blocks this kernel serves): recomputed with the forward's
-      // expression (ln_fwd stage 1) instead of read back - one fp32 activation read less per row
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int m = m0 + r * nwaves;
+      if (m >= M) break;
+      float4 xh[V], d[V], t[V];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < V; ++i) {
-        xv1[i].x = (xv0[i].x - mean0) * rstd0 * g0[i].x + b0[i].x;
-        xv1[i].y = (xv0[i].y - mean0) * rstd0 * g0[i].y + b0[i].y;
-        xv1[i].z = (xv0[i].z - mean0) * rstd0 * g0[i].z + b0[i].z;
-        xv1[i].w = (xv0[i].w - mean0) * rstd0 * g0[i].w + b0[i].w;
+        const int c = lane * 4 + 256 * i;
+        xh[i] = d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) {
+          // x1 is the post-norm output of x0 (no positional table behind the blocks this kernel serves): recomputed with the forward's
+          // expression (ln_fwd stage 1) instead of read back - one fp32 activation read less per row
+          float4 xv;
+          xv.x = (xv0[r][i].x - mean0[r]) * rstd0[r] * g0[i].x + b0[i].x;
+          xv.y = (xv0[r][i].y - mean0[r]) * rstd0[r] * g0[i].y + b0[i].y;
+          xv.z = (xv0[r][i].z - mean0[r]) * rstd0[r] * g0[i].z + b0[i].z;
+          xv.w = (xv0[r][i].w - mean0[r]) * rstd0[r] * g0[i].w + b0[i].w;
+          const float4 g = gy[r][i];
+          xh[i] = make_float4((xv.x - mean1[r]) * rstd1[r], (xv.y - mean1[r]) * rstd1[r], (xv.z - mean1[r]) * rstd1[r], (xv.w - mean1[r]) * rstd1[r]);
+          acc[0][i].x += g.x * xh[i].x; acc[0][i].y += g.y * xh[i].y; acc[0][i].z += g.z * xh[i].z; acc[0][i].w += g.w * xh[i].w;
+          acc[1][i].x += g.x; acc[1][i].y += g.y; acc[1][i].z += g.z; acc[1][i].w += g.w;
+          d[i] = make_float4(g.x * g1[i].x, g.y * g1[i].y, g.z * g1[i].z, g.w * g1[i].w);
+          s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+          s2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
+        }
       }
-    }
+      s1 = wave_sum(s1) / (float)C;
+      s2 = wave_sum(s2) / (float)C;
+      float u1 = 0.f, u2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const int c = lane * 4 + 256 * i;
-      xh[i] = d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < C) {
-        const float4 xv = xv1[i], g = gy[i];
-        xh[i] = make_float4((xv.x - mean1) * rstd1, (xv.y - mean1) * rstd1, (xv.z - mean1) * rstd1, (xv.w - mean1) * rstd1);
-        acc[0][i].x += g.x * xh[i].x; acc[0][i].y += g.y * xh[i].y; acc[0][i].z += g.z * xh[i].z; acc[0][i].w += g.w * xh[i].w;
-        acc[1][i].x += g.x; acc[1][i].y += g.y; acc[1][i].z += g.z; acc[1][i].w += g.w;
-        d[i] = make_float4(g.x * g1[i].x, g.y * g1[i].y, g.z * g1[i].z, g.w * g1[i].w);
-        s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
-        s2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
+      for (int i = 0; i < V; ++i) {
+        const int c = lane * 4 + 256 * i;
+        t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) {
+          const float4 k = kk[r][i], xv = xv0[r][i];
+          t[i].x = rstd1[r] * (d[i].x - s1 - xh[i].x * s2) + rs * k.x;
+          t[i].y = rstd1[r] * (d[i].y - s1 - xh[i].y * s2) + rs * k.y;
+          t[i].z = rstd1[r] * (d[i].z - s1 - xh[i].z * s2) + rs * k.z;
+          t[i].w = rstd1[r] * (d[i].w - s1 - xh[i].w * s2) + rs * k.w;
+          xh[i] = make_float4((xv.x - mean0[r]) * rstd0[r], (xv.y - mean0[r]) * rstd0[r], (xv.z - mean0[r]) * rstd0[r], (xv.w - mean0[r]) * rstd0[r]);
+          acc[2][i].x += t[i].x * xh[i].x; acc[2][i].y += t[i].y * xh[i].y; acc[2][i].z += t[i].z * xh[i].z; acc[2][i].w += t[i].w * xh[i].w;
+          acc[3][i].x += t[i].x; acc[3][i].y += t[i].y; acc[3][i].z += t[i].z; acc[3][i].w += t[i].w;
+          d[i] = make_float4(t[i].x * g0[i].x, t[i].y * g0[i].y, t[i].z * g0[i].z, t[i].w * g0[i].w);
+          u1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+          u2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
+        }
       }
-    }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
-    float u1 = 0.f, u2 = 0.f;
+      u1 = wave_sum(u1) / (float)C;
+      u2 = wave_sum(u2) / (float)C;
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const int c = lane * 4 + 256 * i;
-      t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < C) {
-        const float4 k = kk[i], xv = xv0[i];
-        t[i].x = rstd1 * (d[i].x - s1 - xh[i].x * s2) + rs * k.x;
-        t[i].y = rstd1 * (d[i].y - s1 - xh[i].y * s2) + rs * k.y;
-        t[i].z = rstd1 * (d[i].z - s1 - xh[i].z * s2) + rs * k.z;
-        t[i].w = rstd1 * (d[i].w - s1 - xh[i].w * s2) + rs * k.w;
-        xh[i] = make_float4((xv.x - mean0) * rstd0, (xv.y - mean0) * rstd0, (xv.z - mean0) * rstd0, (xv.w - mean0) * rstd0);
-        acc[2][i].x += t[i].x * xh[i].x; acc[2][i].y += t[i].y * xh[i].y; acc[2][i].z += t[i].z * xh[i].z; acc[2][i].w += t[i].w * xh[i].w;
-        acc[3][i].x += t[i].x; acc[3][i].y += t[i].y; acc[3][i].z += t[i].z; acc[3][i].w += t[i].w;
-        d[i] = make_float4(t[i].x * g0[i].x, t[i].y * g0[i].y, t[i].z * g0[i].z, t[i].w * g0[i].w);
-        u1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
-        u2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
-      }
-    }
-    u1 = wave_sum(u1) / (float)C;
-    u2 = wave_sum(u2) / (float)C;
-#pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const int c = lane * 4 + 256 * i;
-      if (c < C) {
-        const float4 o = make_float4(rstd0 * (d[i].x - u1 - xh[i].x * u2), rstd0 * (d[i].y - u1 - xh[i].y * u2),
-                                     rstd0 * (d[i].z - u1 - xh[i].z * u2), rstd0 * (d[i].w - u1 - xh[i].w * u2));
-        st4(dx + (long)m * C + c, o);
-        if (dx_b16 != nullptr) st4(dx_b16 + (long)m * C + c, make_float4(o.x * ms, o.y * ms, o.z * ms, o.w * ms));
+      for (int i = 0; i < V; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < C) {
+          const float4 o = make_float4(rstd0[r] * (d[i].x - u1 - xh[i].x * u2), rstd0[r] * (d[i].y - u1 - xh[i].y * u2),
+                                       rstd0[r] * (d[i].z - u1 - xh[i].z * u2), rstd0[r] * (d[i].w - u1 - xh[i].w * u2));
+          st4(dx + (long)m * C + c, o);
+          if (dx_b16 != nullptr) st4(dx_b16 + (long)m * C + c, make_float4(o.x * ms[r], o.y * ms[r], o.z * ms[r], o.w * ms[r]));
+        }
       }
     }
   }
@@ -448,13 +460,27 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
             int J, float* dgamma1, float* dbeta1, float* dgamma0, float* dbeta0, int M, int C, float* scratch, long scratch_floats,
             hipStream_t st, hipStream_t st_param, hipEvent_t ev, float rs) {
   MP_CHECK(C % 4 == 0 && C <= 512, MP_ERR_ARG, "ln_bwd2: C=%d unsupported", C);
-  const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
+  MP_CHECK(beta0 != nullptr, MP_ERR_ARG, "ln_bwd2: x1 is recomputed from x0, beta0 is required");
+  // persistent grid = the workgroups that are resident at once (168 VGPRs: 3 waves per SIMD, 3 workgroups per CU).  With LNB_GRID = 1024
+  // workgroups on 768 slots the launch ran one full round and a second one at a third of the occupancy: 720 us where ln_bwd_kernel (128
+  // VGPRs, 1024 slots) moves the same bytes in 470 us.
+  static int slots[2] = {0, 0};
+  if (slots[dy_bf16 ? 1 : 0] == 0) {
+    int dev = 0, cus = 0, per_cu = 0;
+    const void* fn = dy_bf16 ? (const void*)ln_bwd2_kernel<bf16, LNB2_R> : (const void*)ln_bwd2_kernel<float, LNB2_R>;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || cus <= 0 || per_cu <= 0) {
+      (void)hipGetLastError();
+      slots[dy_bf16 ? 1 : 0] = LNB_GRID;
+    } else slots[dy_bf16 ? 1 : 0] = min(cus * per_cu, LNB_GRID);
+  }
+  const int grid = max(1, min(cdiv(M, 4), slots[dy_bf16 ? 1 : 0]));
   MP_CHECK(scratch_floats >= (long)grid * 4 * C, MP_ERR_ARG, "ln_bwd2: scratch too small");
   if (dy_bf16)
-    hipLaunchKernelGGL(ln_bwd2_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
+    hipLaunchKernelGGL((ln_bwd2_kernel<bf16, LNB2_R>), dim3(grid), dim3(256), 0, st, (const bf16*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
                        beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs);
   else
-    hipLaunchKernelGGL(ln_bwd2_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
+    hipLaunchKernelGGL((ln_bwd2_kernel<float, LNB2_R>), dim3(grid), dim3(256), 0, st, (const float*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
                        beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs);
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dgamma1, dbeta1, dgamma0, dbeta0}, {0, C, 2 * C, 3 * C, 4 * C}, {1, 1, 1, 1}};
