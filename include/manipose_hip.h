@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 5
+#define MP_ABI_VERSION 6
 
 int mp_abi_version(void);
 const char* mp_last_error(void);
@@ -146,6 +146,15 @@ int mp_linear_fwd_bf16x3(const void* x_hi, const void* x_lo, const void* W_hi, c
 int mp_linear_fwd_bf16x3_lnres(const void* x_hi, const void* x_lo, const void* W_hi, const void* W_lo, const float* b, float* y,
                                const float* r_in, const float* rstats, const float* rgamma, const float* rbeta, const float* mask, int mask_mode,
                                int T, int J, int M, int N, int K, void* stream);
+/* The same Linear (architectures/mix_ste.py:216-222, 257-261) on the "f16f8" operand format - one fp16 product plus ONE block-scaled fp8
+ * product per 64 reduction indices instead of three bf16 products.  A value v is carried as hi = fp16(v) (x16 / W16, row-major [rows][K])
+ * and a correction plane of the same byte geometry (x8 / W8: 2 K bytes per row): for every 64 reduction indices 128 bytes,
+ *   activation row:  64 x e4m3(2^11 (v - hi))  |  64 x e4m3(hi)
+ *   weight row:      64 x e4m3(2^4 hi)         |  64 x e4m3(2^15 (v - hi))
+ * so that the 128-deep fp8 dot product of an activation row and a weight row is 2^15 (x_lo w_hi + x_hi w_lo).  y = x W^T + b in fp32.
+ * N must be a multiple of 256, K of 64 (>= 128).  Evaluated operator of round 3; the engine does not use it yet. */
+int mp_linear_fwd_f16f8(const void* x16, const void* x8, const void* W16, const void* W8, const float* b, float* y, int M, int N, int K,
+                        void* stream);
 /* attention core on a planar fused qkv buffer, planar output.  scratch: 4*M*C floats, needed only where no MFMA kernel covers the
  * shape (spatial: 16 <= J <= 32 tokens, head dim 64 or 16, <= 8 heads; temporal: T <= 256, head dim 64 or 16); NULL otherwise. */
 int mp_attention_fwd_bf16x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, float* scratch, int temporal,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MANIPOSE_HIP_LIB") or os.path.join(_HERE, "libmanipos
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "manipose_hip.h")
 
 _lib: Optional[C.CDLL] = None
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 vp, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
@@ -65,6 +65,7 @@ _SIGNATURES = {
     "mp_split_bf16": (i32, [vp, vp, vp, i64, vp]),
     "mp_linear_fwd_bf16x3": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mp_linear_fwd_bf16x3_lnres": (i32, [vp] * 11 + [i32] * 6 + [vp]),
+    "mp_linear_fwd_f16f8": (i32, [vp] * 6 + [i32] * 3 + [vp]),
     "mp_attention_fwd_bf16x3": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mp_model_create": (i32, [C.POINTER(ModelConfig), C.POINTER(vp)]),
     "mp_model_destroy": (None, [vp]),

@@ -183,6 +183,13 @@ int mp_linear_fwd_bf16x3_lnres(const void* x_hi, const void* x_lo, const void* W
   g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
   return gemm_bf16x3(g, 1, EPI_BIAS_RESID, (hipStream_t)stream);
 }
+int mp_linear_fwd_f16f8(const void* x16, const void* x8, const void* W16, const void* W8, const float* b, float* y, int M, int N, int K,
+                        void* stream) {
+  MP_CHECK(x16 && x8 && W16 && W8 && y, MP_ERR_ARG, "mp_linear_fwd_f16f8: null argument");
+  GemmB16Args g = {};
+  g.A = x16; g.A_lo = x8; g.lda = K; g.B = W16; g.B_lo = W8; g.ldb = K; g.C = y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b;
+  return gemm_f16f8(g, (hipStream_t)stream);
+}
 int mp_attention_fwd_bf16x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, float* scratch, int temporal,
                             int B, int T, int J, int C, int H, void* stream) {
   MP_CHECK(qkv_hi && qkv_lo && out_hi && out_lo && (!temporal || lse), MP_ERR_ARG, "mp_attention_fwd_bf16x3: null pointer");

@@ -287,7 +287,16 @@ __device__ __forceinline__ bf16x8_t read_frag2(const char* __restrict__ S, int o
 
 // One k-tile (GBK = 64) of MFMAs for a wave's (BT/2) x 64 sub-tile, fragment reads software-pipelined: the ds_reads of
 // step s+1 are issued before the 8 MFMAs of step s.
-template <int TRA, int TRB, int BT, int ABL = 0>
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+// one 16 x 16 x 32 product on bf16 (F16 = 0) or fp16 (F16 = 1) fragments
+template <int F16>
+__device__ __forceinline__ f32x4 mfma16(const bf16x8_t& a, const bf16x8_t& b, const f32x4& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int TRA, int TRB, int BT, int ABL = 0, int F16 = 0>
 __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const char* __restrict__ Bs, f32x4 (&acc)[BT / 32][4], int wr, int wc,
                                           int lane) {
   constexpr int MI = BT / 32;
@@ -307,7 +316,7 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
     // hints) hipcc issues most reads directly in front of an s_waitcnt lgkmcnt(0) and their first use - a dozen exposed LDS round trips per
     // k-tile and wave; and with the reads ahead of the group it still waits with lgkmcnt(0), i.e. for the reads it has just issued.
     __builtin_amdgcn_sched_barrier(0);
-    acc[2 * ip][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[0], a_cur[0], acc[2 * ip][0], 0, 0, 0);   // C^T tile
+    acc[2 * ip][0] = mfma16<F16>(b_cur[0], a_cur[0], acc[2 * ip][0]);   // C^T tile
     __builtin_amdgcn_sched_barrier(0);
     if (step + 1 < NSTEP) {
       const int nks = (step + 1) / HS, nip = (step + 1) % HS;
@@ -323,9 +332,9 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 1; j < 4; ++j) acc[2 * ip][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[j], a_cur[0], acc[2 * ip][j], 0, 0, 0);
+    for (int j = 1; j < 4; ++j) acc[2 * ip][j] = mfma16<F16>(b_cur[j], a_cur[0], acc[2 * ip][j]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[2 * ip + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_cur[j], a_cur[1], acc[2 * ip + 1][j], 0, 0, 0);
+    for (int j = 0; j < 4; ++j) acc[2 * ip + 1][j] = mfma16<F16>(b_cur[j], a_cur[1], acc[2 * ip + 1][j]);
     __builtin_amdgcn_sched_barrier(0);
     if (step + 1 < NSTEP) {
       a_cur[0] = a_nxt[0];
@@ -335,6 +344,64 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
         for (int j = 0; j < 4; ++j) b_cur[j] = b_nxt[j];
       }
     }
+  }
+}
+
+// ---- "f16f8" split (SPLIT = 8): the two correction products of a split-precision Linear on block-scaled fp8 operands ----
+// A value x is carried as hi = fp16(x) plus an 8-bit CORRECTION plane of the same byte geometry (2 bytes per element): per row and per 64
+// reduction indices 128 bytes = 64 x e4m3(2^11 (x - hi)) | 64 x e4m3(hi) for an activation, 64 x e4m3(2^4 hi) | 64 x e4m3(2^15 (w - hi)) for a
+// weight, so that ONE 128-deep fp8 product of the two rows is 2^15 (x_lo w_hi + x_hi w_lo); v_mfma_scale_f32_16x16x128_f8f6f4 multiplies by the
+// 2^-15 (its E8M0 block scales, all equal here) while accumulating into the fp32 registers that hold the fp16 product x_hi w_hi.  The
+// 16 x 16 x 128 fp8 instruction takes twice the cycles of the 16 x 16 x 32 fp16 one for four times the depth: a k-tile costs two
+// matrix-core steps instead of the three of the bf16 split, at fp16's 11 significand bits for the main product (oracle/precision_model.py:
+// 2.3e-5 m against 6.0e-6 m for bf16x3 and 4.4e-4 m for a lone fp16 product, on the full-size model).
+// Fragment of 16 rows: the lane's 32 bytes are the 16-byte chunks g and g + 4 of its row - exactly the two bf16 fragments (k-steps 0 and 1)
+// of the same LDS image, so the reads are the conflict-free ones of the bf16 kernel; WHICH reduction index the hardware assigns to a byte
+// does not matter as long as both operands use the same map (a dot product is invariant under a common permutation of its terms).
+__device__ __forceinline__ i32x8_t read_frag8(const char* __restrict__ S, int ob, int lane) {
+  struct Two { bf16x8_t a, b; } t;
+  t.a = read_frag2<0, 256>(S, ob, 0, lane);
+  t.b = read_frag2<0, 256>(S, ob, 1, lane);
+  return __builtin_bit_cast(i32x8_t, t);
+}
+constexpr int F8_SCALE_A = 0x70707070;      // E8M0 2^(112 - 127) = 2^-15 in every byte
+constexpr int F8_SCALE_B = 0x7F7F7F7F;      // 1
+__device__ __forceinline__ f32x4 mfma_f8(const i32x8_t& a, const i32x8_t& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, F8_SCALE_A, 0, F8_SCALE_B);
+}
+// One 128-byte k-tile of a wave's 128 x 64 sub-tile in either mode, ONE code path: the fragments of both modes are the same 32 bytes per lane
+// and row (16-byte chunks g and g + 4), so the LDS reads, their addresses and their registers are shared and only the matrix instruction
+// differs - f8 = false: the chunks are two fp16 fragments (k-steps 0 and 1), two 16 x 16 x 32 MFMAs per block; f8 = true: one 16 x 16 x 128
+// fp8 MFMA per block.  (Two specialised copies of the stage in the k loop keep two sets of address registers alive and spill 116 VGPRs.)
+// Groups of one 16-row A fragment against the four B fragments; the next A fragment is requested behind the group's first MFMA.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x8_t half_lo(const i32x8_t& v) { return __builtin_bit_cast(f16x8_t, __builtin_shufflevector(v, v, 0, 1, 2, 3)); }
+__device__ __forceinline__ f16x8_t half_hi(const i32x8_t& v) { return __builtin_bit_cast(f16x8_t, __builtin_shufflevector(v, v, 4, 5, 6, 7)); }
+__device__ __forceinline__ void mma_stage_mix(const char* __restrict__ As, const char* __restrict__ Bs, f32x4 (&acc)[8][4], int wr, int wc, int lane,
+                                              bool f8) {
+  i32x8_t b[4], a_cur, a_nxt;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = read_frag8(Bs, wc * 64 + j * 16, lane);
+  a_cur = read_frag8(As, wr * 128, lane);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (f8) acc[i][0] = mfma_f8(b[0], a_cur, acc[i][0]);
+    else acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(half_lo(b[0]), half_lo(a_cur), acc[i][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + 1 < 8) a_nxt = read_frag8(As, wr * 128 + (i + 1) * 16, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if (f8) {
+#pragma unroll
+      for (int j = 1; j < 4; ++j) acc[i][j] = mfma_f8(b[j], a_cur, acc[i][j]);
+    } else {
+#pragma unroll
+      for (int j = 1; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(half_lo(b[j]), half_lo(a_cur), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(half_hi(b[j]), half_hi(a_cur), acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + 1 < 8) a_cur = a_nxt;
   }
 }
 
@@ -740,7 +807,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   auto b_base = [&](int nn, int kt) { return TRB ? B + ((long)kt * GBK * g.ldb + nn) * 2 : B + ((long)nn * g.ldb + kt * GBK) * 2; };
   // SPLIT: A / B above are the hi planes; the lo planes lie at these byte distances
   const long a_lo = SPLIT ? reinterpret_cast<const char*>(g.A_lo) - A : 0, b_lo = SPLIT ? reinterpret_cast<const char*>(g.B_lo) - B : 0;
-  persist_dma(smem, a_base(m0, 0) + a_lo, aoff, wave);       // SPLIT: the first step multiplies (A_lo, B_hi)
+  persist_dma(smem, a_base(m0, 0) + (SPLIT == 8 ? 0 : a_lo), aoff, wave);       // SPLIT 1: the first step multiplies (A_lo, B_hi); 8: the fp16 planes
   persist_dma(smem + OPB, b_base(n0, 0), boff, wave);
   int stage = 0;
   bool landed = false;                                      // this tile's first k-tile was already waited for (before the previous epilogue)
@@ -771,7 +838,33 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT == 8) {
+      // "f16f8": 2 nk steps over the two stages - even steps multiply the fp16 planes of k-tile v / 2 (fp16 MFMA), odd steps its 8-bit
+      // correction planes (one 128-deep fp8 MFMA per 16 x 16 block); the plain kernel's pipeline with alternating source planes
+      for (int v = 0; v < 2 * nk; ++v) {
+        if (v == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only
+        else __builtin_amdgcn_s_waitcnt(0x0070);                       // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        const int par = v & 1;
+        const char* As = smem + par * STAGE;
+        const char* Bs = As + OPB;
+        char* nx = smem + (par ^ 1) * STAGE;
+        const bool last = v + 1 == 2 * nk;
+        if (!last || has_next) {
+          if (last) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+          const int ktn = last ? 0 : (v + 1) >> 1;
+          persist_dma(nx, a_base(last ? m0n : m0, ktn) + (par ? 0 : a_lo), aoff, wave);
+          persist_dma(nx + OPB, b_base(last ? n0n : n0, ktn) + (par ? 0 : b_lo), boff, wave);
+        }
+        if (last && has_bias) {
+          typedef __attribute__((address_space(3))) void* lptr;
+          typedef const __attribute__((address_space(1))) void* gptr;
+          __builtin_amdgcn_global_load_lds((gptr)(g.bias + n0 + wc * 64 + lane), (lptr)img, 4, 0, 0);
+        }
+        mma_stage_mix(As, Bs, acc, wr, wc, lane, par != 0);
+      }
+      (void)stage;
+    } else if constexpr (SPLIT) {
       // three steps per k-tile over four fetched operand tiles; buffers A0 | B0 | A1 | B1 = the two stages (see gemm_bf16_glds_kernel)
       char* const A0 = smem;
       char* const B0 = smem + OPB;
@@ -1105,6 +1198,22 @@ int gemm_bf16x3(GemmB16Args g, int c_f32, int epi, hipStream_t st) {
   if (c_f32 && epi == EPI_BIAS) return launch_glds<0, 0, float, EPI_BIAS, 1>(g, 1, st);
   if (c_f32 && epi == EPI_BIAS_RESID) return launch_glds<0, 0, float, EPI_BIAS_RESID, 1>(g, 1, st);
   MP_CHECK(false, MP_ERR_ARG, "gemm_bf16x3: unsupported variant c_f32=%d epi=%d", c_f32, epi);
+}
+
+// y = x W^T + b with x and W carried as fp16 hi planes + 8-bit correction planes (see mma_stage_f8): persistent kernel only
+// (N % 256 == 0, K % 64 == 0, K >= 128); C fp32.  A_lo / B_lo are the correction planes.
+int gemm_f16f8(GemmB16Args g, hipStream_t st) {
+  g.debug = 0;
+  MP_CHECK(g.M > 0 && g.N > 0 && g.N % 256 == 0 && g.K >= 2 * GBK && g.K % GBK == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 4 == 0, MP_ERR_ARG,
+           "gemm_f16f8: N must be a multiple of 256, K of 64 (M=%d N=%d K=%d)", g.M, g.N, g.K);
+  MP_CHECK(g.A_lo && g.B_lo, MP_ERR_ARG, "gemm_f16f8: correction plane missing");
+  MP_CHECK(256L * g.lda * 2 < (1L << 31) && 256L * g.ldb * 2 < (1L << 31), MP_ERR_ARG, "gemm_f16f8: leading dimension too large");
+  g.k_per_split = g.K;
+  int dev = 0, cus = 0;
+  MP_HIP(hipGetDevice(&dev));
+  MP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int wgs = max(8, (cus / 8) * 8);
+  return launch_persist<0, float, EPI_BIAS, 8>(g, wgs, st);
 }
 
 static void wgrad_split_b16(int Mtok, int Nout, int Kin, int bt, int& splits, int& kper) {

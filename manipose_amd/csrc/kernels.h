@@ -59,6 +59,8 @@ int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, 
 // C = A B^T on planar hi/lo operands ("N","N" layouts: the forward Linear), three bf16 MFMA products per k-tile, fp32 accumulate.
 // epi EPI_BIAS / EPI_BIAS_GELU: C planar (C, C_lo), Z = gelu' as plain bf16; EPI_BIAS_RESID: C fp32 (c_f32 must be 1)
 int gemm_bf16x3(GemmB16Args g, int c_f32, int epi, hipStream_t st);
+// y = x W^T + b on fp16 hi planes + 8-bit correction planes (gemm_bf16.hip, mma_stage_f8): A / B the fp16 planes, A_lo / B_lo the corrections, C fp32
+int gemm_f16f8(GemmB16Args g, hipStream_t st);
 int cast_to_bf16x2(const float* src, bf16* hi, bf16* lo, long n, hipStream_t st);
 int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
                float* slab, long slab_floats, hipStream_t st);

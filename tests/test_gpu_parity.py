@@ -1455,6 +1455,48 @@ def test_bf16x3_linear_forward_epilogues(lib, M, N, K):
     assert (y32.cpu().double() - (pre + r.double())).abs().max().item() / scale < 4e-5
 
 
+def f16f8_planes(v, weight):
+    """The "f16f8" operand format of include/manipose_hip.h (mp_linear_fwd_f16f8), built on the host: fp16 hi plane + the 8-bit correction
+    plane (per row and 64 reduction indices: 64 e4m3 bytes | 64 e4m3 bytes).  Returns (hi, correction bytes, first half, second half)."""
+    R, K = v.shape
+    hi = v.half()
+    lo = v - hi.float()
+    f8 = lambda t: t.clamp(-448, 448).to(torch.float8_e4m3fn)
+    first, second = (f8(hi.float() * 16), f8(lo * 2.0 ** 15)) if weight else (f8(lo * 2.0 ** 11), f8(hi.float()))
+    cat = torch.stack([first.view(torch.uint8).view(R, K // 64, 64), second.view(torch.uint8).view(R, K // 64, 64)], dim=2).reshape(R, 2 * K)
+    return hi.contiguous(), cat.contiguous(), first.double(), second.double()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1027, 512, 512), (4131, 1536, 512), (777, 512, 1024), (66100, 512, 512)])
+def test_f16f8_linear_forward(lib, M, N, K):
+    """Linear forward on fp16 hi planes + block-scaled fp8 correction planes (one fp16 and one 128-deep fp8 matrix-core product per 64
+    reduction indices): (a) the kernel evaluates exactly the products of the rounded planes it is given (fp64 of the same
+    planes, to fp32 accumulation error); (b) against the fp64 product of the fp32 operands it keeps ~2^-15 of the operand precision -
+    a lone fp16 product: 2^-11."""
+    from manipose_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    x16, x8, x_lo8, x_hi8 = f16f8_planes(x, False)
+    W16, W8, W_hi8, W_lo8 = f16f8_planes(W, True)
+    planes = x16.double() @ W16.double().t() + 2.0 ** -15 * (x_lo8 @ W_hi8.t() + x_hi8 @ W_lo8.t()) + b.double()
+    pre = x.double() @ W.double().t() + b.double()
+    scale = float(pre.abs().max())
+    dx16, dx8, dW16, dW8, bd = x16.cuda(), x8.cuda(), W16.cuda(), W8.cuda(), b.cuda()
+    y = torch.empty(M, N, device="cuda")
+    _lib.check(lib.mp_linear_fwd_f16f8(dx16.data_ptr(), dx8.data_ptr(), dW16.data_ptr(), dW8.data_ptr(), bd.data_ptr(), y.data_ptr(), M, N, K, st()))
+    got = y.cpu().double()
+    assert (got - planes).abs().max().item() / scale < 2e-6, (got - planes).abs().max().item() / scale
+    err = (got - pre).abs().max().item() / scale
+    lone = (x16.double() @ W16.double().t() + b.double() - pre).abs().max().item() / scale
+    print(f"f16f8 M={M} N={N} K={K}: max error / max |y| {err:.2e} (lone fp16 product {lone:.2e})")
+    assert err < 4e-5 and err < lone / 8, (err, lone)
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.mp_linear_fwd_f16f8(dx16.data_ptr(), dx8.data_ptr(), dW16.data_ptr(), dW8.data_ptr(), bd.data_ptr(), y.data_ptr(), M, N - 4, K, st()))
+
+
 @pytest.mark.parametrize("temporal,B,T,J,C,H", [(1, 2, 243, 3, 128, 2), (1, 1, 81, 17, 512, 8), (1, 2, 27, 16, 128, 8), (1, 1, 256, 2, 64, 1),
                                                 (1, 1, 17, 2, 32, 2), (1, 1, 300, 2, 128, 2), (1, 1, 100, 2, 64, 4), (1, 3, 243, 17, 512, 8),
                                                 (1, 2, 129, 5, 64, 1), (1, 40, 200, 3, 128, 2), (1, 1, 145, 2, 64, 1),

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/manipose_hip.h but not exported"
         assert n in _lib._SIGNATURES, f"{n} has no ctypes signature in manipose_amd/_lib.py"
-    assert lib.mp_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.mp_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_state_dict_layout_matches_reference(golden_dir):
