@@ -34,6 +34,10 @@ __device__ __forceinline__ float sadd(float a, float b) { return a + b; }
 __device__ __forceinline__ float smul(float a, float b) { return a * b; }
 __device__ __forceinline__ float ssub(float a, float b) { return a - b; }
 
+__device__ __forceinline__ float4 bf16x4_to_float4(const uint2& r) {
+  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+}
+
 template <int D> struct ACfg {
   // LDS bytes per frame row.  Head dim 64: exactly 128 B, the 16-byte chunk index XOR-swizzled by (frame & 7) - conflict-free for
   // both the row reads (ds_read_b128) and the transpose reads (ds_read_b64_tr_b16); a 16-byte pad (144 B rows) made both of them
@@ -47,15 +51,34 @@ template <int D> struct ACfg {
 
 // stage `rows` (frames) x D of a strided bf16 matrix into LDS, zero-filling frames >= T
 // rows: frames of the image (T rounded up to 32: the products reduce over 32-frame blocks; frames >= T are zero-filled)
-template <int D>
-__device__ __forceinline__ void stage_rows(char* __restrict__ S, const bf16* __restrict__ base, long row_stride, int T, int rows, int tid,
-                                           int nthreads) {
-  constexpr int CH = ACfg<D>::CH, ROWB = ACfg<D>::ROWB;
-  for (int idx = tid; idx < rows * CH; idx += nthreads) {
-    const int t = idx / CH, c = idx - t * CH;
-    uint4 x = make_uint4(0u, 0u, 0u, 0u);
-    if (t < T) x = *reinterpret_cast<const uint4*>(base + (long)t * row_stride + c * 8);
-    *reinterpret_cast<uint4*>(S + t * ROWB + ((c ^ ACfg<D>::swz(t)) << 4)) = x;
+// NIMG images at once: img[i] <- rows of base[i] (row strides stride[i]).  Every load of a pass (2 chunks per thread and image) is issued
+// before the first LDS write, from an address that is always valid (frame index clamped to T - 1, zero-filled at the write): the
+// chunk-at-a-time form - `if (t < T) x = load; write x` - compiled to load / s_waitcnt vmcnt(0) / ds_write per chunk, i.e. one memory round
+// trip after the other: 8 of them for the four images of the backward, 8.8 us of a unit's 26 us (round 3, from the ISA).
+template <int D, int NIMG>
+__device__ __forceinline__ void stage_rows_multi(char* const (&S)[NIMG], const bf16* const (&base)[NIMG], const long (&stride)[NIMG], int T, int rows,
+                                                 int tid, int nthreads) {
+  constexpr int CH = ACfg<D>::CH, ROWB = ACfg<D>::ROWB, U = 2;
+  const int total = rows * CH;
+  for (int idx0 = tid; idx0 < total; idx0 += U * nthreads) {
+    uint4 x[NIMG][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = min(idx0 + u * nthreads, total - 1);
+      const int t = idx / CH, c = idx - t * CH, tc = min(t, T - 1);
+#pragma unroll
+      for (int im = 0; im < NIMG; ++im) x[im][u] = *reinterpret_cast<const uint4*>(base[im] + (long)tc * stride[im] + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = idx0 + u * nthreads;
+      const int t = idx / CH, c = idx - t * CH;
+      if (idx < total) {
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im)
+          *reinterpret_cast<uint4*>(S[im] + t * ROWB + ((c ^ ACfg<D>::swz(t)) << 4)) = (t < T) ? x[im][u] : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
   }
 }
 
@@ -168,8 +191,12 @@ __global__ __launch_bounds__(512, 4) void attn_tmfma_fwd_kernel(const bf16* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const long rs3 = (long)J * 3 * C;
   const bf16* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;
-  stage_rows<D>(Ks, qb + C, rs3, T, rows, tid, nw * 64);
-  stage_rows<D>(Vs, qb + 2 * C, rs3, T, rows, tid, nw * 64);
+  {
+    char* const imgs[2] = {Ks, Vs};
+    const bf16* const srcs[2] = {qb + C, qb + 2 * C};
+    const long strides[2] = {rs3, rs3};
+    stage_rows_multi<D, 2>(imgs, srcs, strides, T, rows, tid, nw * 64);
+  }
   __syncthreads();
   const int ntile = NTC ? NTC : (T + 15) >> 4;
   ImgRd<D> Kr, Vr;
@@ -271,25 +298,47 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
   const bf16* qb = qkv + ((long)b * T * J + j) * 3 * C + h * D;
   const bf16* ob = out + ((long)b * T * J + j) * C + h * D;
   const bf16* gb = dout + ((long)b * T * J + j) * C + h * D;
-  stage_rows<D>(Qs, qb, rs3, T, rows, tid, nw * 64);
-  stage_rows<D>(Ks, qb + C, rs3, T, rows, tid, nw * 64);
-  stage_rows<D>(Vs, qb + 2 * C, rs3, T, rows, tid, nw * 64);
-  stage_rows<D>(Gs, gb, rs1, T, rows, tid, nw * 64);
-  for (int t0 = 0; t0 < rows; t0 += nw * 16) {   // delta and log-sum-exp: 4 threads per frame, each a quarter of the head dim
+  // delta and log-sum-exp: 4 threads per frame, each a quarter of the head dim.  The first pass's rows (all of them when rows <= 16 waves x 16)
+  // are requested BEFORE the images are staged - unconditional loads from clamped frames - so that they travel with the image loads
+  // instead of costing two more memory round trips behind them.
+  constexpr int DQ = D / 16;                               // 8-byte loads of dO and of O per thread
+  auto delta_load = [&](int t0, uint2 (&a)[DQ], uint2 (&o)[DQ], float& l) {
+    const int tcl = min(t0 + (tid >> 2), T - 1), part = tid & 3;
+#pragma unroll
+    for (int i = 0; i < DQ; ++i) {
+      a[i] = *reinterpret_cast<const uint2*>(gb + (long)tcl * rs1 + part * (D / 4) + 4 * i);
+      o[i] = *reinterpret_cast<const uint2*>(ob + (long)tcl * rs1 + part * (D / 4) + 4 * i);
+    }
+    l = lse[(long)unit * T + tcl];
+  };
+  auto delta_commit = [&](int t0, const uint2 (&a)[DQ], const uint2 (&o)[DQ], float l) {
     const int t = t0 + (tid >> 2), part = tid & 3;
     float dl = 0.f;
-    if (t < T) {
 #pragma unroll
-      for (int c = part * (D / 4); c < (part + 1) * (D / 4); c += 4) {
-        const float4 a = ld4(gb + (long)t * rs1 + c), o4 = ld4(ob + (long)t * rs1 + c);
-        dl += (a.x * o4.x + a.y * o4.y) + (a.z * o4.z + a.w * o4.w);
-      }
+    for (int i = 0; i < DQ; ++i) {
+      const float4 a4 = bf16x4_to_float4(a[i]), o4 = bf16x4_to_float4(o[i]);
+      dl += (a4.x * o4.x + a4.y * o4.y) + (a4.z * o4.z + a4.w * o4.w);
     }
+    if (t >= T) dl = 0.f;
     dl += __shfl_xor(dl, 1, 64);
     dl += __shfl_xor(dl, 2, 64);
     if (part == 0 && t < rows) {
       Dl[t] = -dl;                                        // stored negated: ds = p (dp + (-delta)) is a packed add + a packed multiply
-      Ls[t] = (t < T) ? lse[(long)unit * T + t] * -1.4426950408889634f : -INFINITY;    // MINUS lse in log2 units
+      Ls[t] = (t < T) ? l * -1.4426950408889634f : -INFINITY;    // MINUS lse in log2 units
+    }
+  };
+  {
+    uint2 da[DQ], dob[DQ];
+    float dlse;
+    delta_load(0, da, dob, dlse);
+    char* const imgs[4] = {Qs, Ks, Vs, Gs};
+    const bf16* const srcs[4] = {qb, qb + C, qb + 2 * C, gb};
+    const long strides[4] = {rs3, rs3, rs3, rs1};
+    stage_rows_multi<D, 4>(imgs, srcs, strides, T, rows, tid, nw * 64);
+    delta_commit(0, da, dob, dlse);
+    for (int t0 = nw * 16; t0 < rows; t0 += nw * 16) {
+      delta_load(t0, da, dob, dlse);
+      delta_commit(t0, da, dob, dlse);
     }
   }
   __syncthreads();
@@ -435,10 +484,37 @@ __device__ __forceinline__ bf16x8_t frag_tokT(const char* __restrict__ S, int pi
   return f;
 }
 
-__device__ __forceinline__ void stage_block(char* __restrict__ S, int pitch, const bf16* __restrict__ src, int rows, int row_bytes,
-                                            int tid, int nthreads) {
+// Staging of a contiguous block of rows x row_bytes into an LDS image of `pitch` bytes per row, in two halves with NB chunks per thread in flight: issue requests the chunks tid, tid + nthreads, ... (clamped to the block's last
+// chunk: always a valid address, no branch around the load), commit writes them.  A chunk-at-a-time loop (load, write, next) compiles to load / s_waitcnt vmcnt(0) /
+// ds_write per chunk - one memory round trip per 16 bytes and thread, 8-9 of them per frame in the spatial backward.  Chunks past
+// NB * nthreads (frames of more than ~21 tokens at head dim 64) are left to stage_block_tail.
+template <int NB>
+__device__ __forceinline__ void stage_block_issue(uint4 (&x)[NB], const bf16* __restrict__ src, int rows, int row_bytes, int tid, int nthreads) {
+  const int total = rows * (row_bytes >> 4);
+#pragma unroll
+  for (int u = 0; u < NB; ++u) x[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src) + (long)min(tid + u * nthreads, total - 1) * 16);
+}
+// the requested chunks pass through an opaque move: without it hipcc sinks every load into the conditional block of its LDS write (the
+// commit below), which restores the one-round-trip-per-chunk sequence
+template <int NB>
+__device__ __forceinline__ void stage_block_pin(uint4 (&x)[NB]) {
+#pragma unroll
+  for (int u = 0; u < NB; ++u) asm volatile("" : "+v"(x[u].x), "+v"(x[u].y), "+v"(x[u].z), "+v"(x[u].w));
+}
+template <int NB>
+__device__ __forceinline__ void stage_block_commit(char* __restrict__ S, int pitch, const uint4 (&x)[NB], int rows, int row_bytes, int tid, int nthreads) {
+  const int cpr = row_bytes >> 4, total = rows * cpr;
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const int c = tid + u * nthreads;
+    const int r = c / cpr, k = c - r * cpr;
+    if (c < total) *reinterpret_cast<uint4*>(S + r * pitch + k * 16) = x[u];
+  }
+}
+template <int NB>
+__device__ __forceinline__ void stage_block_tail(char* __restrict__ S, int pitch, const bf16* __restrict__ src, int rows, int row_bytes, int tid, int nthreads) {
   const int cpr = row_bytes >> 4;
-  for (int c = tid; c < rows * cpr; c += nthreads) {
+  for (int c = tid + NB * nthreads; c < rows * cpr; c += nthreads) {
     const int r = c / cpr, k = c - r * cpr;
     *reinterpret_cast<uint4*>(S + r * pitch + k * 16) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src) + (long)r * row_bytes + k * 16);
   }
@@ -474,7 +550,14 @@ __global__ __launch_bounds__(512) void attn_smfma_fwd_kernel(const bf16* __restr
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const int pitch = 6 * C + 16;
-  stage_block(sm, pitch, qkv + (long)f * N * 3 * C, N, 6 * C, tid, blockDim.x);
+  {
+    constexpr int NBQ = D == 64 ? 8 : 2;                    // 16-byte chunks of the frame's qkv block per thread: 6 N D / 1024 (17 tokens: 6.4 / 1.6)
+    uint4 xq[NBQ];
+    stage_block_issue<NBQ>(xq, qkv + (long)f * N * 3 * C, N, 6 * C, tid, blockDim.x);
+    stage_block_pin<NBQ>(xq);
+    stage_block_commit<NBQ>(sm, pitch, xq, N, 6 * C, tid, blockDim.x);
+    stage_block_tail<NBQ>(sm, pitch, qkv + (long)f * N * 3 * C, N, 6 * C, tid, blockDim.x);
+  }
   __syncthreads();
   const int oq = h * D * 2, ok = 2 * C + oq, ov = 4 * C + oq;
   bf16x8_t qf[2][KS], kf[2][KS];
@@ -518,8 +601,19 @@ __global__ __launch_bounds__(512) void attn_smfma_bwd_kernel(const bf16* __restr
   const int g = lane >> 4, l15 = lane & 15;
   const int pitch = 6 * C + 16, gpitch = 2 * C + 16;
   char* gs = sm + N * pitch;                               // dO block of the frame
-  stage_block(sm, pitch, qkv + (long)f * N * 3 * C, N, 6 * C, tid, blockDim.x);
-  stage_block(gs, gpitch, dout + (long)f * N * C, N, 2 * C, tid, blockDim.x);
+  {
+    // the frame's qkv block (8 chunks per thread) and its dO block (3) are requested together, then written
+    constexpr int NBQ = D == 64 ? 8 : 2, NBG = D == 64 ? 3 : 1;
+    uint4 xq[NBQ], xg[NBG];
+    stage_block_issue<NBQ>(xq, qkv + (long)f * N * 3 * C, N, 6 * C, tid, blockDim.x);
+    stage_block_issue<NBG>(xg, dout + (long)f * N * C, N, 2 * C, tid, blockDim.x);
+    stage_block_pin<NBQ>(xq);
+    stage_block_pin<NBG>(xg);
+    stage_block_commit<NBQ>(sm, pitch, xq, N, 6 * C, tid, blockDim.x);
+    stage_block_commit<NBG>(gs, gpitch, xg, N, 2 * C, tid, blockDim.x);
+    stage_block_tail<NBQ>(sm, pitch, qkv + (long)f * N * 3 * C, N, 6 * C, tid, blockDim.x);
+    stage_block_tail<NBG>(gs, gpitch, dout + (long)f * N * C, N, 2 * C, tid, blockDim.x);
+  }
   __syncthreads();
   const int oq = h * D * 2, ok = 2 * C + oq, ov = 4 * C + oq, og = oq;
   bf16x8_t qf[2][KS], kf[2][KS], vf[2][KS], gf[2][KS];
