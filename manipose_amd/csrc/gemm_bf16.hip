@@ -296,9 +296,15 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x8_t& a, const bf16x8_t& b, co
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int TRA, int TRB, int BT, int ABL = 0, int F16 = 0>
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+// DMA_LATE_STEP: the MFMA group (of 8) behind which the waves of group 1 (waves 4-7: the second wave of every SIMD) issue their share of the
+// next k-tile's operand DMA in the plain persistent loop, instead of at the start of the step like group 0 (-1: everybody at the start).
+#ifndef DMA_LATE_STEP
+#define DMA_LATE_STEP -1
+#endif
+template <int TRA, int TRB, int BT, int ABL = 0, int F16 = 0, typename Mid = NoMid>
 __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const char* __restrict__ Bs, f32x4 (&acc)[BT / 32][4], int wr, int wc,
-                                          int lane) {
+                                          int lane, Mid mid = Mid()) {
   constexpr int MI = BT / 32;
   constexpr int HS = MI / 2, NSTEP = (GBK / 32) * HS;
   bf16x8_t b_cur[4], b_nxt[4], a_cur[2], a_nxt[2];
@@ -336,6 +342,7 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[2 * ip + 1][j] = mfma16<F16>(b_cur[j], a_cur[1], acc[2 * ip + 1][j]);
     __builtin_amdgcn_sched_barrier(0);
+    if (step == DMA_LATE_STEP) { mid(); __builtin_amdgcn_sched_barrier(0); }
     if (step + 1 < NSTEP) {
       a_cur[0] = a_nxt[0];
       a_cur[1] = a_nxt[1];
@@ -940,17 +947,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       const char* Bs = As + OPB;
       char* nx = smem + (stage ^ 1) * STAGE;
       const bool last = ks + 1 == nk;
-      if (!MP_DBG(g, 2) && (!last || has_next)) {
-        if (last) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+      const bool fetch = !MP_DBG(g, 2) && (!last || has_next);
+      const bool late = DMA_LATE_STEP >= 0 && wave >= 4;      // the SIMD partners of waves 0-3 multiply first and issue their DMA mid-step
+      auto issue = [&]() {
         persist_dma(nx, a_base(last ? m0n : m0, last ? 0 : ks + 1), aoff, wave);
         persist_dma(nx + OPB, b_base(last ? n0n : n0, last ? 0 : ks + 1), boff, wave);
+      };
+      if (fetch) {
+        if (last) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+        if (!late) issue();
       }
       if (last && has_bias) {      // this wave's 64 bias values -> its (idle) epilogue image, 4 bytes per lane; covered by the vmcnt(0) below
         typedef __attribute__((address_space(3))) void* lptr;
         typedef const __attribute__((address_space(1))) void* gptr;
         __builtin_amdgcn_global_load_lds((gptr)(g.bias + n0 + wc * 64 + lane), (lptr)img, 4, 0, 0);
       }
-      if (!MP_DBG(g, 1)) mma_stage<0, TRB, BT>(As, Bs, acc, wr, wc, lane);
+      if (!MP_DBG(g, 1)) mma_stage<0, TRB, BT>(As, Bs, acc, wr, wc, lane, [&]() { if (fetch && late) issue(); });
 #ifdef MP_GEMM_DIAG
       dg_mma += __builtin_readcyclecounter() - tk2;
 #endif
