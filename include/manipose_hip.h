@@ -153,6 +153,9 @@ int mp_linear_fwd_bf16x3_lnres(const void* x_hi, const void* x_lo, const void* W
  *   weight row:      64 x e4m3(2^4 hi)         |  64 x e4m3(2^15 (v - hi))
  * so that the 128-deep fp8 dot product of an activation row and a weight row is 2^15 (x_lo w_hi + x_hi w_lo).  y = x W^T + b in fp32.
  * N must be a multiple of 256, K of 64 (>= 128).  Evaluated operator of round 3; the engine does not use it yet. */
+/* fp32 -> the two planes of that format for a matrix whose rows are multiples of 64 elements long (n = rows * K elements; hi16: n fp16
+ * values, corr8: 2 n bytes); weight != 0 selects the weight form of the correction rows. */
+int mp_split_f16f8(const float* src, void* hi16, void* corr8, int64_t n, int weight, void* stream);
 int mp_linear_fwd_f16f8(const void* x16, const void* x8, const void* W16, const void* W8, const float* b, float* y, int M, int N, int K,
                         void* stream);
 /* attention core on a planar fused qkv buffer, planar output.  scratch: 4*M*C floats, needed only where no MFMA kernel covers the

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "mp_linear_fwd_bf16x3": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mp_linear_fwd_bf16x3_lnres": (i32, [vp] * 11 + [i32] * 6 + [vp]),
     "mp_linear_fwd_f16f8": (i32, [vp] * 6 + [i32] * 3 + [vp]),
+    "mp_split_f16f8": (i32, [vp, vp, vp, i64, i32, vp]),
     "mp_attention_fwd_bf16x3": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mp_model_create": (i32, [C.POINTER(ModelConfig), C.POINTER(vp)]),
     "mp_model_destroy": (None, [vp]),

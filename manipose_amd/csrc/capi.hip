@@ -183,6 +183,10 @@ int mp_linear_fwd_bf16x3_lnres(const void* x_hi, const void* x_lo, const void* W
   g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
   return gemm_bf16x3(g, 1, EPI_BIAS_RESID, (hipStream_t)stream);
 }
+int mp_split_f16f8(const float* src, void* hi16, void* corr8, int64_t n, int weight, void* stream) {
+  MP_CHECK(src && hi16 && corr8 && n > 0 && n % 64 == 0, MP_ERR_ARG, "mp_split_f16f8: bad argument (n must be a multiple of 64)");
+  return cast_to_f16f8(src, hi16, corr8, (long)n, weight, (hipStream_t)stream);
+}
 int mp_linear_fwd_f16f8(const void* x16, const void* x8, const void* W16, const void* W8, const float* b, float* y, int M, int N, int K,
                         void* stream) {
   MP_CHECK(x16 && x8 && W16 && W8 && y, MP_ERR_ARG, "mp_linear_fwd_f16f8: null argument");

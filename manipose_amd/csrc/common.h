@@ -86,6 +86,33 @@ __device__ __forceinline__ void st4(bf16p* p, float4 v, long lo_off) {
 }
 __device__ __forceinline__ void st4(float* p, float4 v, long) { st4(p, v); }
 __device__ __forceinline__ void st4(bf16* p, float4 v, long) { st4(p, v); }
+
+// ---- "f16f8" operand format (include/manipose_hip.h, mp_linear_fwd_f16f8; gemm_bf16.hip, mma_stage_mix): hi = fp16(v) in a plane of 2-byte
+// elements plus a correction plane of the same byte geometry - per row and 64 reduction indices 128 bytes,
+//   activation:  64 x e4m3(2^11 (v - hi)) | 64 x e4m3(hi)            weight:  64 x e4m3(2^4 hi) | 64 x e4m3(2^15 (v - hi))
+// `f16f8` tags a pointer to the fp16 plane.  Values are clamped to the e4m3 range (+-448) ahead of the conversion.
+struct f16f8 { unsigned short v; };
+__device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);       // bytes 0, 1
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);            // bytes 2, 3
+  return (unsigned)r;
+}
+// the 4 consecutive elements v of columns c .. c + 3 (c % 4 == 0) of a row: hi16 = their place in the fp16 plane, cat_row = the row's start in the
+// correction plane (2 K bytes per row)
+__device__ __forceinline__ void st4_f16f8(f16f8* hi16, char* cat_row, int c, float4 v, bool weight) {
+  typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+  const h4_t h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  *reinterpret_cast<uint2*>(hi16) = __builtin_bit_cast(uint2, h);
+  const float4 hf = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+  const float4 lo = make_float4(v.x - hf.x, v.y - hf.y, v.z - hf.z, v.w - hf.w);
+  const float s1 = weight ? 16.f : 2048.f, s2 = weight ? 32768.f : 1.f;
+  const float4 f1 = weight ? hf : lo, f2 = weight ? lo : hf;
+  char* q = cat_row + (c >> 6) * 128 + (c & 63);
+  *reinterpret_cast<unsigned*>(q) = pack_e4m3x4(f1.x * s1, f1.y * s1, f1.z * s1, f1.w * s1);
+  *reinterpret_cast<unsigned*>(q + 64) = pack_e4m3x4(f2.x * s2, f2.y * s2, f2.z * s2, f2.w * s2);
+}
 __device__ __forceinline__ float4 ld4(const bf16p* p, long lo_off) {
   const float4 h = ld4(reinterpret_cast<const bf16*>(p)), l = ld4(reinterpret_cast<const bf16*>(p + lo_off));
   return make_float4(h.x + l.x, h.y + l.y, h.z + l.z, h.w + l.w);

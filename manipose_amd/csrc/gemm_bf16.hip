@@ -1280,6 +1280,21 @@ __global__ void cast_bf16x2_kernel(const float* __restrict__ src, bf16p* __restr
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) st4(hi + 4 * i, ld4(src + 4 * i), lo_off);
 }
+// fp32 -> "f16f8" planes (common.h) of a buffer whose rows are multiples of 64 elements long and start at multiples of 64 elements (the flat
+// parameter buffer: 256-byte slots; an activation matrix with K % 64 == 0): every 64-element block lies inside one row, so the conversion
+// is flat - block j of the source becomes bytes 128 j .. 128 j + 127 of the correction plane
+__global__ void cast_f16f8_kernel(const float* __restrict__ src, f16f8* __restrict__ hi16, char* __restrict__ cat8, long n4, int weight) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const long e = 4 * i;
+  st4_f16f8(hi16 + e, cat8 + (e >> 6) * 128, (int)(e & 63), ld4(src + e), weight != 0);
+}
+int cast_to_f16f8(const float* src, void* hi16, void* cat8, long n, int weight, hipStream_t st) {
+  MP_CHECK(n % 64 == 0, MP_ERR_ARG, "cast_to_f16f8: n %% 64");
+  hipLaunchKernelGGL(cast_f16f8_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, src, reinterpret_cast<f16f8*>(hi16), reinterpret_cast<char*>(cat8), n / 4, weight);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
 int cast_to_bf16x2(const float* src, bf16* hi, bf16* lo, long n, hipStream_t st) {
   MP_CHECK(n % 4 == 0, MP_ERR_ARG, "cast_to_bf16x2: n %% 4");
   hipLaunchKernelGGL(cast_bf16x2_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, src, reinterpret_cast<bf16p*>(hi), (long)(lo - hi), n / 4);

@@ -61,6 +61,7 @@ int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, 
 int gemm_bf16x3(GemmB16Args g, int c_f32, int epi, hipStream_t st);
 // y = x W^T + b on fp16 hi planes + 8-bit correction planes (gemm_bf16.hip, mma_stage_f8): A / B the fp16 planes, A_lo / B_lo the corrections, C fp32
 int gemm_f16f8(GemmB16Args g, hipStream_t st);
+int cast_to_f16f8(const float* src, void* hi16, void* cat8, long n, int weight, hipStream_t st);     // n % 64 == 0; see common.h "f16f8"
 int cast_to_bf16x2(const float* src, bf16* hi, bf16* lo, long n, hipStream_t st);
 int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
                float* slab, long slab_floats, hipStream_t st);

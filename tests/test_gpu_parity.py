@@ -1495,6 +1495,17 @@ def test_f16f8_linear_forward(lib, M, N, K):
     assert err < 4e-5 and err < lone / 8, (err, lone)
     with pytest.raises(RuntimeError):
         _lib.check(lib.mp_linear_fwd_f16f8(dx16.data_ptr(), dx8.data_ptr(), dW16.data_ptr(), dW8.data_ptr(), bd.data_ptr(), y.data_ptr(), M, N - 4, K, st()))
+    # the device-side splitter writes the same planes, bit for bit (fp16 and e4m3 round to nearest even; +-448 clamp)
+    for v, weight, want16, want8 in ((x, 0, x16, x8), (W, 1, W16, W8)):
+        big = v.clone()
+        big[0, :4] = torch.tensor([1000.0, -1000.0, 447.0, 3e-5]) * (1.0 if not weight else 1 / 16)       # clamp and subnormal cases
+        b16, b8, _, _ = f16f8_planes(big, bool(weight))
+        src = big.cuda()
+        o16 = torch.empty(v.shape, device="cuda", dtype=torch.float16)
+        o8 = torch.empty(v.shape[0], 2 * v.shape[1], device="cuda", dtype=torch.uint8)
+        _lib.check(lib.mp_split_f16f8(src.data_ptr(), o16.data_ptr(), o8.data_ptr(), src.numel(), weight, st()))
+        assert torch.equal(o16.cpu(), b16)
+        assert torch.equal(o8.cpu(), b8), (o8.cpu() != b8).sum().item()
 
 
 @pytest.mark.parametrize("temporal,B,T,J,C,H", [(1, 2, 243, 3, 128, 2), (1, 1, 81, 17, 512, 8), (1, 2, 27, 16, 128, 8), (1, 1, 256, 2, 64, 1),
