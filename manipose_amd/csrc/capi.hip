@@ -192,7 +192,7 @@ int mp_linear_fwd_f16f8(const void* x16, const void* x8, const void* W16, const 
   MP_CHECK(x16 && x8 && W16 && W8 && y, MP_ERR_ARG, "mp_linear_fwd_f16f8: null argument");
   GemmB16Args g = {};
   g.A = x16; g.A_lo = x8; g.lda = K; g.B = W16; g.B_lo = W8; g.ldb = K; g.C = y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b;
-  return gemm_f16f8(g, (hipStream_t)stream);
+  return gemm_f16f8(g, 1, EPI_BIAS, (hipStream_t)stream);
 }
 int mp_attention_fwd_bf16x3(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, float* lse, float* scratch, int temporal,
                             int B, int T, int J, int C, int H, void* stream) {
@@ -291,6 +291,7 @@ int mp_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_persist_mode")) { gemm_bf16_persist_mode(value); return MP_OK; }
   if (!strcmp(name, "side_streams")) { engine_side_streams(value); return MP_OK; }
   if (!strcmp(name, "attn_two_phase")) { attn_two_phase(value); return MP_OK; }
+  if (!strcmp(name, "f16f8_inputs")) { engine_f16f8(value); return MP_OK; }
   MP_CHECK(false, MP_ERR_ARG, "mp_set_option: unknown option '%s'", name);
 }
 

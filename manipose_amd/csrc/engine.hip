@@ -14,6 +14,15 @@ namespace mp {
 // debugging hook (mp_set_option("side_streams", 0)): enqueue the bones net on the caller's stream instead of the engine's side stream
 static int g_side_streams = 1;
 void engine_side_streams(int on) { g_side_streams = on; }
+// "f16f8" inputs of the qkv and fc1 Linear layers (precision 2, widths that are multiples of 256): -1 = MANIPOSE_F16F8 or the default (on),
+// 0 / 1 = mp_set_option("f16f8_inputs", v); read when a model is created
+static int g_f16f8 = -1;
+void engine_f16f8(int on) { g_f16f8 = on; }
+static bool f16f8_wanted() {
+  if (g_f16f8 >= 0) return g_f16f8 != 0;
+  const char* e = getenv("MANIPOSE_F16F8");
+  return e ? atoi(e) != 0 : true;
+}
 
 const char* last_error();
 long wgrad_f32_slab_floats(int Mtok, int Nout, int Kin);
@@ -24,6 +33,7 @@ struct BlockWS {
   float *x_in, *st1, *lse, *x_mid, *st2, *x_out, *stp;
   void *a1, *qkv, *ao, *a2, *z, *f;        // void*: fp32 or bf16 by precision
   void *a1l, *qkvl, *aol, *a2l, *fl;       // precision 2 (split, common.h): the lo planes; a1 ... f are then the hi planes (= the bf16 tensors the backward reads)
+  void *a1h, *a2h;                         // Module::f8: fp16 planes of a1 / a2 ("f16f8", common.h); a1l / a2l then hold their 8-bit correction planes, a1 / a2 the bf16 copies
 };
 struct MaskBranch { std::string name; float keep; int spatial; };
 
@@ -32,6 +42,7 @@ struct Module {
   bool is_rot;
   int N, C, H, depth;     // tokens per frame (17 joints / 16 bones), width, heads, depth
   int K, O;               // heads, out features per head
+  bool f8 = false;        // precision 2: the qkv and fc1 Linear layers read "f16f8" operands (one fp16 + one fp8 matrix-core step per k-tile instead of three bf16 ones)
   float qk_scale, rs, readout;   // attention softmax scale (0 = head_dim^-0.5), residual scale, MuReadout input multiplier (1 unless muP)
   float *hw_eff, *hdw;    // readout != 1: the heads' weights times readout (forward / dx) and the scratch their gradient lands in
   int emb_w, emb_b, spos, tpos, sn_w, sn_b, tn_w, tn_b;
@@ -60,6 +71,8 @@ struct mp_model {
   void *tmp2C = nullptr, *tmp3C = nullptr;   // dz / dqkv: fp32 or bf16 by precision
   bf16* wbf = nullptr;                       // bf16 shadow of the flat parameter buffer (precision 1; precision 2: its hi plane)
   bf16* wbf_lo = nullptr;                    // precision 2: lo plane of the shadow
+  void* w16 = nullptr;                       // a module with f8: "f16f8" shadow of the flat parameter buffer (fp16 plane, 8-bit correction plane in the weight form)
+  char* w8 = nullptr;
   long xattn_half = 0;
   float* xattn = nullptr;                    // precision 2, attention shapes without an MFMA kernel: fp32 scratch (4 M C floats) of the join -> fp32 kernel -> split route
   float *slab = nullptr, *small = nullptr, *lengths = nullptr, *dlen_pose = nullptr, *maskbuf = nullptr, *dscore_zero = nullptr;
@@ -187,6 +200,8 @@ static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int prec
     w.ao = act(M * C);         w.x_mid = bp.take(M * C);   w.st2 = bp.take(M * 2);  w.a2 = act(M * C);
     w.z = act(M * 2 * C);      w.f = act(M * 2 * C);       w.x_out = bp.take(M * C); w.stp = bp.take(M * 2);
     w.a1l = lo(M * C); w.qkvl = lo(M * 3 * C); w.aol = lo(M * C); w.a2l = lo(M * C); w.fl = lo(M * 2 * C);
+    w.a1h = md.f8 ? bp.take((M * C + 1) / 2) : nullptr;
+    w.a2h = md.f8 ? bp.take((M * C + 1) / 2) : nullptr;
   }
   md.x_final = bp.take(M * C);
   md.hw_eff = md.readout != 1.0f ? bp.take((long)md.K * md.O * C) : nullptr;
@@ -216,6 +231,10 @@ static void carve_all(mp_model* m, Bump& bp) {
   if (half) m->wbf = reinterpret_cast<bf16*>(bp.take((m->flat_size + 1) / 2));
   if (m->cfg.precision == 2) {
     m->wbf_lo = reinterpret_cast<bf16*>(bp.take((m->flat_size + 1) / 2));
+    if (m->rot.f8 || m->seg.f8) {
+      m->w16 = bp.take((m->flat_size + 1) / 2);
+      m->w8 = reinterpret_cast<char*>(bp.take((m->flat_size + 1) / 2));
+    }
     long need = 0;
     if (attn_x3_needs_scratch(0, T, m->rot.N, m->rot.C, m->rot.H) || attn_x3_needs_scratch(1, T, m->rot.N, m->rot.C, m->rot.H)) need = max(need, 4 * Mr * m->rot.C);
     if (m->has_seg && (attn_x3_needs_scratch(0, T, m->seg.N, m->seg.C, m->seg.H) || attn_x3_needs_scratch(1, T, m->seg.N, m->seg.C, m->seg.H)))
@@ -315,7 +334,8 @@ static float* G(const mp_model* m, float* flat, int idx) { return flat + m->para
 // rstats / rgamma / rbeta (bf16 mode, residual epilogue): the residual is LayerNorm(R) recomputed in the epilogue (kernels.h)
 static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* A, int widx, int bidx, void* Cc, long M, int N, int K,
                       int epi, void* Z, const float* R, const float* mask, int mask_mode, int T, int J, const float* rstats = nullptr,
-                      const float* rgamma = nullptr, const float* rbeta = nullptr, const void* A_lo = nullptr, void* C_lo = nullptr) {
+                      const float* rgamma = nullptr, const float* rbeta = nullptr, const void* A_lo = nullptr, void* C_lo = nullptr,
+                      bool f8in = false) {
   if (m->cfg.precision == 0) {
     GemmF32Args g = {};
     g.A = (const float*)A; g.lda = K; g.B = P(m, fp, widx); g.ldb = K; g.C = (float*)Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
@@ -328,6 +348,17 @@ static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* 
   g.A = A; g.lda = K; g.B = m->wbf + m->params[widx].offset; g.ldb = K; g.C = Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
   g.bias = P(m, fp, bidx); g.Z = Z; g.R = R; g.mask = mask; g.mask_mode = mask ? mask_mode : 0; g.T = T; g.J = J;
   g.rstats = rstats; g.rgamma = rgamma; g.rbeta = rbeta; g.rscale = m->cur_rs;
+  if (m->cfg.precision == 2 && f8in) {
+    // "f16f8" operands: A = the fp16 plane, A_lo = its correction plane, weights from the f16f8 shadow; planar bf16 outputs as below
+    g.A_lo = A_lo; g.B = reinterpret_cast<const char*>(m->w16) + m->params[widx].offset * 2; g.B_lo = m->w8 + m->params[widx].offset * 2; g.C_lo = C_lo;
+    const double ob = 4.0 * M * N + (epi == EPI_BIAS_GELU ? 2.0 * M * N : 0.0);
+    {
+      ProfScope ps__(m, st, PC_GEMM_FWD, 4.0 * M * N * K, 4.0 * (M * K + (double)N * K) + ob, 2.0 * M * N * K);   // two matrix-core steps per k-tile (one fp16, one fp8 at twice the depth)
+      int rc__ = gemm_f16f8(g, 0, epi, st);
+      if (rc__) return rc__;
+    }
+    return MP_OK;
+  }
   if (m->cfg.precision == 2) {
     // split precision: planar hi/lo A and weights (both planes read), planar outputs (+ the plain-bf16 gelu'), fp32 residual in + out
     g.A_lo = A_lo; g.B_lo = m->wbf_lo + m->params[widx].offset; g.C_lo = C_lo;
@@ -414,7 +445,7 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
 
 static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hipStream_t st) {
   const int T = m->cfg.num_frame, N = md.N, C = md.C, H = md.H, L = 2 * md.depth;
-  const int half = m->cfg.precision;          // LayerNorm output mode: 0 fp32, 1 bf16, 2 planar hi/lo bf16
+  const int half = md.f8 ? 3 : m->cfg.precision;          // LayerNorm output mode: 0 fp32, 1 bf16, 2 planar hi/lo bf16, 3 f16f8 planes + bf16 copy
   const bool x3 = m->cfg.precision == 2;
   float* const xattn = (x3 && m->xattn) ? m->xattn + (st == m->st2 ? m->xattn_half : 0) : nullptr;
   const long M = (long)B * T * N;
@@ -423,6 +454,7 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     LnFwdArgs a = {};
     a.x = md.ws[0].x_in; a.M = (int)M; a.C = C;
     a.g2 = P(m, fp, md.bp[0].n1w); a.b2 = P(m, fp, md.bp[0].n1b); a.eps2 = 1e-6f; a.y2 = md.ws[0].a1; a.y2_lo = md.ws[0].a1l; a.stats2 = md.ws[0].st1;
+    if (md.f8) { a.y2 = md.ws[0].a1h; a.y2_b16 = md.ws[0].a1; }
     RUN(PC_LN, 0, ln_fwd(a, half, st));
   }
   for (int l = 0; l < L; ++l) {
@@ -430,8 +462,8 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     BlockWS& w = md.ws[l];
     const bool spatial = (l % 2 == 0);
     const int mode = spatial ? 1 : 2;
-    int rc = linear_fwd(m, st, fp, w.a1, q.qkvw, q.qkvb, w.qkv, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr,
-                        w.a1l, w.qkvl);
+    int rc = linear_fwd(m, st, fp, md.f8 ? w.a1h : w.a1, q.qkvw, q.qkvb, w.qkv, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr,
+                        w.a1l, w.qkvl, md.f8);
     if (rc) return rc;
     if (x3) {
       if (spatial) RUN(PC_ATTN, 12.0 * B * T * N * N * C, attn_spatial_fwd_x3((const bf16*)w.qkv, (const bf16*)w.qkvl, (bf16*)w.ao, (bf16*)w.aol, xattn, B, T, N, C, H, st));
@@ -455,9 +487,11 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
       LnFwdArgs a = {};
       a.x = w.x_mid; a.M = (int)M; a.C = C;
       a.g2 = P(m, fp, q.n2w); a.b2 = P(m, fp, q.n2b); a.eps2 = 1e-6f; a.y2 = w.a2; a.y2_lo = w.a2l; a.stats2 = w.st2;
+      if (md.f8) { a.y2 = w.a2h; a.y2_b16 = w.a2; }
       RUN(PC_LN, 0, ln_fwd(a, half, st));
     }
-    rc = linear_fwd(m, st, fp, w.a2, q.f1w, q.f1b, w.f, M, 2 * C, C, EPI_BIAS_GELU, w.z, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr, w.a2l, w.fl);
+    rc = linear_fwd(m, st, fp, md.f8 ? w.a2h : w.a2, q.f1w, q.f1b, w.f, M, 2 * C, C, EPI_BIAS_GELU, w.z, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr, w.a2l, w.fl,
+                    md.f8);
     if (rc) return rc;
     rc = linear_fwd(m, st, fp, w.f, q.f2w, q.f2b, w.x_out, M, C, 2 * C, EPI_BIAS_RESID, nullptr, w.x_mid,
                     branch_mask(m, md, l, 1, B, m->train), mode, T, N, nullptr, nullptr, nullptr, w.fl);
@@ -473,6 +507,7 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     if (l + 1 < L) {
       a.g2 = P(m, fp, md.bp[l + 1].n1w); a.b2 = P(m, fp, md.bp[l + 1].n1b); a.eps2 = 1e-6f;
       a.y2 = md.ws[l + 1].a1; a.y2_lo = md.ws[l + 1].a1l; a.stats2 = md.ws[l + 1].st1;
+      if (md.f8) { a.y2 = md.ws[l + 1].a1h; a.y2_b16 = md.ws[l + 1].a1; }
     }
     RUN(PC_LN, 0, ln_fwd(a, half, st));
   }
@@ -691,6 +726,9 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
     *out = m;
     return MP_OK;
   }
+  // f16f8 inputs: the rotations net when its width lets every such GEMM run the persistent 256 x 256 kernel (N = 3 C, 2 C multiples of 256, K = C of 64)
+  m->rot.f8 = cfg->precision == 2 && f16f8_wanted() && m->rot.C % 256 == 0 && m->rot.C >= 256;
+  m->seg.f8 = false;
   Bump dry;
   carve_all(m, dry);
   m->arena_bytes = dry.off;
@@ -846,6 +884,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
   }
   if (m->cfg.precision == 1) RUN(PC_OTHER, 0, cast_to_bf16(fp, m->wbf, m->flat_size, st));
   if (m->cfg.precision == 2) RUN(PC_OTHER, 0, cast_to_bf16x2(fp, m->wbf, m->wbf_lo, m->flat_size, st));
+  if (m->w16 != nullptr) RUN(PC_OTHER, 0, cast_to_f16f8(fp, m->w16, m->w8, m->flat_size, 1, st));
   // fork: the side stream may start once the masks / bf16 weights above are in place
   const hipStream_t side = g_side_streams ? m->st2 : st;
   MP_HIP(hipEventRecord(m->ev_fork, st));

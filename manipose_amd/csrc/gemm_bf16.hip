@@ -1213,8 +1213,10 @@ int gemm_bf16x3(GemmB16Args g, int c_f32, int epi, hipStream_t st) {
 }
 
 // y = x W^T + b with x and W carried as fp16 hi planes + 8-bit correction planes (see mma_stage_f8): persistent kernel only
-// (N % 256 == 0, K % 64 == 0, K >= 128); C fp32.  A_lo / B_lo are the correction planes.
-int gemm_f16f8(GemmB16Args g, hipStream_t st) {
+// (N % 256 == 0, K % 64 == 0, K >= 128).  A_lo / B_lo are the correction planes.  Outputs: c_f32 with EPI_BIAS: fp32; otherwise the planar
+// bf16 hi / lo pair of the bf16x3 kernels (C, C_lo), EPI_BIAS or EPI_BIAS_GELU (+ Z = gelu' as plain bf16) - what the attention kernels and
+// the fc2 GEMM of the engine read.
+int gemm_f16f8(GemmB16Args g, int c_f32, int epi, hipStream_t st) {
   g.debug = 0;
   MP_CHECK(g.M > 0 && g.N > 0 && g.N % 256 == 0 && g.K >= 2 * GBK && g.K % GBK == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && g.ldc % 4 == 0, MP_ERR_ARG,
            "gemm_f16f8: N must be a multiple of 256, K of 64 (M=%d N=%d K=%d)", g.M, g.N, g.K);
@@ -1225,7 +1227,11 @@ int gemm_f16f8(GemmB16Args g, hipStream_t st) {
   MP_HIP(hipGetDevice(&dev));
   MP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int wgs = max(8, (cus / 8) * 8);
-  return launch_persist<0, float, EPI_BIAS, 8>(g, wgs, st);
+  if (c_f32 && epi == EPI_BIAS) return launch_persist<0, float, EPI_BIAS, 8>(g, wgs, st);
+  MP_CHECK(!c_f32 && g.C_lo != nullptr, MP_ERR_ARG, "gemm_f16f8: planar output without its lo plane");
+  if (epi == EPI_BIAS) return launch_persist<0, bf16p, EPI_BIAS, 8>(g, wgs, st);
+  if (epi == EPI_BIAS_GELU) { MP_CHECK(g.Z != nullptr, MP_ERR_ARG, "gemm_f16f8: gelu' output missing"); return launch_persist<0, bf16p, EPI_BIAS_GELU, 8>(g, wgs, st); }
+  MP_CHECK(false, MP_ERR_ARG, "gemm_f16f8: unsupported variant c_f32=%d epi=%d", c_f32, epi);
 }
 
 static void wgrad_split_b16(int Mtok, int Nout, int Kin, int bt, int& splits, int& kper) {

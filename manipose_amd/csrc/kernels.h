@@ -60,7 +60,7 @@ int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, 
 // epi EPI_BIAS / EPI_BIAS_GELU: C planar (C, C_lo), Z = gelu' as plain bf16; EPI_BIAS_RESID: C fp32 (c_f32 must be 1)
 int gemm_bf16x3(GemmB16Args g, int c_f32, int epi, hipStream_t st);
 // y = x W^T + b on fp16 hi planes + 8-bit correction planes (gemm_bf16.hip, mma_stage_f8): A / B the fp16 planes, A_lo / B_lo the corrections, C fp32
-int gemm_f16f8(GemmB16Args g, hipStream_t st);
+int gemm_f16f8(GemmB16Args g, int c_f32, int epi, hipStream_t st);
 int cast_to_f16f8(const float* src, void* hi16, void* cat8, long n, int weight, hipStream_t st);     // n % 64 == 0; see common.h "f16f8"
 int cast_to_bf16x2(const float* src, bf16* hi, bf16* lo, long n, hipStream_t st);
 int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
@@ -69,6 +69,7 @@ int cast_to_bf16(const float* src, bf16* dst, long n, hipStream_t st);
 void gemm_bf16_force_small_tile(bool on);          // test hooks (mp_set_option)
 void gemm_bf16_persist_min_tiles(int n);
 void gemm_bf16_persist_mode(int mode);
+void engine_f16f8(int on);                        // engine.hip: models created afterwards in precision 2 feed their qkv / fc1 GEMMs "f16f8" operands (1, default) or bf16 planes (0)
 void engine_side_streams(int on);                 // engine.hip: 0 = the bones net runs on the caller's stream (debugging)
 int gemm_bf16_take_last_persist();                  // 1 if this thread's last gemm_bf16() ran the persistent kernel (and clears it)
 
@@ -83,9 +84,10 @@ struct LnFwdArgs {
   // stage 2 (optional, g2 != null): y2 = LN(stage-1 output or x; g2,b2,eps2)
   const float* g2; const float* b2; float eps2;
   void* y2; float* stats2;
-  void* y2_lo;           // out mode 2 (planar hi/lo bf16, common.h): the lo plane
+  void* y2_lo;           // out mode 2 (planar hi/lo bf16, common.h): the lo plane; out mode 3: the 8-bit correction plane (2 C bytes per row)
+  void* y2_b16;          // out mode 3 ("f16f8", common.h: y2 = the fp16 plane): a plain bf16 copy of the output as well (the backward's operand)
 };
-int ln_fwd(const LnFwdArgs& a, int out_mode /* 0 fp32, 1 bf16, 2 planar bf16 hi/lo */, hipStream_t st);
+int ln_fwd(const LnFwdArgs& a, int out_mode /* 0 fp32, 1 bf16, 2 planar bf16 hi/lo, 3 f16f8 planes + bf16 copy (C % 64 == 0) */, hipStream_t st);
 // dx = [dskip +] LN'(dy); partial param grads are reduced and ADDED into dgamma/dbeta.
 // dx = [rs * dskip +] LN'(dy) (rs: the block's residual scale, 1 unless muP)
 int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
