@@ -18,7 +18,9 @@ Prints ONE JSON line on rank 0 with
   `rccl`          (N>1) backend name and the sum of a ones tensor all-reduced over the process group = the ranks RCCL really joined;
   `other_precisions`  (N=1) poses/s and the same parity figure of the other two precisions, a few steps each;
   `cpu_baseline`  oracle/manipose_ref.py timed on the host cores (rank 0, N=1 only).
-Default precision: "bf16x3" (split bf16 hi/lo operands, three matrix-core products per product, fp32 accumulate) - the fastest
+Default precision: "bf16x3" (split operands, fp32 accumulate: proj / fc2 / attention products as three bf16 matrix-core products of bf16
+hi/lo planes; the qkv and fc1 products - MANIPOSE_F16F8=0 switches this off - as one fp16 product plus one block-scaled fp8 correction
+product, `config.split_forms`) - the fastest
 precision whose drift stays inside the 1e-4 m bound; "bf16" (BASELINE config #3's wording) is faster but drifts ~3 mm.
 """
 import argparse
@@ -368,6 +370,10 @@ def main():
                "config": {"workload": f"H36M lifting T={T} J=17 K={args.hyp} ManiPose full (C=512, depth 8), train step "
                                       f"fwd+WTA loss+bwd+allreduce+Adam", "windows_per_gpu": B, "global_batch": world * B,
                           "seq_len": T, "parallelism": f"dp{world}", "precision": args.precision, "drop_path_rate": 0.1,
+                          **({"split_forms": ("qkv, fc1: f16f8 (fp16 hi plane x fp16 hi plane + ONE block-scaled e4m3 product of 8-bit correction planes per 64 "
+                                              "reduction indices); proj, fc2, attention: bf16x3 (three bf16 products of bf16 hi/lo planes)"
+                                              if os.environ.get("MANIPOSE_F16F8", "1") != "0" else "all: bf16x3 (three bf16 products of bf16 hi/lo planes)")}
+                             if args.precision == "bf16x3" else {}),
                           "gradient_exchange": ("none" if world == 1 else ("8 layer buckets overlapped with the backward + remainder" if args.grad_buckets
                                                                           else "one all-reduce of the flat buffer (137.8 MB) behind the backward"))},
                "loss": loss, "model_tflops": poses_per_s * gf / 1e3}
@@ -391,8 +397,9 @@ def main():
                 k = sub
                 kname = ("gemm_bf16_persist_kernel (forward + dgrad Linear GEMMs: persistent, direct-to-LDS 256x256x64 tiles, "
                          "v_mfma_f32_16x16x32_bf16; all instantiations" +
-                         ("; the split-precision forward instantiations read planar hi/lo operands and issue 3 products per k-tile; "
-                          "flops = 2 M N K, bytes = both planes)" if args.precision == "bf16x3" else ")"))
+                         ("; the split-precision forward instantiations read two planes per operand and issue 3 bf16 products per k-tile "
+                          "(proj, fc2) or one fp16 + one double-depth fp8 product (qkv, fc1: v_mfma_f32_16x16x32_f16 + "
+                          "v_mfma_scale_f32_16x16x128_f8f6f4); flops = 2 M N K, bytes = both planes)" if args.precision == "bf16x3" else ")"))
             else:
                 k = prof["gemm_fwd"]
                 kname = ("gemm_bf16_glds_kernel (forward Linear GEMMs)" if args.precision != "fp32"
@@ -419,8 +426,9 @@ def main():
                                "mfma_issue_tflops": issued_tflops, "mfma_issue_frac": issued_tflops / peak_tf,
                                "issued_flops_per_launch": k["flops"] / nl,
                                "note": ("flops = 2 M N K per GEMM (SURVEY 8d). bf16x3: the forward launches issue 3 bf16 matrix-core products per "
-                                        "product (6 M N K, mfma_issue_*), so fp32-grade products have an effective roof of peak / 3 in the forward; "
-                                        "dgrad launches are plain bf16." if args.precision == "bf16x3" else "flops = 2 M N K per GEMM (SURVEY 8d)")}
+                                        "product (6 M N K, mfma_issue_*) - or, for the qkv / fc1 launches in the f16f8 form, one fp16 product and one fp8 "
+                                        "product of twice the depth at twice the rate (counted as 4 M N K of bf16-rate issue) - so fp32-grade products "
+                                        "have an effective roof of peak / 3 (peak / 2) in the forward; dgrad launches are plain bf16." if args.precision == "bf16x3" else "flops = 2 M N K per GEMM (SURVEY 8d)")}
             tot = sum(v["ms"] for v in prof.values())
             out["kernel_classes"] = {n: {"ms_per_step": v["ms"] / args.steps, "share": v["ms"] / tot if tot else 0.0,
                                          "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}

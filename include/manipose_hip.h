@@ -152,7 +152,7 @@ int mp_linear_fwd_bf16x3_lnres(const void* x_hi, const void* x_lo, const void* W
  *   activation row:  64 x e4m3(2^11 (v - hi))  |  64 x e4m3(hi)
  *   weight row:      64 x e4m3(2^4 hi)         |  64 x e4m3(2^15 (v - hi))
  * so that the 128-deep fp8 dot product of an activation row and a weight row is 2^15 (x_lo w_hi + x_hi w_lo).  y = x W^T + b in fp32.
- * N must be a multiple of 256, K of 64 (>= 128).  Evaluated operator of round 3; the engine does not use it yet. */
+ * N must be a multiple of 256, K of 64 (>= 128).  The engine runs its qkv and fc1 forward GEMMs in this form (precision 2, "f16f8_inputs"). */
 /* fp32 -> the two planes of that format for a matrix whose rows are multiples of 64 elements long (n = rows * K elements; hi16: n fp16
  * values, corr8: 2 n bytes); weight != 0 selects the weight form of the correction rows. */
 int mp_split_f16f8(const float* src, void* hi16, void* corr8, int64_t n, int weight, void* stream);
@@ -333,7 +333,9 @@ int mp_procrustes_errors(const float* pred, const float* gt, const uint8_t* mask
  * "gemm_persist_min_tiles" (output-tile count from which the persistent GEMM kernels are used; 0 = default),
  * "gemm_persist_mode" (0 tiled kernels only, 1 = default: persistent kernel where it applies), "side_streams" (0 = the bones net is
  * enqueued on the caller's stream instead of the engine's side stream; 1 = default), "attn_two_phase" (0 = the one-strip-at-a-time
- * split-precision temporal attention forward for every shape; 1 = default: the two-phase kernel for head dim 64 and T > 128). */
+ * split-precision temporal attention forward for every shape; 1 = default: the two-phase kernel for head dim 64 and T > 128),
+ * "f16f8_inputs" (models created afterwards in precision 2: 1 = default, the qkv and fc1 Linear layers of a rotations net whose width is a
+ * multiple of 256 read "f16f8" operands; 0 = bf16 hi / lo planes everywhere). */
 int mp_set_option(const char* name, int value);
 
 #ifdef __cplusplus
