@@ -148,10 +148,10 @@ int mp_linear_fwd_bf16x3_lnres(const void* x_hi, const void* x_lo, const void* W
                                int T, int J, int M, int N, int K, void* stream);
 /* The same Linear (architectures/mix_ste.py:216-222, 257-261) on the "f16f8" operand format - one fp16 product plus ONE block-scaled fp8
  * product per 64 reduction indices instead of three bf16 products.  A value v is carried as hi = fp16(v) (x16 / W16, row-major [rows][K])
- * and a correction plane of the same byte geometry (x8 / W8: 2 K bytes per row): for every 64 reduction indices 128 bytes,
- *   activation row:  64 x e4m3(2^11 (v - hi))  |  64 x e4m3(hi)
- *   weight row:      64 x e4m3(2^4 hi)         |  64 x e4m3(2^15 (v - hi))
- * so that the 128-deep fp8 dot product of an activation row and a weight row is 2^15 (x_lo w_hi + x_hi w_lo).  y = x W^T + b in fp32.
+ * and a correction plane of the same byte geometry (x8 / W8: 2 K bytes per row): for every four reduction indices 4 q .. 4 q + 3 the 8 bytes
+ *   activation row:  4 x e4m3(2^11 (v - hi))  |  4 x e4m3(hi)
+ *   weight row:      4 x e4m3(2^4 hi)         |  4 x e4m3(2^15 (v - hi))
+ * so that the fp8 dot product of an activation row and a weight row is 2^15 (x_lo w_hi + x_hi w_lo).  y = x W^T + b in fp32.
  * N must be a multiple of 256, K of 64 (>= 128).  The engine runs its qkv and fc1 forward GEMMs in this form (precision 2, "f16f8_inputs"). */
 /* fp32 -> the two planes of that format for a matrix whose rows are multiples of 64 elements long (n = rows * K elements; hi16: n fp16
  * values, corr8: 2 n bytes); weight != 0 selects the weight form of the correction rows. */

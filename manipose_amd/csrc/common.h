@@ -88,9 +88,11 @@ __device__ __forceinline__ void st4(float* p, float4 v, long) { st4(p, v); }
 __device__ __forceinline__ void st4(bf16* p, float4 v, long) { st4(p, v); }
 
 // ---- "f16f8" operand format (include/manipose_hip.h, mp_linear_fwd_f16f8; gemm_bf16.hip, mma_stage_mix): hi = fp16(v) in a plane of 2-byte
-// elements plus a correction plane of the same byte geometry - per row and 64 reduction indices 128 bytes,
-//   activation:  64 x e4m3(2^11 (v - hi)) | 64 x e4m3(hi)            weight:  64 x e4m3(2^4 hi) | 64 x e4m3(2^15 (v - hi))
-// `f16f8` tags a pointer to the fp16 plane.  Values are clamped to the e4m3 range (+-448) ahead of the conversion.
+// elements plus a correction plane of the same byte geometry - 2 bytes per element, the 8 bytes of elements 4 q .. 4 q + 3 of a row being
+//   activation:  4 x e4m3(2^11 (v - hi)) | 4 x e4m3(hi)            weight:  4 x e4m3(2^4 hi) | 4 x e4m3(2^15 (v - hi))
+// (groups of four so that a thread holding four consecutive channels writes ONE 8-byte store and a wave whole 128-byte lines; the matrix
+// instruction only needs both operands to use the same byte order).  `f16f8` tags a pointer to the fp16 plane.  Values are clamped to the
+// e4m3 range (+-448) ahead of the conversion.
 struct f16f8 { unsigned short v; };
 __device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float d) {
   a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
@@ -99,9 +101,9 @@ __device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float
   r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);            // bytes 2, 3
   return (unsigned)r;
 }
-// the 4 consecutive elements v of columns c .. c + 3 (c % 4 == 0) of a row: hi16 = their place in the fp16 plane, cat_row = the row's start in the
-// correction plane (2 K bytes per row)
-__device__ __forceinline__ void st4_f16f8(f16f8* hi16, char* cat_row, int c, float4 v, bool weight) {
+// four consecutive elements v (columns c .. c + 3, c % 4 == 0) of a row: hi16 = their place in the fp16 plane, corr8 = their 8 bytes in the
+// correction plane (byte offset 2 (row K + c))
+__device__ __forceinline__ void st4_f16f8(f16f8* hi16, char* corr8, float4 v, bool weight) {
   typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
   const h4_t h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
   *reinterpret_cast<uint2*>(hi16) = __builtin_bit_cast(uint2, h);
@@ -109,9 +111,7 @@ __device__ __forceinline__ void st4_f16f8(f16f8* hi16, char* cat_row, int c, flo
   const float4 lo = make_float4(v.x - hf.x, v.y - hf.y, v.z - hf.z, v.w - hf.w);
   const float s1 = weight ? 16.f : 2048.f, s2 = weight ? 32768.f : 1.f;
   const float4 f1 = weight ? hf : lo, f2 = weight ? lo : hf;
-  char* q = cat_row + (c >> 6) * 128 + (c & 63);
-  *reinterpret_cast<unsigned*>(q) = pack_e4m3x4(f1.x * s1, f1.y * s1, f1.z * s1, f1.w * s1);
-  *reinterpret_cast<unsigned*>(q + 64) = pack_e4m3x4(f2.x * s2, f2.y * s2, f2.z * s2, f2.w * s2);
+  *reinterpret_cast<uint2*>(corr8) = make_uint2(pack_e4m3x4(f1.x * s1, f1.y * s1, f1.z * s1, f1.w * s1), pack_e4m3x4(f2.x * s2, f2.y * s2, f2.z * s2, f2.w * s2));
 }
 __device__ __forceinline__ float4 ld4(const bf16p* p, long lo_off) {
   const float4 h = ld4(reinterpret_cast<const bf16*>(p)), l = ld4(reinterpret_cast<const bf16*>(p + lo_off));

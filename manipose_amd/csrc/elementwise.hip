@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
           o.z = (v[i].z - mean) * rstd * g2[i].z + b2[i].z;
           o.w = (v[i].w - mean) * rstd * g2[i].w + b2[i].w;
           if constexpr (sizeof(T) == 2 && __is_same(T, f16f8)) {
-            st4_f16f8(yr + c, reinterpret_cast<char*>(a.y2_lo) + (long)m * 2 * C, c, o, false);
+            st4_f16f8(yr + c, reinterpret_cast<char*>(a.y2_lo) + ((long)m * C + c) * 2, o, false);
             st4(reinterpret_cast<bf16*>(a.y2_b16) + (long)m * C + c, o);
           } else st4(yr + c, o, lo_off);
         }

@@ -355,9 +355,9 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
 }
 
 // ---- "f16f8" split (SPLIT = 8): the two correction products of a split-precision Linear on block-scaled fp8 operands ----
-// A value x is carried as hi = fp16(x) plus an 8-bit CORRECTION plane of the same byte geometry (2 bytes per element): per row and per 64
-// reduction indices 128 bytes = 64 x e4m3(2^11 (x - hi)) | 64 x e4m3(hi) for an activation, 64 x e4m3(2^4 hi) | 64 x e4m3(2^15 (w - hi)) for a
-// weight, so that ONE 128-deep fp8 product of the two rows is 2^15 (x_lo w_hi + x_hi w_lo); v_mfma_scale_f32_16x16x128_f8f6f4 multiplies by the
+// A value x is carried as hi = fp16(x) plus an 8-bit CORRECTION plane of the same byte geometry (2 bytes per element; common.h): per four
+// reduction indices 8 bytes = 4 x e4m3(2^11 (x - hi)) | 4 x e4m3(hi) for an activation, 4 x e4m3(2^4 hi) | 4 x e4m3(2^15 (w - hi)) for a
+// weight, so that ONE 128-deep fp8 product of the two rows' 128 bytes per 64 indices is 2^15 (x_lo w_hi + x_hi w_lo); v_mfma_scale_f32_16x16x128_f8f6f4 multiplies by the
 // 2^-15 (its E8M0 block scales, all equal here) while accumulating into the fp32 registers that hold the fp16 product x_hi w_hi.  The
 // 16 x 16 x 128 fp8 instruction takes twice the cycles of the 16 x 16 x 32 fp16 one for four times the depth: a k-tile costs two
 // matrix-core steps instead of the three of the bf16 split, at fp16's 11 significand bits for the main product (oracle/precision_model.py:
@@ -1286,14 +1286,12 @@ __global__ void cast_bf16x2_kernel(const float* __restrict__ src, bf16p* __restr
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) st4(hi + 4 * i, ld4(src + 4 * i), lo_off);
 }
-// fp32 -> "f16f8" planes (common.h) of a buffer whose rows are multiples of 64 elements long and start at multiples of 64 elements (the flat
-// parameter buffer: 256-byte slots; an activation matrix with K % 64 == 0): every 64-element block lies inside one row, so the conversion
-// is flat - block j of the source becomes bytes 128 j .. 128 j + 127 of the correction plane
+// fp32 -> "f16f8" planes (common.h): flat, elements 4 q .. 4 q + 3 of the source become bytes 8 q .. 8 q + 7 of the correction plane
 __global__ void cast_f16f8_kernel(const float* __restrict__ src, f16f8* __restrict__ hi16, char* __restrict__ cat8, long n4, int weight) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const long e = 4 * i;
-  st4_f16f8(hi16 + e, cat8 + (e >> 6) * 128, (int)(e & 63), ld4(src + e), weight != 0);
+  st4_f16f8(hi16 + e, cat8 + 2 * e, ld4(src + e), weight != 0);
 }
 int cast_to_f16f8(const float* src, void* hi16, void* cat8, long n, int weight, hipStream_t st) {
   MP_CHECK(n % 64 == 0, MP_ERR_ARG, "cast_to_f16f8: n %% 64");

@@ -1457,13 +1457,13 @@ def test_bf16x3_linear_forward_epilogues(lib, M, N, K):
 
 def f16f8_planes(v, weight):
     """The "f16f8" operand format of include/manipose_hip.h (mp_linear_fwd_f16f8), built on the host: fp16 hi plane + the 8-bit correction
-    plane (per row and 64 reduction indices: 64 e4m3 bytes | 64 e4m3 bytes).  Returns (hi, correction bytes, first half, second half)."""
+    plane (per four reduction indices: 4 e4m3 bytes | 4 e4m3 bytes).  Returns (hi, correction bytes, first half, second half)."""
     R, K = v.shape
     hi = v.half()
     lo = v - hi.float()
     f8 = lambda t: t.clamp(-448, 448).to(torch.float8_e4m3fn)
     first, second = (f8(hi.float() * 16), f8(lo * 2.0 ** 15)) if weight else (f8(lo * 2.0 ** 11), f8(hi.float()))
-    cat = torch.stack([first.view(torch.uint8).view(R, K // 64, 64), second.view(torch.uint8).view(R, K // 64, 64)], dim=2).reshape(R, 2 * K)
+    cat = torch.stack([first.view(torch.uint8).view(R, K // 4, 4), second.view(torch.uint8).view(R, K // 4, 4)], dim=2).reshape(R, 2 * K)
     return hi.contiguous(), cat.contiguous(), first.double(), second.double()
 
 

@@ -20,8 +20,8 @@ for (N, K, name) in [(1536, 512, "qkv"), (512, 512, "proj"), (1024, 512, "fc1"),
     lib.mp_split_bf16(W.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), W.numel(), st)
     x16, W16 = x.half(), W.half()
     # correction planes: e4m3 bytes of random values of the real magnitudes (lo parts scaled as the format says)
-    x8 = torch.cat([((x - x16.float()) * 2.0 ** 11).view(M, K // 64, 64), x16.float().view(M, K // 64, 64)], dim=2).to(torch.float8_e4m3fn).view(torch.uint8).reshape(M, 2 * K).contiguous()
-    W8 = torch.cat([(W16.float() * 16).view(N, K // 64, 64), ((W - W16.float()) * 2.0 ** 15).view(N, K // 64, 64)], dim=2).to(torch.float8_e4m3fn).view(torch.uint8).reshape(N, 2 * K).contiguous()
+    x8 = torch.cat([((x - x16.float()) * 2.0 ** 11).view(M, K // 4, 4), x16.float().view(M, K // 4, 4)], dim=2).to(torch.float8_e4m3fn).view(torch.uint8).reshape(M, 2 * K).contiguous()
+    W8 = torch.cat([(W16.float() * 16).view(N, K // 4, 4), ((W - W16.float()) * 2.0 ** 15).view(N, K // 4, 4)], dim=2).to(torch.float8_e4m3fn).view(torch.uint8).reshape(N, 2 * K).contiguous()
     del x
     b = torch.randn(N, device="cuda")
     yh, yl = torch.empty(M, N, device="cuda", dtype=torch.bfloat16), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
