@@ -227,8 +227,10 @@ int mp_model_mask_info(const mp_model* m, int B, int index, char* name, int name
 int64_t mp_model_mask_floats(const mp_model* m, int B);
 
 /* forward: x (B, T, 17, 2) -> poses (B, K, T, 17, 3) [, scores (B, K, T, 1) for arch 0].
- * train != 0 applies DropPath: masks = masks_override (device, layout above) if non-NULL, else drawn from
- * (seed, step).  Activations needed by mp_model_backward are kept inside the model until the next forward. */
+ * train is a bit set: bit 0 applies DropPath: masks = masks_override (device, layout above) if non-NULL, else drawn from
+ * (seed, step); bit 1 (value 2) announces that NO mp_model_backward will follow this forward (torch.no_grad() evaluation): tensors that
+ * only the backward reads are then not written, and mp_model_backward returns MP_ERR_STATE.  Otherwise the activations needed by
+ * mp_model_backward are kept inside the model until the next forward. */
 int mp_model_forward(mp_model* m, const float* flat_params, const float* x, int B, float* poses, float* scores, int train,
                      const float* masks_override, uint64_t seed, uint64_t step, void* stream);
 /* backward of the LAST forward: d_poses (B,K,T,17,3), d_scores (B,K,T,1) or NULL; parameter gradients are

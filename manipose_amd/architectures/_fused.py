@@ -13,10 +13,10 @@ class _LiftFunction(torch.autograd.Function):
     """(x, *params) -> poses[, scores] through mp_model_forward; backward through mp_model_backward."""
 
     @staticmethod
-    def forward(ctx, model, x, train, masks, *params):
+    def forward(ctx, model, x, train, masks, infer, *params):
         eng = model._engine
         model._step_counter += 1
-        poses, scores = eng.forward(model._flat, x, train=train, masks=masks, seed=model._seed, step=model._step_counter)
+        poses, scores = eng.forward(model._flat, x, train=train, masks=masks, seed=model._seed, step=model._step_counter, infer=infer)
         ctx.model = model
         ctx.save_for_backward(x)          # the engine reads x again in the embedding backward: keep it alive
         ctx.has_scores = scores is not None
@@ -38,7 +38,7 @@ class _LiftFunction(torch.autograd.Function):
         eng.backward(model._flat, flat_grads, d_poses, d_scores)
         model._last_flat_grad = flat_grads
         grads = tuple(flat_grads[off:off + n].view(p.shape) for (off, n), p in zip(model._slots, model._plist))
-        return (None, None, None, None) + grads
+        return (None, None, None, None, None) + grads
 
 
 class FusedLiftingMixin:
@@ -155,4 +155,6 @@ class FusedLiftingMixin:
         masks = None
         if self.training and self._injected_masks is not None:
             masks = self._engine.pack_masks(x.shape[0], self._injected_masks)
-        return _LiftFunction.apply(self, x, self.training, masks, *self._plist)
+        # under torch.no_grad() (or with nothing to differentiate) no backward can follow: tell the engine
+        infer = not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self._plist)))
+        return _LiftFunction.apply(self, x, self.training, masks, infer, *self._plist)

@@ -79,12 +79,13 @@ class LiftEngine:
         return flat
 
     def forward(self, flat_params: torch.Tensor, x: torch.Tensor, train: bool = False,
-                masks: Optional[torch.Tensor] = None, seed: int = 0, step: int = 0):
+                masks: Optional[torch.Tensor] = None, seed: int = 0, step: int = 0, infer: bool = False):
+        """infer: no backward will follow (torch.no_grad()): the engine skips what only the backward reads."""
         B, T = x.shape[0], x.shape[1]
         poses = torch.empty(B, self.K, T, 17, 3, dtype=torch.float32, device=x.device)
         scores = torch.empty(B, self.K, T, 1, dtype=torch.float32, device=x.device) if self.arch == "rmcl_manifold" else None
         _lib.check(self.lib.mp_model_forward(self.handle, _lib.ptr(flat_params), _lib.ptr(x), B, _lib.ptr(poses),
-                                             _lib.ptr(scores), int(train), _lib.ptr(masks), seed, step, _lib.stream_ptr()),
+                                             _lib.ptr(scores), int(bool(train)) | (2 if infer else 0), _lib.ptr(masks), seed, step, _lib.stream_ptr()),
                    "mp_model_forward")
         return poses, scores
 

@@ -100,6 +100,7 @@ struct mp_model {
   // state of the last forward
   int B = 0;
   bool train = false;
+  bool infer = false;                        // last forward: the caller announced that no backward follows (mp_model_forward, train bit 1)
   const float* x_in = nullptr;
   // profiling
   bool prof = false;
@@ -454,7 +455,7 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     LnFwdArgs a = {};
     a.x = md.ws[0].x_in; a.M = (int)M; a.C = C;
     a.g2 = P(m, fp, md.bp[0].n1w); a.b2 = P(m, fp, md.bp[0].n1b); a.eps2 = 1e-6f; a.y2 = md.ws[0].a1; a.y2_lo = md.ws[0].a1l; a.stats2 = md.ws[0].st1;
-    if (md.f8) { a.y2 = md.ws[0].a1h; a.y2_b16 = md.ws[0].a1; }
+    if (md.f8) { a.y2 = md.ws[0].a1h; a.y2_b16 = m->infer ? nullptr : md.ws[0].a1; }
     RUN(PC_LN, 0, ln_fwd(a, half, st));
   }
   for (int l = 0; l < L; ++l) {
@@ -487,7 +488,7 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
       LnFwdArgs a = {};
       a.x = w.x_mid; a.M = (int)M; a.C = C;
       a.g2 = P(m, fp, q.n2w); a.b2 = P(m, fp, q.n2b); a.eps2 = 1e-6f; a.y2 = w.a2; a.y2_lo = w.a2l; a.stats2 = w.st2;
-      if (md.f8) { a.y2 = w.a2h; a.y2_b16 = w.a2; }
+      if (md.f8) { a.y2 = w.a2h; a.y2_b16 = m->infer ? nullptr : w.a2; }
       RUN(PC_LN, 0, ln_fwd(a, half, st));
     }
     rc = linear_fwd(m, st, fp, md.f8 ? w.a2h : w.a2, q.f1w, q.f1b, w.f, M, 2 * C, C, EPI_BIAS_GELU, w.z, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr, w.a2l, w.fl,
@@ -507,7 +508,7 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     if (l + 1 < L) {
       a.g2 = P(m, fp, md.bp[l + 1].n1w); a.b2 = P(m, fp, md.bp[l + 1].n1b); a.eps2 = 1e-6f;
       a.y2 = md.ws[l + 1].a1; a.y2_lo = md.ws[l + 1].a1l; a.stats2 = md.ws[l + 1].st1;
-      if (md.f8) { a.y2 = md.ws[l + 1].a1h; a.y2_b16 = md.ws[l + 1].a1; }
+      if (md.f8) { a.y2 = md.ws[l + 1].a1h; a.y2_b16 = m->infer ? nullptr : md.ws[l + 1].a1; }
     }
     RUN(PC_LN, 0, ln_fwd(a, half, st));
   }
@@ -864,7 +865,8 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
   hipStream_t st = (hipStream_t)stream;
   const int T = m->cfg.num_frame, J = m->cfg.num_joints, S = m->cfg.num_bones, K = m->rot.K;
   m->B = B;
-  m->train = train != 0 && m->cfg.drop_path_rate > 0.f;
+  m->train = (train & 1) != 0 && m->cfg.drop_path_rate > 0.f;
+  m->infer = (train & 2) != 0;         // no backward will follow: tensors only the backward reads are not written
   m->x_in = x;
   if (m->train) {
     if (masks_override) {
@@ -944,6 +946,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
 int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_poses, const float* d_scores, void* stream) {
   MP_CHECK(m && fp && fg && d_poses, MP_ERR_ARG, "mp_model_backward: null argument");
   MP_CHECK(m->B >= 1, MP_ERR_STATE, "mp_model_backward: no forward has been run");
+  MP_CHECK(!m->infer, MP_ERR_STATE, "mp_model_backward: the last forward was run in inference mode (train bit 1 set)");
   hipStream_t st = (hipStream_t)stream;
   const int B = m->B, T = m->cfg.num_frame, J = m->cfg.num_joints, S = m->cfg.num_bones, K = m->rot.K;
   const long Mr = (long)B * T * J, Ms = (long)B * T * S;

@@ -85,7 +85,7 @@ struct LnFwdArgs {
   const float* g2; const float* b2; float eps2;
   void* y2; float* stats2;
   void* y2_lo;           // out mode 2 (planar hi/lo bf16, common.h): the lo plane; out mode 3: the 8-bit correction plane (2 C bytes per row)
-  void* y2_b16;          // out mode 3 ("f16f8", common.h: y2 = the fp16 plane): a plain bf16 copy of the output as well (the backward's operand)
+  void* y2_b16;          // out mode 3 ("f16f8", common.h: y2 = the fp16 plane): a plain bf16 copy of the output as well (the backward's operand), or null
 };
 int ln_fwd(const LnFwdArgs& a, int out_mode /* 0 fp32, 1 bf16, 2 planar bf16 hi/lo, 3 f16f8 planes + bf16 copy (C % 64 == 0) */, hipStream_t st);
 // dx = [dskip +] LN'(dy); partial param grads are reduced and ADDED into dgamma/dbeta.

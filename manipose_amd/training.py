@@ -104,7 +104,7 @@ class LiftingTrainer:
         B, T = X.shape[0], X.shape[1]
         m._ensure_engine(B, X.device)
         eng = m._engine
-        poses, scores = eng.forward(m._flat, X.contiguous().float(), train=False)
+        poses, scores = eng.forward(m._flat, X.contiguous().float(), train=False, infer=True)
         bf = self._buffers(B, T, X.device)
         st = _lib.stream_ptr()
         y = y.contiguous().float()

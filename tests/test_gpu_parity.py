@@ -1508,6 +1508,49 @@ def test_f16f8_linear_forward(lib, M, N, K):
         assert torch.equal(o8.cpu(), b8), (o8.cpu() != b8).sum().item()
 
 
+@pytest.mark.gpu
+def test_f16f8_inputs_of_the_model_and_the_inference_flag(lib):
+    """The qkv / fc1 Linear layers of a rotations net whose width is a multiple of 256 read "f16f8" operands (option f16f8_inputs, default on):
+    (a) with and without them the model stays inside the 1e-4 m bound of the CPU oracle and the two forwards differ (the option really
+    switches the kernels); (b) a forward under torch.no_grad() tells the engine that no backward follows (train bit 1: the bf16 copies of the
+    LayerNorm outputs are not written) and gives the same bits; mp_model_backward refuses to run after it."""
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton, _lib
+    T, C, H, K, B = 27, 256, 4, 3, 2
+    cfg = dict(T=T, J=17, num_bones=16, C_rot=C, depth_rot=3, heads_rot=H, C_seg=32, depth_seg=1, heads_seg=4, n_hyp=K)
+    state = orc.make_state(cfg, seed=11)
+    X, y = orc.synthetic_batch(B, T, seed=12)
+    with torch.no_grad():
+        want, _ = orc.rmcl_manifold_forward(X, state, orc.oracle_cfg(cfg))
+    kw = dict(skeleton=h36m_skeleton(), num_frame=T, embed_dim_rot=C, depth_rot=3, num_heads_rot=H, embed_dim_seg=32, depth_seg=1,
+              num_heads_seg=4, drop_path_rate=0.0, n_hyp=K)
+    outs = {}
+    try:
+        for on in (1, 0):
+            _lib.check(lib.mp_set_option(b"f16f8_inputs", on))
+            model = RMCLManifoldMixSTE(**kw)
+            model.load_state_dict(state, strict=True)
+            model.precision = "bf16x3"
+            model = model.cuda().eval()
+            poses, scores = model(X.cuda())
+            err = (poses.cpu() - want).norm(dim=-1).mean().item()
+            print(f"f16f8_inputs={on}: MPJPE vs oracle {err:.2e} m")
+            assert err <= 1e-4
+            outs[on] = poses.detach().clone()
+            if on:
+                with torch.no_grad():
+                    p2, s2 = model(X.cuda())
+                assert torch.equal(p2, poses.detach()) and torch.equal(s2, scores.detach())
+                g = torch.zeros_like(model._flat)
+                rc = lib.mp_model_backward(model._engine.handle, _lib.ptr(model._flat), _lib.ptr(g), _lib.ptr(torch.zeros_like(p2)), None, _lib.stream_ptr())
+                assert rc != 0                                     # the last forward announced that no backward follows
+                poses3, scores3 = model(X.cuda())                  # a differentiable forward again: the backward runs
+                (poses3.sum() + scores3.sum()).backward()
+                assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    finally:
+        _lib.check(lib.mp_set_option(b"f16f8_inputs", -1))
+    assert not torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("temporal,B,T,J,C,H", [(1, 2, 243, 3, 128, 2), (1, 1, 81, 17, 512, 8), (1, 2, 27, 16, 128, 8), (1, 1, 256, 2, 64, 1),
                                                 (1, 1, 17, 2, 32, 2), (1, 1, 300, 2, 128, 2), (1, 1, 100, 2, 64, 4), (1, 3, 243, 17, 512, 8),
                                                 (1, 2, 129, 5, 64, 1), (1, 40, 200, 3, 128, 2), (1, 1, 145, 2, 64, 1),
