@@ -491,7 +491,8 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
       if (md.f8) { a.y2 = w.a2h; a.y2_b16 = m->infer ? nullptr : w.a2; }
       RUN(PC_LN, 0, ln_fwd(a, half, st));
     }
-    rc = linear_fwd(m, st, fp, md.f8 ? w.a2h : w.a2, q.f1w, q.f1b, w.f, M, 2 * C, C, EPI_BIAS_GELU, w.z, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr, w.a2l, w.fl,
+    // (inference, precision >= 1: gelu' - read by the fc2 dgrad only - is not written)
+    rc = linear_fwd(m, st, fp, md.f8 ? w.a2h : w.a2, q.f1w, q.f1b, w.f, M, 2 * C, C, EPI_BIAS_GELU, (m->infer && m->cfg.precision >= 1) ? nullptr : w.z, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr, w.a2l, w.fl,
                     md.f8);
     if (rc) return rc;
     rc = linear_fwd(m, st, fp, w.f, q.f2w, q.f2b, w.x_out, M, C, 2 * C, EPI_BIAS_RESID, nullptr, w.x_mid,

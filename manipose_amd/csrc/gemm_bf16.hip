@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmB16Args g) {
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
       }
       if (EPI == EPI_BIAS_GELU) {
-        const float4 d = gelu_fwd4_fast(v);     // v <- gelu(v); Z keeps gelu' (all the backward needs from the pre-activation)
-        st4(Z + o, d);
+        const float4 d = gelu_fwd4_fast(v);     // v <- gelu(v); Z keeps gelu' (all the backward needs from the pre-activation); null: inference
+        if (Z != nullptr) st4(Z + o, d);
       } else if (EPI == EPI_BIAS_RESID) {
         const float4 r = ld4(g.R + o);
         v = make_float4(r.x * rsc + dscale * v.x, r.y * rsc + dscale * v.y, r.z * rsc + dscale * v.z, r.w * rsc + dscale * v.w);
@@ -658,8 +658,8 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
       const long o = (long)row * g.ldc + col;
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
       if (EPI == EPI_BIAS_GELU) {
-        const float4 d = gelu_fwd4_fast(v);     // v <- gelu(v); Z keeps gelu' (all the backward needs from the pre-activation)
-        st4(Z + o, d);
+        const float4 d = gelu_fwd4_fast(v);     // v <- gelu(v); Z keeps gelu' (all the backward needs from the pre-activation); null: inference
+        if (Z != nullptr) st4(Z + o, d);
       } else if (EPI == EPI_BIAS_RESID) {
         const float dscale = dp.scale(row);
         float4 r = ld4(g.R + o);
@@ -752,7 +752,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
       if (EPI == EPI_BIAS_GELU) {
         const float4 d = gelu_fwd4_fast(v);     // v <- gelu(v); Z keeps gelu' (all the backward needs from the pre-activation)
-        if (FULL || row < g.M) st4(Z + o, d);
+        if ((FULL || row < g.M) && Z != nullptr) st4(Z + o, d);      // Z null: inference, nobody reads gelu'
       } else if (EPI == EPI_BIAS_RESID) {
         v = make_float4(in[it].x + ds[it] * v.x, in[it].y + ds[it] * v.y, in[it].z + ds[it] * v.z, in[it].w + ds[it] * v.w);
       } else if (EPI == EPI_DGELU) {
@@ -1230,7 +1230,7 @@ int gemm_f16f8(GemmB16Args g, int c_f32, int epi, hipStream_t st) {
   if (c_f32 && epi == EPI_BIAS) return launch_persist<0, float, EPI_BIAS, 8>(g, wgs, st);
   MP_CHECK(!c_f32 && g.C_lo != nullptr, MP_ERR_ARG, "gemm_f16f8: planar output without its lo plane");
   if (epi == EPI_BIAS) return launch_persist<0, bf16p, EPI_BIAS, 8>(g, wgs, st);
-  if (epi == EPI_BIAS_GELU) { MP_CHECK(g.Z != nullptr, MP_ERR_ARG, "gemm_f16f8: gelu' output missing"); return launch_persist<0, bf16p, EPI_BIAS_GELU, 8>(g, wgs, st); }
+  if (epi == EPI_BIAS_GELU) return launch_persist<0, bf16p, EPI_BIAS_GELU, 8>(g, wgs, st);      // Z may be null (inference: gelu' is not kept)
   MP_CHECK(false, MP_ERR_ARG, "gemm_f16f8: unsupported variant c_f32=%d epi=%d", c_f32, epi);
 }
 
