@@ -170,6 +170,20 @@ __device__ __forceinline__ void store4(bf16* p, const f32x4& v, float s) {
   *reinterpret_cast<uint2*>(p) = r;
 }
 
+// gradient outputs (dQ, dK, dV) of the backward kernels: bf16, or - gout != 0 - fp16 of gout * value (a layer whose dgrad / weight-gradient GEMMs
+// run on fp16 operands: kernels.h GemmB16Args::f16; gout is a power of two that lifts the gradients into fp16's normal range)
+__device__ __forceinline__ void store4g(bf16* p, const f32x4& v, float s, float gout) {
+  if (gout != 0.f) {
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    s *= gout;
+    const h4_t h = {(_Float16)(v[0] * s), (_Float16)(v[1] * s), (_Float16)(v[2] * s), (_Float16)(v[3] * s)};
+    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
+  } else store4(p, v, s);
+}
+// set by the engine for the backward launches issued next on this thread (0 = bf16 outputs); see store4g
+static thread_local float g_grad_f16 = 0.f;
+void attn_grad_f16_override(float gout) { g_grad_f16 = gout; }
+
 // =============================================================================================
 // forward: O = softmax(scale Q K^T) V ; lse = log sum exp of the scaled scores
 // =============================================================================================
@@ -282,7 +296,7 @@ template <int D, int NTC>
 __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                                const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                bf16* __restrict__ dqkv, int T, int J, int C, int H, float scale,
-                                                               int debug) {
+                                                               int debug, float gout) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB, NW = 16, UNR = NTC ? NTC / 2 : 1;
   const int rows = NTC ? TP : (T + 31) & ~31, nw = NTC ? NW : (int)(blockDim.x >> 6);     // short windows: see the forward kernel
@@ -398,7 +412,7 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
     }
     if (tq < T) {
 #pragma unroll
-      for (int db = 0; db < DB; ++db) store4(dq_base + (long)tq * rs3 + 16 * db + 4 * g, dq[db], scale);
+      for (int db = 0; db < DB; ++db) store4g(dq_base + (long)tq * rs3 + 16 * db + 4 * g, dq[db], scale, gout);
     }
   }
 #ifdef MP_GEMM_DIAG
@@ -448,8 +462,8 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
     if (tk < T) {
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        store4(dq_base + C + (long)tk * rs3 + 16 * db + 4 * g, dk[db], scale);
-        store4(dq_base + 2 * C + (long)tk * rs3 + 16 * db + 4 * g, dv[db], 1.0f);
+        store4g(dq_base + C + (long)tk * rs3 + 16 * db + 4 * g, dk[db], scale, gout);
+        store4g(dq_base + 2 * C + (long)tk * rs3 + 16 * db + 4 * g, dv[db], 1.0f, gout);
       }
     }
   }
@@ -594,7 +608,7 @@ __global__ __launch_bounds__(512) void attn_smfma_fwd_kernel(const bf16* __restr
 
 template <int D>
 __global__ __launch_bounds__(512) void attn_smfma_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
-                                                               bf16* __restrict__ dqkv, int N, int C, int H, float scale) {
+                                                               bf16* __restrict__ dqkv, int N, int C, int H, float scale, float gout) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int KS = ACfg<D>::KS, DB = ACfg<D>::DB;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -678,7 +692,7 @@ __global__ __launch_bounds__(512) void attn_smfma_bwd_kernel(const bf16* __restr
     for (int db = 0; db < DB; ++db) {
       f32x4 dq = {0.f, 0.f, 0.f, 0.f};
       dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokT<D>(sm, pitch, ok, db, lane, N), bds, dq, 0, 0, 0);
-      if (tq < N) store4(dbase + (long)tq * 3 * C + 16 * db + 4 * g, dq, scale);
+      if (tq < N) store4g(dbase + (long)tq * 3 * C + 16 * db + 4 * g, dq, scale, gout);
     }
   }
   // ---- pass B ([query][key] orientation): dK, dV.  Row statistics come from pass A's column statistics by shuffle ----
@@ -712,8 +726,8 @@ __global__ __launch_bounds__(512) void attn_smfma_bwd_kernel(const bf16* __restr
       dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokT<D>(gs, gpitch, og, db, lane, N), bp, dv, 0, 0, 0);
       dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokT<D>(sm, pitch, oq, db, lane, N), bds, dk, 0, 0, 0);
       if (tk < N) {
-        store4(dbase + C + (long)tk * 3 * C + 16 * db + 4 * g, dk, scale);
-        store4(dbase + 2 * C + (long)tk * 3 * C + 16 * db + 4 * g, dv, 1.0f);
+        store4g(dbase + C + (long)tk * 3 * C + 16 * db + 4 * g, dk, scale, gout);
+        store4g(dbase + 2 * C + (long)tk * 3 * C + 16 * db + 4 * g, dv, 1.0f, gout);
       }
     }
   }
@@ -753,9 +767,9 @@ int attn_smfma_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, int B, int T, 
       MP_HIP(hipFuncSetAttribute((const void*)attn_smfma_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
-    hipLaunchKernelGGL(attn_smfma_bwd_kernel<64>, dim3(B * T), dim3(H * 64), lds, st, qkv, dout, dqkv, J, C, H, scale);
+    hipLaunchKernelGGL(attn_smfma_bwd_kernel<64>, dim3(B * T), dim3(H * 64), lds, st, qkv, dout, dqkv, J, C, H, scale, g_grad_f16);
   } else {
-    hipLaunchKernelGGL(attn_smfma_bwd_kernel<16>, dim3(B * T), dim3(H * 64), lds, st, qkv, dout, dqkv, J, C, H, scale);
+    hipLaunchKernelGGL(attn_smfma_bwd_kernel<16>, dim3(B * T), dim3(H * 64), lds, st, qkv, dout, dqkv, J, C, H, scale, g_grad_f16);
   }
   MP_LAUNCH_CHECK();
   return MP_OK;
@@ -1424,8 +1438,7 @@ static int launch_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, 
                                (int)(4 * TP * ACfg<D>::ROWB + 2 * TP * sizeof(float))));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_tmfma_bwd_kernel<D, NTC>), dim3(units), dim3(64 * waves), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale,
-                     dbg);
+  hipLaunchKernelGGL((attn_tmfma_bwd_kernel<D, NTC>), dim3(units), dim3(64 * waves), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg, g_grad_f16);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

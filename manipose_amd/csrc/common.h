@@ -94,6 +94,12 @@ __device__ __forceinline__ void st4(bf16* p, float4 v, long) { st4(p, v); }
 // instruction only needs both operands to use the same byte order).  `f16f8` tags a pointer to the fp16 plane.  Values are clamped to the
 // e4m3 range (+-448) ahead of the conversion.
 struct f16f8 { unsigned short v; };
+// four values as fp16 of s * value (a gradient operand carried as scaled fp16: kernels.h GemmB16Args::f16 / gout)
+__device__ __forceinline__ void st4_f16(void* p, float4 v, float s) {
+  typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+  const h4_t h = {(_Float16)(v.x * s), (_Float16)(v.y * s), (_Float16)(v.z * s), (_Float16)(v.w * s)};
+  *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
+}
 __device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float d) {
   a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
   c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);

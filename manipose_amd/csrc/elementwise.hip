@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
                                                       const float* dskip, float* dx, bf16* __restrict__ dx_b16,
                                                       const float* __restrict__ mask, int mask_mode, int T, int J,
-                                                      float* __restrict__ partial, int M, int C, float rs) {
+                                                      float* __restrict__ partial, int M, int C, float rs, float dys) {
   __shared__ float red[4 * 2 * 256 * V];  // [wave][dgamma|dbeta][C <= 256 V]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
       for (int i = 0; i < V; ++i) {
         const int c = lane * 4 + 256 * i;
         if (c < C) {
-          const float4 gg = g[r][i];
+          const float4 gg = make_float4(g[r][i].x * dys, g[r][i].y * dys, g[r][i].z * dys, g[r][i].w * dys);      // dys: 1, or the inverse of the scale dy carries
           xh[i] = make_float4((xv[r][i].x - mean[r]) * rstd[r], (xv[r][i].y - mean[r]) * rstd[r], (xv[r][i].z - mean[r]) * rstd[r],
                               (xv[r][i].w - mean[r]) * rstd[r]);
           dg[i].x += gg.x * xh[i].x; dg[i].y += gg.y * xh[i].y; dg[i].z += gg.z * xh[i].z; dg[i].w += gg.w * xh[i].w;
@@ -306,13 +306,13 @@ static bool param_stream(hipStream_t& st, hipStream_t st_param, hipEvent_t ev) {
 
 int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
            const float* mask, int mask_mode, int T, int J, float* dgamma, float* dbeta, int M, int C, float* scratch,
-           long scratch_floats, hipStream_t st, hipStream_t st_param, hipEvent_t ev, float rs) {
+           long scratch_floats, hipStream_t st, hipStream_t st_param, hipEvent_t ev, float rs, float dy_scale) {
   MP_CHECK(C % 4 == 0 && C <= 1024, MP_ERR_ARG, "ln_bwd: C=%d unsupported", C);
   const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
   MP_CHECK(scratch_floats >= (long)grid * 2 * C, MP_ERR_ARG, "ln_bwd: scratch too small");
 #define MP_LN_BWD(TDY, V, R)                                                                                                             \
   hipLaunchKernelGGL((ln_bwd_kernel<TDY, V, R>), dim3(grid), dim3(256), 0, st, (const TDY*)dy, x, stats, gamma, dskip, dx, (bf16*)dx_b16, \
-                     mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs)
+                     mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs, dy_scale)
   if (C <= 512) { if (dy_bf16) MP_LN_BWD(bf16, 2, 2); else MP_LN_BWD(float, 2, 2); }
   else          { if (dy_bf16) MP_LN_BWD(bf16, 4, 1); else MP_LN_BWD(float, 4, 1); }
 #undef MP_LN_BWD
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy
                                                        const float* __restrict__ stats0, const float* __restrict__ gamma0,
                                                        const float* __restrict__ beta0, float* dx,
                                                        bf16* __restrict__ dx_b16, const float* __restrict__ mask, int mask_mode, int T,
-                                                       int J, float* __restrict__ partial, int M, int C, float rs) {
+                                                       int J, float* __restrict__ partial, int M, int C, float rs, float dys) {
   constexpr int V = 2;
   __shared__ float red[4 * 4 * 512];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy
           xv.y = (xv0[r][i].y - mean0[r]) * rstd0[r] * g0[i].y + b0[i].y;
           xv.z = (xv0[r][i].z - mean0[r]) * rstd0[r] * g0[i].z + b0[i].z;
           xv.w = (xv0[r][i].w - mean0[r]) * rstd0[r] * g0[i].w + b0[i].w;
-          const float4 g = gy[r][i];
+          const float4 g = make_float4(gy[r][i].x * dys, gy[r][i].y * dys, gy[r][i].z * dys, gy[r][i].w * dys);      // dys: 1, or the inverse of the scale dy1 carries
           xh[i] = make_float4((xv.x - mean1[r]) * rstd1[r], (xv.y - mean1[r]) * rstd1[r], (xv.z - mean1[r]) * rstd1[r], (xv.w - mean1[r]) * rstd1[r]);
           acc[0][i].x += g.x * xh[i].x; acc[0][i].y += g.y * xh[i].y; acc[0][i].z += g.z * xh[i].z; acc[0][i].w += g.w * xh[i].w;
           acc[1][i].x += g.x; acc[1][i].y += g.y; acc[1][i].z += g.z; acc[1][i].w += g.w;
@@ -462,7 +462,7 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
             const float* x0, const float* stats0, const float* gamma0, const float* beta0, float* dx, void* dx_b16, const float* mask,
             int mask_mode, int T,
             int J, float* dgamma1, float* dbeta1, float* dgamma0, float* dbeta0, int M, int C, float* scratch, long scratch_floats,
-            hipStream_t st, hipStream_t st_param, hipEvent_t ev, float rs) {
+            hipStream_t st, hipStream_t st_param, hipEvent_t ev, float rs, float dy_scale) {
   MP_CHECK(C % 4 == 0 && C <= 512, MP_ERR_ARG, "ln_bwd2: C=%d unsupported", C);
   MP_CHECK(beta0 != nullptr, MP_ERR_ARG, "ln_bwd2: x1 is recomputed from x0, beta0 is required");
   // persistent grid = the workgroups that are resident at once (168 VGPRs: 3 waves per SIMD, 3 workgroups per CU).  With LNB_GRID = 1024
@@ -482,10 +482,10 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
   MP_CHECK(scratch_floats >= (long)grid * 4 * C, MP_ERR_ARG, "ln_bwd2: scratch too small");
   if (dy_bf16)
     hipLaunchKernelGGL((ln_bwd2_kernel<bf16, LNB2_R>), dim3(grid), dim3(256), 0, st, (const bf16*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
-                       beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs);
+                       beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs, dy_scale);
   else
     hipLaunchKernelGGL((ln_bwd2_kernel<float, LNB2_R>), dim3(grid), dim3(256), 0, st, (const float*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
-                       beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs);
+                       beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs, dy_scale);
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dgamma1, dbeta1, dgamma0, dbeta0}, {0, C, 2 * C, 3 * C, 4 * C}, {1, 1, 1, 1}};
   if (!param_stream(st, st_param, ev)) return MP_ERR_HIP;

@@ -18,6 +18,15 @@ void engine_side_streams(int on) { g_side_streams = on; }
 // 0 / 1 = mp_set_option("f16f8_inputs", v); read when a model is created
 static int g_f16f8 = -1;
 void engine_f16f8(int on) { g_f16f8 = on; }
+bool attn_tmfma_supported(int T, int D);            // attention_mfma.hip
+bool attn_smfma_supported(int N, int D, int H);
+// Gradient operands of a layer whose backward GEMMs run on fp16 operands are carried as fp16 of GRAD_F16_SCALE * value: 2^12 maps
+// 1.5e-8 ... 16 onto fp16's normal range (smaller values keep fp16's subnormal resolution, 1.5e-11); the consumers multiply by its inverse
+constexpr float GRAD_F16_SCALE = 4096.f;
+static bool f16_backward_wanted() {
+  const char* e = getenv("MANIPOSE_F16BWD");
+  return e ? atoi(e) != 0 : true;
+}
 static bool f16f8_wanted() {
   if (g_f16f8 >= 0) return g_f16f8 != 0;
   const char* e = getenv("MANIPOSE_F16F8");
@@ -43,6 +52,8 @@ struct Module {
   int N, C, H, depth;     // tokens per frame (17 joints / 16 bones), width, heads, depth
   int K, O;               // heads, out features per head
   bool f8 = false;        // precision 2: the qkv and fc1 Linear layers read "f16f8" operands (one fp16 + one fp8 matrix-core step per k-tile instead of three bf16 ones)
+  bool f8g = false;       // f8 and the backward of the qkv and fc1 layers on fp16 operands (dqkv / dz written as scaled fp16 by the attention backward kernels / the
+                          // fc2 dgrad, the fp16 planes of a1 / a2 as the weight-gradient operands, the f16f8 shadow's fp16 plane as the dgrads' weights): a1, a2 need no bf16 copy
   float qk_scale, rs, readout;   // attention softmax scale (0 = head_dim^-0.5), residual scale, MuReadout input multiplier (1 unless muP)
   float *hw_eff, *hdw;    // readout != 1: the heads' weights times readout (forward / dx) and the scratch their gradient lands in
   int emb_w, emb_b, spos, tpos, sn_w, sn_b, tn_w, tn_b;
@@ -378,7 +389,7 @@ static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* 
 }
 // dX[M,K] = dY[M,N] W[N,K]  (optionally * gelu'(Z)).  dy_f32 / dx_f32: storage of dY / dX in bf16 mode.
 static int linear_dgrad(mp_model* m, hipStream_t st, const float* fp, const void* dY, int dy_f32, int widx, void* dX, int dx_f32,
-                        long M, int N, int K, void* Z) {
+                        long M, int N, int K, void* Z, bool f16 = false, float gout = 0.f) {
   if (m->cfg.precision == 0) {
     GemmF32Args g = {};
     g.A = (const float*)dY; g.lda = N; g.B = P(m, fp, widx); g.ldb = K; g.C = (float*)dX; g.ldc = K; g.M = (int)M; g.N = K; g.K = N;
@@ -388,16 +399,22 @@ static int linear_dgrad(mp_model* m, hipStream_t st, const float* fp, const void
   }
   GemmB16Args g = {};
   g.A = dY; g.lda = N; g.B = m->wbf + m->params[widx].offset; g.ldb = K; g.C = dX; g.ldc = K; g.M = (int)M; g.N = K; g.K = N; g.Z = Z;
+  g.gout = gout;
+  if (f16) {      // dY = fp16(GRAD_F16_SCALE * gradient), weights from the fp16 plane of the f16f8 shadow; the epilogue drops the scale
+    g.f16 = 1;      // (the bf16 output keeps dY's scale: the LayerNorm backward that reads it gets dy_scale = 1 / GRAD_F16_SCALE)
+    g.B = reinterpret_cast<const char*>(m->w16) + m->params[widx].offset * 2;
+  }
   RUNB(PC_GEMM_DGRAD, 2.0 * M * N * K, (dy_f32 ? 4.0 : 2.0) * M * N + 2.0 * N * K + (dx_f32 ? 4.0 : 2.0) * M * K + (Z ? 2.0 * M * K : 0.0),
        gemm_bf16(g, dy_f32, 0, 1, dx_f32, Z ? EPI_DGELU : EPI_BIAS, st));
   return MP_OK;
 }
 static int linear_wgrad(mp_model* m, hipStream_t st, const void* dY, int dy_f32, const void* X, float* dW, float* db, long M, int N,
-                        int K) {
+                        int K, bool f16 = false) {
   if (m->cfg.precision == 0)
     RUN(PC_GEMM_WGRAD, 2.0 * M * N * K, wgrad_f32((const float*)dY, N, (const float*)X, K, (int)M, N, K, dW, db, m->slab, m->slab_floats, st));
   else
-    RUN(PC_GEMM_WGRAD, 2.0 * M * N * K, wgrad_bf16(dY, dy_f32, N, (const bf16*)X, K, (int)M, N, K, dW, db, m->slab, m->slab_floats, st));
+    RUN(PC_GEMM_WGRAD, 2.0 * M * N * K, wgrad_bf16(dY, dy_f32, N, (const bf16*)X, K, (int)M, N, K, dW, db, m->slab, m->slab_floats, st, f16 ? 1 : 0,
+                                                   1.0f / GRAD_F16_SCALE));
   return MP_OK;
 }
 
@@ -455,7 +472,7 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     LnFwdArgs a = {};
     a.x = md.ws[0].x_in; a.M = (int)M; a.C = C;
     a.g2 = P(m, fp, md.bp[0].n1w); a.b2 = P(m, fp, md.bp[0].n1b); a.eps2 = 1e-6f; a.y2 = md.ws[0].a1; a.y2_lo = md.ws[0].a1l; a.stats2 = md.ws[0].st1;
-    if (md.f8) { a.y2 = md.ws[0].a1h; a.y2_b16 = m->infer ? nullptr : md.ws[0].a1; }
+    if (md.f8) { a.y2 = md.ws[0].a1h; a.y2_b16 = (m->infer || md.f8g) ? nullptr : md.ws[0].a1; }
     RUN(PC_LN, 0, ln_fwd(a, half, st));
   }
   for (int l = 0; l < L; ++l) {
@@ -488,7 +505,7 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
       LnFwdArgs a = {};
       a.x = w.x_mid; a.M = (int)M; a.C = C;
       a.g2 = P(m, fp, q.n2w); a.b2 = P(m, fp, q.n2b); a.eps2 = 1e-6f; a.y2 = w.a2; a.y2_lo = w.a2l; a.stats2 = w.st2;
-      if (md.f8) { a.y2 = w.a2h; a.y2_b16 = m->infer ? nullptr : w.a2; }
+      if (md.f8) { a.y2 = w.a2h; a.y2_b16 = (m->infer || md.f8g) ? nullptr : w.a2; }
       RUN(PC_LN, 0, ln_fwd(a, half, st));
     }
     // (inference, precision >= 1: gelu' - read by the fc2 dgrad only - is not written)
@@ -509,7 +526,7 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     if (l + 1 < L) {
       a.g2 = P(m, fp, md.bp[l + 1].n1w); a.b2 = P(m, fp, md.bp[l + 1].n1b); a.eps2 = 1e-6f;
       a.y2 = md.ws[l + 1].a1; a.y2_lo = md.ws[l + 1].a1l; a.stats2 = md.ws[l + 1].st1;
-      if (md.f8) { a.y2 = md.ws[l + 1].a1h; a.y2_b16 = m->infer ? nullptr : md.ws[l + 1].a1; }
+      if (md.f8) { a.y2 = md.ws[l + 1].a1h; a.y2_b16 = (m->infer || md.f8g) ? nullptr : md.ws[l + 1].a1; }
     }
     RUN(PC_LN, 0, ln_fwd(a, half, st));
   }
@@ -564,21 +581,22 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
     if (rc) return rc;
     W_DONE(0);
     if (have_prev) WAIT_W(par ^ 1, 1);                             // previous block's fc1 wgrad still reads tmp2C
-    rc = linear_dgrad(m, st, fp, gb, 0, q.f2w, m->tmp2C, 0, M, C, 2 * C, w.z);
+    rc = linear_dgrad(m, st, fp, gb, 0, q.f2w, m->tmp2C, 0, M, C, 2 * C, w.z, false, md.f8g ? GRAD_F16_SCALE : 0.f);      // f8g: dz as scaled fp16
     if (rc) return rc;
     // (c) fc1
     E_READY(1);                                                    // dz (tmp2C) is ready
-    rc = linear_wgrad(m, sw, m->tmp2C, 0, w.a2, G(m, fg, q.f1w), G(m, fg, q.f1b), M, 2 * C, C);
+    rc = linear_wgrad(m, sw, m->tmp2C, 0, md.f8g ? w.a2h : w.a2, G(m, fg, q.f1w), G(m, fg, q.f1b), M, 2 * C, C, md.f8g);
     if (rc) return rc;
     W_DONE(1);
-    rc = linear_dgrad(m, st, fp, m->tmp2C, 0, q.f1w, m->tmpC, 0, M, 2 * C, C, nullptr);     // d(norm2 out): bf16 in precision 1
+    rc = linear_dgrad(m, st, fp, m->tmp2C, 0, q.f1w, m->tmpC, 0, M, 2 * C, C, nullptr, md.f8g);     // d(norm2 out): bf16 in precision 1
     if (rc) return rc;
     WAIT_W(par, 0);                                                // the fc2 wgrad must be done with gb before (d) rewrites it
     // (d) norm2 + skip
     const float* mk1 = branch_mask(m, md, l, 0, B, m->train);
     float* lsc2 = ln_scratch();
     RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, m->g_b16, mk1, mode, T, N, G(m, fg, q.n2w),
-                         G(m, fg, q.n2b), (int)M, C, lsc2, ln_floats(lsc2), st, lsc2 == m->small ? nullptr : lst, lev, md.rs));
+                         G(m, fg, q.n2b), (int)M, C, lsc2, ln_floats(lsc2), st, lsc2 == m->small ? nullptr : lst, lev, md.rs,
+                         md.f8g ? 1.0f / GRAD_F16_SCALE : 1.0f));
     // (e) attention branch: proj
     gb = half ? (const void*)m->g_b16 : (const void*)g;
     if (mk1 && !half) {
@@ -593,14 +611,16 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
     if (rc) return rc;
     if (have_prev) WAIT_W(par ^ 1, 3);                             // previous block's qkv wgrad still reads tmp3C
     // (f) attention core
+    attn_grad_f16_override(md.f8g ? GRAD_F16_SCALE : 0.f);        // f8g: dqkv leaves as scaled fp16 (its two consumers below run on fp16 operands)
     if (spatial) RUN(PC_ATTN, 10.0 * B * T * N * N * C, attn_spatial_bwd(w.qkv, m->tmpC, m->tmp3C, half, B, T, N, C, H, st));
     else RUN(PC_ATTN, 10.0 * B * N * (double)T * T * C, attn_temporal_bwd(w.qkv, w.ao, m->tmpC, w.lse, m->delta, m->tmp3C, half, B, T, N, C, H, st));
+    attn_grad_f16_override(0.f);
     // (g) qkv
     E_READY(3);                                                    // dqkv (tmp3C) is ready
-    rc = linear_wgrad(m, sw, m->tmp3C, 0, w.a1, G(m, fg, q.qkvw), G(m, fg, q.qkvb), M, 3 * C, C);
+    rc = linear_wgrad(m, sw, m->tmp3C, 0, md.f8g ? w.a1h : w.a1, G(m, fg, q.qkvw), G(m, fg, q.qkvb), M, 3 * C, C, md.f8g);
     if (rc) return rc;
     W_DONE(3);
-    rc = linear_dgrad(m, st, fp, m->tmp3C, 0, q.qkvw, m->tmpC, 0, M, 3 * C, C, nullptr);   // d(norm1 out): bf16 in precision 1
+    rc = linear_dgrad(m, st, fp, m->tmp3C, 0, q.qkvw, m->tmpC, 0, M, 3 * C, C, nullptr, md.f8g);   // d(norm1 out): bf16 in precision 1
     if (rc) return rc;
     WAIT_W(par, 2);                                                // the proj wgrad must be done with gb before (h) rewrites it
     have_prev = true;
@@ -615,12 +635,13 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
       RUN(PC_LN, 0, ln_bwd2(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, wp.x_out, wp.stp, P(m, fp, pspatial ? md.sn_w : md.tn_w),
                             P(m, fp, pspatial ? md.sn_b : md.tn_b), g, m->g_b16, mkp, pspatial ? 1 : 2, T, N, G(m, fg, q.n1w), G(m, fg, q.n1b),
                             G(m, fg, pspatial ? md.sn_w : md.tn_w), G(m, fg, pspatial ? md.sn_b : md.tn_b), (int)M, C, lsc3,
-                            ln_floats(lsc3), st, lsc3 == m->small ? nullptr : lst, lev, md.rs));
+                            ln_floats(lsc3), st, lsc3 == m->small ? nullptr : lst, lev, md.rs, md.f8g ? 1.0f / GRAD_F16_SCALE : 1.0f));
       post_done = true;
     } else {
       float* lsc4 = ln_scratch();
       RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, g, nullptr, nullptr, 0, T, N, G(m, fg, q.n1w),
-                           G(m, fg, q.n1b), (int)M, C, lsc4, ln_floats(lsc4), st, lsc4 == m->small ? nullptr : lst, lev, md.rs));
+                           G(m, fg, q.n1b), (int)M, C, lsc4, ln_floats(lsc4), st, lsc4 == m->small ? nullptr : lst, lev, md.rs,
+                           md.f8g ? 1.0f / GRAD_F16_SCALE : 1.0f));
     }
     // gradient bucket of layer i = l / 2 (STE_i and TTE_i: one contiguous range of the flat buffer): everything that writes it has been
     // enqueued - the weight-gradient stream first waits for the main stream's position, then carries the event
@@ -731,6 +752,8 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   // f16f8 inputs: the rotations net when its width lets every such GEMM run the persistent 256 x 256 kernel (N = 3 C, 2 C multiples of 256, K = C of 64)
   m->rot.f8 = cfg->precision == 2 && f16f8_wanted() && m->rot.C % 256 == 0 && m->rot.C >= 256;
   m->seg.f8 = false;
+  m->rot.f8g = m->rot.f8 && f16_backward_wanted() && attn_tmfma_supported(cfg->num_frame, m->rot.C / m->rot.H) &&
+               attn_smfma_supported(m->rot.N, m->rot.C / m->rot.H, m->rot.H);
   Bump dry;
   carve_all(m, dry);
   m->arena_bytes = dry.off;

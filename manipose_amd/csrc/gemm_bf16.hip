@@ -302,6 +302,11 @@ struct NoMid { __device__ __forceinline__ void operator()() const {} };
 #ifndef DMA_LATE_STEP
 #define DMA_LATE_STEP -1
 #endif
+template <bool F16>
+__device__ __forceinline__ float lds16_to_float(unsigned short b) {
+  if constexpr (F16) return (float)__builtin_bit_cast(_Float16, b);
+  else return __uint_as_float((unsigned)b << 16);
+}
 template <int TRA, int TRB, int BT, int ABL = 0, int F16 = 0, typename Mid = NoMid>
 __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const char* __restrict__ Bs, f32x4 (&acc)[BT / 32][4], int wr, int wc,
                                           int lane, Mid mid = Mid()) {
@@ -511,10 +516,10 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   // moments of the k-tile instead of all at once (measured on the weight-gradient shapes: 3-18 % fewer fabric reads, same isolated time)
   const bool b_first = (tm + tn) & 1;
   if (b_first) glds_tile<TRB, BT, NW>(smem + OPB, B, g.ldb, n0, kbeg, g.N, kend, lane, wave);
-  glds_tile<TRA, BT, NW>(smem, SPLIT ? reinterpret_cast<const bf16*>(g.A_lo) : A, g.lda, m0, kbeg, g.M, kend, lane, wave);
+  glds_tile<TRA, BT, NW>(smem, (SPLIT & 1) ? reinterpret_cast<const bf16*>(g.A_lo) : A, g.lda, m0, kbeg, g.M, kend, lane, wave);
   if (!b_first) glds_tile<TRB, BT, NW>(smem + OPB, B, g.ldb, n0, kbeg, g.N, kend, lane, wave);
   int stage = 0;
-  if constexpr (SPLIT) {
+  if constexpr (SPLIT & 1) {
     // Three steps per k-tile kt, each one mma_stage over 64 reduction indices, with FOUR operand tiles fetched (not six): the buffers are
     // A0 | B0 | A1 | B1 (the two stages of the plain kernel) and
     //   step 0 multiplies (A0 = A_lo[kt], B0 = B_hi[kt])   while A1 <- A_hi[kt] is fetched
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
       if (tn == 0 && tid < BT) {
         const int oc = tid >> 3, wi = tid & 7;
         for (int r = 0; r < GBK; ++r)
-          bsum += __uint_as_float((unsigned)(*reinterpret_cast<const unsigned short*>(As + r * (BT * 2) + ((oc ^ t_swz(r)) << 4) + wi * 2)) << 16);
+          bsum += lds16_to_float<SPLIT == 16>(*reinterpret_cast<const unsigned short*>(As + r * (BT * 2) + ((oc ^ t_swz(r)) << 4) + wi * 2));
       }
     }
     if (EPI == EPI_SLAB && TRA == 1 && BT == 256 && bias_here && ((k0 - kbeg) / GBK) % bias_parts == tn && !MP_DBG(g, 8)) {
@@ -588,14 +593,14 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
       // MFMAs and four fragment reads per wave and k-tile (wave w owns the output rows 32 w .. 32 w + 31 of the tile); the element-wise
       // LDS walk above cost 13 % of the kernel at this tile size
       union { unsigned u[4]; bf16x8_t v; } ones;
-      ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3F803F80u;
+      ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = (SPLIT == 16) ? 0x3C003C00u : 0x3F803F80u;      // 1.0 in fp16 / bf16
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int ks = 0; ks < GBK / 32; ++ks)
-          accb[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, read_frag2<1, BT>(As, (2 * wave + f) * 16, ks, lane), accb[f], 0, 0, 0);
+          accb[f] = mfma16<SPLIT == 16>(ones.v, read_frag2<1, BT>(As, (2 * wave + f) * 16, ks, lane), accb[f]);
     }
-    mma_stage<TRA, TRB, BT>(As, Bs, acc, wr, wc, lane);
+    mma_stage<TRA, TRB, BT, 0, (SPLIT == 16)>(As, Bs, acc, wr, wc, lane);
   }
   }
 
@@ -679,7 +684,10 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
         const float4 z = ld4(Z + o);
         v = make_float4(v.x * z.x, v.y * z.y, v.z * z.z, v.w * z.w);      // Z holds gelu'(pre-activation)
       }
-      st4(C + o, v, lo_off);
+      if constexpr (EPI == EPI_DGELU && sizeof(TC) == 2) {
+        if (g.gout != 0.f) st4_f16(C + o, v, g.gout);
+        else st4(C + o, v, lo_off);
+      } else st4(C + o, v, lo_off);
     }
   }
 }
@@ -758,7 +766,12 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
       } else if (EPI == EPI_DGELU) {
         v = make_float4(v.x * in[it].x, v.y * in[it].y, v.z * in[it].z, v.w * in[it].w);      // Z holds gelu'(pre-activation)
       }
-      if (FULL || row < g.M) st4(C + o, v, lo_off);
+      if (FULL || row < g.M) {
+        if constexpr (EPI == EPI_DGELU && sizeof(TC) == 2) {      // dz: bf16, or scaled fp16 for an fc1 layer whose backward GEMMs run on fp16 operands
+          if (g.gout != 0.f) st4_f16(C + o, v, g.gout);
+          else st4(C + o, v, lo_off);
+        } else st4(C + o, v, lo_off);
+      }
     }
   }
 }
@@ -813,7 +826,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   auto a_base = [&](int mm, int kt) { return A + ((long)mm * g.lda + kt * GBK) * 2; };
   auto b_base = [&](int nn, int kt) { return TRB ? B + ((long)kt * GBK * g.ldb + nn) * 2 : B + ((long)nn * g.ldb + kt * GBK) * 2; };
   // SPLIT: A / B above are the hi planes; the lo planes lie at these byte distances
-  const long a_lo = SPLIT ? reinterpret_cast<const char*>(g.A_lo) - A : 0, b_lo = SPLIT ? reinterpret_cast<const char*>(g.B_lo) - B : 0;
+  constexpr bool PLANES = (SPLIT & 1) || SPLIT == 8;        // two planes per operand (SPLIT 0 / 16: one, bf16 / fp16)
+  const long a_lo = PLANES ? reinterpret_cast<const char*>(g.A_lo) - A : 0, b_lo = PLANES ? reinterpret_cast<const char*>(g.B_lo) - B : 0;
   persist_dma(smem, a_base(m0, 0) + (SPLIT == 8 ? 0 : a_lo), aoff, wave);       // SPLIT 1: the first step multiplies (A_lo, B_hi); 8: the fp16 planes
   persist_dma(smem + OPB, b_base(n0, 0), boff, wave);
   int stage = 0;
@@ -871,7 +885,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
         mma_stage_mix(As, Bs, acc, wr, wc, lane, par != 0);
       }
       (void)stage;
-    } else if constexpr (SPLIT) {
+    } else if constexpr (SPLIT & 1) {
       // three steps per k-tile over four fetched operand tiles; buffers A0 | B0 | A1 | B1 = the two stages (see gemm_bf16_glds_kernel)
       char* const A0 = smem;
       char* const B0 = smem + OPB;
@@ -962,7 +976,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
         typedef const __attribute__((address_space(1))) void* gptr;
         __builtin_amdgcn_global_load_lds((gptr)(g.bias + n0 + wc * 64 + lane), (lptr)img, 4, 0, 0);
       }
-      if (!MP_DBG(g, 1)) mma_stage<0, TRB, BT>(As, Bs, acc, wr, wc, lane, [&]() { if (fetch && late) issue(); });
+      if (!MP_DBG(g, 1)) mma_stage<0, TRB, BT, 0, (SPLIT == 16)>(As, Bs, acc, wr, wc, lane, [&]() { if (fetch && late) issue(); });
 #ifdef MP_GEMM_DIAG
       dg_mma += __builtin_readcyclecounter() - tk2;
 #endif
@@ -986,7 +1000,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (has_bias) bias4 = *reinterpret_cast<const float4*>(img + 4 * e15);
       bool done = false;
-      if constexpr (sizeof(TC) == 2 && EPI == EPI_BIAS && SPLIT == 0) {      // plain bf16 output (bf16p is the planar tag: SPLIT kernels only)
+      if constexpr (sizeof(TC) == 2 && EPI == EPI_BIAS && (SPLIT == 0 || SPLIT == 16)) {      // plain bf16 output (bf16p is the planar tag: SPLIT kernels only)
         if (!has_bias) {
           int el = lane;
           asm volatile("" : "+v"(el));
@@ -1109,7 +1123,7 @@ static int launch_glds(const GemmB16Args& g, int splits, hipStream_t st) {
 // outputs, 21-64 slabs deep).
 constexpr int RS_OUT = 64;
 __global__ __launch_bounds__(256) void reduce_slabs_b16_kernel(const float* __restrict__ slabW, float* __restrict__ dW, long nW4,
-                                                               const float* __restrict__ slabB, float* __restrict__ db, long nB4, int S, int SB) {
+                                                               const float* __restrict__ slabB, float* __restrict__ db, long nB4, int S, int SB, float scale) {
   __shared__ float4 part[3][RS_OUT];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   long i = (long)blockIdx.x * RS_OUT + lane;
@@ -1145,7 +1159,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_b16_kernel(const float* __re
     float4 o = reinterpret_cast<float4*>(out)[i];
 #pragma unroll
     for (int r = 0; r < 3; ++r) { s.x += part[r][lane].x; s.y += part[r][lane].y; s.z += part[r][lane].z; s.w += part[r][lane].w; }
-    o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+    o.x += s.x * scale; o.y += s.y * scale; o.z += s.z * scale; o.w += s.w * scale;      // scale: 1, or what the fp16 operands carried
     reinterpret_cast<float4*>(out)[i] = o;
   }
 }
@@ -1177,6 +1191,10 @@ int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, 
   if (!a_f32 && !a_tr && !b_tr && !c_f32 && epi == EPI_BIAS_GELU) return launch_glds<0, 0, bf16, EPI_BIAS_GELU>(g, 1, st);
   if (a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_DGELU) return launch_b16<float, 0, bf16, 1, bf16, EPI_DGELU>(g, 1, st);
   if (!a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_DGELU) return launch_glds<0, 1, bf16, EPI_DGELU>(g, 1, st);
+  if (!a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_BIAS && g.f16) {      // dgrad on fp16 operands (dY a scaled fp16 gradient, weights from the f16f8 shadow); bf16 out, which KEEPS dY's scale
+    MP_CHECK(g.bias == nullptr, MP_ERR_ARG, "gemm_bf16: the fp16-operand dgrad takes no bias");
+    return launch_glds<0, 1, bf16, EPI_BIAS, 16>(g, 1, st);
+  }
   if (!a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_BIAS) return launch_glds<0, 1, bf16, EPI_BIAS>(g, 1, st);
   if (a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_BIAS) return launch_b16<float, 0, bf16, 1, bf16, EPI_BIAS>(g, 1, st);
   if (!a_f32 && !a_tr && b_tr && c_f32 && epi == EPI_BIAS) return launch_glds<0, 1, float, EPI_BIAS>(g, 1, st);
@@ -1245,7 +1263,7 @@ static void wgrad_split_b16(int Mtok, int Nout, int Kin, int bt, int& splits, in
 
 // dW[N',K'] += dY[Mtok,N']^T X[Mtok,K'] (X bf16; dY bf16 or fp32) ; db += colsum(dY)
 int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
-               float* slab, long slab_floats, hipStream_t st) {
+               float* slab, long slab_floats, hipStream_t st, int f16, float oscale) {
   MP_CHECK(Mtok > 0 && Nout % 8 == 0 && Kin % 8 == 0, MP_ERR_ARG, "wgrad_bf16: bad dims %d %d %d", Mtok, Nout, Kin);
   GemmB16Args g = {};
   g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx;
@@ -1267,11 +1285,13 @@ int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, i
   { static const int dbg = [] { const char* e = getenv("MANIPOSE_GEMM_DEBUG"); return e ? atoi(e) : 0; }(); g.debug = dbg; }   // timing ablations: 1 no MFMA, 2 no DMA, 8 no bias column sums
 #endif
   g.k_per_split = kper;
+  MP_CHECK(!f16 || !dy_f32, MP_ERR_ARG, "wgrad_bf16: fp16 operands with an fp32 dY");
   int rc = dy_f32 ? launch_b16<float, 1, bf16, 1, float, EPI_SLAB>(g, splits, st)
-                  : launch_glds<1, 1, float, EPI_SLAB>(g, splits, st);
+                  : (f16 ? launch_glds<1, 1, float, EPI_SLAB, 16>(g, splits, st) : launch_glds<1, 1, float, EPI_SLAB>(g, splits, st));
   if (rc) return rc;
   const long nW4 = (long)Nout * Kin / 4, nB4 = db != nullptr ? Nout / 4 : 0;        // Nout, Kin are multiples of 8
-  hipLaunchKernelGGL(reduce_slabs_b16_kernel, dim3(cdiv(nW4, (long)RS_OUT) + cdiv(nB4, (long)RS_OUT)), dim3(256), 0, st, slab, dW, nW4, g.bias_slab, db, nB4, splits, splits * bparts);
+  hipLaunchKernelGGL(reduce_slabs_b16_kernel, dim3(cdiv(nW4, (long)RS_OUT) + cdiv(nB4, (long)RS_OUT)), dim3(256), 0, st, slab, dW, nW4, g.bias_slab, db, nB4, splits, splits * bparts,
+                     (f16 && oscale != 0.f) ? oscale : 1.0f);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
