@@ -212,8 +212,9 @@ static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int prec
     w.ao = act(M * C);         w.x_mid = bp.take(M * C);   w.st2 = bp.take(M * 2);  w.a2 = act(M * C);
     w.z = act(M * 2 * C);      w.f = act(M * 2 * C);       w.x_out = bp.take(M * C); w.stp = bp.take(M * 2);
     w.a1l = lo(M * C); w.qkvl = lo(M * 3 * C); w.aol = lo(M * C); w.a2l = lo(M * C); w.fl = lo(M * 2 * C);
-    w.a1h = md.f8 ? bp.take((M * C + 1) / 2) : nullptr;
-    w.a2h = md.f8 ? bp.take((M * C + 1) / 2) : nullptr;
+    // f8g: nobody reads a bf16 a1 / a2 (the backward runs on the fp16 planes): the fp16 planes take their place
+    w.a1h = md.f8 ? (md.f8g ? w.a1 : bp.take((M * C + 1) / 2)) : nullptr;
+    w.a2h = md.f8 ? (md.f8g ? w.a2 : bp.take((M * C + 1) / 2)) : nullptr;
   }
   md.x_final = bp.take(M * C);
   md.hw_eff = md.readout != 1.0f ? bp.take((long)md.K * md.O * C) : nullptr;
