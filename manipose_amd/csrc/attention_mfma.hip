@@ -180,9 +180,9 @@ __device__ __forceinline__ void store4g(bf16* p, const f32x4& v, float s, float 
     *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
   } else store4(p, v, s);
 }
-// set by the engine for the backward launches issued next on this thread (0 = bf16 outputs); see store4g
-static thread_local float g_grad_f16 = 0.f;
-void attn_grad_f16_override(float gout) { g_grad_f16 = gout; }
+// set by the engine for the backward launches issued next on this thread: device address of the scale (null = bf16 outputs); see store4g
+static thread_local const float* g_grad_f16 = nullptr;
+void attn_grad_f16_override(const float* gout) { g_grad_f16 = gout; }
 
 // =============================================================================================
 // forward: O = softmax(scale Q K^T) V ; lse = log sum exp of the scaled scores
@@ -296,9 +296,10 @@ template <int D, int NTC>
 __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                                const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                bf16* __restrict__ dqkv, int T, int J, int C, int H, float scale,
-                                                               int debug, float gout) {
+                                                               int debug, const float* __restrict__ gout_p) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB, NW = 16, UNR = NTC ? NTC / 2 : 1;
+  const float gout = gout_p != nullptr ? *gout_p : 0.f;      // this backward's gradient scale (engine: grad_scale_kernel), or bf16 outputs
   const int rows = NTC ? TP : (T + 31) & ~31, nw = NTC ? NW : (int)(blockDim.x >> 6);     // short windows: see the forward kernel
   char* Qs = sm;
   char* Ks = Qs + rows * ROWB;
@@ -608,7 +609,8 @@ __global__ __launch_bounds__(512) void attn_smfma_fwd_kernel(const bf16* __restr
 
 template <int D>
 __global__ __launch_bounds__(512) void attn_smfma_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
-                                                               bf16* __restrict__ dqkv, int N, int C, int H, float scale, float gout) {
+                                                               bf16* __restrict__ dqkv, int N, int C, int H, float scale, const float* __restrict__ gout_p) {
+  const float gout = gout_p != nullptr ? *gout_p : 0.f;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int KS = ACfg<D>::KS, DB = ACfg<D>::DB;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -94,6 +94,9 @@ __device__ __forceinline__ void st4(bf16* p, float4 v, long) { st4(p, v); }
 // instruction only needs both operands to use the same byte order).  `f16f8` tags a pointer to the fp16 plane.  Values are clamped to the
 // e4m3 range (+-448) ahead of the conversion.
 struct f16f8 { unsigned short v; };
+// GEMM epilogue form: p = the element in the fp16 plane, lo_off = distance to the correction plane in 2-byte elements (both planes have 2 bytes per element)
+__device__ __forceinline__ void st4_f16f8(f16f8* hi16, char* corr8, float4 v, bool weight);
+__device__ __forceinline__ void st4(f16f8* p, float4 v, long lo_off) { st4_f16f8(p, reinterpret_cast<char*>(p + lo_off), v, false); }
 // four values as fp16 of s * value (a gradient operand carried as scaled fp16: kernels.h GemmB16Args::f16 / gout)
 __device__ __forceinline__ void st4_f16(void* p, float4 v, float s) {
   typedef _Float16 h4_t __attribute__((ext_vector_type(4)));

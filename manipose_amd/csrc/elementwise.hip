@@ -167,8 +167,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
                                                       const float* dskip, float* dx, bf16* __restrict__ dx_b16,
                                                       const float* __restrict__ mask, int mask_mode, int T, int J,
-                                                      float* __restrict__ partial, int M, int C, float rs, float dys) {
+                                                      float* __restrict__ partial, int M, int C, float rs, const float* __restrict__ dys_p,
+                                                      const float* __restrict__ b16_gs_p) {
   __shared__ float red[4 * 2 * 256 * V];  // [wave][dgamma|dbeta][C <= 256 V]
+  const float dys = dys_p != nullptr ? *dys_p : 1.0f, b16_gs = b16_gs_p != nullptr ? *b16_gs_p : 0.f;      // this backward's gradient scale (engine: grad_scale_kernel)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -234,8 +236,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
           o.w = rstd[r] * (d[i].w - s1 - xh[i].w * s2);
           if (dskip != nullptr) { o.x += rs * k[r][i].x; o.y += rs * k[r][i].y; o.z += rs * k[r][i].z; o.w += rs * k[r][i].w; }
           st4(dx + (long)m * C + c, o);
-          if (dx_b16 != nullptr)     // bf16 copy, pre-scaled by the consumer branch's DropPath mask: A operand of its GEMMs
-            st4(dx_b16 + (long)m * C + c, make_float4(o.x * ms[r], o.y * ms[r], o.z * ms[r], o.w * ms[r]));
+          if (dx_b16 != nullptr) {   // 2-byte copy, pre-scaled by the consumer branch's DropPath mask: A operand of its GEMMs - bf16, or (b16_gs != 0) fp16 of b16_gs x value
+            if (b16_gs != 0.f) st4_f16(dx_b16 + (long)m * C + c, o, ms[r] * b16_gs);
+            else st4(dx_b16 + (long)m * C + c, make_float4(o.x * ms[r], o.y * ms[r], o.z * ms[r], o.w * ms[r]));
+          }
         }
       }
     }
@@ -306,13 +310,13 @@ static bool param_stream(hipStream_t& st, hipStream_t st_param, hipEvent_t ev) {
 
 int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
            const float* mask, int mask_mode, int T, int J, float* dgamma, float* dbeta, int M, int C, float* scratch,
-           long scratch_floats, hipStream_t st, hipStream_t st_param, hipEvent_t ev, float rs, float dy_scale) {
+           long scratch_floats, hipStream_t st, hipStream_t st_param, hipEvent_t ev, float rs, const float* dy_scale, const float* b16_gs) {
   MP_CHECK(C % 4 == 0 && C <= 1024, MP_ERR_ARG, "ln_bwd: C=%d unsupported", C);
   const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
   MP_CHECK(scratch_floats >= (long)grid * 2 * C, MP_ERR_ARG, "ln_bwd: scratch too small");
 #define MP_LN_BWD(TDY, V, R)                                                                                                             \
   hipLaunchKernelGGL((ln_bwd_kernel<TDY, V, R>), dim3(grid), dim3(256), 0, st, (const TDY*)dy, x, stats, gamma, dskip, dx, (bf16*)dx_b16, \
-                     mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs, dy_scale)
+                     mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs, dy_scale, b16_gs)
   if (C <= 512) { if (dy_bf16) MP_LN_BWD(bf16, 2, 2); else MP_LN_BWD(float, 2, 2); }
   else          { if (dy_bf16) MP_LN_BWD(bf16, 4, 1); else MP_LN_BWD(float, 4, 1); }
 #undef MP_LN_BWD
@@ -340,8 +344,10 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy
                                                        const float* __restrict__ stats0, const float* __restrict__ gamma0,
                                                        const float* __restrict__ beta0, float* dx,
                                                        bf16* __restrict__ dx_b16, const float* __restrict__ mask, int mask_mode, int T,
-                                                       int J, float* __restrict__ partial, int M, int C, float rs, float dys) {
+                                                       int J, float* __restrict__ partial, int M, int C, float rs, const float* __restrict__ dys_p,
+                                                       const float* __restrict__ b16_gs_p) {
   constexpr int V = 2;
+  const float dys = dys_p != nullptr ? *dys_p : 1.0f, b16_gs = b16_gs_p != nullptr ? *b16_gs_p : 0.f;
   __shared__ float red[4 * 4 * 512];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -435,7 +441,10 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy
           const float4 o = make_float4(rstd0[r] * (d[i].x - u1 - xh[i].x * u2), rstd0[r] * (d[i].y - u1 - xh[i].y * u2),
                                        rstd0[r] * (d[i].z - u1 - xh[i].z * u2), rstd0[r] * (d[i].w - u1 - xh[i].w * u2));
           st4(dx + (long)m * C + c, o);
-          if (dx_b16 != nullptr) st4(dx_b16 + (long)m * C + c, make_float4(o.x * ms[r], o.y * ms[r], o.z * ms[r], o.w * ms[r]));
+          if (dx_b16 != nullptr) {
+            if (b16_gs != 0.f) st4_f16(dx_b16 + (long)m * C + c, o, ms[r] * b16_gs);
+            else st4(dx_b16 + (long)m * C + c, make_float4(o.x * ms[r], o.y * ms[r], o.z * ms[r], o.w * ms[r]));
+          }
         }
       }
     }
@@ -462,7 +471,7 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
             const float* x0, const float* stats0, const float* gamma0, const float* beta0, float* dx, void* dx_b16, const float* mask,
             int mask_mode, int T,
             int J, float* dgamma1, float* dbeta1, float* dgamma0, float* dbeta0, int M, int C, float* scratch, long scratch_floats,
-            hipStream_t st, hipStream_t st_param, hipEvent_t ev, float rs, float dy_scale) {
+            hipStream_t st, hipStream_t st_param, hipEvent_t ev, float rs, const float* dy_scale, const float* b16_gs) {
   MP_CHECK(C % 4 == 0 && C <= 512, MP_ERR_ARG, "ln_bwd2: C=%d unsupported", C);
   MP_CHECK(beta0 != nullptr, MP_ERR_ARG, "ln_bwd2: x1 is recomputed from x0, beta0 is required");
   // persistent grid = the workgroups that are resident at once (168 VGPRs: 3 waves per SIMD, 3 workgroups per CU).  With LNB_GRID = 1024
@@ -482,14 +491,45 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
   MP_CHECK(scratch_floats >= (long)grid * 4 * C, MP_ERR_ARG, "ln_bwd2: scratch too small");
   if (dy_bf16)
     hipLaunchKernelGGL((ln_bwd2_kernel<bf16, LNB2_R>), dim3(grid), dim3(256), 0, st, (const bf16*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
-                       beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs, dy_scale);
+                       beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs, dy_scale, b16_gs);
   else
     hipLaunchKernelGGL((ln_bwd2_kernel<float, LNB2_R>), dim3(grid), dim3(256), 0, st, (const float*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
-                       beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs, dy_scale);
+                       beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs, dy_scale, b16_gs);
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dgamma1, dbeta1, dgamma0, dbeta0}, {0, C, 2 * C, 3 * C, 4 * C}, {1, 1, 1, 1}};
   if (!param_stream(st, st_param, ev)) return MP_ERR_HIP;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(4 * C, RP_OUT)), dim3(256), 0, st, scratch, grid, 4 * C, d);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gradient scale of one backward (the layers whose backward GEMMs run on fp16 operands): S = the power of two that brings the largest
+// incoming gradient |d_poses|, |d_scores| into [1, 2) - every gradient operand of those layers is carried as fp16 of S x value, so the
+// loss may be normalised any way (a summed loss gives gradients ~1e7 times those of a mean over a 79-window batch; a fixed scale
+// overflowed fp16 on the former).  gsc[0] = S, gsc[1] = 1 / S, gsc[2] = scratch (bits of the maximum), gsc[3] = 1.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_amax_kernel(const float* __restrict__ a, long na, const float* __restrict__ b, long nb, unsigned* __restrict__ out) {
+  float mx = 0.f;
+  const long stride = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long i = i0; i < na; i += stride) mx = fmaxf(mx, fabsf(a[i]));
+  for (long i = i0; i < nb; i += stride) mx = fmaxf(mx, fabsf(b[i]));
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(mx));      // non-negative floats order like their bit patterns
+}
+__global__ void grad_scale_kernel(float* gsc) {
+  const unsigned bits = reinterpret_cast<const unsigned*>(gsc)[2];
+  int be = (int)((bits >> 23) & 0xffu);                 // biased exponent of the maximum; 0 (all gradients zero or denormal): no scaling
+  be = bits == 0u ? 127 : min(max(be, 127 - 60), 127 + 60);
+  gsc[0] = __uint_as_float((unsigned)(254 - be) << 23);
+  gsc[1] = __uint_as_float((unsigned)be << 23);
+  gsc[3] = 1.0f;
+}
+int grad_scale(const float* d_poses, long n_poses, const float* d_scores, long n_scores, float* gsc, hipStream_t st) {
+  if (hipMemsetAsync(gsc + 2, 0, sizeof(float), st) != hipSuccess) { set_error("grad_scale: memset failed"); return MP_ERR_HIP; }
+  hipLaunchKernelGGL(grad_amax_kernel, dim3(256), dim3(256), 0, st, d_poses, n_poses, d_scores, d_scores ? n_scores : 0L, reinterpret_cast<unsigned*>(gsc + 2));
+  MP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, st, gsc);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

@@ -20,9 +20,9 @@ static int g_f16f8 = -1;
 void engine_f16f8(int on) { g_f16f8 = on; }
 bool attn_tmfma_supported(int T, int D);            // attention_mfma.hip
 bool attn_smfma_supported(int N, int D, int H);
-// Gradient operands of a layer whose backward GEMMs run on fp16 operands are carried as fp16 of GRAD_F16_SCALE * value: 2^12 maps
-// 1.5e-8 ... 16 onto fp16's normal range (smaller values keep fp16's subnormal resolution, 1.5e-11); the consumers multiply by its inverse
-constexpr float GRAD_F16_SCALE = 4096.f;
+// Gradient operands of a layer whose backward GEMMs run on fp16 operands are carried as fp16 of S x value, S a power of two chosen per
+// backward on the device (grad_scale, elementwise.hip: the largest incoming gradient lands in [1, 2), which leaves fp16 a factor 6.5e4 of
+// headroom above it and 1.6e4 of normal range below); producers and consumers read S and 1 / S from mp_model::gsc.
 static bool f16_backward_wanted() {
   const char* e = getenv("MANIPOSE_F16BWD");
   return e ? atoi(e) != 0 : true;
@@ -54,6 +54,8 @@ struct Module {
   bool f8 = false;        // precision 2: the qkv and fc1 Linear layers read "f16f8" operands (one fp16 + one fp8 matrix-core step per k-tile instead of three bf16 ones)
   bool f8g = false;       // f8 and the backward of the qkv and fc1 layers on fp16 operands (dqkv / dz written as scaled fp16 by the attention backward kernels / the
                           // fc2 dgrad, the fp16 planes of a1 / a2 as the weight-gradient operands, the f16f8 shadow's fp16 plane as the dgrads' weights): a1, a2 need no bf16 copy
+  bool f8m = false;       // f8g and the fc2 layer too: f (the GELU output) is written as f16f8 planes by the fc1 epilogue and read so by the fc2 forward GEMM; its
+                          // backward runs on fp16 operands (the gradient copy of the LayerNorm backward behind the block as scaled fp16)
   float qk_scale, rs, readout;   // attention softmax scale (0 = head_dim^-0.5), residual scale, MuReadout input multiplier (1 unless muP)
   float *hw_eff, *hdw;    // readout != 1: the heads' weights times readout (forward / dx) and the scratch their gradient lands in
   int emb_w, emb_b, spos, tpos, sn_w, sn_b, tn_w, tn_b;
@@ -84,6 +86,7 @@ struct mp_model {
   bf16* wbf_lo = nullptr;                    // precision 2: lo plane of the shadow
   void* w16 = nullptr;                       // a module with f8: "f16f8" shadow of the flat parameter buffer (fp16 plane, 8-bit correction plane in the weight form)
   char* w8 = nullptr;
+  float* gsc = nullptr;                      // {S, 1 / S, scratch, 1}: the gradient scale of the current backward (modules with f8g)
   long xattn_half = 0;
   float* xattn = nullptr;                    // precision 2, attention shapes without an MFMA kernel: fp32 scratch (4 M C floats) of the join -> fp32 kernel -> split route
   float *slab = nullptr, *small = nullptr, *lengths = nullptr, *dlen_pose = nullptr, *maskbuf = nullptr, *dscore_zero = nullptr;
@@ -247,6 +250,7 @@ static void carve_all(mp_model* m, Bump& bp) {
     if (m->rot.f8 || m->seg.f8) {
       m->w16 = bp.take((m->flat_size + 1) / 2);
       m->w8 = reinterpret_cast<char*>(bp.take((m->flat_size + 1) / 2));
+      m->gsc = bp.take(64);
     }
     long need = 0;
     if (attn_x3_needs_scratch(0, T, m->rot.N, m->rot.C, m->rot.H) || attn_x3_needs_scratch(1, T, m->rot.N, m->rot.C, m->rot.H)) need = max(need, 4 * Mr * m->rot.C);
@@ -348,7 +352,7 @@ static float* G(const mp_model* m, float* flat, int idx) { return flat + m->para
 static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* A, int widx, int bidx, void* Cc, long M, int N, int K,
                       int epi, void* Z, const float* R, const float* mask, int mask_mode, int T, int J, const float* rstats = nullptr,
                       const float* rgamma = nullptr, const float* rbeta = nullptr, const void* A_lo = nullptr, void* C_lo = nullptr,
-                      bool f8in = false) {
+                      bool f8in = false, bool f8out = false) {
   if (m->cfg.precision == 0) {
     GemmF32Args g = {};
     g.A = (const float*)A; g.lda = K; g.B = P(m, fp, widx); g.ldb = K; g.C = (float*)Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
@@ -364,10 +368,11 @@ static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* 
   if (m->cfg.precision == 2 && f8in) {
     // "f16f8" operands: A = the fp16 plane, A_lo = its correction plane, weights from the f16f8 shadow; planar bf16 outputs as below
     g.A_lo = A_lo; g.B = reinterpret_cast<const char*>(m->w16) + m->params[widx].offset * 2; g.B_lo = m->w8 + m->params[widx].offset * 2; g.C_lo = C_lo;
-    const double ob = 4.0 * M * N + (epi == EPI_BIAS_GELU ? 2.0 * M * N : 0.0);
+    g.out_f16f8 = f8out ? 1 : 0;
+    const double ob = epi == EPI_BIAS_RESID ? 8.0 * M * N : 4.0 * M * N + (epi == EPI_BIAS_GELU ? 2.0 * M * N : 0.0);
     {
       ProfScope ps__(m, st, PC_GEMM_FWD, 4.0 * M * N * K, 4.0 * (M * K + (double)N * K) + ob, 2.0 * M * N * K);   // two matrix-core steps per k-tile (one fp16, one fp8 at twice the depth)
-      int rc__ = gemm_f16f8(g, 0, epi, st);
+      int rc__ = gemm_f16f8(g, epi == EPI_BIAS_RESID ? 1 : 0, epi, st);
       if (rc__) return rc__;
     }
     return MP_OK;
@@ -390,7 +395,7 @@ static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* 
 }
 // dX[M,K] = dY[M,N] W[N,K]  (optionally * gelu'(Z)).  dy_f32 / dx_f32: storage of dY / dX in bf16 mode.
 static int linear_dgrad(mp_model* m, hipStream_t st, const float* fp, const void* dY, int dy_f32, int widx, void* dX, int dx_f32,
-                        long M, int N, int K, void* Z, bool f16 = false, float gout = 0.f) {
+                        long M, int N, int K, void* Z, bool f16 = false, const float* gout = nullptr) {
   if (m->cfg.precision == 0) {
     GemmF32Args g = {};
     g.A = (const float*)dY; g.lda = N; g.B = P(m, fp, widx); g.ldb = K; g.C = (float*)dX; g.ldc = K; g.M = (int)M; g.N = K; g.K = N;
@@ -401,8 +406,8 @@ static int linear_dgrad(mp_model* m, hipStream_t st, const float* fp, const void
   GemmB16Args g = {};
   g.A = dY; g.lda = N; g.B = m->wbf + m->params[widx].offset; g.ldb = K; g.C = dX; g.ldc = K; g.M = (int)M; g.N = K; g.K = N; g.Z = Z;
   g.gout = gout;
-  if (f16) {      // dY = fp16(GRAD_F16_SCALE * gradient), weights from the fp16 plane of the f16f8 shadow; the epilogue drops the scale
-    g.f16 = 1;      // (the bf16 output keeps dY's scale: the LayerNorm backward that reads it gets dy_scale = 1 / GRAD_F16_SCALE)
+  if (f16) {      // dY = fp16(S x gradient), weights from the fp16 plane of the f16f8 shadow
+    g.f16 = 1;      // (the bf16 output keeps dY's scale: the LayerNorm backward that reads it gets dy_scale = 1 / S)
     g.B = reinterpret_cast<const char*>(m->w16) + m->params[widx].offset * 2;
   }
   RUNB(PC_GEMM_DGRAD, 2.0 * M * N * K, (dy_f32 ? 4.0 : 2.0) * M * N + 2.0 * N * K + (dx_f32 ? 4.0 : 2.0) * M * K + (Z ? 2.0 * M * K : 0.0),
@@ -415,7 +420,7 @@ static int linear_wgrad(mp_model* m, hipStream_t st, const void* dY, int dy_f32,
     RUN(PC_GEMM_WGRAD, 2.0 * M * N * K, wgrad_f32((const float*)dY, N, (const float*)X, K, (int)M, N, K, dW, db, m->slab, m->slab_floats, st));
   else
     RUN(PC_GEMM_WGRAD, 2.0 * M * N * K, wgrad_bf16(dY, dy_f32, N, (const bf16*)X, K, (int)M, N, K, dW, db, m->slab, m->slab_floats, st, f16 ? 1 : 0,
-                                                   1.0f / GRAD_F16_SCALE));
+                                                   f16 ? m->gsc + 1 : nullptr));
   return MP_OK;
 }
 
@@ -511,10 +516,10 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     }
     // (inference, precision >= 1: gelu' - read by the fc2 dgrad only - is not written)
     rc = linear_fwd(m, st, fp, md.f8 ? w.a2h : w.a2, q.f1w, q.f1b, w.f, M, 2 * C, C, EPI_BIAS_GELU, (m->infer && m->cfg.precision >= 1) ? nullptr : w.z, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr, w.a2l, w.fl,
-                    md.f8);
+                    md.f8, md.f8m);
     if (rc) return rc;
     rc = linear_fwd(m, st, fp, w.f, q.f2w, q.f2b, w.x_out, M, C, 2 * C, EPI_BIAS_RESID, nullptr, w.x_mid,
-                    branch_mask(m, md, l, 1, B, m->train), mode, T, N, nullptr, nullptr, nullptr, w.fl);
+                    branch_mask(m, md, l, 1, B, m->train), mode, T, N, nullptr, nullptr, nullptr, w.fl, nullptr, md.f8m);
     if (rc) return rc;
     // shared post-norm (mix_ste.py:143,154,166,170), Temporal_pos_embed after the first spatial block (:149),
     // fused with the next block's norm1
@@ -568,7 +573,7 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
       float* lsc = ln_scratch();
       RUN(PC_LN, 0, ln_bwd(g, 0, w.x_out, w.stp, P(m, fp, spatial ? md.sn_w : md.tn_w), nullptr, g, m->g_b16, mk2, mode, T, N,
                            G(m, fg, spatial ? md.sn_w : md.tn_w), G(m, fg, spatial ? md.sn_b : md.tn_b), (int)M, C, lsc,
-                           ln_floats(lsc), st, lsc == m->small ? nullptr : lst, lev));
+                           ln_floats(lsc), st, lsc == m->small ? nullptr : lst, lev, 1.0f, nullptr, md.f8m ? m->gsc : nullptr));
     }
     post_done = false;
     // (b) mlp branch: fc2 (gb = DropPath-scaled branch gradient; a bf16 copy emitted by the LN backward in precision 1)
@@ -578,11 +583,12 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
       gb = m->tmpMask;
     }
     E_READY(0);                                                    // gb is ready
-    int rc = linear_wgrad(m, sw, gb, 0, w.f, G(m, fg, q.f2w), G(m, fg, q.f2b), M, C, 2 * C);
+    int rc = linear_wgrad(m, sw, gb, 0, w.f, G(m, fg, q.f2w), G(m, fg, q.f2b), M, C, 2 * C, md.f8m);      // f8m: gb and f are fp16
     if (rc) return rc;
     W_DONE(0);
     if (have_prev) WAIT_W(par ^ 1, 1);                             // previous block's fc1 wgrad still reads tmp2C
-    rc = linear_dgrad(m, st, fp, gb, 0, q.f2w, m->tmp2C, 0, M, C, 2 * C, w.z, false, md.f8g ? GRAD_F16_SCALE : 0.f);      // f8g: dz as scaled fp16
+    // f8g: dz leaves as scaled fp16; f8m: gb already carries the scale (fp16 operands), so the epilogue adds none
+    rc = linear_dgrad(m, st, fp, gb, 0, q.f2w, m->tmp2C, 0, M, C, 2 * C, w.z, md.f8m, md.f8m ? m->gsc + 3 : (md.f8g ? m->gsc : nullptr));
     if (rc) return rc;
     // (c) fc1
     E_READY(1);                                                    // dz (tmp2C) is ready
@@ -597,7 +603,7 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
     float* lsc2 = ln_scratch();
     RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, m->g_b16, mk1, mode, T, N, G(m, fg, q.n2w),
                          G(m, fg, q.n2b), (int)M, C, lsc2, ln_floats(lsc2), st, lsc2 == m->small ? nullptr : lst, lev, md.rs,
-                         md.f8g ? 1.0f / GRAD_F16_SCALE : 1.0f));
+                         md.f8g ? m->gsc + 1 : nullptr));
     // (e) attention branch: proj
     gb = half ? (const void*)m->g_b16 : (const void*)g;
     if (mk1 && !half) {
@@ -612,10 +618,10 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
     if (rc) return rc;
     if (have_prev) WAIT_W(par ^ 1, 3);                             // previous block's qkv wgrad still reads tmp3C
     // (f) attention core
-    attn_grad_f16_override(md.f8g ? GRAD_F16_SCALE : 0.f);        // f8g: dqkv leaves as scaled fp16 (its two consumers below run on fp16 operands)
+    attn_grad_f16_override(md.f8g ? m->gsc : nullptr);        // f8g: dqkv leaves as scaled fp16 (its two consumers below run on fp16 operands)
     if (spatial) RUN(PC_ATTN, 10.0 * B * T * N * N * C, attn_spatial_bwd(w.qkv, m->tmpC, m->tmp3C, half, B, T, N, C, H, st));
     else RUN(PC_ATTN, 10.0 * B * N * (double)T * T * C, attn_temporal_bwd(w.qkv, w.ao, m->tmpC, w.lse, m->delta, m->tmp3C, half, B, T, N, C, H, st));
-    attn_grad_f16_override(0.f);
+    attn_grad_f16_override(nullptr);
     // (g) qkv
     E_READY(3);                                                    // dqkv (tmp3C) is ready
     rc = linear_wgrad(m, sw, m->tmp3C, 0, md.f8g ? w.a1h : w.a1, G(m, fg, q.qkvw), G(m, fg, q.qkvb), M, 3 * C, C, md.f8g);
@@ -636,13 +642,14 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
       RUN(PC_LN, 0, ln_bwd2(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, wp.x_out, wp.stp, P(m, fp, pspatial ? md.sn_w : md.tn_w),
                             P(m, fp, pspatial ? md.sn_b : md.tn_b), g, m->g_b16, mkp, pspatial ? 1 : 2, T, N, G(m, fg, q.n1w), G(m, fg, q.n1b),
                             G(m, fg, pspatial ? md.sn_w : md.tn_w), G(m, fg, pspatial ? md.sn_b : md.tn_b), (int)M, C, lsc3,
-                            ln_floats(lsc3), st, lsc3 == m->small ? nullptr : lst, lev, md.rs, md.f8g ? 1.0f / GRAD_F16_SCALE : 1.0f));
+                            ln_floats(lsc3), st, lsc3 == m->small ? nullptr : lst, lev, md.rs, md.f8g ? m->gsc + 1 : nullptr,
+                            md.f8m ? m->gsc : nullptr));
       post_done = true;
     } else {
       float* lsc4 = ln_scratch();
       RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, g, nullptr, nullptr, 0, T, N, G(m, fg, q.n1w),
                            G(m, fg, q.n1b), (int)M, C, lsc4, ln_floats(lsc4), st, lsc4 == m->small ? nullptr : lst, lev, md.rs,
-                           md.f8g ? 1.0f / GRAD_F16_SCALE : 1.0f));
+                           md.f8g ? m->gsc + 1 : nullptr));
     }
     // gradient bucket of layer i = l / 2 (STE_i and TTE_i: one contiguous range of the flat buffer): everything that writes it has been
     // enqueued - the weight-gradient stream first waits for the main stream's position, then carries the event
@@ -753,8 +760,13 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   // f16f8 inputs: the rotations net when its width lets every such GEMM run the persistent 256 x 256 kernel (N = 3 C, 2 C multiples of 256, K = C of 64)
   m->rot.f8 = cfg->precision == 2 && f16f8_wanted() && m->rot.C % 256 == 0 && m->rot.C >= 256;
   m->seg.f8 = false;
+  m->rot.f8m = false;
   m->rot.f8g = m->rot.f8 && f16_backward_wanted() && attn_tmfma_supported(cfg->num_frame, m->rot.C / m->rot.H) &&
                attn_smfma_supported(m->rot.N, m->rot.C / m->rot.H, m->rot.H);
+  {
+    const char* e = getenv("MANIPOSE_F16F8_FC2");
+    m->rot.f8m = m->rot.f8g && (m->rot.rs == 0.f || m->rot.rs == 1.0f) && (e ? atoi(e) != 0 : false);      // off: measured neutral in the step; a residual scale other than 1 - muP - keeps the tiled bf16x3 fc2 anyway
+  }
   Bump dry;
   carve_all(m, dry);
   m->arena_bytes = dry.off;
@@ -976,6 +988,10 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   const int B = m->B, T = m->cfg.num_frame, J = m->cfg.num_joints, S = m->cfg.num_bones, K = m->rot.K;
   const long Mr = (long)B * T * J, Ms = (long)B * T * S;
   use_scratch(m, 0);
+  if (m->rot.f8g) {      // this backward's gradient scale, from the incoming gradients (device side: no host round trip)
+    const long np = (long)B * K * T * J * 3, ns = (long)B * K * T;
+    RUN(PC_OTHER, 0, grad_scale(d_poses, np, d_scores, ns, m->gsc, st));
+  }
   // parameter gradients of the heads / score heads are needed by nobody downstream: with the weight-gradient stream on they run there,
   // at the start of the backward where that stream is idle (own scratch, ordered behind the last writer of dheadout)
   hipStream_t pst = m->wgrad_async ? m->st3 : nullptr;

@@ -107,9 +107,13 @@ template <typename TC> __device__ __forceinline__ long c_lo_off(const GemmB16Arg
 template <> __device__ __forceinline__ long c_lo_off<bf16p>(const GemmB16Args& g) {
   return reinterpret_cast<const bf16p*>(g.C_lo) - reinterpret_cast<const bf16p*>(g.C);
 }
+template <> __device__ __forceinline__ long c_lo_off<f16f8>(const GemmB16Args& g) {      // f16f8 output planes: the same arithmetic (2 bytes per element in both)
+  return reinterpret_cast<const f16f8*>(g.C_lo) - reinterpret_cast<const f16f8*>(g.C);
+}
 // storage of the second output gelu' (kept for the backward): plain bf16 next to a planar C (the backward runs on the hi planes)
 template <typename TC> struct ZType { typedef TC type; };
 template <> struct ZType<bf16p> { typedef bf16 type; };
+template <> struct ZType<f16f8> { typedef bf16 type; };
 
 template <typename TC> __device__ __forceinline__ void store_c(TC* p, float v);
 template <> __device__ __forceinline__ void store_c<float>(float* p, float v) { *p = v; }
@@ -625,6 +629,7 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
   typename ZType<TC>::type* Z = reinterpret_cast<typename ZType<TC>::type*>(g.Z);
   const long lo_off = c_lo_off<TC>(g);
   const float rsc = g.rscale != 0.f ? g.rscale : 1.0f;     // residual scale (muP: 1 / sqrt(depth))
+  const float gout_v = (EPI == EPI_DGELU && g.gout != nullptr) ? *g.gout : 0.f;
   __syncthreads();                                   // every wave is done with the operand stages: reuse them
   float* img = reinterpret_cast<float*>(smem + wave * 16384);
   const int l15 = lane & 15, gq = lane >> 4;
@@ -685,7 +690,7 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
         v = make_float4(v.x * z.x, v.y * z.y, v.z * z.z, v.w * z.w);      // Z holds gelu'(pre-activation)
       }
       if constexpr (EPI == EPI_DGELU && sizeof(TC) == 2) {
-        if (g.gout != 0.f) st4_f16(C + o, v, g.gout);
+        if (g.gout != nullptr) st4_f16(C + o, v, gout_v);
         else st4(C + o, v, lo_off);
       } else st4(C + o, v, lo_off);
     }
@@ -711,6 +716,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
                                                  const float4& bias4, TC* __restrict__ C, typename ZType<TC>::type* __restrict__ Z, int l15, int gq) {
   constexpr bool LOADS = (EPI == EPI_BIAS_RESID || EPI == EPI_DGELU);
   const long lo_off = c_lo_off<TC>(g);
+  const float gout_v = (EPI == EPI_DGELU && g.gout != nullptr) ? *g.gout : 0.f;      // this backward's gradient scale (a device scalar)
   float4 in_nxt[4];
   float ds_nxt[4];
   // residual = LayerNorm(R) recomputed from R and its row statistics (GemmB16Args::rstats): per-lane gamma / beta of its 4 columns
@@ -768,7 +774,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
       }
       if (FULL || row < g.M) {
         if constexpr (EPI == EPI_DGELU && sizeof(TC) == 2) {      // dz: bf16, or scaled fp16 for an fc1 layer whose backward GEMMs run on fp16 operands
-          if (g.gout != 0.f) st4_f16(C + o, v, g.gout);
+          if (g.gout != nullptr) st4_f16(C + o, v, gout_v);
           else st4(C + o, v, lo_off);
         } else st4(C + o, v, lo_off);
       }
@@ -1123,7 +1129,9 @@ static int launch_glds(const GemmB16Args& g, int splits, hipStream_t st) {
 // outputs, 21-64 slabs deep).
 constexpr int RS_OUT = 64;
 __global__ __launch_bounds__(256) void reduce_slabs_b16_kernel(const float* __restrict__ slabW, float* __restrict__ dW, long nW4,
-                                                               const float* __restrict__ slabB, float* __restrict__ db, long nB4, int S, int SB, float scale) {
+                                                               const float* __restrict__ slabB, float* __restrict__ db, long nB4, int S, int SB,
+                                                               const float* __restrict__ scale_p) {
+  const float scale = scale_p != nullptr ? *scale_p : 1.0f;      // 1, or the inverse of the scale this backward's fp16 operands carried
   __shared__ float4 part[3][RS_OUT];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   long i = (long)blockIdx.x * RS_OUT + lane;
@@ -1190,6 +1198,7 @@ int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, 
   if (!a_f32 && !a_tr && !b_tr && c_f32 && epi == EPI_BIAS_RESID) return launch_glds<0, 0, float, EPI_BIAS_RESID>(g, 1, st);
   if (!a_f32 && !a_tr && !b_tr && !c_f32 && epi == EPI_BIAS_GELU) return launch_glds<0, 0, bf16, EPI_BIAS_GELU>(g, 1, st);
   if (a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_DGELU) return launch_b16<float, 0, bf16, 1, bf16, EPI_DGELU>(g, 1, st);
+  if (!a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_DGELU && g.f16) return launch_glds<0, 1, bf16, EPI_DGELU, 16>(g, 1, st);      // fp16 dY and weights
   if (!a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_DGELU) return launch_glds<0, 1, bf16, EPI_DGELU>(g, 1, st);
   if (!a_f32 && !a_tr && b_tr && !c_f32 && epi == EPI_BIAS && g.f16) {      // dgrad on fp16 operands (dY a scaled fp16 gradient, weights from the f16f8 shadow); bf16 out, which KEEPS dY's scale
     MP_CHECK(g.bias == nullptr, MP_ERR_ARG, "gemm_bf16: the fp16-operand dgrad takes no bias");
@@ -1246,8 +1255,13 @@ int gemm_f16f8(GemmB16Args g, int c_f32, int epi, hipStream_t st) {
   MP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int wgs = max(8, (cus / 8) * 8);
   if (c_f32 && epi == EPI_BIAS) return launch_persist<0, float, EPI_BIAS, 8>(g, wgs, st);
+  if (c_f32 && epi == EPI_BIAS_RESID) {
+    MP_CHECK(g.R != nullptr && (g.rscale == 0.f || g.rscale == 1.0f), MP_ERR_ARG, "gemm_f16f8: residual epilogue needs R and a residual scale of 1");
+    return launch_persist<0, float, EPI_BIAS_RESID, 8>(g, wgs, st);
+  }
   MP_CHECK(!c_f32 && g.C_lo != nullptr, MP_ERR_ARG, "gemm_f16f8: planar output without its lo plane");
   if (epi == EPI_BIAS) return launch_persist<0, bf16p, EPI_BIAS, 8>(g, wgs, st);
+  if (epi == EPI_BIAS_GELU && g.out_f16f8) return launch_persist<0, f16f8, EPI_BIAS_GELU, 8>(g, wgs, st);      // C / C_lo = fp16 + correction planes (the fc2 GEMM's f16f8 input)
   if (epi == EPI_BIAS_GELU) return launch_persist<0, bf16p, EPI_BIAS_GELU, 8>(g, wgs, st);      // Z may be null (inference: gelu' is not kept)
   MP_CHECK(false, MP_ERR_ARG, "gemm_f16f8: unsupported variant c_f32=%d epi=%d", c_f32, epi);
 }
@@ -1263,7 +1277,7 @@ static void wgrad_split_b16(int Mtok, int Nout, int Kin, int bt, int& splits, in
 
 // dW[N',K'] += dY[Mtok,N']^T X[Mtok,K'] (X bf16; dY bf16 or fp32) ; db += colsum(dY)
 int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
-               float* slab, long slab_floats, hipStream_t st, int f16, float oscale) {
+               float* slab, long slab_floats, hipStream_t st, int f16, const float* oscale) {
   MP_CHECK(Mtok > 0 && Nout % 8 == 0 && Kin % 8 == 0, MP_ERR_ARG, "wgrad_bf16: bad dims %d %d %d", Mtok, Nout, Kin);
   GemmB16Args g = {};
   g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx;
@@ -1291,7 +1305,7 @@ int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, i
   if (rc) return rc;
   const long nW4 = (long)Nout * Kin / 4, nB4 = db != nullptr ? Nout / 4 : 0;        // Nout, Kin are multiples of 8
   hipLaunchKernelGGL(reduce_slabs_b16_kernel, dim3(cdiv(nW4, (long)RS_OUT) + cdiv(nB4, (long)RS_OUT)), dim3(256), 0, st, slab, dW, nW4, g.bias_slab, db, nB4, splits, splits * bparts,
-                     (f16 && oscale != 0.f) ? oscale : 1.0f);
+                     f16 ? oscale : (const float*)nullptr);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

@@ -58,7 +58,8 @@ struct GemmB16Args {
   // kernels with v_mfma_f32_16x16x32_f16.  The dgrad's bf16 output keeps that scale (its consumer, a LayerNorm backward, divides it out: dy_scale);
   // the weight gradient's slab reduction multiplies by wgrad_bf16's oscale.
   int f16;
-  float gout;          // EPI_DGELU with a 2-byte output: != 0 writes dz as fp16 of gout * value instead of bf16 (the operand format above)
+  int out_f16f8;       // gemm_f16f8 with EPI_BIAS_GELU: C / C_lo are the fp16 / correction planes of the "f16f8" format instead of bf16 hi / lo planes
+  const float* gout;   // EPI_DGELU with a 2-byte output: non-null writes dz as fp16 of *gout x value instead of bf16 (device address; the operand format above)
 };
 int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, hipStream_t st);
 // C = A B^T on planar hi/lo operands ("N","N" layouts: the forward Linear), three bf16 MFMA products per k-tile, fp32 accumulate.
@@ -69,7 +70,7 @@ int gemm_f16f8(GemmB16Args g, int c_f32, int epi, hipStream_t st);
 int cast_to_f16f8(const float* src, void* hi16, void* cat8, long n, int weight, hipStream_t st);     // n % 64 == 0; see common.h "f16f8"
 int cast_to_bf16x2(const float* src, bf16* hi, bf16* lo, long n, hipStream_t st);
 int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
-               float* slab, long slab_floats, hipStream_t st, int f16 = 0, float oscale = 0.f);      // f16: dY and X are fp16, dW += oscale * dY^T X
+               float* slab, long slab_floats, hipStream_t st, int f16 = 0, const float* oscale = nullptr);      // f16: dY and X are fp16, dW += *oscale x dY^T X (device address)
 int cast_to_bf16(const float* src, bf16* dst, long n, hipStream_t st);
 void gemm_bf16_force_small_tile(bool on);          // test hooks (mp_set_option)
 void gemm_bf16_persist_min_tiles(int n);
@@ -97,11 +98,16 @@ int ln_fwd(const LnFwdArgs& a, int out_mode /* 0 fp32, 1 bf16, 2 planar bf16 hi/
 // dx = [rs * dskip +] LN'(dy) (rs: the block's residual scale, 1 unless muP)
 int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, const float* gamma, const float* dskip, float* dx, void* dx_b16,
            const float* mask, int mask_mode, int T, int J, float* dgamma, float* dbeta, int M, int C, float* scratch,
-           long scratch_floats, hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr, float rs = 1.0f, float dy_scale = 1.0f);
+           long scratch_floats, hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr, float rs = 1.0f,
+           const float* dy_scale = nullptr, const float* b16_gs = nullptr);      // device addresses: *dy_scale multiplies dy on load (null = 1); b16_gs non-null:
+                                                                                 // dx_b16 is written as fp16 of *b16_gs x value instead of bf16
 int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, const float* gamma1, const float* dskip,
             const float* x0, const float* stats0, const float* gamma0, const float* beta0 /* non-null: x1 == LN0(x0) is recomputed */,
             float* dx, void* dx_b16, const float* mask, int mask_mode, int T, int J, float* dgamma1, float* dbeta1, float* dgamma0, float* dbeta0, int M, int C, float* scratch, long scratch_floats,
-            hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr, float rs = 1.0f, float dy_scale = 1.0f);      // dy_scale multiplies dy (dy1) on load
+            hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr, float rs = 1.0f, const float* dy_scale = nullptr,
+            const float* b16_gs = nullptr);      // as in ln_bwd (dy_scale applies to dy1)
+// gsc (4 floats on the device) <- {S, 1 / S, scratch, 1} with S the power of two that brings max(|d_poses|, |d_scores|) into [1, 2) (elementwise.hip)
+int grad_scale(const float* d_poses, long n_poses, const float* d_scores, long n_scores, float* gsc, hipStream_t st);
 // dst = s * src ; dst += s * src  (muP readout multiplier on the head weights / their gradients)
 int scale_copy(float* dst, const float* src, float s, long n, hipStream_t st);
 int axpy_scaled(float* dst, const float* src, float s, long n, hipStream_t st);
@@ -124,7 +130,7 @@ int droppath_masks(float* masks, const MaskDesc* descs, int ndesc, unsigned long
                    hipStream_t st);
 
 // ---------------------------------------------------------------- attention.hip
-void attn_grad_f16_override(float gout);   // attention_mfma.hip: the MFMA backward launches issued next on this thread write dQ / dK / dV as fp16(gout * value) (0 = bf16)
+void attn_grad_f16_override(const float* gout);   // attention_mfma.hip: the MFMA backward launches issued next on this thread write dQ / dK / dV as fp16(*gout x value) (device address; null = bf16)
 void attn_scale_override(float s);   // softmax scale of the attention launches issued next on this thread (0 = head_dim ** -0.5)
 // qkv: [M][3C] (q | k | v, head-major inside each), out: [M][C]; token layout m = (b*T + t)*J + j
 int attn_spatial_fwd(const void* qkv, void* out, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st);

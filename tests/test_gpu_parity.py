@@ -1546,6 +1546,20 @@ def test_f16f8_inputs_of_the_model_and_the_inference_flag(lib):
                 poses3, scores3 = model(X.cuda())                  # a differentiable forward again: the backward runs
                 (poses3.sum() + scores3.sum()).backward()
                 assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+                # the backward of the qkv / fc1 layers runs on fp16 operands carried with a per-backward power-of-two scale taken from the
+                # incoming gradient: a loss 1e12 times larger or smaller must give the same gradient direction as the oracle's autograd
+                req = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+                op, osc = orc.rmcl_manifold_forward(X, req, orc.oracle_cfg(cfg))
+                (op.square().sum() + osc.square().sum()).backward()
+                for factor in (1e6, 1e-6, 1.0):
+                    model.zero_grad(set_to_none=True)
+                    pf, sf = model(X.cuda())
+                    (factor * (pf.square().sum() + sf.square().sum())).backward()
+                    cos = min(torch.nn.functional.cosine_similarity(p.grad.cpu().reshape(-1).double(), req[k].grad.reshape(-1).double(), dim=0).item()
+                              for k, p in model.named_parameters())
+                    ratio = max((p.grad.cpu().norm() / (factor * req[k].grad.norm())).item() for k, p in model.named_parameters())
+                    print(f"loss x {factor:g}: worst gradient cosine {cos:.6f}, largest norm ratio {ratio:.4f}")
+                    assert cos > 0.999 and 0.98 < ratio < 1.02
     finally:
         _lib.check(lib.mp_set_option(b"f16f8_inputs", -1))
     assert not torch.equal(outs[0], outs[1])
