@@ -337,7 +337,7 @@ int mp_procrustes_errors(const float* pred, const float* gt, const uint8_t* mask
  * enqueued on the caller's stream instead of the engine's side stream; 1 = default), "attn_two_phase" (0 = the one-strip-at-a-time
  * split-precision temporal attention forward for every shape; 1 = default: the two-phase kernel for head dim 64 and T > 128),
  * "f16f8_inputs" (models created afterwards in precision 2: 1 = default, the qkv and fc1 Linear layers of a rotations net whose width is a
- * multiple of 256 read "f16f8" operands; 0 = bf16 hi / lo planes everywhere). */
+ * multiple of 256 read "f16f8" operands, their backward runs on fp16 operands; 2 = the fc2 layer as well; 0 = bf16 hi / lo planes everywhere). */
 int mp_set_option(const char* name, int value);
 
 #ifdef __cplusplus

@@ -14,8 +14,8 @@ namespace mp {
 // debugging hook (mp_set_option("side_streams", 0)): enqueue the bones net on the caller's stream instead of the engine's side stream
 static int g_side_streams = 1;
 void engine_side_streams(int on) { g_side_streams = on; }
-// "f16f8" inputs of the qkv and fc1 Linear layers (precision 2, widths that are multiples of 256): -1 = MANIPOSE_F16F8 or the default (on),
-// 0 / 1 = mp_set_option("f16f8_inputs", v); read when a model is created
+// "f16f8" inputs of the qkv and fc1 Linear layers (precision 2, widths that are multiples of 256): -1 = MANIPOSE_F16F8 or the default (1),
+// 0 / 1 / 2 = mp_set_option("f16f8_inputs", v) (2: the fc2 layer as well); read when a model is created
 static int g_f16f8 = -1;
 void engine_f16f8(int on) { g_f16f8 = on; }
 bool attn_tmfma_supported(int T, int D);            // attention_mfma.hip
@@ -27,11 +27,12 @@ static bool f16_backward_wanted() {
   const char* e = getenv("MANIPOSE_F16BWD");
   return e ? atoi(e) != 0 : true;
 }
-static bool f16f8_wanted() {
-  if (g_f16f8 >= 0) return g_f16f8 != 0;
+static int f16f8_level() {      // 0 off, 1 (default) the qkv and fc1 layers, 2 the fc2 layer as well (neutral in the step: DESIGN section 5)
+  if (g_f16f8 >= 0) return g_f16f8;
   const char* e = getenv("MANIPOSE_F16F8");
-  return e ? atoi(e) != 0 : true;
+  return e ? atoi(e) : 1;
 }
+static bool f16f8_wanted() { return f16f8_level() != 0; }
 
 const char* last_error();
 long wgrad_f32_slab_floats(int Mtok, int Nout, int Kin);
@@ -763,10 +764,7 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   m->rot.f8m = false;
   m->rot.f8g = m->rot.f8 && f16_backward_wanted() && attn_tmfma_supported(cfg->num_frame, m->rot.C / m->rot.H) &&
                attn_smfma_supported(m->rot.N, m->rot.C / m->rot.H, m->rot.H);
-  {
-    const char* e = getenv("MANIPOSE_F16F8_FC2");
-    m->rot.f8m = m->rot.f8g && (m->rot.rs == 0.f || m->rot.rs == 1.0f) && (e ? atoi(e) != 0 : false);      // off: measured neutral in the step; a residual scale other than 1 - muP - keeps the tiled bf16x3 fc2 anyway
-  }
+  m->rot.f8m = m->rot.f8g && (m->rot.rs == 0.f || m->rot.rs == 1.0f) && f16f8_level() >= 2;      // (a residual scale other than 1 - muP - keeps the tiled bf16x3 fc2)
   Bump dry;
   carve_all(m, dry);
   m->arena_bytes = dry.off;

@@ -1525,7 +1525,7 @@ def test_f16f8_inputs_of_the_model_and_the_inference_flag(lib):
               num_heads_seg=4, drop_path_rate=0.0, n_hyp=K)
     outs = {}
     try:
-        for on in (1, 0):
+        for on in (1, 2, 0):                                       # 2: the fc2 layer in the same form too
             _lib.check(lib.mp_set_option(b"f16f8_inputs", on))
             model = RMCLManifoldMixSTE(**kw)
             model.load_state_dict(state, strict=True)
@@ -1562,7 +1562,7 @@ def test_f16f8_inputs_of_the_model_and_the_inference_flag(lib):
                     assert cos > 0.999 and 0.98 < ratio < 1.02
     finally:
         _lib.check(lib.mp_set_option(b"f16f8_inputs", -1))
-    assert not torch.equal(outs[0], outs[1])
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
 
 
 @pytest.mark.parametrize("temporal,B,T,J,C,H", [(1, 2, 243, 3, 128, 2), (1, 1, 81, 17, 512, 8), (1, 2, 27, 16, 128, 8), (1, 1, 256, 2, 64, 1),
