@@ -372,6 +372,9 @@ def main():
                           "seq_len": T, "parallelism": f"dp{world}", "precision": args.precision, "drop_path_rate": 0.1,
                           **({"split_forms": ("qkv, fc1: f16f8 (fp16 hi plane x fp16 hi plane + ONE block-scaled e4m3 product of 8-bit correction planes per 64 "
                                               "reduction indices); proj, fc2, attention: bf16x3 (three bf16 products of bf16 hi/lo planes)"
+                                              + ("; backward of those layers on fp16 operands with a per-backward device-side power-of-two gradient scale"
+                                                 if os.environ.get("MANIPOSE_F16BWD", "1") != "0" else "")
+                                              + ("; MANIPOSE_F16F8=2: fc2 in the f16f8 form as well" if os.environ.get("MANIPOSE_F16F8", "1") == "2" else "")
                                               if os.environ.get("MANIPOSE_F16F8", "1") != "0" else "all: bf16x3 (three bf16 products of bf16 hi/lo planes)")}
                              if args.precision == "bf16x3" else {}),
                           "gradient_exchange": ("none" if world == 1 else ("8 layer buckets overlapped with the backward + remainder" if args.grad_buckets
