@@ -338,7 +338,7 @@ int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, cons
 // R rows in flight per wave: every load of the R rows is issued before the first row is reduced (one row per wave left ~60 KB in flight per
 // CU and the kernel at 4.2 TB/s of its 16 B per element, against 5.8 TB/s for ln_bwd_kernel with its two rows).
 template <typename TDY, int R>
-__global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy1, const float* __restrict__ x1,
+__global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy1,
                                                        const float* __restrict__ stats1, const float* __restrict__ gamma1,
                                                        const float* dskip, const float* __restrict__ x0,
                                                        const float* __restrict__ stats0, const float* __restrict__ gamma0,
@@ -474,6 +474,7 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
             hipStream_t st, hipStream_t st_param, hipEvent_t ev, float rs, const float* dy_scale, const float* b16_gs) {
   MP_CHECK(C % 4 == 0 && C <= 512, MP_ERR_ARG, "ln_bwd2: C=%d unsupported", C);
   MP_CHECK(beta0 != nullptr, MP_ERR_ARG, "ln_bwd2: x1 is recomputed from x0, beta0 is required");
+  (void)x1;      // (kept in the signature: the stored block input of the blocks that have one; the kernel recomputes it from x0)
   // persistent grid = the workgroups that are resident at once (168 VGPRs: 3 waves per SIMD, 3 workgroups per CU).  With LNB_GRID = 1024
   // workgroups on 768 slots the launch ran one full round and a second one at a third of the occupancy: 720 us where ln_bwd_kernel (128
   // VGPRs, 1024 slots) moves the same bytes in 470 us.
@@ -490,10 +491,10 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
   const int grid = max(1, min(cdiv(M, 4), slots[dy_bf16 ? 1 : 0]));
   MP_CHECK(scratch_floats >= (long)grid * 4 * C, MP_ERR_ARG, "ln_bwd2: scratch too small");
   if (dy_bf16)
-    hipLaunchKernelGGL((ln_bwd2_kernel<bf16, LNB2_R>), dim3(grid), dim3(256), 0, st, (const bf16*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
+    hipLaunchKernelGGL((ln_bwd2_kernel<bf16, LNB2_R>), dim3(grid), dim3(256), 0, st, (const bf16*)dy1, stats1, gamma1, dskip, x0, stats0, gamma0,
                        beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs, dy_scale, b16_gs);
   else
-    hipLaunchKernelGGL((ln_bwd2_kernel<float, LNB2_R>), dim3(grid), dim3(256), 0, st, (const float*)dy1, x1, stats1, gamma1, dskip, x0, stats0, gamma0,
+    hipLaunchKernelGGL((ln_bwd2_kernel<float, LNB2_R>), dim3(grid), dim3(256), 0, st, (const float*)dy1, stats1, gamma1, dskip, x0, stats0, gamma0,
                        beta0, dx, (bf16*)dx_b16, mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs, dy_scale, b16_gs);
   MP_LAUNCH_CHECK();
   ReduceDst d = {{dgamma1, dbeta1, dgamma0, dbeta0}, {0, C, 2 * C, 3 * C, 4 * C}, {1, 1, 1, 1}};
