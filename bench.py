@@ -18,10 +18,10 @@ Prints ONE JSON line on rank 0 with
   `rccl`          (N>1) backend name and the sum of a ones tensor all-reduced over the process group = the ranks RCCL really joined;
   `other_precisions`  (N=1) poses/s and the same parity figure of the other two precisions, a few steps each;
   `cpu_baseline`  oracle/manipose_ref.py timed on the host cores (rank 0, N=1 only).
-Default precision: "bf16x3" (split operands, fp32 accumulate: proj / fc2 / attention products as three bf16 matrix-core products of bf16
-hi/lo planes; the qkv and fc1 products - MANIPOSE_F16F8=0 switches this off - as one fp16 product plus one block-scaled fp8 correction
-product, `config.split_forms`) - the fastest
-precision whose drift stays inside the 1e-4 m bound; "bf16" (BASELINE config #3's wording) is faster but drifts ~3 mm.
+Default precision: "bf16x3" (split operands, fp32 accumulate: every Linear and attention product as three bf16 matrix-core products of bf16
+hi / lo planes, bf16 backward) - the fastest precision whose drift stays inside the 1e-4 m bound; "bf16" (BASELINE config #3's wording) is
+faster but drifts ~3 mm.  `--f16f8 1 [--f16-backward]` runs the qkv / fc1 products as one fp16 + one block-scaled fp8 product instead
+(mp_model_config::f16f8, ABI v7; named in `config.split_forms`): <= 1 % faster, 1.3e-5 m instead of 0.9e-5 m, so it is an option, not the default.
 """
 import argparse
 import json
@@ -37,14 +37,18 @@ PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}                 
 PEAK_HBM_GBPS = 8000.0                                         # HBM3E spec peak (measured copy peak on this pool: ~5.5-6.3 TB/s)
 
 
-def pmc_traffic_per_launch(precision, batch):
+def pmc_traffic_per_launch(precision, batch, forms=""):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (2 x FETCH_SIZE per the gfx950 correction of
     MI355X_MICROARCH.md section HBM, + WRITE_SIZE): profiles/pmc_traffic.json, written by tools/refresh_profiles.sh together with the
-    <tag>_pmc_hbm_traffic.csv whose last row it repeats (one source, so the two cannot diverge).  None when that configuration
-    was never profiled."""
+    <tag>_pmc_hbm_traffic.csv whose last row it repeats (one source, so the two cannot diverge).  It is NOT measured in this run (counters
+    need rocprofv3 around the process): the record says where it comes from.  None when that configuration was never profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(f"{precision}:{batch}", {}).get("bytes_per_launch")
+            e = json.load(f).get(f"{precision}{forms}:{batch}")
+        if not e or e.get("bytes_per_launch") is None:
+            return None
+        return {"bytes_per_launch": e["bytes_per_launch"],
+                "source": f"{e.get('source', 'profiles/pmc_traffic.json')} (offline rocprofv3 --pmc passes of this command, not a measurement of this run)"}
     except (OSError, ValueError):
         return None
 
@@ -134,6 +138,13 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("MANIPOSE_PRECISION", "bf16x3"), choices=["bf16", "bf16x3", "fp32"],
                     help="bf16x3 (default) = split bf16 hi/lo operands, 3 matrix-core products per product: inside the 1e-4 m parity bound; "
                          "bf16 = plain bf16 matrix cores (fp32 accumulate/residual/softmax), ~3 mm drift; fp32 = fp32 matrix cores")
+    ap.add_argument("--f16f8", type=int, default=0, choices=[0, 1, 2],
+                    help="bf16x3 only (mp_model_config::f16f8): 1 = qkv / fc1 as one fp16 + one block-scaled fp8 product, 2 = fc2 as well")
+    ap.add_argument("--f16-backward", action="store_true", help="with --f16f8 >= 1: backward GEMMs of those layers on saturating scaled-fp16 operands")
+    ap.add_argument("--single-queue", action="store_true",
+                    help="every kernel on the caller's stream (mp_model_config::streams = 3): isolated kernel durations under rocprofv3")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="mp_set_option test / tuning hook (e.g. attn_two_phase=0, gemm_persist_wgs=192); A/B timing only")
     ap.add_argument("--grad-buckets", action="store_true",
                     help="N > 1: overlap the gradient exchange with the backward (one all-reduce per layer of the rotations net on a communication "
                          "stream) instead of one all-reduce of the flat buffer behind it; off by default (never measured on a multi-GPU box)")
@@ -176,15 +187,16 @@ def main():
                 if n.endswith("pos_embed"):
                     p.normal_(0.0, 0.02)
         mdl.precision = precision
+        if precision == "bf16x3":
+            mdl.f16f8, mdl.f16_backward = args.f16f8, args.f16_backward
+        mdl.side_stream = mdl.wgrad_stream = not args.single_queue
         mdl.max_batch_hint = batch
         return mdl
 
-    if os.environ.get("MANIPOSE_ATTN_TWO_PHASE"):       # A/B timing of the two-phase temporal attention kernels (bit 0 forward, bit 1 backward)
+    for opt in args.option:                             # process-wide kernel selectors (A/B timing): include/manipose_hip.h, mp_set_option
         from manipose_amd import _lib as _l
-        _l.check(_l.load().mp_set_option(b"attn_two_phase", int(os.environ["MANIPOSE_ATTN_TWO_PHASE"])))
-    if os.environ.get("MANIPOSE_SIDE_STREAMS"):         # 0: every kernel on one queue (isolated kernel durations under rocprofv3; a profiling aid)
-        from manipose_amd import _lib as _l
-        _l.check(_l.load().mp_set_option(b"side_streams", int(os.environ["MANIPOSE_SIDE_STREAMS"])))
+        name, _, val = opt.partition("=")
+        _l.check(_l.load().mp_set_option(name.encode(), int(val)), f"mp_set_option({name})")
     model = build_model(args.precision, args.batch)
     cpu_json, oracle_out = None, None
     # parity windows: the same on every rank (own generator), placed at the start, middle and end of the timed batch
@@ -319,11 +331,38 @@ def main():
     dt = time.perf_counter() - t0
     log(f"timed region done: {dt:.3f} s")
     prof = eng.prof_collect() if not args.no_prof else None
+    kinds = eng.prof_kinds() if not args.no_prof else None
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     loss = float(terms.sum().item())
+
+    # N > 1: the open question of DESIGN section 6, answered by the run itself - a few steps in each exchange mode with device events around
+    # the backward and the exchange: does the backward get longer with RCCL kernels resident (bucketed), and how much of the single
+    # collective is exposed behind it?
+    exchange = None
+    if world > 1:
+        exchange = {}
+        nx = max(2, min(5, args.steps))
+        for mode in ("single", "bucketed"):
+            trainer.grad_buckets = mode == "bucketed"
+            trainer.train_step(X, y)                      # one untimed step in the mode (communication stream / buffers)
+            trainer.time_exchange = True
+            barrier()
+            tx0 = time.perf_counter()
+            for _ in range(nx):
+                trainer.train_step(X, y)
+            barrier()
+            dtx = torch.tensor([time.perf_counter() - tx0], device="cuda", dtype=torch.float64)
+            dist.all_reduce(dtx, op=dist.ReduceOp.MAX)
+            tm = trainer.exchange_times()
+            trainer.time_exchange = False
+            tt = torch.tensor([tm["backward_ms"], tm["exposed_exchange_ms"]], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            exchange[mode] = {"ms_per_step": 1e3 * dtx.item() / nx, "backward_ms": tt[0].item(), "exposed_exchange_ms": tt[1].item(), "steps": nx,
+                              "timed_mode": mode == ("bucketed" if args.grad_buckets else "single")}
+        trainer.grad_buckets = args.grad_buckets
 
     # N=1: the other precisions on the same workload, a few steps each (their own batch sizes), with the same parity measurement
     other = {}
@@ -361,6 +400,7 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:       # noqa: BLE001
                 other[prec] = {"error": f"{type(e).__name__}: {e}"}
+    forms = "" if args.precision != "bf16x3" or args.f16f8 == 0 else f"+f16f8{args.f16f8}" + ("b" if args.f16_backward else "")
     if rank == 0:
         poses_per_s = world * B * T * args.steps / dt
         gf = TRAIN_GFLOP_PER_POSE.get(T, 3.705)
@@ -370,13 +410,15 @@ def main():
                "config": {"workload": f"H36M lifting T={T} J=17 K={args.hyp} ManiPose full (C=512, depth 8), train step "
                                       f"fwd+WTA loss+bwd+allreduce+Adam", "windows_per_gpu": B, "global_batch": world * B,
                           "seq_len": T, "parallelism": f"dp{world}", "precision": args.precision, "drop_path_rate": 0.1,
-                          **({"split_forms": ("qkv, fc1: f16f8 (fp16 hi plane x fp16 hi plane + ONE block-scaled e4m3 product of 8-bit correction planes per 64 "
-                                              "reduction indices); proj, fc2, attention: bf16x3 (three bf16 products of bf16 hi/lo planes)"
-                                              + ("; backward of those layers on fp16 operands with a per-backward device-side power-of-two gradient scale"
-                                                 if os.environ.get("MANIPOSE_F16BWD", "1") != "0" else "")
-                                              + ("; MANIPOSE_F16F8=2: fc2 in the f16f8 form as well" if os.environ.get("MANIPOSE_F16F8", "1") == "2" else "")
-                                              if os.environ.get("MANIPOSE_F16F8", "1") != "0" else "all: bf16x3 (three bf16 products of bf16 hi/lo planes)")}
+                          **({"split_forms": (("qkv, fc1" + (", fc2" if args.f16f8 >= 2 else "") + ": f16f8 (fp16 hi plane x fp16 hi plane + ONE block-scaled e4m3 "
+                                               "product of 8-bit correction planes per 64 reduction indices); " + ("proj" if args.f16f8 >= 2 else "proj, fc2")
+                                               + ", attention: bf16x3 (three bf16 products of bf16 hi/lo planes)"
+                                               + ("; backward of the f16f8 layers on saturating fp16 operands with a per-backward device-side power-of-two "
+                                                  "gradient scale" if args.f16_backward else "; bf16 backward"))
+                                              if args.f16f8 >= 1 else "all: bf16x3 (three bf16 products of bf16 hi/lo planes), bf16 backward")}
                              if args.precision == "bf16x3" else {}),
+                          **({"single_queue": True} if args.single_queue else {}), **({"options": args.option} if args.option else {}),
+                          **({"traffic_key_suffix": forms} if forms else {}),
                           "gradient_exchange": ("none" if world == 1 else ("8 layer buckets overlapped with the backward + remainder" if args.grad_buckets
                                                                           else "one all-reduce of the flat buffer (137.8 MB) behind the backward"))},
                "loss": loss, "model_tflops": poses_per_s * gf / 1e3}
@@ -390,6 +432,10 @@ def main():
                                         f"(oracle/manipose_ref.py) run in a CPU child process of this job")
         if rccl is not None:
             out["rccl"] = rccl
+        if exchange is not None:
+            out["gradient_exchange"] = dict(exchange, note="device events on the caller's stream, max over ranks: backward_ms = mp_model_backward alone "
+                                            "(bucketed: with the per-layer all-reduces running beside it on a communication stream), exposed_exchange_ms = the "
+                                            "wait between the end of the backward and the optimizer step; `value` is timed in the mode with timed_mode = true")
         if other:
             out["other_precisions"] = other
         if prof is not None:
@@ -418,20 +464,55 @@ def main():
             gbps = k["bytes"] / sec / 1e9 if sec > 0 else 0.0
             peak_tf, peak_bw = PEAK_TFLOPS[args.precision], PEAK_HBM_GBPS
             nl = max(1, k["launches"])
-            out["roofline"] = {"bound": "mfma", "kernel": kname,
+            ridge = peak_tf * 1e12 / (peak_bw * 1e9)
+
+            def roof(flops, nbytes, ms):
+                """Roofline position of a set of launches on ALGORITHMIC work: bound by intensity against the ridge (not a literal), the
+                fraction of the dense matrix peak and of the roof the model allows at that intensity, min(peak, intensity x 8 TB/s)."""
+                sec_ = ms * 1e-3
+                inten = flops / nbytes if nbytes > 0 else None
+                tf = flops / sec_ / 1e12 if sec_ > 0 else 0.0
+                attainable = min(peak_tf, inten * peak_bw / 1e3) if inten is not None else peak_tf
+                return {"bound": "mfma" if (inten is None or inten >= ridge) else "hbm", "tflops": tf, "frac": tf / peak_tf,
+                        "attainable_tflops": attainable, "frac_attainable": tf / attainable if attainable > 0 else None,
+                        "intensity_flop_per_byte": inten, "hbm_gbps": nbytes / sec_ / 1e9 if sec_ > 0 else 0.0}
+            r = roof(k["model_flops"], k["bytes"], k["ms"])
+            out["roofline"] = {"bound": r["bound"], "kernel": kname,
                                "achieved": model_tflops, "peak": peak_tf, "unit": "TFLOP/s", "frac": model_tflops / peak_tf,
-                               "traffic": pmc_traffic_per_launch(args.precision, B),
+                               "attainable": r["attainable_tflops"], "frac_attainable": r["frac_attainable"],
+                               "traffic": pmc_traffic_per_launch(args.precision, B, forms),
                                "avg_launch_ms": k["ms"] / nl, "launches": k["launches"],
                                "flops_per_launch": k["model_flops"] / nl, "bytes_per_launch": k["bytes"] / nl,
-                               "intensity_flop_per_byte": k["model_flops"] / k["bytes"] if k["bytes"] > 0 else None,
-                               "ridge_flop_per_byte": peak_tf * 1e12 / (peak_bw * 1e9),
+                               "intensity_flop_per_byte": r["intensity_flop_per_byte"],
+                               "ridge_flop_per_byte": ridge,
                                "hbm_gbps": gbps, "hbm_frac": gbps / peak_bw,
                                "mfma_issue_tflops": issued_tflops, "mfma_issue_frac": issued_tflops / peak_tf,
                                "issued_flops_per_launch": k["flops"] / nl,
-                               "note": ("flops = 2 M N K per GEMM (SURVEY 8d). bf16x3: the forward launches issue 3 bf16 matrix-core products per "
-                                        "product (6 M N K, mfma_issue_*) - or, for the qkv / fc1 launches in the f16f8 form, one fp16 product and one fp8 "
-                                        "product of twice the depth at twice the rate (counted as 4 M N K of bf16-rate issue) - so fp32-grade products "
-                                        "have an effective roof of peak / 3 (peak / 2) in the forward; dgrad launches are plain bf16." if args.precision == "bf16x3" else "flops = 2 M N K per GEMM (SURVEY 8d)")}
+                               "note": ("`bound` = intensity (2 M N K / algorithmic bytes, SURVEY 8d) against the ridge 2500 TF / 8 TB/s; `frac` = achieved / "
+                                        "dense bf16 matrix peak, `frac_attainable` = achieved / min(peak, intensity x 8 TB/s). All instantiations of the "
+                                        "kernel are averaged here: `per_instantiation` splits them."
+                                        + (" bf16x3: a forward launch issues 3 bf16 matrix-core products per product (6 M N K, mfma_issue_*; f16f8 "
+                                           "launches: one fp16 + one double-rate fp8 product = 4 M N K of bf16-rate issue), so fp32-grade products have an "
+                                           "effective matrix roof of peak / 3 (peak / 2); dgrad launches are plain bf16." if args.precision == "bf16x3" else ""))}
+            if kinds:
+                # the same accounting per instantiation (rotations net; the weight-gradient rows run gemm_bf16_glds_kernel and carry no byte count)
+                tab = {}
+                for name, v in kinds.items():
+                    if not name.startswith("rot.") or v["launches"] == 0:
+                        continue
+                    nlk = v["launches"]
+                    e = {"launches_per_step": nlk / args.steps, "persistent_kernel": v["persist_launches"] == nlk, "ms_per_launch": v["ms"] / nlk,
+                         "ms_per_step": v["ms"] / args.steps, "flops_2mnk_per_launch": v["model_flops"] / nlk,
+                         "issued_flops_per_launch": v["flops"] / nlk}
+                    if v["bytes"] > 0:
+                        rr = roof(v["model_flops"], v["bytes"], v["ms"])
+                        e.update({"algorithmic_bytes_per_launch": v["bytes"] / nlk, "bound": rr["bound"], "tflops": rr["tflops"], "frac": rr["frac"],
+                                  "frac_attainable": rr["frac_attainable"], "hbm_gbps": rr["hbm_gbps"]})
+                    else:
+                        tf = v["model_flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+                        e.update({"tflops": tf, "frac": tf / peak_tf})
+                    tab[name[4:]] = e
+                out["roofline"]["per_instantiation"] = tab
             tot = sum(v["ms"] for v in prof.values())
             out["kernel_classes"] = {n: {"ms_per_step": v["ms"] / args.steps, "share": v["ms"] / tot if tot else 0.0,
                                          "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}

@@ -40,6 +40,7 @@ def instantiate_model(cfg):
         model = MixSTE(num_frame=cfg.data.seq_len, num_joints=sk.num_joints, in_chans=2, out_dim=3, num_heads=cfg.model.nheads,
                        depth=cfg.model.layers, embed_dim=cfg.model.channels, drop_path_rate=cfg.model.drop_path_rate, mup=cfg.model.mup)
         model.precision = cfg.model.precision
+        _engine_options(model, cfg)
         return model
     kw = dict(skeleton=sk, num_frame=cfg.data.seq_len, num_joints=sk.num_joints, num_bones=sk.num_bones, in_chans=2,
               rot_rep_dim=cfg.model.rot_dim, num_heads_rot=cfg.model.nheads, depth_rot=cfg.model.layers,
@@ -52,7 +53,15 @@ def instantiate_model(cfg):
     else:
         raise ValueError(f"Only MixSTE, Manifold-MixSTE and RMCL-Manifold-MixSTE implemented for now. Got option {cfg.model.arch}.")
     model.precision = cfg.model.precision
+    _engine_options(model, cfg)
     return model
+
+
+def _engine_options(model, cfg):
+    """model.f16f8 / model.f16_backward of the config (mp_model_config, ABI v7): the operand form of the qkv / fc1 (/ fc2) layers of a
+    bf16x3 model.  Defaults (0 / false): three bf16 products everywhere, bf16 backward."""
+    model.f16f8 = int(getattr(cfg.model, "f16f8", 0))
+    model.f16_backward = bool(getattr(cfg.model, "f16_backward", False))
 
 
 def synthetic_windows(n, T, device, seed):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 6
+#define MP_ABI_VERSION 7
 
 int mp_abi_version(void);
 const char* mp_last_error(void);
@@ -197,7 +197,8 @@ typedef struct mp_model_config {
   float drop_path_rate;/* stochastic depth: linspace(0, rate, depth) per module (mix_ste.py:70) */
   int max_batch;       /* workspace is sized for this many windows; 0 = layout-only handle (no device memory) */
   int precision;       /* 0 = fp32 matrix cores; 1 = bf16 matrix cores / fp32 accumulate; 2 = "bf16x3": split-precision forward (planar hi/lo
-                        * bf16 operands, three matrix-core products each: within the 1e-4 m MPJPE bound), bf16 backward on the hi planes */
+                        * bf16 operands, three matrix-core products each: within the 1e-4 m MPJPE bound); the backward runs in bf16 on the hi
+                        * planes unless f16_backward (below) moves the qkv / fc1 (/ fc2) layers of an f16f8 model to fp16 operands */
   int rot_rep_dim;     /* 6 (default when 0) or 4: rotation representation the heads emit (pose_decoder.py:22-31) */
   /* mu-parametrisation (model.mup, conf/config.yaml:52) and explicit attention scales; per backbone (rotations / segments), 0 = default:
    *   qk_scale      softmax scale of Attention (mix_ste.py:243-244): default head_dim^-0.5; muP 1 / head_dim
@@ -206,6 +207,20 @@ typedef struct mp_model_config {
    *                 y = W (readout_mult * x) + b with readout_mult = output_mult / width_mult; default 1 */
   float qk_scale_rot, resid_scale_rot, readout_mult_rot;
   float qk_scale_seg, resid_scale_seg, readout_mult_seg;
+  /* ABI v7: the numerics- and scheduling-affecting knobs of ONE model (they were process-wide options / environment variables up to v6;
+   * the library reads no environment variable).  All 0 = the defaults.
+   *   f16f8         precision 2 only, rotations net of a width that is a multiple of 256: 0 (default) = every Linear product as three bf16
+   *                 products of bf16 hi / lo planes; 1 = the qkv and fc1 Linear layers read "f16f8" operands (mp_linear_fwd_f16f8: one fp16
+   *                 product + one block-scaled fp8 correction product per 64 reduction indices); 2 = the fc2 layer as well (needs f16_backward)
+   *   f16_backward  with f16f8 >= 1: 1 = the backward GEMMs of those layers run on fp16 operands - gradients carried as fp16 of S x value,
+   *                 S a power of two chosen per backward on the device, stores saturate at +-65504 and are counted (mp_model_grad_health);
+   *                 0 (default) = bf16 backward on a bf16 copy of those activations
+   *   streams       bit 0 set: the segments net is enqueued on the caller's stream instead of the engine's side stream; bit 1 set: the
+   *                 weight-gradient GEMMs likewise instead of the engine's third stream (debugging / single-queue profiles; results are
+   *                 bit-identical either way) */
+  int f16f8;
+  int f16_backward;
+  int streams;
 } mp_model_config;
 
 int mp_model_create(const mp_model_config* cfg, mp_model** out);
@@ -247,6 +262,12 @@ int mp_model_backward(mp_model* m, const float* flat_params, float* flat_grads, 
 int mp_model_grad_bucket_count(const mp_model* m);
 int mp_model_grad_bucket_info(const mp_model* m, int index, int64_t* offset, int64_t* numel);
 int mp_model_grad_bucket_wait(mp_model* m, int index, void* stream);
+/* Health of the scaled-fp16 gradient operands of the LAST mp_model_backward (f16_backward models; zeros otherwise): copies 4 floats to the
+ * HOST after synchronising `stream`: out[0] = S, the power-of-two scale of that backward; out[1] = number of fp16 gradient elements that
+ * hit the +-65504 clamp (stores saturate, they never write inf); out[2] = number of non-finite gradient elements met at those stores
+ * (written as 0); out[3] = largest |S x value| stored.  A trainer that sees out[1] + out[2] > 0 should redo the step with f16_backward
+ * off or skip it. */
+int mp_model_grad_health(mp_model* m, float* out4_host, void* stream);
 /* intermediate outputs of the last forward (device pointers owned by the model): 0 = head output
  * (K, B*T*17, O), 1 = segment lengths (B, 16), 2 = the DropPath multipliers of the last train-mode forward (layout: mp_model_mask_info);
  * the fp32 residual stream block by block (blocks in execution order STE0, TTE0, STE1, ...; (B*T*N, C) each): 100 + 2 l = after the
@@ -263,10 +284,17 @@ int mp_model_peek_copy(const mp_model* m, int which, float* dst, int64_t numel, 
  * algorithmic FLOPs (and, for the forward / dgrad GEMM classes, algorithmic bytes: every operand read once, every output written
  * once) per class since the last reset and resets. */
 #define MP_PROF_CLASSES 7
+/* The Linear GEMM launches of the same interval by KIND = module * 12 + direction * 4 + layer (module 0 rotations / 1 segments net;
+ * direction 0 forward, 1 dgrad, 2 weight gradient; layer 0 qkv, 1 proj, 2 fc1, 3 fc2: architectures/mix_ste.py:216-222,257-261,280-281):
+ * what mp_prof_collect added up at its last call - elapsed ms, launches, how many of them ran gemm_bf16_persist_kernel, issued matrix-core
+ * FLOPs, algorithmic bytes (forward / dgrad kinds) and 2 M N K - so that a forward instantiation running at 0.14 of the matrix peak is not
+ * averaged with a dgrad running at 0.38.  Arrays of MP_PROF_KINDS entries; all but ms / launches may be NULL. */
+#define MP_PROF_KINDS 24
 int mp_prof_enable(mp_model* m, int on);
 int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops, double* bytes /* nullable: algorithmic bytes, GEMM classes */,
                     double* model_flops /* nullable: 2 M N K of the mathematical products; `flops` counts the matrix-core work issued, 3x that for the
                                          * split-precision forward */);
+int mp_prof_kinds(const mp_model* m, double* ms, int64_t* launches, int64_t* persist_launches, double* flops, double* bytes, double* model_flops);
 
 /* GPU-resident PoseSequenceGenerator (hpe/mh_so3_hpe/data/generators.py:44-219) + PoseFlip
  * (hpe/mh_so3_hpe/augmentations/transforms.py:7-28, functional.py:7-31): cuts B windows of T frames out of pose sequences stored
@@ -331,13 +359,13 @@ int mp_pose_metrics(const float* pred, const int64_t* pred_strides, const float*
 int mp_procrustes_errors(const float* pred, const float* gt, const uint8_t* mask, int64_t N, int J, float pred_scale, float gt_scale,
                          float pck_threshold, float auc_max, int auc_steps, float* out, float* scratch, int64_t scratch_floats, void* stream);
 
-/* test / tuning hooks (no reference counterpart): "gemm_small_tile" (1 = 128x128 GEMM tiles everywhere),
- * "gemm_persist_min_tiles" (output-tile count from which the persistent GEMM kernels are used; 0 = default),
- * "gemm_persist_mode" (0 tiled kernels only, 1 = default: persistent kernel where it applies), "side_streams" (0 = the bones net is
- * enqueued on the caller's stream instead of the engine's side stream; 1 = default), "attn_two_phase" (0 = the one-strip-at-a-time
+/* test / tuning hooks (no reference counterpart; process-wide, they select between kernels that the GPU tests hold to the same results):
+ * "gemm_small_tile" (1 = 128x128 GEMM tiles everywhere), "gemm_persist_min_tiles" (output-tile count from which the persistent GEMM
+ * kernels are used; 0 = default), "gemm_persist_mode" (0 tiled kernels only, 1 = default: persistent kernel where it applies),
+ * "gemm_persist_wgs" (workgroups = CUs the persistent GEMMs occupy; 0 = default: all), "attn_two_phase" (0 = the one-strip-at-a-time
  * split-precision temporal attention forward for every shape; 1 = default: the two-phase kernel for head dim 64 and T > 128),
- * "f16f8_inputs" (models created afterwards in precision 2: 1 = default, the qkv and fc1 Linear layers of a rotations net whose width is a
- * multiple of 256 read "f16f8" operands, their backward runs on fp16 operands; 2 = the fc2 layer as well; 0 = bf16 hi / lo planes everywhere). */
+ * "heads_mfma" (0 = row kernels for the output heads, 1 = default: matrix cores wherever covered, 2 = only from 16 outputs up).
+ * Everything that changes a model's arithmetic or stream use is a field of mp_model_config. */
 int mp_set_option(const char* name, int value);
 
 #ifdef __cplusplus

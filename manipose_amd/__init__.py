@@ -8,3 +8,4 @@ from .architectures import ManifoldMixSTE, MixSTE, RMCLManifoldMixSTE  # noqa: F
 from .data import Skeleton, h36m_skeleton  # noqa: F401
 
 __version__ = "0.1.0"
+from . import ops  # noqa: F401  (registers torch.ops.manipose.*)

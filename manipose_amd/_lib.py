@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MANIPOSE_HIP_LIB") or os.path.join(_HERE, "libmanipos
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "manipose_hip.h")
 
 _lib: Optional[C.CDLL] = None
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 vp, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
@@ -32,7 +32,8 @@ class ModelConfig(C.Structure):
                 ("embed_dim_seg", i32), ("depth_seg", i32), ("num_heads_seg", i32),
                 ("n_hyp", i32), ("drop_path_rate", f32), ("max_batch", i32), ("precision", i32), ("rot_rep_dim", i32),
                 ("qk_scale_rot", f32), ("resid_scale_rot", f32), ("readout_mult_rot", f32),
-                ("qk_scale_seg", f32), ("resid_scale_seg", f32), ("readout_mult_seg", f32)]
+                ("qk_scale_seg", f32), ("resid_scale_seg", f32), ("readout_mult_seg", f32),
+                ("f16f8", i32), ("f16_backward", i32), ("streams", i32)]
 
 
 _SIGNATURES = {
@@ -82,6 +83,7 @@ _SIGNATURES = {
     "mp_model_grad_bucket_count": (i32, [vp]),
     "mp_model_grad_bucket_info": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
     "mp_model_grad_bucket_wait": (i32, [vp, i32, vp]),
+    "mp_model_grad_health": (i32, [vp, C.POINTER(f32), vp]),
     "mp_model_peek": (i32, [vp, i32, C.POINTER(vp), C.POINTER(i64)]),
     "mp_model_peek_copy": (i32, [vp, i32, vp, i64, vp]),
     "mp_gather_windows": (i32, [vp, vp, vp, i32, vp, vp, vp, C.POINTER(i32), vp, vp, i32, i32, i32, vp, vp, vp]),
@@ -93,8 +95,10 @@ _SIGNATURES = {
     "mp_pose_metrics": (i32, [vp, C.POINTER(i64), vp, C.POINTER(i64), vp, i32, i32, i32, f32, f32, f32, f32, i32, i32, vp, vp, vp, i64, vp]),
     "mp_set_option": (i32, [C.c_char_p, i32]),
     "mp_prof_enable": (i32, [vp, i32]),
+    "mp_prof_kinds": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mp_prof_collect": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
+PROF_KINDS = tuple(f"{mod}.{lay}.{d}" for mod in ("rot", "seg") for d in ("fwd", "dgrad", "wgrad") for lay in ("qkv", "proj", "fc1", "fc2"))   # index = mp_prof_kinds kind
 PROF_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "attention", "layernorm", "other", "gemm_persist")   # last: subset of the first two
 
 

@@ -10,17 +10,24 @@ from .engine import LiftEngine
 
 
 class _LiftFunction(torch.autograd.Function):
-    """(x, *params) -> poses[, scores] through mp_model_forward; backward through mp_model_backward."""
+    """(x, *params) -> poses[, scores] through mp_model_forward; backward through mp_model_backward.
+
+    The engine keeps the activations of ONE forward (its arena is sized for one batch).  Ordinary autograd semantics are kept on top of that:
+    when a backward arrives for a forward whose activations have been overwritten since (``l1 = f(model(x1)); l2 = f(model(x2));
+    (l1 + l2).backward()``), that forward is re-run first from the saved input with the same DropPath stream position - the engine is
+    deterministic (same bits), so the gradients are those of the original graph, at the price of one extra forward.  The reference's own
+    loop (one forward, one backward) never pays it."""
 
     @staticmethod
     def forward(ctx, model, x, train, masks, infer, *params):
         eng = model._engine
         model._step_counter += 1
         poses, scores = eng.forward(model._flat, x, train=train, masks=masks, seed=model._seed, step=model._step_counter, infer=infer)
+        ctx.held = [id(eng), eng.forward_serial if not infer else -1]            # the engine forward whose activations belong to this graph node
         ctx.model = model
-        ctx.save_for_backward(x)          # the engine reads x again in the embedding backward: keep it alive
+        ctx.save_for_backward(x) if masks is None else ctx.save_for_backward(x, masks)   # x is read again by the embedding backward
         ctx.has_scores = scores is not None
-        ctx.fwd_id = model._step_counter
+        ctx.fwd = (model._step_counter, bool(train), model._seed)
         if scores is None:
             return poses
         return poses, scores
@@ -28,14 +35,19 @@ class _LiftFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_poses, d_scores=None):
         model = ctx.model
-        if ctx.fwd_id != model._step_counter:
-            raise RuntimeError("manipose_amd: backward() must follow the forward it belongs to (the engine keeps the "
-                               "activations of the last forward only)")
         eng = model._engine
+        step, train, seed = ctx.fwd
+        if eng is None or ctx.held != [id(eng), eng.forward_serial]:         # some other forward (of any caller) has run on the engine since
+            x, *mk = ctx.saved_tensors
+            if eng is None or eng.max_batch < x.shape[0]:
+                raise RuntimeError("manipose_amd: the engine of this forward no longer exists (the model was moved or its batch capacity rebuilt)")
+            eng.forward(model._flat, x, train=train, masks=mk[0] if mk else None, seed=seed, step=step, infer=False)
+            ctx.held = [id(eng), eng.forward_serial]
         flat_grads = torch.zeros_like(model._flat)
         d_poses = d_poses.contiguous()
         d_scores = d_scores.contiguous() if (ctx.has_scores and d_scores is not None) else None
         eng.backward(model._flat, flat_grads, d_poses, d_scores)
+        ctx.held = None                       # (a second backward through a retained graph re-runs the forward: the backward reuses scratch)
         model._last_flat_grad = flat_grads
         grads = tuple(flat_grads[off:off + n].view(p.shape) for (off, n), p in zip(model._slots, model._plist))
         return (None, None, None, None, None) + grads
@@ -58,9 +70,19 @@ class FusedLiftingMixin:
         self._seed = 42
         self._injected_masks: Optional[Dict[str, torch.Tensor]] = None
         self.precision = os.environ.get("MANIPOSE_PRECISION", "fp32")
+        # engine options of THIS model (mp_model_config, ABI v7; read when the engine is (re)built): f16f8 0 / 1 / 2 and f16_backward = the
+        # operand form of the qkv / fc1 (/ fc2) layers of a bf16x3 model (default: three bf16 products everywhere, bf16 backward);
+        # side_stream / wgrad_stream = the engine's two extra HIP streams (off: everything on the caller's stream, same bits)
+        self.f16f8 = 0
+        self.f16_backward = False
+        self.side_stream = True
+        self.wgrad_stream = True
         self.max_batch_hint = 0
 
     # -- engine / flat storage -----------------------------------------------------------------
+    def _engine_options(self) -> dict:
+        return dict(f16f8=int(self.f16f8), f16_backward=bool(self.f16_backward), side_stream=bool(self.side_stream), wgrad_stream=bool(self.wgrad_stream))
+
     def _ensure_engine(self, B: int, device: torch.device):
         if device.type != "cuda":
             raise RuntimeError("manipose_amd: this model runs on MI355X through hand-written HIP kernels only; move the "
@@ -70,7 +92,7 @@ class FusedLiftingMixin:
             with torch.cuda.device(device):
                 self._engine = None
                 eng = LiftEngine(arch=self._arch, max_batch=max(B, self.max_batch_hint), precision=self.precision,
-                                 **self._engine_cfg, **self._scale_cfg())
+                                 **self._engine_cfg, **self._scale_cfg(), **self._engine_options())
             self._engine = eng
             self._flat = None
         if self._flat is None or not self._views_intact():

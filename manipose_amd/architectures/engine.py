@@ -20,7 +20,9 @@ class LiftEngine:
                  num_heads_rot: int, embed_dim_seg: int, depth_seg: int, num_heads_seg: int, n_hyp: int,
                  drop_path_rate: float, max_batch: int, precision: str = "fp32", rot_rep_dim: int = 6, qk_scale_rot: float = 0.0,
                  resid_scale_rot: float = 0.0, readout_mult_rot: float = 0.0, qk_scale_seg: float = 0.0, resid_scale_seg: float = 0.0,
-                 readout_mult_seg: float = 0.0):
+                 readout_mult_seg: float = 0.0, f16f8: int = 0, f16_backward: bool = False, side_stream: bool = True, wgrad_stream: bool = True):
+        """f16f8 / f16_backward / side_stream / wgrad_stream: mp_model_config::f16f8, f16_backward, streams (include/manipose_hip.h) - the
+        operand form of the qkv / fc1 (/ fc2) Linear layers of a bf16x3 model, and which of the engine's two extra streams it uses."""
         self.lib = _lib.load()
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {list(PRECISIONS)}, got {precision}")
@@ -31,7 +33,9 @@ class LiftEngine:
                                     drop_path_rate=drop_path_rate, max_batch=max_batch,
                                     precision=PRECISIONS[precision], rot_rep_dim=rot_rep_dim, qk_scale_rot=qk_scale_rot,
                                     resid_scale_rot=resid_scale_rot, readout_mult_rot=readout_mult_rot, qk_scale_seg=qk_scale_seg,
-                                    resid_scale_seg=resid_scale_seg, readout_mult_seg=readout_mult_seg)
+                                    resid_scale_seg=resid_scale_seg, readout_mult_seg=readout_mult_seg,
+                                    f16f8=int(f16f8), f16_backward=int(bool(f16_backward)),
+                                    streams=(0 if side_stream else 1) | (0 if wgrad_stream else 2))
         self.arch = arch
         self.K = max(1, n_hyp) if arch == "rmcl_manifold" else 1
         self.max_batch = max_batch
@@ -39,6 +43,7 @@ class LiftEngine:
         h = C.c_void_p()
         _lib.check(self.lib.mp_model_create(C.byref(self.cfg), C.byref(h)), "mp_model_create")
         self.handle = h
+        self.forward_serial = 0          # counts mp_model_forward calls: the engine holds the activations of the last one only (_fused.py)
         self.flat_size = int(self.lib.mp_model_flat_size(h))
         self.layout: List[Tuple[str, int, int]] = []
         buf = C.create_string_buffer(256)
@@ -82,6 +87,7 @@ class LiftEngine:
                 masks: Optional[torch.Tensor] = None, seed: int = 0, step: int = 0, infer: bool = False):
         """infer: no backward will follow (torch.no_grad()): the engine skips what only the backward reads."""
         B, T = x.shape[0], x.shape[1]
+        self.forward_serial += 1
         poses = torch.empty(B, self.K, T, 17, 3, dtype=torch.float32, device=x.device)
         scores = torch.empty(B, self.K, T, 1, dtype=torch.float32, device=x.device) if self.arch == "rmcl_manifold" else None
         _lib.check(self.lib.mp_model_forward(self.handle, _lib.ptr(flat_params), _lib.ptr(x), B, _lib.ptr(poses),
@@ -116,6 +122,13 @@ class LiftEngine:
         """Make `stream` wait (on the device) until bucket `index` of the last backward is final."""
         _lib.check(self.lib.mp_model_grad_bucket_wait(self.handle, index, stream.cuda_stream), "mp_model_grad_bucket_wait")
 
+    def grad_health(self) -> Dict[str, float]:
+        """Scaled-fp16 gradient operands of the last backward (f16_backward models): the scale S and how many stores hit the +-65504 clamp /
+        met a non-finite value.  Synchronises the current stream."""
+        out = (C.c_float * 4)()
+        _lib.check(self.lib.mp_model_grad_health(self.handle, out, _lib.stream_ptr()), "mp_model_grad_health")
+        return {"scale": out[0], "saturated": int(out[1]), "non_finite": int(out[2]), "inv_scale": out[3]}
+
     def prof_enable(self, on: bool = True) -> None:
         _lib.check(self.lib.mp_prof_enable(self.handle, int(on)), "mp_prof_enable")
 
@@ -124,3 +137,11 @@ class LiftEngine:
         ms, cnt, fl, by, mf = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
         _lib.check(self.lib.mp_prof_collect(self.handle, ms, cnt, fl, by, mf), "mp_prof_collect")
         return {name: {"ms": ms[i], "launches": int(cnt[i]), "flops": fl[i], "bytes": by[i], "model_flops": mf[i]} for i, name in enumerate(_lib.PROF_CLASSES)}
+
+    def prof_kinds(self) -> Dict[str, Dict[str, float]]:
+        """The Linear GEMM launches of the interval the last prof_collect() closed, by kind ("rot.qkv.fwd", ...: mp_prof_kinds)."""
+        n = len(_lib.PROF_KINDS)
+        ms, cnt, per, fl, by, mf = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        _lib.check(self.lib.mp_prof_kinds(self.handle, ms, cnt, per, fl, by, mf), "mp_prof_kinds")
+        return {name: {"ms": ms[i], "launches": int(cnt[i]), "persist_launches": int(per[i]), "flops": fl[i], "bytes": by[i], "model_flops": mf[i]}
+                for i, name in enumerate(_lib.PROF_KINDS) if cnt[i] > 0}

@@ -172,12 +172,10 @@ __device__ __forceinline__ void store4(bf16* p, const f32x4& v, float s) {
 
 // gradient outputs (dQ, dK, dV) of the backward kernels: bf16, or - gout != 0 - fp16 of gout * value (a layer whose dgrad / weight-gradient GEMMs
 // run on fp16 operands: kernels.h GemmB16Args::f16; gout is a power of two that lifts the gradients into fp16's normal range)
-__device__ __forceinline__ void store4g(bf16* p, const f32x4& v, float s, float gout) {
+__device__ __forceinline__ void store4g(bf16* p, const f32x4& v, float s, float gout, unsigned* __restrict__ cnt) {
   if (gout != 0.f) {
-    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
     s *= gout;
-    const h4_t h = {(_Float16)(v[0] * s), (_Float16)(v[1] * s), (_Float16)(v[2] * s), (_Float16)(v[3] * s)};
-    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
+    *reinterpret_cast<uint2*>(p) = sat_f16x4(v[0] * s, v[1] * s, v[2] * s, v[3] * s, cnt);      // saturating: common.h
   } else store4(p, v, s);
 }
 // set by the engine for the backward launches issued next on this thread: device address of the scale (null = bf16 outputs); see store4g
@@ -300,6 +298,7 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB, NW = 16, UNR = NTC ? NTC / 2 : 1;
   const float gout = gout_p != nullptr ? *gout_p : 0.f;      // this backward's gradient scale (engine: grad_scale_kernel), or bf16 outputs
+  unsigned* const gcnt = gout_p != nullptr ? reinterpret_cast<unsigned*>(const_cast<float*>(gout_p)) + 4 : nullptr;      // its saturation counters
   const int rows = NTC ? TP : (T + 31) & ~31, nw = NTC ? NW : (int)(blockDim.x >> 6);     // short windows: see the forward kernel
   char* Qs = sm;
   char* Ks = Qs + rows * ROWB;
@@ -413,7 +412,7 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
     }
     if (tq < T) {
 #pragma unroll
-      for (int db = 0; db < DB; ++db) store4g(dq_base + (long)tq * rs3 + 16 * db + 4 * g, dq[db], scale, gout);
+      for (int db = 0; db < DB; ++db) store4g(dq_base + (long)tq * rs3 + 16 * db + 4 * g, dq[db], scale, gout, gcnt);
     }
   }
 #ifdef MP_GEMM_DIAG
@@ -463,8 +462,8 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
     if (tk < T) {
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        store4g(dq_base + C + (long)tk * rs3 + 16 * db + 4 * g, dk[db], scale, gout);
-        store4g(dq_base + 2 * C + (long)tk * rs3 + 16 * db + 4 * g, dv[db], 1.0f, gout);
+        store4g(dq_base + C + (long)tk * rs3 + 16 * db + 4 * g, dk[db], scale, gout, gcnt);
+        store4g(dq_base + 2 * C + (long)tk * rs3 + 16 * db + 4 * g, dv[db], 1.0f, gout, gcnt);
       }
     }
   }
@@ -611,6 +610,7 @@ template <int D>
 __global__ __launch_bounds__(512) void attn_smfma_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                                bf16* __restrict__ dqkv, int N, int C, int H, float scale, const float* __restrict__ gout_p) {
   const float gout = gout_p != nullptr ? *gout_p : 0.f;
+  unsigned* const gcnt = gout_p != nullptr ? reinterpret_cast<unsigned*>(const_cast<float*>(gout_p)) + 4 : nullptr;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int KS = ACfg<D>::KS, DB = ACfg<D>::DB;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(512) void attn_smfma_bwd_kernel(const bf16* __restr
     for (int db = 0; db < DB; ++db) {
       f32x4 dq = {0.f, 0.f, 0.f, 0.f};
       dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokT<D>(sm, pitch, ok, db, lane, N), bds, dq, 0, 0, 0);
-      if (tq < N) store4g(dbase + (long)tq * 3 * C + 16 * db + 4 * g, dq, scale, gout);
+      if (tq < N) store4g(dbase + (long)tq * 3 * C + 16 * db + 4 * g, dq, scale, gout, gcnt);
     }
   }
   // ---- pass B ([query][key] orientation): dK, dV.  Row statistics come from pass A's column statistics by shuffle ----
@@ -728,8 +728,8 @@ __global__ __launch_bounds__(512) void attn_smfma_bwd_kernel(const bf16* __restr
       dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokT<D>(gs, gpitch, og, db, lane, N), bp, dv, 0, 0, 0);
       dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokT<D>(sm, pitch, oq, db, lane, N), bds, dk, 0, 0, 0);
       if (tk < N) {
-        store4g(dbase + C + (long)tk * 3 * C + 16 * db + 4 * g, dk, scale, gout);
-        store4g(dbase + 2 * C + (long)tk * 3 * C + 16 * db + 4 * g, dv, 1.0f, gout);
+        store4g(dbase + C + (long)tk * 3 * C + 16 * db + 4 * g, dk, scale, gout, gcnt);
+        store4g(dbase + 2 * C + (long)tk * 3 * C + 16 * db + 4 * g, dv, 1.0f, gout, gcnt);
       }
     }
   }

@@ -282,17 +282,17 @@ int mp_pose_metrics(const float* pred, const int64_t* pred_strides, const float*
                       scale_align, out, len0, scratch, (long)scratch_floats, (hipStream_t)stream);
 }
 
-/* test / tuning hooks: "gemm_small_tile" (1 = 128x128 tiles everywhere), "gemm_persist_min_tiles" (tile count from which the
- * persistent GEMM kernels run; 0 = default), "gemm_persist_mode" (0 tiled kernels only, 1 persistent kernel where it applies) */
+/* test / tuning hooks (include/manipose_hip.h): process-wide selectors between kernels that are tested to agree; everything that changes a
+ * model's arithmetic or its stream use is a field of mp_model_config */
 int mp_set_option(const char* name, int value) {
   MP_CHECK(name, MP_ERR_ARG, "mp_set_option: null name");
   if (!strcmp(name, "gemm_small_tile")) { gemm_bf16_force_small_tile(value != 0); return MP_OK; }
   if (!strcmp(name, "gemm_persist_min_tiles")) { gemm_bf16_persist_min_tiles(value); return MP_OK; }
   if (!strcmp(name, "gemm_persist_mode")) { gemm_bf16_persist_mode(value); return MP_OK; }
-  if (!strcmp(name, "side_streams")) { engine_side_streams(value); return MP_OK; }
+  if (!strcmp(name, "gemm_persist_wgs")) { gemm_bf16_persist_wgs(value); return MP_OK; }
   if (!strcmp(name, "attn_two_phase")) { attn_two_phase(value); return MP_OK; }
-  if (!strcmp(name, "f16f8_inputs")) { engine_f16f8(value); return MP_OK; }
-  MP_CHECK(false, MP_ERR_ARG, "mp_set_option: unknown option '%s'", name);
+  if (!strcmp(name, "heads_mfma")) { heads_mfma_mode(value); return MP_OK; }
+  MP_CHECK(false, MP_ERR_ARG, "mp_set_option: unknown option '%s' (side_streams / f16f8_inputs became mp_model_config::streams / f16f8 in ABI v7)", name);
 }
 
 }  // extern "C"

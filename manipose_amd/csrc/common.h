@@ -97,11 +97,35 @@ struct f16f8 { unsigned short v; };
 // GEMM epilogue form: p = the element in the fp16 plane, lo_off = distance to the correction plane in 2-byte elements (both planes have 2 bytes per element)
 __device__ __forceinline__ void st4_f16f8(f16f8* hi16, char* corr8, float4 v, bool weight);
 __device__ __forceinline__ void st4(f16f8* p, float4 v, long lo_off) { st4_f16f8(p, reinterpret_cast<char*>(p + lo_off), v, false); }
-// four values as fp16 of s * value (a gradient operand carried as scaled fp16: kernels.h GemmB16Args::f16 / gout)
-__device__ __forceinline__ void st4_f16(void* p, float4 v, float s) {
+// Four gradient values as SATURATING fp16 (a gradient operand carried as fp16 of S x value: kernels.h GemmB16Args::f16 / gout).  fp16 ends at
+// 65504 and S is chosen from the loss gradient only (grad_scale, elementwise.hip), so an interior gradient far above it must not become inf -
+// inf in one operand element is NaN in a whole weight gradient, and Adam spreads that over every weight.  Values beyond +-65504 are clamped,
+// non-finite ones are written as 0, and both are counted in cnt[0] / cnt[1] (mp_model::gsc + 4; mp_model_grad_health) - on a path that
+// costs three max, three adds and a compare per four elements while nothing saturates.
+__device__ __forceinline__ uint2 sat_f16x4(float a, float b, float c, float d, unsigned* __restrict__ cnt) {
   typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-  const h4_t h = {(_Float16)(v.x * s), (_Float16)(v.y * s), (_Float16)(v.z * s), (_Float16)(v.w * s)};
-  *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
+  const float m = fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d)));      // (fmaxf drops a NaN operand: the sum below catches those)
+  const float t = (a + b) + (c + d);
+  if (__builtin_expect(!(m <= 65504.f) || t != t, 0)) {
+    unsigned ns = 0, nn = 0;
+    float* const v[4] = {&a, &b, &c, &d};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x = *v[i];
+      if (!(fabsf(x) <= 3.0e38f)) { x = 0.f; ++nn; }                  // NaN or inf
+      else if (fabsf(x) > 65504.f) { x = copysignf(65504.f, x); ++ns; }
+      *v[i] = x;
+    }
+    if (cnt != nullptr) {
+      if (ns) atomicAdd(cnt, ns);
+      if (nn) atomicAdd(cnt + 1, nn);
+    }
+  }
+  const h4_t h = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+  return __builtin_bit_cast(uint2, h);
+}
+__device__ __forceinline__ void st4_f16(void* p, float4 v, float s, unsigned* __restrict__ cnt) {
+  *reinterpret_cast<uint2*>(p) = sat_f16x4(v.x * s, v.y * s, v.z * s, v.w * s, cnt);
 }
 __device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float d) {
   a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
@@ -134,8 +158,11 @@ __device__ __forceinline__ float4 ld4(const bf16p* p, long lo_off) {
 // rows: different in every run, more often with other streams busy, with every s_waitcnt in place and also when the register had been
 // written by the VALU.  Seen in two places: the tiled GEMM's recomputed-LayerNorm residual epilogue ((mean, rstd) pair: 2 mm errors on
 // the segment lengths at the benchmark's batch) and the LayerNorm backward (non-reproducible gradients).  Such ops only come out of the
-// SLP vectoriser pairing scalar code, so the library is built with -fno-slp-vectorize (build.sh): the explicitly vector-typed packed
-// math (GELU, softmax, accumulator scaling) stays and never needs that operand form; the step time did not change.
+// SLP vectoriser pairing scalar code, so the library is built with -fno-slp-vectorize - and, since later in round 3, with the packed fp32
+// instructions switched off altogether (build.sh: -target-feature -packed-fp32-ops; the vector-typed GELU / softmax source below compiles
+// to plain v_mul / v_fma), so NO v_pk_*_f32 exists in the device code; the step time did not change.
+// Status of the diagnosis (round 4): tools/probes/pk_opsel.hip isolates the operand form in a stand-alone kernel; its result is recorded in
+// profiles/r04_pk_opsel_probe.log and DESIGN.md section 2 - read that before citing this as a hardware erratum.
 // tools/scan_pk_opsel.py audits the generated code of every kernel for the operand form (a CPU test runs it), and the reproducibility
 // tests in tests/test_gpu_parity.py hold two identical training steps to identical bits.
 // lone(): additionally gives a memory-loaded scalar that is multiplied into several values a VALU-written register of its own.

@@ -158,6 +158,8 @@ int ln_fwd(const LnFwdArgs& a_in, int out_mode, hipStream_t st) {
 // dxhat = dy * gamma.  dgamma/dbeta: per-wave register sums -> per-block LDS sum -> partial rows
 // in scratch -> reduce_partials_kernel (deterministic, no atomics).
 // ---------------------------------------------------------------------------------------------
+// saturation / non-finite counters of the scaled-fp16 gradient stores (common.h sat_f16x4): 4 floats behind the scale (mp_model::gsc)
+__device__ __forceinline__ unsigned* gs_cnt(const float* gsc) { return reinterpret_cast<unsigned*>(const_cast<float*>(gsc)) + 4; }
 constexpr int LNB_GRID = 1024;   // 4 workgroups (16 waves) per CU
 
 // V float4 per lane (C <= 256 V); R rows in flight per wave: every load of the R rows (x, dy, skip gradient, statistics, DropPath
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
           if (dskip != nullptr) { o.x += rs * k[r][i].x; o.y += rs * k[r][i].y; o.z += rs * k[r][i].z; o.w += rs * k[r][i].w; }
           st4(dx + (long)m * C + c, o);
           if (dx_b16 != nullptr) {   // 2-byte copy, pre-scaled by the consumer branch's DropPath mask: A operand of its GEMMs - bf16, or (b16_gs != 0) fp16 of b16_gs x value
-            if (b16_gs != 0.f) st4_f16(dx_b16 + (long)m * C + c, o, ms[r] * b16_gs);
+            if (b16_gs != 0.f) st4_f16(dx_b16 + (long)m * C + c, o, ms[r] * b16_gs, gs_cnt(b16_gs_p));
             else st4(dx_b16 + (long)m * C + c, make_float4(o.x * ms[r], o.y * ms[r], o.z * ms[r], o.w * ms[r]));
           }
         }
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy
                                        rstd0[r] * (d[i].z - u1 - xh[i].z * u2), rstd0[r] * (d[i].w - u1 - xh[i].w * u2));
           st4(dx + (long)m * C + c, o);
           if (dx_b16 != nullptr) {
-            if (b16_gs != 0.f) st4_f16(dx_b16 + (long)m * C + c, o, ms[r] * b16_gs);
+            if (b16_gs != 0.f) st4_f16(dx_b16 + (long)m * C + c, o, ms[r] * b16_gs, gs_cnt(b16_gs_p));
             else st4(dx_b16 + (long)m * C + c, make_float4(o.x * ms[r], o.y * ms[r], o.z * ms[r], o.w * ms[r]));
           }
         }
@@ -508,7 +510,8 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
 // Gradient scale of one backward (the layers whose backward GEMMs run on fp16 operands): S = the power of two that brings the largest
 // incoming gradient |d_poses|, |d_scores| into [1, 2) - every gradient operand of those layers is carried as fp16 of S x value, so the
 // loss may be normalised any way (a summed loss gives gradients ~1e7 times those of a mean over a 79-window batch; a fixed scale
-// overflowed fp16 on the former).  gsc[0] = S, gsc[1] = 1 / S, gsc[2] = scratch (bits of the maximum), gsc[3] = 1.
+// overflowed fp16 on the former).  gsc[0] = S, gsc[1] = 1 / S, gsc[2] = scratch (bits of the maximum), gsc[3] = 1, gsc[4], gsc[5] = counters (unsigned) of the
+// fp16 gradient stores of this backward that hit the +-65504 clamp / met a non-finite value (mp_model_grad_health).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void grad_amax_kernel(const float* __restrict__ a, long na, const float* __restrict__ b, long nb, unsigned* __restrict__ out) {
   float mx = 0.f;
@@ -525,6 +528,7 @@ __global__ void grad_scale_kernel(float* gsc) {
   gsc[0] = __uint_as_float((unsigned)(254 - be) << 23);
   gsc[1] = __uint_as_float((unsigned)be << 23);
   gsc[3] = 1.0f;
+  gsc[4] = 0.f; gsc[5] = 0.f;      // this backward's saturation / non-finite counters (unsigned, common.h sat_f16x4)
 }
 int grad_scale(const float* d_poses, long n_poses, const float* d_scores, long n_scores, float* gsc, hipStream_t st) {
   if (hipMemsetAsync(gsc + 2, 0, sizeof(float), st) != hipSuccess) { set_error("grad_scale: memset failed"); return MP_ERR_HIP; }

@@ -3,6 +3,7 @@
 // one kernel stream, no host synchronisation, no tensor transposes.  The Python nn.Module mirror
 // (manipose_amd/architectures) only hands over device pointers.
 #include <stdlib.h>
+#include <string.h>
 #include <string>
 #include <vector>
 #include "common.h"
@@ -11,31 +12,23 @@
 
 namespace mp {
 
-// debugging hook (mp_set_option("side_streams", 0)): enqueue the bones net on the caller's stream instead of the engine's side stream
-static int g_side_streams = 1;
-void engine_side_streams(int on) { g_side_streams = on; }
-// "f16f8" inputs of the qkv and fc1 Linear layers (precision 2, widths that are multiples of 256): -1 = MANIPOSE_F16F8 or the default (1),
-// 0 / 1 / 2 = mp_set_option("f16f8_inputs", v) (2: the fc2 layer as well); read when a model is created
-static int g_f16f8 = -1;
-void engine_f16f8(int on) { g_f16f8 = on; }
 bool attn_tmfma_supported(int T, int D);            // attention_mfma.hip
 bool attn_smfma_supported(int N, int D, int H);
-// Gradient operands of a layer whose backward GEMMs run on fp16 operands are carried as fp16 of S x value, S a power of two chosen per
-// backward on the device (grad_scale, elementwise.hip: the largest incoming gradient lands in [1, 2), which leaves fp16 a factor 6.5e4 of
-// headroom above it and 1.6e4 of normal range below); producers and consumers read S and 1 / S from mp_model::gsc.
-static bool f16_backward_wanted() {
-  const char* e = getenv("MANIPOSE_F16BWD");
-  return e ? atoi(e) != 0 : true;
-}
-static int f16f8_level() {      // 0 off, 1 (default) the qkv and fc1 layers, 2 the fc2 layer as well (neutral in the step: DESIGN section 5)
-  if (g_f16f8 >= 0) return g_f16f8;
-  const char* e = getenv("MANIPOSE_F16F8");
-  return e ? atoi(e) : 1;
-}
-static bool f16f8_wanted() { return f16f8_level() != 0; }
+// Gradient operands of a layer whose backward GEMMs run on fp16 operands (mp_model_config::f16_backward) are carried as fp16 of S x value,
+// S a power of two chosen per backward on the device (grad_scale, elementwise.hip: the largest incoming gradient lands in [1, 2), which
+// leaves fp16 a factor 6.5e4 of headroom above it and 1.6e4 of normal range below); producers and consumers read S and 1 / S from
+// mp_model::gsc, every store saturates and is counted there (common.h sat_f16x4, mp_model_grad_health).
 
 const char* last_error();
 long wgrad_f32_slab_floats(int Mtok, int Nout, int Kin);
+
+// the attention backward launches issued inside the guard's scope write dQ / dK / dV as scaled fp16 (null: bf16); reset on every exit path
+struct AttnGradF16Scope {
+  explicit AttnGradF16Scope(const float* gsc) { attn_grad_f16_override(gsc); }
+  ~AttnGradF16Scope() { attn_grad_f16_override(nullptr); }
+  AttnGradF16Scope(const AttnGradF16Scope&) = delete;
+  AttnGradF16Scope& operator=(const AttnGradF16Scope&) = delete;
+};
 
 struct ParamDesc { std::string name; long offset, numel; };
 struct BlockP { int n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b; };
@@ -123,6 +116,10 @@ struct mp_model {
   std::vector<int> ev_cls;
   std::vector<double> ev_flops, ev_bytes, ev_mflops;   // issued matrix-core flops, algorithmic bytes, flops of the mathematical product (2 M N K)
   std::vector<char> ev_tag;              // 1: the launch ran gemm_bf16_persist_kernel
+  std::vector<signed char> ev_kind;      // Linear GEMM launches: module * 12 + direction * 4 + layer (mp_prof_kinds), -1 otherwise
+  int cur_kind = -1;                     // kind of the GEMM being enqueued (set by the backbone code around linear_fwd / dgrad / wgrad)
+  double kind_ms[MP_PROF_KINDS] = {}, kind_flops[MP_PROF_KINDS] = {}, kind_bytes[MP_PROF_KINDS] = {}, kind_mflops[MP_PROF_KINDS] = {};
+  int64_t kind_launches[MP_PROF_KINDS] = {}, kind_persist[MP_PROF_KINDS] = {};
   size_t ev_used = 0;
 };
 
@@ -306,6 +303,8 @@ static void use_scratch(mp_model* m, int i) {
 }
 
 // ---- profiling helpers -------------------------------------------------------------------------
+enum { PC_GEMM_FWD = 0, PC_GEMM_DGRAD = 1, PC_GEMM_WGRAD = 2, PC_ATTN = 3, PC_LN = 4, PC_OTHER = 5 };
+enum { LK_QKV = 0, LK_PROJ = 1, LK_FC1 = 2, LK_FC2 = 3 };
 struct ProfScope {
   mp_model* m;
   hipStream_t st;
@@ -317,6 +316,7 @@ struct ProfScope {
       m->ev_flops.push_back(flops);
       m->ev_bytes.push_back(bytes);
       m->ev_mflops.push_back(mflops >= 0.0 ? mflops : flops);
+      m->ev_kind.push_back((signed char)((cls <= PC_GEMM_WGRAD) ? m->cur_kind : -1));
       (void)gemm_bf16_take_last_persist();
       (void)hipEventRecord(m->ev[m->ev_used], st);
     }
@@ -342,7 +342,6 @@ struct ProfScope {
     int rc__ = (call);                                 \
     if (rc__) return rc__;                             \
   } while (0)
-enum { PC_GEMM_FWD = 0, PC_GEMM_DGRAD = 1, PC_GEMM_WGRAD = 2, PC_ATTN = 3, PC_LN = 4, PC_OTHER = 5 };
 
 static const float* P(const mp_model* m, const float* flat, int idx) { return flat + m->params[idx].offset; }
 static float* G(const mp_model* m, float* flat, int idx) { return flat + m->params[idx].offset; }
@@ -407,6 +406,7 @@ static int linear_dgrad(mp_model* m, hipStream_t st, const float* fp, const void
   GemmB16Args g = {};
   g.A = dY; g.lda = N; g.B = m->wbf + m->params[widx].offset; g.ldb = K; g.C = dX; g.ldc = K; g.M = (int)M; g.N = K; g.K = N; g.Z = Z;
   g.gout = gout;
+  g.gsat = gout != nullptr ? reinterpret_cast<unsigned*>(m->gsc + 4) : nullptr;
   if (f16) {      // dY = fp16(S x gradient), weights from the fp16 plane of the f16f8 shadow
     g.f16 = 1;      // (the bf16 output keeps dY's scale: the LayerNorm backward that reads it gets dy_scale = 1 / S)
     g.B = reinterpret_cast<const char*>(m->w16) + m->params[widx].offset * 2;
@@ -455,6 +455,7 @@ static int backbone_fwd(mp_model* m, Module& md, const float* fp, int B, hipStre
   attn_scale_override(md.qk_scale);
   m->cur_rs = md.rs;
   const int rc = backbone_fwd_impl(m, md, fp, B, st);
+  m->cur_kind = -1;
   attn_scale_override(0.f);
   m->cur_rs = 1.0f;
   return rc;
@@ -463,6 +464,7 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
   attn_scale_override(md.qk_scale);
   m->cur_rs = md.rs;
   const int rc = backbone_bwd_impl(m, md, fp, fg, B, st);
+  m->cur_kind = -1;
   attn_scale_override(0.f);
   m->cur_rs = 1.0f;
   return rc;
@@ -487,6 +489,7 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     BlockWS& w = md.ws[l];
     const bool spatial = (l % 2 == 0);
     const int mode = spatial ? 1 : 2;
+    m->cur_kind = (md.is_rot ? 0 : 12) + 0 * 4 + LK_QKV;
     int rc = linear_fwd(m, st, fp, md.f8 ? w.a1h : w.a1, q.qkvw, q.qkvb, w.qkv, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr,
                         w.a1l, w.qkvl, md.f8);
     if (rc) return rc;
@@ -500,10 +503,12 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     const bool lazy_in = lazy_block_input(m, md, l);
     if (lazy_in) {
       const bool pspatial = ((l - 1) % 2 == 0);
+      m->cur_kind = (md.is_rot ? 0 : 12) + 0 * 4 + LK_PROJ;
       rc = linear_fwd(m, st, fp, w.ao, q.pw, q.pb, w.x_mid, M, C, C, EPI_BIAS_RESID, nullptr, md.ws[l - 1].x_out,
                       branch_mask(m, md, l, 0, B, m->train), mode, T, N, md.ws[l - 1].stp, P(m, fp, pspatial ? md.sn_w : md.tn_w),
                       P(m, fp, pspatial ? md.sn_b : md.tn_b), w.aol);
     } else {
+      m->cur_kind = (md.is_rot ? 0 : 12) + 0 * 4 + LK_PROJ;
       rc = linear_fwd(m, st, fp, w.ao, q.pw, q.pb, w.x_mid, M, C, C, EPI_BIAS_RESID, nullptr, w.x_in,
                       branch_mask(m, md, l, 0, B, m->train), mode, T, N, nullptr, nullptr, nullptr, w.aol);
     }
@@ -516,9 +521,11 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
       RUN(PC_LN, 0, ln_fwd(a, half, st));
     }
     // (inference, precision >= 1: gelu' - read by the fc2 dgrad only - is not written)
+    m->cur_kind = (md.is_rot ? 0 : 12) + 0 * 4 + LK_FC1;
     rc = linear_fwd(m, st, fp, md.f8 ? w.a2h : w.a2, q.f1w, q.f1b, w.f, M, 2 * C, C, EPI_BIAS_GELU, (m->infer && m->cfg.precision >= 1) ? nullptr : w.z, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr, w.a2l, w.fl,
                     md.f8, md.f8m);
     if (rc) return rc;
+    m->cur_kind = (md.is_rot ? 0 : 12) + 0 * 4 + LK_FC2;
     rc = linear_fwd(m, st, fp, w.f, q.f2w, q.f2b, w.x_out, M, C, 2 * C, EPI_BIAS_RESID, nullptr, w.x_mid,
                     branch_mask(m, md, l, 1, B, m->train), mode, T, N, nullptr, nullptr, nullptr, w.fl, nullptr, md.f8m);
     if (rc) return rc;
@@ -584,18 +591,22 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
       gb = m->tmpMask;
     }
     E_READY(0);                                                    // gb is ready
+    m->cur_kind = (md.is_rot ? 0 : 12) + 2 * 4 + LK_FC2;
     int rc = linear_wgrad(m, sw, gb, 0, w.f, G(m, fg, q.f2w), G(m, fg, q.f2b), M, C, 2 * C, md.f8m);      // f8m: gb and f are fp16
     if (rc) return rc;
     W_DONE(0);
     if (have_prev) WAIT_W(par ^ 1, 1);                             // previous block's fc1 wgrad still reads tmp2C
     // f8g: dz leaves as scaled fp16; f8m: gb already carries the scale (fp16 operands), so the epilogue adds none
+    m->cur_kind = (md.is_rot ? 0 : 12) + 1 * 4 + LK_FC2;
     rc = linear_dgrad(m, st, fp, gb, 0, q.f2w, m->tmp2C, 0, M, C, 2 * C, w.z, md.f8m, md.f8m ? m->gsc + 3 : (md.f8g ? m->gsc : nullptr));
     if (rc) return rc;
     // (c) fc1
     E_READY(1);                                                    // dz (tmp2C) is ready
+    m->cur_kind = (md.is_rot ? 0 : 12) + 2 * 4 + LK_FC1;
     rc = linear_wgrad(m, sw, m->tmp2C, 0, md.f8g ? w.a2h : w.a2, G(m, fg, q.f1w), G(m, fg, q.f1b), M, 2 * C, C, md.f8g);
     if (rc) return rc;
     W_DONE(1);
+    m->cur_kind = (md.is_rot ? 0 : 12) + 1 * 4 + LK_FC1;
     rc = linear_dgrad(m, st, fp, m->tmp2C, 0, q.f1w, m->tmpC, 0, M, 2 * C, C, nullptr, md.f8g);     // d(norm2 out): bf16 in precision 1
     if (rc) return rc;
     WAIT_W(par, 0);                                                // the fc2 wgrad must be done with gb before (d) rewrites it
@@ -612,22 +623,27 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
       gb = m->tmpMask;
     }
     E_READY(2);                                                    // gb (second half of the block) is ready
+    m->cur_kind = (md.is_rot ? 0 : 12) + 2 * 4 + LK_PROJ;
     rc = linear_wgrad(m, sw, gb, 0, w.ao, G(m, fg, q.pw), G(m, fg, q.pb), M, C, C);
     if (rc) return rc;
     W_DONE(2);
+    m->cur_kind = (md.is_rot ? 0 : 12) + 1 * 4 + LK_PROJ;
     rc = linear_dgrad(m, st, fp, gb, 0, q.pw, m->tmpC, 0, M, C, C, nullptr);          // d(attention out): bf16 in bf16 mode
     if (rc) return rc;
     if (have_prev) WAIT_W(par ^ 1, 3);                             // previous block's qkv wgrad still reads tmp3C
     // (f) attention core
-    attn_grad_f16_override(md.f8g ? m->gsc : nullptr);        // f8g: dqkv leaves as scaled fp16 (its two consumers below run on fp16 operands)
-    if (spatial) RUN(PC_ATTN, 10.0 * B * T * N * N * C, attn_spatial_bwd(w.qkv, m->tmpC, m->tmp3C, half, B, T, N, C, H, st));
-    else RUN(PC_ATTN, 10.0 * B * N * (double)T * T * C, attn_temporal_bwd(w.qkv, w.ao, m->tmpC, w.lse, m->delta, m->tmp3C, half, B, T, N, C, H, st));
-    attn_grad_f16_override(nullptr);
+    {
+      AttnGradF16Scope f16_out(md.f8g ? m->gsc : nullptr);      // f8g: dqkv leaves as scaled fp16 (its two consumers below run on fp16 operands)
+      if (spatial) RUN(PC_ATTN, 10.0 * B * T * N * N * C, attn_spatial_bwd(w.qkv, m->tmpC, m->tmp3C, half, B, T, N, C, H, st));
+      else RUN(PC_ATTN, 10.0 * B * N * (double)T * T * C, attn_temporal_bwd(w.qkv, w.ao, m->tmpC, w.lse, m->delta, m->tmp3C, half, B, T, N, C, H, st));
+    }
     // (g) qkv
     E_READY(3);                                                    // dqkv (tmp3C) is ready
+    m->cur_kind = (md.is_rot ? 0 : 12) + 2 * 4 + LK_QKV;
     rc = linear_wgrad(m, sw, m->tmp3C, 0, md.f8g ? w.a1h : w.a1, G(m, fg, q.qkvw), G(m, fg, q.qkvb), M, 3 * C, C, md.f8g);
     if (rc) return rc;
     W_DONE(3);
+    m->cur_kind = (md.is_rot ? 0 : 12) + 1 * 4 + LK_QKV;
     rc = linear_dgrad(m, st, fp, m->tmp3C, 0, q.qkvw, m->tmpC, 0, M, 3 * C, C, nullptr, md.f8g);   // d(norm1 out): bf16 in precision 1
     if (rc) return rc;
     WAIT_W(par, 2);                                                // the proj wgrad must be done with gb before (h) rewrites it
@@ -660,7 +676,6 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
         MP_HIP(hipStreamWaitEvent(sw, m->ev_sync, 0));
       }
       MP_HIP(hipEventRecord(m->ev_bucket[l / 2], sw));
-      m->buckets_recorded = true;
     }
   }
   if (wasync && have_prev) {    // the last block's fc1 / qkv weight gradients
@@ -733,6 +748,11 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   MP_CHECK(cfg->arch != 0 || (cfg->n_hyp >= 1 && cfg->n_hyp <= 8), MP_ERR_ARG, "mp_model_create: n_hyp in 1..8");
   MP_CHECK(cfg->rot_rep_dim == 0 || cfg->rot_rep_dim == 4 || cfg->rot_rep_dim == 6, MP_ERR_ARG,
            "mp_model_create: rot_rep_dim %d (4 or 6; 0 = 6)", cfg->rot_rep_dim);
+  MP_CHECK(cfg->f16f8 >= 0 && cfg->f16f8 <= 2 && (cfg->f16_backward == 0 || cfg->f16_backward == 1) && cfg->streams >= 0 && cfg->streams <= 3, MP_ERR_ARG,
+           "mp_model_create: f16f8 %d (0..2), f16_backward %d (0/1), streams %d (bit set 0..3)", cfg->f16f8, cfg->f16_backward, cfg->streams);
+  MP_CHECK(cfg->f16f8 == 0 || cfg->precision == 2, MP_ERR_ARG, "mp_model_create: f16f8 operands belong to precision 2 (bf16x3)");
+  MP_CHECK(cfg->f16_backward == 0 || cfg->f16f8 >= 1, MP_ERR_ARG, "mp_model_create: f16_backward needs f16f8 >= 1");
+  MP_CHECK(cfg->f16f8 < 2 || cfg->f16_backward == 1, MP_ERR_ARG, "mp_model_create: f16f8 = 2 (the fc2 layer) needs f16_backward");
   mp_model* m = new mp_model();
   m->cfg = *cfg;
   if (cfg->rot_rep_dim == 0) m->cfg.rot_rep_dim = 6;
@@ -759,12 +779,12 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
     return MP_OK;
   }
   // f16f8 inputs: the rotations net when its width lets every such GEMM run the persistent 256 x 256 kernel (N = 3 C, 2 C multiples of 256, K = C of 64)
-  m->rot.f8 = cfg->precision == 2 && f16f8_wanted() && m->rot.C % 256 == 0 && m->rot.C >= 256;
+  m->rot.f8 = cfg->precision == 2 && cfg->f16f8 >= 1 && m->rot.C % 256 == 0 && m->rot.C >= 256;
   m->seg.f8 = false;
   m->rot.f8m = false;
-  m->rot.f8g = m->rot.f8 && f16_backward_wanted() && attn_tmfma_supported(cfg->num_frame, m->rot.C / m->rot.H) &&
+  m->rot.f8g = m->rot.f8 && cfg->f16_backward != 0 && attn_tmfma_supported(cfg->num_frame, m->rot.C / m->rot.H) &&
                attn_smfma_supported(m->rot.N, m->rot.C / m->rot.H, m->rot.H);
-  m->rot.f8m = m->rot.f8g && (m->rot.rs == 0.f || m->rot.rs == 1.0f) && f16f8_level() >= 2;      // (a residual scale other than 1 - muP - keeps the tiled bf16x3 fc2)
+  m->rot.f8m = m->rot.f8g && (m->rot.rs == 0.f || m->rot.rs == 1.0f) && cfg->f16f8 >= 2;      // (a residual scale other than 1 - muP - keeps the tiled bf16x3 fc2)
   Bump dry;
   carve_all(m, dry);
   m->arena_bytes = dry.off;
@@ -779,16 +799,7 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   real.base = m->arena;
   carve_all(m, real);
   use_scratch(m, 0);
-  // MANIPOSE_SIDE_PRIORITY: queue priority of the side streams relative to the caller's stream (probe; default 0 = same priority).
-  // digit 1 = bones-net stream, digit 2 = weight-gradient stream: 0 normal, 1 low, 2 high  (e.g. 11 = both low)
-  auto side_stream = [](hipStream_t* st, int which) {
-    const char* e = getenv("MANIPOSE_SIDE_PRIORITY");
-    const int v = e ? atoi(e) : 0, mode = which == 0 ? v % 10 : (v / 10) % 10;
-    if (mode == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, mode == 1 ? least : greatest);
-  };
+  auto side_stream = [](hipStream_t* st, int) { return hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
   if (side_stream(&m->st2, 0) != hipSuccess || hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {
     set_error("mp_model_create: could not create the side stream / events");
@@ -797,8 +808,7 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
     return MP_ERR_HIP;
   }
   {
-    const char* ev = getenv("MANIPOSE_WGRAD_STREAM");
-    m->wgrad_async = !(ev && atoi(ev) == 0);
+    m->wgrad_async = (cfg->streams & 2) == 0;
     bool ok = side_stream(&m->st3, 1) == hipSuccess;
     for (int a = 0; a < 2 && ok; ++a)
       for (int b = 0; b < 4 && ok; ++b)
@@ -900,6 +910,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
   hipStream_t st = (hipStream_t)stream;
   const int T = m->cfg.num_frame, J = m->cfg.num_joints, S = m->cfg.num_bones, K = m->rot.K;
   m->B = B;
+  m->buckets_recorded = false;         // the bucket events belong to a backward of an earlier forward
   m->train = (train & 1) != 0 && m->cfg.drop_path_rate > 0.f;
   m->infer = (train & 2) != 0;         // no backward will follow: tensors only the backward reads are not written
   m->x_in = x;
@@ -923,7 +934,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
   if (m->cfg.precision == 2) RUN(PC_OTHER, 0, cast_to_bf16x2(fp, m->wbf, m->wbf_lo, m->flat_size, st));
   if (m->w16 != nullptr) RUN(PC_OTHER, 0, cast_to_f16f8(fp, m->w16, m->w8, m->flat_size, 1, st));
   // fork: the side stream may start once the masks / bf16 weights above are in place
-  const hipStream_t side = g_side_streams ? m->st2 : st;
+  const hipStream_t side = (m->cfg.streams & 1) ? st : m->st2;
   MP_HIP(hipEventRecord(m->ev_fork, st));
   MP_HIP(hipStreamWaitEvent(side, m->ev_fork, 0));
   use_scratch(m, 0);
@@ -985,6 +996,7 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   hipStream_t st = (hipStream_t)stream;
   const int B = m->B, T = m->cfg.num_frame, J = m->cfg.num_joints, S = m->cfg.num_bones, K = m->rot.K;
   const long Mr = (long)B * T * J, Ms = (long)B * T * S;
+  m->buckets_recorded = false;         // set again below, once every bucket event of THIS backward has been enqueued
   use_scratch(m, 0);
   if (m->rot.f8g) {      // this backward's gradient scale, from the incoming gradients (device side: no host round trip)
     const long np = (long)B * K * T * J * 3, ns = (long)B * K * T;
@@ -1014,7 +1026,7 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     MP_HIP(hipStreamWaitEvent(pst, m->ev_heads, 0));
   }
   // fork: the bones-net backward only needs the per-pose length gradients of the decoder backward
-  const hipStream_t side = g_side_streams ? m->st2 : st;
+  const hipStream_t side = (m->cfg.streams & 1) ? st : m->st2;
   MP_HIP(hipEventRecord(m->ev_fork, st));
   MP_HIP(hipStreamWaitEvent(side, m->ev_fork, 0));
   use_scratch(m, 0);
@@ -1065,9 +1077,25 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     MP_HIP(hipEventRecord(m->ev_heads, pst));
     MP_HIP(hipStreamWaitEvent(st, m->ev_heads, 0));
   }
+  m->buckets_recorded = true;
   return MP_OK;
 }
 
+int mp_model_grad_health(mp_model* m, float* out, void* stream) {
+  MP_CHECK(m && out, MP_ERR_ARG, "mp_model_grad_health: null argument");
+  out[0] = out[1] = out[2] = out[3] = 0.f;
+  if (m->gsc == nullptr || !m->rot.f8g) return MP_OK;
+  float h[8];
+  MP_HIP(hipMemcpyAsync(h, m->gsc, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  MP_HIP(hipStreamSynchronize((hipStream_t)stream));
+  unsigned c[2];
+  memcpy(c, h + 4, sizeof(c));
+  out[0] = h[0]; out[1] = (float)c[0]; out[2] = (float)c[1]; out[3] = h[1];
+  return MP_OK;
+}
+
+// (the bucket LAYOUT is a property of the parameter layout and also answered by a layout-only handle; waiting needs a device model, whose
+// ev_bucket holds exactly rot.depth events - mp_model_grad_bucket_wait checks the index against it)
 int mp_model_grad_bucket_count(const mp_model* m) { return m ? m->rot.depth : 0; }
 
 int mp_model_grad_bucket_info(const mp_model* m, int index, int64_t* offset, int64_t* numel) {
@@ -1083,8 +1111,8 @@ int mp_model_grad_bucket_info(const mp_model* m, int index, int64_t* offset, int
 }
 
 int mp_model_grad_bucket_wait(mp_model* m, int index, void* stream) {
-  MP_CHECK(m && index >= 0 && index < (int)m->ev_bucket.size(), MP_ERR_ARG, "mp_model_grad_bucket_wait: bad index %d", index);
-  MP_CHECK(m->buckets_recorded, MP_ERR_STATE, "mp_model_grad_bucket_wait: no backward has been run");
+  MP_CHECK(m && index >= 0 && index < (int)m->ev_bucket.size(), MP_ERR_ARG, "mp_model_grad_bucket_wait: bad index %d (a layout-only handle has no events)", index);
+  MP_CHECK(m->buckets_recorded, MP_ERR_STATE, "mp_model_grad_bucket_wait: no completed mp_model_backward since the last mp_model_forward");
   MP_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev_bucket[index], 0));
   return MP_OK;
 }
@@ -1108,6 +1136,17 @@ int mp_model_peek(const mp_model* m, int which, const float** ptr, int64_t* nume
     MP_CHECK(k >= 0 && k / 2 < (int)md.ws.size(), MP_ERR_ARG, "mp_model_peek: block %d of %d", k / 2, (int)md.ws.size());
     *ptr = (k & 1) ? md.ws[k / 2].x_out : md.ws[k / 2].x_mid;
     *numel = M * md.C;
+    return MP_OK;
+  }
+  // 2-byte gradient operands of the LAST block the backward differentiated (STE0 of the rotations net), as the backward left them in its scratch:
+  // 500 = dz (M x 2C), 501 = dqkv (M x 3C), 502 = the 2-byte copy of the residual gradient (M x C) - bf16, or scaled fp16 in an f16_backward
+  // model; numel counts FLOATS (two elements each).  For tests that look at where these values sit in the fp16 range.
+  if (which >= 500 && which <= 502) {
+    const long MC = Mr * m->rot.C;
+    const mp_model::ScratchSet& sc = m->sets[0];
+    *ptr = which == 500 ? (const float*)sc.tmp2C : (which == 501 ? (const float*)sc.tmp3C : (const float*)sc.g_b16);
+    MP_CHECK(m->cfg.precision >= 1 && *ptr != nullptr, MP_ERR_ARG, "mp_model_peek: %d needs a bf16 / bf16x3 model", which);
+    *numel = (which == 500 ? 2 : (which == 501 ? 3 : 1)) * MC / 2;
     return MP_OK;
   }
   MP_CHECK(false, MP_ERR_ARG, "mp_model_peek: which=%d", which);
@@ -1136,12 +1175,14 @@ int mp_prof_enable(mp_model* m, int on) {
   m->ev_bytes.clear();
   m->ev_mflops.clear();
   m->ev_tag.clear();
+  m->ev_kind.clear();
   return MP_OK;
 }
 
 int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops, double* bytes, double* model_flops) {
   MP_CHECK(m && ms && launches && flops, MP_ERR_ARG, "mp_prof_collect: null argument");
   for (int c = 0; c < MP_PROF_CLASSES; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; if (bytes) bytes[c] = 0; if (model_flops) model_flops[c] = 0; }
+  for (int k = 0; k < MP_PROF_KINDS; ++k) { m->kind_ms[k] = m->kind_flops[k] = m->kind_bytes[k] = m->kind_mflops[k] = 0.0; m->kind_launches[k] = m->kind_persist[k] = 0; }
   for (size_t i = 0; i < m->ev_cls.size() && 2 * i + 1 < m->ev_used; ++i) {
     MP_HIP(hipEventSynchronize(m->ev[2 * i + 1]));
     float t = 0.f;
@@ -1152,6 +1193,12 @@ int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops, d
     flops[c] += m->ev_flops[i];
     if (bytes) bytes[c] += m->ev_bytes[i];
     if (model_flops) model_flops[c] += m->ev_mflops[i];
+    const int kd = i < m->ev_kind.size() ? m->ev_kind[i] : -1;
+    if (kd >= 0 && kd < MP_PROF_KINDS) {
+      m->kind_ms[kd] += t; m->kind_launches[kd] += 1; m->kind_flops[kd] += m->ev_flops[i]; m->kind_bytes[kd] += m->ev_bytes[i];
+      m->kind_mflops[kd] += m->ev_mflops[i];
+      if (i < m->ev_tag.size() && m->ev_tag[i]) m->kind_persist[kd] += 1;
+    }
     if (i < m->ev_tag.size() && m->ev_tag[i]) {         // class 6: the launches of classes 0/1 that ran gemm_bf16_persist_kernel
       ms[6] += t;
       launches[6] += 1;
@@ -1166,6 +1213,19 @@ int mp_prof_collect(mp_model* m, double* ms, int64_t* launches, double* flops, d
   m->ev_bytes.clear();
   m->ev_mflops.clear();
   m->ev_tag.clear();
+  m->ev_kind.clear();
+  return MP_OK;
+}
+
+int mp_prof_kinds(const mp_model* m, double* ms, int64_t* launches, int64_t* persist_launches, double* flops, double* bytes, double* model_flops) {
+  MP_CHECK(m && ms && launches, MP_ERR_ARG, "mp_prof_kinds: null argument");
+  for (int k = 0; k < MP_PROF_KINDS; ++k) {
+    ms[k] = m->kind_ms[k]; launches[k] = m->kind_launches[k];
+    if (persist_launches) persist_launches[k] = m->kind_persist[k];
+    if (flops) flops[k] = m->kind_flops[k];
+    if (bytes) bytes[k] = m->kind_bytes[k];
+    if (model_flops) model_flops[k] = m->kind_mflops[k];
+  }
   return MP_OK;
 }
 

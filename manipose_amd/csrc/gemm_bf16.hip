@@ -690,7 +690,7 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
         v = make_float4(v.x * z.x, v.y * z.y, v.z * z.z, v.w * z.w);      // Z holds gelu'(pre-activation)
       }
       if constexpr (EPI == EPI_DGELU && sizeof(TC) == 2) {
-        if (g.gout != nullptr) st4_f16(C + o, v, gout_v);
+        if (g.gout != nullptr) st4_f16(C + o, v, gout_v, g.gsat);
         else st4(C + o, v, lo_off);
       } else st4(C + o, v, lo_off);
     }
@@ -774,7 +774,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
       }
       if (FULL || row < g.M) {
         if constexpr (EPI == EPI_DGELU && sizeof(TC) == 2) {      // dz: bf16, or scaled fp16 for an fc1 layer whose backward GEMMs run on fp16 operands
-          if (g.gout != nullptr) st4_f16(C + o, v, gout_v);
+          if (g.gout != nullptr) st4_f16(C + o, v, gout_v, g.gsat);
           else st4(C + o, v, lo_off);
         } else st4(C + o, v, lo_off);
       }
@@ -1037,24 +1037,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
 static int g_persist_min_tiles = 0;        // test hook: 0 = default (2 tiles per workgroup), else the tile count from which the persistent kernel runs
 void gemm_bf16_persist_min_tiles(int n) { g_persist_min_tiles = n; }
 
-// 0 tiled kernels only, 1 (default) the persistent kernel where it applies; env MANIPOSE_GEMM_PERSIST or
-// mp_set_option("gemm_persist_mode") for A/B timing and tests
-static int g_persist_mode = -1;
+// mp_set_option("gemm_persist_mode"): 0 tiled kernels only, 1 (default) the persistent kernel where it applies (A/B timing and tests);
+// mp_set_option("gemm_persist_wgs"): run the persistent GEMMs on fewer workgroups (= CUs), leaving the rest of the chip to kernels of other
+// streams (a persistent workgroup takes a CU's whole LDS and register file); a multiple of 8 (one share per XCD), 0 = all CUs
+static int g_persist_mode = 1;
 void gemm_bf16_persist_mode(int mode) { g_persist_mode = mode; }
+static int g_persist_wgs = 0;
+void gemm_bf16_persist_wgs(int n) { g_persist_wgs = n; }
 static int persist_workgroups() {
-  static int n = -1;
-  if (n < 0) {
+  static int cus8 = -1;
+  if (cus8 < 0) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-    n = (cus / 8) * 8;
-    // MANIPOSE_GEMM_WGS: run the persistent GEMMs on fewer workgroups (= CUs), leaving the rest of the chip to kernels of other
-    // streams (a persistent workgroup takes a CU's whole LDS and register file); a multiple of 8 (one share per XCD)
-    if (const char* e = getenv("MANIPOSE_GEMM_WGS")) { const int w = atoi(e); if (w >= 8 && w <= n) n = (w / 8) * 8; }
+    cus8 = (cus / 8) * 8;
   }
-  if (g_persist_mode < 0) {
-    const char* e = getenv("MANIPOSE_GEMM_PERSIST");
-    g_persist_mode = e ? atoi(e) : 1;
-  }
+  int n = cus8;
+  if (g_persist_wgs >= 8 && g_persist_wgs <= n) n = (g_persist_wgs / 8) * 8;
   return g_persist_mode == 0 ? 0 : n;
 }
 
@@ -1106,9 +1104,7 @@ static int launch_glds_bt(const GemmB16Args& g, int splits, hipStream_t st) {
 // 256x256 tiles (1 workgroup of 8 waves per CU: 2x the MFMA work per byte moved through the CU's vector-memory path and
 // LDS) whenever the problem is wide enough; 128x128 tiles for the narrow bones-net layers.
 static bool use_big_tile(const GemmB16Args& g) {
-  static int env = -1;
-  if (env < 0) { const char* e = getenv("MANIPOSE_GEMM_TILE"); env = e ? atoi(e) : 0; }
-  if (env == 128 || g_force_small_tile) return false;
+  if (g_force_small_tile) return false;
   return g.M >= 256 && g.N >= 256 && g.N % 256 == 0;
 }
 template <int TRA, int TRB, typename TC, int EPI, int SPLIT = 0>

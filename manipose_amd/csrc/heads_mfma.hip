@@ -126,10 +126,12 @@ static int hm_grid(int M) {
 }
 
 bool heads_mfma_supported(int K, int O, int C) { return K >= 1 && O >= 1 && O <= 8 && K * O <= HM_NPAD && (C == 512 || C == 256 || C == 128); }
-// MANIPOSE_HEADS_MFMA: 0 = row kernels everywhere, 1 (default) = matrix cores wherever covered (a 16-wide tile for the bones head's single
+// mp_set_option("heads_mfma"): 0 = row kernels everywhere, 1 (default) = matrix cores wherever covered (a 16-wide tile for the bones head's single
 // output wastes most of the MFMA, but the kernel is bound by reading x either way), 2 = matrix cores only from 16 outputs up
+static int g_heads_mfma = 1;
+void heads_mfma_mode(int mode) { g_heads_mfma = mode; }
 bool heads_use_mfma(int K, int O, int C) {
-  static const int on = [] { const char* e = getenv("MANIPOSE_HEADS_MFMA"); return e ? atoi(e) : 1; }();
+  const int on = g_heads_mfma;
   return on && (on == 1 || K * O >= 16) && heads_mfma_supported(K, O, C);
 }
 

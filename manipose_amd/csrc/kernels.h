@@ -60,6 +60,7 @@ struct GemmB16Args {
   int f16;
   int out_f16f8;       // gemm_f16f8 with EPI_BIAS_GELU: C / C_lo are the fp16 / correction planes of the "f16f8" format instead of bf16 hi / lo planes
   const float* gout;   // EPI_DGELU with a 2-byte output: non-null writes dz as fp16 of *gout x value instead of bf16 (device address; the operand format above)
+  unsigned* gsat;      // with gout: the two counters of its saturating stores (clamped / non-finite elements; common.h sat_f16x4), may be null
 };
 int gemm_bf16(GemmB16Args g, int a_f32, int a_tr, int b_tr, int c_f32, int epi, hipStream_t st);
 // C = A B^T on planar hi/lo operands ("N","N" layouts: the forward Linear), three bf16 MFMA products per k-tile, fp32 accumulate.
@@ -75,8 +76,7 @@ int cast_to_bf16(const float* src, bf16* dst, long n, hipStream_t st);
 void gemm_bf16_force_small_tile(bool on);          // test hooks (mp_set_option)
 void gemm_bf16_persist_min_tiles(int n);
 void gemm_bf16_persist_mode(int mode);
-void engine_f16f8(int on);                        // engine.hip: models created afterwards in precision 2 feed their qkv / fc1 GEMMs "f16f8" operands (1, default) or bf16 planes (0)
-void engine_side_streams(int on);                 // engine.hip: 0 = the bones net runs on the caller's stream (debugging)
+void gemm_bf16_persist_wgs(int n);                 // workgroups (= CUs) of the persistent kernels; 0 = all
 int gemm_bf16_take_last_persist();                  // 1 if this thread's last gemm_bf16() ran the persistent kernel (and clears it)
 
 // ---------------------------------------------------------------- elementwise.hip
@@ -106,7 +106,7 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
             float* dx, void* dx_b16, const float* mask, int mask_mode, int T, int J, float* dgamma1, float* dbeta1, float* dgamma0, float* dbeta0, int M, int C, float* scratch, long scratch_floats,
             hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr, float rs = 1.0f, const float* dy_scale = nullptr,
             const float* b16_gs = nullptr);      // as in ln_bwd (dy_scale applies to dy1)
-// gsc (4 floats on the device) <- {S, 1 / S, scratch, 1} with S the power of two that brings max(|d_poses|, |d_scores|) into [1, 2) (elementwise.hip)
+// gsc (8 floats on the device) <- {S, 1 / S, scratch, 1, 0u, 0u (saturation / non-finite counters of this backward's fp16 stores)} with S the power of two that brings max(|d_poses|, |d_scores|) into [1, 2) (elementwise.hip)
 int grad_scale(const float* d_poses, long n_poses, const float* d_scores, long n_scores, float* gsc, hipStream_t st);
 // dst = s * src ; dst += s * src  (muP readout multiplier on the head weights / their gradients)
 int scale_copy(float* dst, const float* src, float s, long n, hipStream_t st);
@@ -158,7 +158,8 @@ bool heads_mfma_supported(int K, int O, int C);
 // heads on the fp32 matrix cores (heads_mfma.hip), same results as heads_fwd / heads_bwd.  fold: heads_fold_floats(C) floats owned by the
 // module, written by the forward and read by the same step's backward, which also reads the forward's head outputs (`out`).
 inline long heads_fold_floats(int C) { return 48L * C + 48; }
-bool heads_use_mfma(int K, int O, int C);   // the engine's choice: K O >= 16 outputs and a covered width; MANIPOSE_HEADS_MFMA=0 keeps the row kernels
+bool heads_use_mfma(int K, int O, int C);   // the engine's choice: a covered width (mp_set_option("heads_mfma"): 0 row kernels everywhere, 2 only from 16 outputs up)
+void heads_mfma_mode(int mode);
 int heads_fwd_mfma(const float* x, const HeadParams& p, int K, int O, float* out, float* stats, int M, int C, float* fold, hipStream_t st);
 int heads_bwd_mfma(const float* x, const float* stats, const float* fold, const float* out, const HeadParams& p, const HeadGrads& gp, int K, int O,
                    const float* dout, float* dx, int M, int C, float* scratch, long scratch_floats, hipStream_t st, hipStream_t st_param);

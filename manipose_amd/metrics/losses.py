@@ -96,8 +96,12 @@ class _FusedLoss(torch.autograd.Function):
 
 def rmcl_training_loss(poses, scores, y, w_loss: bool = True, vel_loss: float = 2.0, smooth_reg: float = 0.5,
                        rmcl_score_reg: float = 0.1, sq_loss: bool = False) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-    """Whole default multi-hypothesis loss (make_loss with conf/config.yaml:31-38) in ONE kernel launch."""
-    terms, _ = _FusedLoss.apply(poses, scores, y, rmcl_score_reg, vel_loss, smooth_reg, int(w_loss), int(sq_loss))
+    """Whole default multi-hypothesis loss (make_loss with conf/config.yaml:31-38) in ONE kernel launch, through the registered custom
+    operator ``torch.ops.manipose.wta_loss`` (manipose_amd/ops.py; value and gradient come out of the same launch)."""
+    from .. import ops  # noqa: F401  (registers torch.ops.manipose.*)
+    if not poses.is_cuda:
+        raise RuntimeError("manipose_amd: HIP kernels need tensors on a ROCm device (got a CPU tensor); there is no CPU fallback")
+    terms = torch.ops.manipose.wta_loss(poses, scores, y, float(rmcl_score_reg), float(vel_loss), float(smooth_reg), int(w_loss), int(sq_loss))[0]
     names = ("wloss", "score_reg", "vloss", "sreg")
     return terms.sum(), {n: terms[i] for i, n in enumerate(names)}
 

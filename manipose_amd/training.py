@@ -41,6 +41,10 @@ class LiftingTrainer:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         # every rank draws its own DropPath masks (the reference draws independent per-sample masks over the whole batch)
         self.seed = seed + (dist.get_rank(process_group) if self.world > 1 else 0)
+        # time_exchange: record device events around the backward and the gradient exchange of every step (bench.py at N > 1:
+        # "how long is the backward with / without collective kernels resident, how much of the exchange is exposed"); read with exchange_times()
+        self.time_exchange = False
+        self._xev = []
         self.flat_grads: Optional[torch.Tensor] = None
         self.rmcl = model._arch == "rmcl_manifold"
         self._bufs = {}
@@ -85,7 +89,12 @@ class LiftingTrainer:
         if self.flat_grads is None or self.flat_grads.shape != m._flat.shape:
             self.flat_grads = torch.empty_like(m._flat)
         self.flat_grads.zero_()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.time_exchange else None
+        if ev:
+            ev[0].record()
         eng.backward(m._flat, self.flat_grads, bf["d_poses"], bf["d_scores"])
+        if ev:
+            ev[1].record()
         if self.world > 1:
             # one collective per step over the single flat gradient buffer (137.8 MB fp32 at full size); RCCL picks the
             # all-links algorithm over the xGMI mesh.  Averaging is folded into the Adam kernel (grad_scale).
@@ -95,8 +104,24 @@ class LiftingTrainer:
                 allreduce_gradients_bucketed(self.flat_grads, eng, self._comm_stream, self.pg)
             else:
                 allreduce_gradients(self.flat_grads, self.pg)
+        if ev:
+            ev[2].record()             # the current stream has the reduced gradients from here on
+            self._xev.append(ev)
         self.opt.step(self.flat_grads, grad_scale=1.0 / self.world)
         return bf["terms"]
+
+    def exchange_times(self):
+        """Mean device times (ms) over the steps recorded since the last call (time_exchange): `backward_ms` = the backward on the caller's
+        stream (with grad_buckets the collectives of finished layers run beside it), `exposed_exchange_ms` = what the caller's stream then
+        still waits for before the optimizer step.  Synchronises."""
+        if not self._xev:
+            return None
+        torch.cuda.synchronize()
+        b = sum(e[0].elapsed_time(e[1]) for e in self._xev) / len(self._xev)
+        x = sum(e[1].elapsed_time(e[2]) for e in self._xev) / len(self._xev)
+        n = len(self._xev)
+        self._xev = []
+        return {"backward_ms": b, "exposed_exchange_ms": x, "steps": n}
 
     @torch.no_grad()
     def eval_loss(self, X: torch.Tensor, y: torch.Tensor) -> torch.Tensor:

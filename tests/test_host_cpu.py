@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/manipose_hip.h but not exported"
         assert n in _lib._SIGNATURES, f"{n} has no ctypes signature in manipose_amd/_lib.py"
-    assert lib.mp_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.mp_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_state_dict_layout_matches_reference(golden_dir):
@@ -464,17 +464,65 @@ def test_generated_code_has_no_packed_op_reading_a_freshly_loaded_high_register(
         pytest.skip("hipcc not available")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scan_pk_opsel.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "0 suspicious packed ops" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+    import glob
+    nsrc = len(glob.glob(os.path.join(ROOT, "manipose_amd", "csrc", "*.hip")))
+    assert f"0 suspicious packed ops in {nsrc} files" in r.stdout, r.stdout[-500:]        # every source was compiled and scanned
+    assert "0 packed fp32 ops" in r.stdout, r.stdout[-500:]                                # build.sh: -packed-fp32-ops (no v_pk_*_f32 at all)
 
 
-def test_product_library_has_no_timing_ablation_switches():
-    """The wrong-by-design timing ablations (MANIPOSE_GEMM_DEBUG / MANIPOSE_GEMM_ABL / MANIPOSE_ATTN_DEBUG and the extra kernel
-    instantiations behind them) are compiled into the diagnostics build only (MP_DIAG=1 build.sh): the product library does not even
-    contain the variable names, so no environment can switch them on."""
+def test_product_library_reads_no_environment_variable():
+    """ABI v7: everything that changes a model's arithmetic or stream use is a field of mp_model_config, the kernel selectors are explicit
+    mp_set_option calls, and the product library reads NO environment variable: it does not import getenv, contains no MANIPOSE_* name
+    (the wrong-by-design timing ablations MANIPOSE_GEMM_DEBUG / _ABL / MANIPOSE_ATTN_DEBUG exist in the diagnostics build only, MP_DIAG=1
+    build.sh), and every getenv in the sources sits inside an #ifdef MP_GEMM_DIAG block."""
+    import glob, re, subprocess
     from manipose_amd import _lib
     blob = open(_lib.LIB_PATH, "rb").read()
-    for name in (b"MANIPOSE_GEMM_DEBUG", b"MANIPOSE_GEMM_ABL", b"MANIPOSE_ATTN_DEBUG", b"MANIPOSE_GEMM_STAMPS", b"MANIPOSE_GEMM_STAGGER"):
-        assert name not in blob, name
-    assert b"MANIPOSE_GEMM_PERSIST" in blob      # (the scan does see environment names: the documented tuning knobs are there)
+    assert b"MANIPOSE_" not in blob, re.findall(rb"MANIPOSE_[A-Z0-9_]+", blob)[:5]
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        assert "getenv" not in nm.stdout
+    for path in glob.glob(os.path.join(ROOT, "manipose_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "manipose_amd", "csrc", "*.h")):
+        depth = 0                                   # nesting depth inside #ifdef MP_GEMM_DIAG
+        stack = []
+        for no, line in enumerate(open(path), 1):
+            t = line.strip()
+            if t.startswith("#if"):
+                stack.append("MP_GEMM_DIAG" in t and not t.startswith("#ifndef"))
+            elif t.startswith("#else") and stack:
+                stack[-1] = False
+            elif t.startswith("#endif") and stack:
+                stack.pop()
+            if "getenv" in line and not t.startswith("//"):
+                assert any(stack), f"{path}:{no}: getenv outside the diagnostics build: {t}"
+
+
+def test_model_config_carries_the_engine_options():
+    """mp_model_config (ABI v7) <-> _lib.ModelConfig <-> the model attributes: f16f8 / f16_backward / streams reach the engine per model,
+    default to 0 (three bf16 products everywhere, bf16 backward, both extra streams), and a layout-only handle accepts them without a GPU."""
+    import re
+    from manipose_amd import RMCLManifoldMixSTE, _lib, h36m_skeleton
+    from manipose_amd.architectures.engine import LiftEngine
+    hdr = open(_lib.HEADER_PATH).read()
+    body = hdr[hdr.index("typedef struct mp_model_config {"):hdr.index("} mp_model_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [n for decl in re.findall(r"(?:int|float)\s+([^;]+);", body) for n in re.split(r"\s*,\s*", decl.strip())]
+    assert fields == [n for n, _ in _lib.ModelConfig._fields_], (fields, [n for n, _ in _lib.ModelConfig._fields_])
+    assert fields[-3:] == ["f16f8", "f16_backward", "streams"]
+    base = dict(arch="rmcl_manifold", num_frame=27, num_joints=17, num_bones=16, embed_dim_rot=256, depth_rot=2, num_heads_rot=4, embed_dim_seg=32,
+                depth_seg=1, num_heads_seg=4, n_hyp=2, drop_path_rate=0.0, max_batch=0, precision="bf16x3")
+    e0 = LiftEngine(**base)
+    assert (e0.cfg.f16f8, e0.cfg.f16_backward, e0.cfg.streams) == (0, 0, 0)
+    e1 = LiftEngine(**base, f16f8=2, f16_backward=True, side_stream=False, wgrad_stream=False)
+    assert (e1.cfg.f16f8, e1.cfg.f16_backward, e1.cfg.streams) == (2, 1, 3)
+    assert e0.layout == e1.layout                               # the parameter layout does not depend on the operand form
+    with pytest.raises(RuntimeError, match="f16_backward"):
+        LiftEngine(**base, f16f8=2, f16_backward=False)
+    m = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=27, embed_dim_rot=256, depth_rot=2, num_heads_rot=4, embed_dim_seg=32, depth_seg=1,
+                           num_heads_seg=4, n_hyp=2)
+    assert m._engine_options() == dict(f16f8=0, f16_backward=False, side_stream=True, wgrad_stream=True)
+    m.f16f8, m.f16_backward, m.wgrad_stream = 1, True, False
+    assert m._engine_options() == dict(f16f8=1, f16_backward=True, side_stream=True, wgrad_stream=False)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

@@ -30,14 +30,15 @@ X[idx] = Xp
 
 def run(x, mode, side=1):
     _lib.check(lib.mp_set_option(b"gemm_persist_mode", mode))
-    _lib.check(lib.mp_set_option(b"side_streams", side))
+    if (m.side_stream, m.wgrad_stream) != (bool(side), bool(side)):      # the engine's extra streams are per-model state (mp_model_config::streams): rebuild
+        m.side_stream = m.wgrad_stream = bool(side)
+        m._engine = None
     with torch.no_grad():
         p, s = m(x)
         h = m._engine.peek(0).clone()
         ln = m._engine.peek(1).clone()
     torch.cuda.synchronize()
     _lib.check(lib.mp_set_option(b"gemm_persist_mode", 1))
-    _lib.check(lib.mp_set_option(b"side_streams", 1))
     return p.clone(), s.clone(), h, ln
 
 

@@ -13,7 +13,7 @@ BEGIN, END = "<!-- BEGIN GENERATED: ctypes declarations (tools/gen_integration_s
 # entry points shown in the document: the path's stand-alone operators and the model engine
 SHOWN = ["mp_abi_version", "mp_last_error", "mp_fk_decode_fwd", "mp_fk_decode_bwd", "mp_wta_loss", "mp_aggregate", "mp_mpjpe_sum", "mp_adam_step",
          "mp_split_bf16", "mp_linear_fwd_bf16x3", "mp_linear_fwd_bf16x3_lnres", "mp_split_f16f8", "mp_linear_fwd_f16f8", "mp_attention_fwd_bf16x3", "mp_heads_fwd", "mp_heads_bwd", "mp_model_create", "mp_model_destroy", "mp_model_flat_size",
-         "mp_model_num_params", "mp_model_param_info", "mp_model_forward", "mp_model_backward", "mp_pose_metrics", "mp_gather_windows"]
+         "mp_model_num_params", "mp_model_param_info", "mp_model_forward", "mp_model_backward", "mp_model_grad_health", "mp_prof_kinds", "mp_set_option", "mp_pose_metrics", "mp_gather_windows"]
 
 
 def tname(t):

@@ -1,0 +1,74 @@
+// Isolating probe for the hazard csrc/common.h describes ("gfx950 hazard guard"): does a packed fp32 multiply whose LOW lane takes the HIGH
+// register of a VGPR pair (op_sel:[0,1]) return wrong low-lane results on gfx950?  The kernel's ONLY arithmetic is that instruction, on
+//   mode 0: a pair that global_load_dwordx2 has just written (load; s_waitcnt vmcnt(0); v_pk_mul_f32 - the sequence of the faulty epilogue)
+//   mode 1: a pair written by two v_mov_b32 (VALU-written)
+// checked bit for bit against two v_mul_f32 of the same operands, ~1e9 lane-operations per mode, with a bandwidth-bound kernel busy on a
+// second stream.  Mismatches are counted per lane group (lanes 0-47 / 48-63).  Build + run ONCE on the GPU box:
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/pk_opsel.hip -o /tmp/pk_opsel && /tmp/pk_opsel
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define CK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("%s: %s\n", #e, hipGetErrorString(r_)); exit(2); } } while (0)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void probe(const f2* __restrict__ xy, const f2* __restrict__ st, long n, int iters, unsigned* __restrict__ bad) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (long)gridDim.x * blockDim.x;
+  unsigned lo_bad = 0, hi_bad = 0;
+  for (int it = 0; it < iters; ++it) {
+    const long i = (tid + (long)it * nthr * 7) % n;
+    const f2 v = xy[i];                       // the values scaled
+    const f2* sp = st + i;
+    f2 pair, res;
+    if (MODE == 0) {                          // (mean, rstd) pair straight out of a load, consumed on the spot
+      asm volatile("global_load_dwordx2 %0, %2, off\n\ts_waitcnt vmcnt(0)\n\tv_pk_mul_f32 %1, %3, %0 op_sel:[0,1] op_sel_hi:[1,1]"
+                   : "=&v"(pair), "=&v"(res) : "v"(sp), "v"(v) : "memory");
+    } else {                                  // the same pair written by the VALU
+      const f2 s = *sp;
+      float a, b;
+      asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(a), "=&v"(b) : "v"(s[0]), "v"(s[1]));
+      pair = f2{a, b};                        // (if the two are not an aligned pair yet the compiler moves them into one: VALU-written either way)
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=&v"(res) : "v"(v), "v"(pair));
+    }
+    float r0, r1;                             // reference: two scalar multiplies by the pair's HIGH element
+    asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4" : "=&v"(r0), "=&v"(r1) : "v"(v[0]), "v"(v[1]), "v"(pair[1]));
+    const bool wrong_lo = __float_as_uint(res[0]) != __float_as_uint(r0), wrong_hi = __float_as_uint(res[1]) != __float_as_uint(r1);
+    lo_bad += wrong_lo; hi_bad += wrong_hi;
+  }
+  const int grp = (threadIdx.x & 63) >= 48;
+  if (lo_bad) atomicAdd(bad + 2 * grp, lo_bad);
+  if (hi_bad) atomicAdd(bad + 2 * grp + 1, hi_bad);
+}
+__global__ void hog(const float4* __restrict__ a, float4* __restrict__ b, long n4, int reps) {      // bandwidth-bound neighbour on the other stream
+  for (int r = 0; r < reps; ++r)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) b[i] = a[(i + r) % n4];
+}
+int main() {
+  const long n = 1L << 24;                    // 16 M pairs = 128 MB per array: beyond the L2s
+  std::vector<f2> hx(n), hs(n);
+  srand(1);
+  for (long i = 0; i < n; ++i) {
+    hx[i] = f2{(float)rand() / RAND_MAX - 0.5f, (float)rand() / RAND_MAX - 0.5f};
+    hs[i] = f2{(float)rand() / RAND_MAX * 3.f - 1.5f, 0.5f + (float)rand() / RAND_MAX * 4.f};
+  }
+  f2 *dx, *ds; unsigned* dbad; float4 *ha, *hb;
+  CK(hipMalloc(&dx, n * sizeof(f2))); CK(hipMalloc(&ds, n * sizeof(f2))); CK(hipMalloc(&dbad, 16 * sizeof(unsigned)));
+  const long hn4 = 1L << 26;                  // 1 GiB source + 1 GiB destination for the neighbour
+  CK(hipMalloc(&ha, hn4 * 16)); CK(hipMalloc(&hb, hn4 * 16)); CK(hipMemset(ha, 1, hn4 * 16));
+  CK(hipMemcpy(dx, hx.data(), n * sizeof(f2), hipMemcpyHostToDevice)); CK(hipMemcpy(ds, hs.data(), n * sizeof(f2), hipMemcpyHostToDevice));
+  hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+  const int grid = 1024, iters = 4096;        // 1024 x 256 threads x 4096 = 1.07e9 lane-operations per launch
+  for (int busy = 0; busy < 2; ++busy)
+    for (int mode = 0; mode < 2; ++mode) {
+      CK(hipMemset(dbad, 0, 16 * sizeof(unsigned)));
+      if (busy) hipLaunchKernelGGL(hog, dim3(2048), dim3(256), 0, s2, ha, hb, hn4, 24);
+      if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(grid), dim3(256), 0, s1, dx, ds, n, iters, dbad);
+      else hipLaunchKernelGGL(probe<1>, dim3(grid), dim3(256), 0, s1, dx, ds, n, iters, dbad);
+      CK(hipDeviceSynchronize());
+      unsigned h[4]; CK(hipMemcpy(h, dbad, sizeof(h), hipMemcpyDeviceToHost));
+      printf("pair %-12s neighbour stream %-4s: %.3g lane-ops; wrong LOW lanes: lanes 0-47 %u, lanes 48-63 %u; wrong HIGH lanes: %u / %u\n",
+             mode ? "VALU-written" : "just loaded", busy ? "busy" : "idle", (double)grid * 256 * iters, h[0], h[2], h[1], h[3]);
+    }
+  return 0;
+}

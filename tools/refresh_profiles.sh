@@ -8,16 +8,17 @@
 #   pmc_traffic.json                  profiles/pmc_traffic.json with this configuration's entry replaced by the last row of that csv
 # The files are written under gpurun_out/ (merged back by gpurun); copy them into profiles/ afterwards.
 set -eu
-TAG="${1:-r03_bf16x3_B79}"
+TAG="${1:-r04_bf16x3_B79}"
+EXTRA="${2:-}"          # extra bench flags of the configuration profiled, e.g. "--f16f8 1 --f16-backward"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/profiles_new; rm -rf "$O"; mkdir -p "$O"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-extra > "$O/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-extra $EXTRA > "$O/stats.log" 2>&1
 find "$O/stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$O/${TAG}_kernel_stats.csv"
 grep "^{" "$O/stats.log" > "$O/${TAG}_bench_under_rocprof.json"
 find "$O/stats" -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/stream_timeline.py {} > "$O/${TAG}_stream_timeline.txt"
 find "$O/stats" -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/gap_list.py {} 40 > "$O/${TAG}_main_queue_gaps.txt"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_$c" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra --no-prof > "$O/pmc_$c.log" 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_$c" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra --no-prof $EXTRA > "$O/pmc_$c.log" 2>&1
   find "$O/pmc_$c" -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} "$O/pmc_$c.csv"
 done
 python - "$O" "$TAG" <<'PY'
@@ -47,7 +48,8 @@ with open(f"{O}/{TAG}_pmc_hbm_traffic.csv", "w") as fh:
         import json
         line = json.loads(open(f"{O}/{TAG}_bench_under_rocprof.json").read().strip().splitlines()[-1])
         tj = json.load(open("profiles/pmc_traffic.json"))
-        tj[f"{line['dtype']}:{line['config']['windows_per_gpu']}"] = {"bytes_per_launch": round((2 * F + W) * 1024, 0), "source": f"profiles/{TAG}_pmc_hbm_traffic.csv"}
+        forms = line.get("config", {}).get("traffic_key_suffix", "")
+        tj[f"{line['dtype']}{forms}:{line['config']['windows_per_gpu']}"] = {"bytes_per_launch": round((2 * F + W) * 1024, 0), "source": f"profiles/{TAG}_pmc_hbm_traffic.csv"}
         json.dump(tj, open(f"{O}/pmc_traffic.json", "w"), indent=1)
 st = list(csv.DictReader(open(f"{O}/{TAG}_kernel_stats.csv")))
 tp = [(float(r["TotalDurationNs"]), int(r["Calls"])) for r in st if "persist_kernel" in r["Name"]]

@@ -73,16 +73,29 @@ def main():
         procs = []
         for src in sorted(glob.glob(os.path.join(ROOT, "manipose_amd", "csrc", "*.hip"))):
             out = os.path.join(tmp, os.path.basename(src)[:-4] + ".s")
-            procs.append((out, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + build_flags() + ["-S", "--cuda-device-only", "-o", out, src],
-                                                stderr=subprocess.DEVNULL)))
-        for out, p in procs:
-            if p.wait() == 0:
+            procs.append((src, out, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + build_flags() + ["-S", "--cuda-device-only", "-o", out, src],
+                                                     stderr=subprocess.PIPE, text=True)))
+        failed = []
+        for src, out, p in procs:
+            err = p.communicate()[1]
+            if p.returncode == 0 and os.path.getsize(out) > 0:
                 files.append(out)
-    total = 0
+            else:
+                failed.append(src)
+                sys.stderr.write(f"scan_pk_opsel: compiling {src} failed (exit {p.returncode}):\n{err[-2000:]}\n")
+        # an audit that skipped a source has audited nothing: every csrc/*.hip must have compiled
+        if failed or len(files) != len(procs):
+            print(f"{len(failed)} of {len(procs)} sources did not compile: {[os.path.basename(f) for f in failed]}")
+            sys.exit(2)
+    total, packed = 0, 0
+    for f in files:
+        packed += sum(1 for line in open(f) if PK.match(line.split(";")[0]))
     for f in files:
         for k, v in scan(f).items():
             total += len(v)
             print(f"{os.path.basename(f)}: {k[:100]}: {len(v)} packed fp32 ops take the high register of a pair for their low lane, e.g. {v[0][:130]}")
+    # (with build.sh's -target-feature -packed-fp32-ops no v_pk_*_f32 exists at all, so the op_sel form cannot either: both counts are printed)
+    print(f"{packed} packed fp32 ops (v_pk_mul/add/fma_f32) in the generated code")
     print(f"{total} suspicious packed ops in {len(files)} files")
     sys.exit(1 if total else 0)
 

@@ -1,9 +1,7 @@
 """Bitwise run-to-run reproducibility of a full training step (forward + backward) at full width; names the parameters whose
 gradients differ between identical steps, in backward order (heads first), to locate a racy kernel.
-python tools/step_determinism.py [batch] [runs] [precision] [wgrad_stream 0|1]"""
+python tools/step_determinism.py [batch] [runs] [precision] [wgrad_stream 0|1]   (STEP_SIDE=0: the segments net on the caller's stream)"""
 import os, sys
-if len(sys.argv) > 4:
-    os.environ["MANIPOSE_WGRAD_STREAM"] = sys.argv[4]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from manipose_amd import RMCLManifoldMixSTE, _lib, h36m_skeleton
@@ -12,12 +10,12 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 prec = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
 lib = _lib.load()
-if os.environ.get("STEP_SIDE") == "0":
-    _lib.check(lib.mp_set_option(b"side_streams", 0))
 torch.manual_seed(42)
 model = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=243, n_hyp=5, drop_path_rate=0.1)
 model.precision = prec
 model.max_batch_hint = B
+model.wgrad_stream = not (len(sys.argv) > 4 and sys.argv[4] == "0")
+model.side_stream = os.environ.get("STEP_SIDE") != "0"
 model = model.cuda().train()
 g = torch.Generator(device="cuda").manual_seed(1)
 X = (0.3 * torch.randn(B, 243, 17, 2, device="cuda", generator=g)).clamp(-1, 1)

@@ -1,10 +1,13 @@
 """Probe: do two independent half-batch training streams (two models, two torch streams, complementary kernels interleaving) beat one
-full-batch stream?  MANIPOSE_GEMM_WGS limits the persistent GEMMs' workgroups so that the other stream's kernels find free CUs."""
+full-batch stream?  WGS=<n> (mp_set_option "gemm_persist_wgs") limits the persistent GEMMs' workgroups so that the other stream's kernels find free CUs."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
 from manipose_amd.training import LiftingTrainer
+from manipose_amd import _lib
+if os.environ.get("WGS"):
+    _lib.check(_lib.load().mp_set_option(b"gemm_persist_wgs", int(os.environ["WGS"])))
 
 B = int(os.environ.get("B", "79")); NS = int(os.environ.get("NS", "2")); prec = os.environ.get("PREC", "bf16x3")
 def make(b):
@@ -29,4 +32,4 @@ t0 = time.perf_counter(); n = 8
 for _ in range(n): step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
-print(f"streams={NS} per-stream batch={per} wgs={os.environ.get('MANIPOSE_GEMM_WGS','all')} prec={prec}: {dt*1e3:.1f} ms/step, {B*243/dt:.0f} poses/s", flush=True)
+print(f"streams={NS} per-stream batch={per} wgs={os.environ.get('WGS','all')} prec={prec}: {dt*1e3:.1f} ms/step, {B*243/dt:.0f} poses/s", flush=True)
