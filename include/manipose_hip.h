@@ -213,7 +213,8 @@ typedef struct mp_model_config {
    *                 products of bf16 hi / lo planes; 1 = the qkv and fc1 Linear layers read "f16f8" operands (mp_linear_fwd_f16f8: one fp16
    *                 product + one block-scaled fp8 correction product per 64 reduction indices); 2 = the fc2 layer as well (needs f16_backward)
    *   f16_backward  with f16f8 >= 1: 1 = the backward GEMMs of those layers run on fp16 operands - gradients carried as fp16 of S x value,
-   *                 S a power of two chosen per backward on the device, stores saturate at +-65504 and are counted (mp_model_grad_health);
+   *                 S a power of two chosen per backward on the device from the residual gradient at the top of the backbone, stores saturate at
+   *                 +-65504 and are counted (mp_model_grad_health);
    *                 0 (default) = bf16 backward on a bf16 copy of those activations
    *   streams       bit 0 set: the segments net is enqueued on the caller's stream instead of the engine's side stream; bit 1 set: the
    *                 weight-gradient GEMMs likewise instead of the engine's third stream (debugging / single-queue profiles; results are
@@ -272,7 +273,8 @@ int mp_model_grad_health(mp_model* m, float* out4_host, void* stream);
  * (K, B*T*17, O), 1 = segment lengths (B, 16), 2 = the DropPath multipliers of the last train-mode forward (layout: mp_model_mask_info);
  * the fp32 residual stream block by block (blocks in execution order STE0, TTE0, STE1, ...; (B*T*N, C) each): 100 + 2 l = after the
  * attention branch of block l of the rotations net, 101 + 2 l = after its MLP branch, 99 = its embedding output; 300 + 2 l, 301 + 2 l,
- * 299 the same for the segments net */
+ * 299 the same for the segments net; 500 / 501 / 502 = the 2-byte gradient operands dz (M x 2C) / dqkv (M x 3C) / residual-gradient copy (M x C) of the
+ * LAST block the last backward differentiated (bf16, or scaled fp16 for dz / dqkv of an f16_backward model; numel counts floats = element pairs) */
 int mp_model_peek(const mp_model* m, int which, const float** ptr, int64_t* numel);
 /* copy `numel` floats of intermediate `which` into dst (device) on `stream` */
 int mp_model_peek_copy(const mp_model* m, int which, float* dst, int64_t numel, void* stream);

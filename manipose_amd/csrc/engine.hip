@@ -15,8 +15,9 @@ namespace mp {
 bool attn_tmfma_supported(int T, int D);            // attention_mfma.hip
 bool attn_smfma_supported(int N, int D, int H);
 // Gradient operands of a layer whose backward GEMMs run on fp16 operands (mp_model_config::f16_backward) are carried as fp16 of S x value,
-// S a power of two chosen per backward on the device (grad_scale, elementwise.hip: the largest incoming gradient lands in [1, 2), which
-// leaves fp16 a factor 6.5e4 of headroom above it and 1.6e4 of normal range below); producers and consumers read S and 1 / S from
+// S a power of two chosen per backward on the device (grad_scale, elementwise.hip: the largest element of the residual gradient at the top
+// of the backbone lands in [2^11, 2^12), which leaves fp16 a factor 2^4 of headroom above it and 2^25 of normal range below - measured, see
+// there and mp_model_backward); producers and consumers read S and 1 / S from
 // mp_model::gsc, every store saturates and is counted there (common.h sat_f16x4, mp_model_grad_health).
 
 const char* last_error();
@@ -998,10 +999,6 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   const long Mr = (long)B * T * J, Ms = (long)B * T * S;
   m->buckets_recorded = false;         // set again below, once every bucket event of THIS backward has been enqueued
   use_scratch(m, 0);
-  if (m->rot.f8g) {      // this backward's gradient scale, from the incoming gradients (device side: no host round trip)
-    const long np = (long)B * K * T * J * 3, ns = (long)B * K * T;
-    RUN(PC_OTHER, 0, grad_scale(d_poses, np, d_scores, ns, m->gsc, st));
-  }
   // parameter gradients of the heads / score heads are needed by nobody downstream: with the weight-gradient stream on they run there,
   // at the start of the backward where that stream is idle (own scratch, ordered behind the last writer of dheadout)
   hipStream_t pst = m->wgrad_async ? m->st3 : nullptr;
@@ -1042,6 +1039,11 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     RUN(PC_OTHER, 0, heads_bwd(m->rot.x_final, m->rot.hstats, hp, hg, K, m->rot.O, m->rot.dheadout, m->g, (int)Mr, m->rot.C,
                                pst ? m->hsmall : m->small, pst ? m->hsmall_floats : m->small_floats, st, pst));
   { int rf = flush_head_grads(m, m->rot, fg, pst ? pst : st); if (rf) return rf; }
+  // f16_backward: this backward's gradient scale S, chosen on the device (no host round trip) from the residual gradient the backbone
+  // starts from - NOT from d_poses: the WTA loss gradient is a unit vector per joint whatever the error, so its maximum is a constant of the
+  // batch shape while the interior gradients shrank by four orders of magnitude over 200 optimisation steps (measured, round 4: 38 % of
+  // dz's true values would have been fp16-subnormal at an S taken from d_poses).  One read of g (M x C floats, ~0.13 ms at full size).
+  if (m->rot.f8g) RUN(PC_OTHER, 0, grad_scale(m->g, Mr * m->rot.C, nullptr, 0, m->gsc, st));
   int rc = backbone_bwd(m, m->rot, fp, fg, B, st);
   if (rc) return rc;
   RUN(PC_OTHER, 0, embed_bwd(m->g, m->x_in, G(m, fg, m->rot.emb_w), G(m, fg, m->rot.emb_b), G(m, fg, m->rot.spos), (int)Mr, m->rot.C, J,
@@ -1139,8 +1141,9 @@ int mp_model_peek(const mp_model* m, int which, const float** ptr, int64_t* nume
     return MP_OK;
   }
   // 2-byte gradient operands of the LAST block the backward differentiated (STE0 of the rotations net), as the backward left them in its scratch:
-  // 500 = dz (M x 2C), 501 = dqkv (M x 3C), 502 = the 2-byte copy of the residual gradient (M x C) - bf16, or scaled fp16 in an f16_backward
-  // model; numel counts FLOATS (two elements each).  For tests that look at where these values sit in the fp16 range.
+  // 500 = dz (M x 2C), 501 = dqkv (M x 3C) - bf16, or scaled fp16 in an f16_backward model; 502 = the 2-byte copy of the residual gradient
+  // (M x C) as its LAST writer left it: the attention-branch copy, which feeds the proj layer and is always bf16.  numel counts FLOATS (two
+  // elements each).  For tests that look at where these values sit in the fp16 range.
   if (which >= 500 && which <= 502) {
     const long MC = Mr * m->rot.C;
     const mp_model::ScratchSet& sc = m->sets[0];

@@ -106,7 +106,7 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
             float* dx, void* dx_b16, const float* mask, int mask_mode, int T, int J, float* dgamma1, float* dbeta1, float* dgamma0, float* dbeta0, int M, int C, float* scratch, long scratch_floats,
             hipStream_t st, hipStream_t st_param = nullptr, hipEvent_t ev = nullptr, float rs = 1.0f, const float* dy_scale = nullptr,
             const float* b16_gs = nullptr);      // as in ln_bwd (dy_scale applies to dy1)
-// gsc (8 floats on the device) <- {S, 1 / S, scratch, 1, 0u, 0u (saturation / non-finite counters of this backward's fp16 stores)} with S the power of two that brings max(|d_poses|, |d_scores|) into [1, 2) (elementwise.hip)
+// gsc (8 floats on the device) <- {S, 1 / S, scratch, 1, 0u, 0u (saturation / non-finite counters of this backward's fp16 stores)} with S the power of two that brings the largest |element| of the two tensors (the second may be null) into [2^11, 2^12) (elementwise.hip)
 int grad_scale(const float* d_poses, long n_poses, const float* d_scores, long n_scores, float* gsc, hipStream_t st);
 // dst = s * src ; dst += s * src  (muP readout multiplier on the head weights / their gradients)
 int scale_copy(float* dst, const float* src, float s, long n, hipStream_t st);

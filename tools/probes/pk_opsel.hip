@@ -3,7 +3,8 @@
 //   mode 0: a pair that global_load_dwordx2 has just written (load; s_waitcnt vmcnt(0); v_pk_mul_f32 - the sequence of the faulty epilogue)
 //   mode 1: a pair written by two v_mov_b32 (VALU-written)
 // checked bit for bit against two v_mul_f32 of the same operands, ~1e9 lane-operations per mode, with a bandwidth-bound kernel busy on a
-// second stream.  Mismatches are counted per lane group (lanes 0-47 / 48-63).  Build + run ONCE on the GPU box:
+// second stream (modes 2 / 3 further down: the whole instruction sequence of the faulty epilogue).  Mismatches are counted per lane group
+// (lanes 0-47 / 48-63).  Build + run ONCE on the GPU box:
 //   hipcc --offload-arch=gfx950 -O2 tools/probes/pk_opsel.hip -o /tmp/pk_opsel && /tmp/pk_opsel
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -44,6 +45,50 @@ __global__ void hog(const float4* __restrict__ a, float4* __restrict__ b, long n
   for (int r = 0; r < reps; ++r)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) b[i] = a[(i + r) % n4];
 }
+// Modes 2 / 3: the instruction SEQUENCE of the faulty epilogue as hipcc emitted it at commit 56afc52^ (gemm_bf16_glds_kernel, recomputed-LayerNorm
+// residual): a row of R by vector loads, the (mean, rstd) pair by a dwordx2 load INTO ITS OWN ADDRESS REGISTERS, s_waitcnt vmcnt(0), then at once
+// two v_pk_add_f32 (op_sel_hi:[1,0], negated) and two v_pk_mul_f32 op_sel:[0,1] reading that pair; 512-thread workgroups, an LDS image read per
+// iteration, a store per iteration.  Mode 3 = the same with 16 idle cycles (two s_nop 7) between the wait and the first packed op: a fault that
+// shows in mode 2 and not in mode 3 would be a data-return race of the pair's high register, not an operand-form erratum.
+// Reference: the same statistics by two separate dword loads, full wait, idle cycles, scalar v_sub / v_mul.
+template <int NOPS>
+__global__ __launch_bounds__(512) void probe_seq(const f2* __restrict__ R, const f2* __restrict__ st, long n, int iters, unsigned* __restrict__ bad, float* __restrict__ sink) {
+  __shared__ float img[8 * 1024];
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (long)gridDim.x * blockDim.x;
+  for (int i = threadIdx.x; i < 8 * 1024; i += 512) img[i] = (float)i;
+  __syncthreads();
+  unsigned nbad = 0;
+  float acc = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    const long row = (tid + (long)it * nthr * 5) % n;
+    const f2* rp = R + 2 * (row % (n / 2));
+    unsigned long long sa = (unsigned long long)(st + row);      // address in, (mean, rstd) out: the load overwrites its own address pair
+    f2 r01, r23;
+    acc += img[(threadIdx.x * 4 + it) & 8191];                   // LDS traffic beside it, as in the epilogue's image read-back
+    if (NOPS)
+      asm volatile("global_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %3, off offset:8\n\tglobal_load_dwordx2 %2, %2, off\n\ts_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\t"
+                   "v_pk_add_f32 %0, %0, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                   "v_pk_mul_f32 %0, %0, %2 op_sel:[0,1]\n\tv_pk_mul_f32 %1, %1, %2 op_sel:[0,1]"
+                   : "=&v"(r01), "=&v"(r23), "+v"(sa) : "v"(rp) : "memory");
+    else
+      asm volatile("global_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %3, off offset:8\n\tglobal_load_dwordx2 %2, %2, off\n\ts_waitcnt vmcnt(0)\n\t"
+                   "v_pk_add_f32 %0, %0, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                   "v_pk_mul_f32 %0, %0, %2 op_sel:[0,1]\n\tv_pk_mul_f32 %1, %1, %2 op_sel:[0,1]"
+                   : "=&v"(r01), "=&v"(r23), "+v"(sa) : "v"(rp) : "memory");
+    float mean, rstd, e0, e1, e2, e3;                            // reference path: separate loads, a long wait, scalar arithmetic
+    const f2 a = rp[0], b = rp[1];
+    asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:4\n\ts_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7"
+                 : "=&v"(mean), "=&v"(rstd) : "v"(st + row) : "memory");
+    asm volatile("v_sub_f32 %0, %4, %8\n\tv_sub_f32 %1, %5, %8\n\tv_sub_f32 %2, %6, %8\n\tv_sub_f32 %3, %7, %8\n\t"
+                 "v_mul_f32 %0, %0, %9\n\tv_mul_f32 %1, %1, %9\n\tv_mul_f32 %2, %2, %9\n\tv_mul_f32 %3, %3, %9"
+                 : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3) : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]), "v"(mean), "v"(rstd));
+    nbad += (__float_as_uint(r01[0]) != __float_as_uint(e0)) + (__float_as_uint(r01[1]) != __float_as_uint(e1)) +
+            (__float_as_uint(r23[0]) != __float_as_uint(e2)) + (__float_as_uint(r23[1]) != __float_as_uint(e3));
+    if ((it & 63) == 0) sink[tid] = r01[0] + r23[1] + acc;       // a store in flight now and then (vmcnt counts stores too)
+  }
+  if (nbad) atomicAdd(bad + ((threadIdx.x & 63) >= 48), nbad);
+}
+
 int main() {
   const long n = 1L << 24;                    // 16 M pairs = 128 MB per array: beyond the L2s
   std::vector<f2> hx(n), hs(n);
@@ -69,6 +114,18 @@ int main() {
       unsigned h[4]; CK(hipMemcpy(h, dbad, sizeof(h), hipMemcpyDeviceToHost));
       printf("pair %-12s neighbour stream %-4s: %.3g lane-ops; wrong LOW lanes: lanes 0-47 %u, lanes 48-63 %u; wrong HIGH lanes: %u / %u\n",
              mode ? "VALU-written" : "just loaded", busy ? "busy" : "idle", (double)grid * 256 * iters, h[0], h[2], h[1], h[3]);
+    }
+  float* sink; CK(hipMalloc(&sink, (size_t)512 * 512 * 4));
+  for (int busy = 0; busy < 2; ++busy)
+    for (int nops = 0; nops < 2; ++nops) {
+      CK(hipMemset(dbad, 0, 16 * sizeof(unsigned)));
+      if (busy) hipLaunchKernelGGL(hog, dim3(2048), dim3(256), 0, s2, ha, hb, hn4, 24);
+      if (nops) hipLaunchKernelGGL(probe_seq<1>, dim3(512), dim3(512), 0, s1, dx, ds, n, iters, dbad, sink);
+      else hipLaunchKernelGGL(probe_seq<0>, dim3(512), dim3(512), 0, s1, dx, ds, n, iters, dbad, sink);
+      CK(hipDeviceSynchronize());
+      unsigned h[2]; CK(hipMemcpy(h, dbad, sizeof(h), hipMemcpyDeviceToHost));
+      printf("epilogue sequence%s, neighbour stream %-4s: %.3g rows x 4 values; wrong values: lanes 0-47 %u, lanes 48-63 %u\n",
+             nops ? " + 16 idle cycles behind the wait" : "", busy ? "busy" : "idle", (double)512 * 512 * iters, h[0], h[1]);
     }
   return 0;
 }
