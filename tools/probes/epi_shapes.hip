@@ -1,0 +1,200 @@
+// What the epilogue of the persistent 256 x 256 GEMM costs as a function of its STORE SHAPE, without the GEMM around it.
+// 256 workgroups of 8 waves walk output tiles; per tile every wave runs a register-only MFMA loop (the "main loop": no LDS, no DMA, one
+// barrier per step) and then writes its 128 x 64 fp32 accumulator tile in one of these forms:
+//   planar bf16 (hi / lo planes, bias added): the qkv / fc1 outputs of the split-precision forward
+//     0  nothing (accumulators kept alive)                      -> the baseline the other forms are measured against
+//     1  as shipped: 16 rows per pass through a wave-private 4 KiB LDS image, read back row-major, dwordx2 stores: 4 rows x 128 B per instruction
+//     2  no LDS, the MFMA columns PERMUTED (a lane owns two runs of 8 consecutive columns): dwordx4 stores, 16 rows x 64 B per instruction
+//     3  no LDS, natural MFMA columns (a lane owns 4 consecutive columns per block): dwordx2 stores, 16 rows x 32 B per instruction
+//   fp32 with an fp32 residual read (proj / fc2):
+//     4  as shipped: LDS image, dwordx4 loads / stores of 4 rows x 256 B per instruction
+//     5  no LDS, natural columns: dwordx4 loads / stores of 16 rows x 64 B per instruction
+// hipcc --offload-arch=gfx950 -O3 tools/probes/epi_shapes.hip -o /tmp/epi_shapes && /tmp/epi_shapes [steps per tile]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const unsigned ha = bf16_rne(a), hb = bf16_rne(b);
+  hi = ha | (hb << 16);
+  lo = bf16_rne(a - __uint_as_float(ha << 16)) | (bf16_rne(b - __uint_as_float(hb << 16)) << 16);
+}
+
+template <int V>
+__global__ __launch_bounds__(512) void epi_kernel(unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, float* __restrict__ c32,
+                                                  const float* __restrict__ resid, const float* __restrict__ bias, int tiles_n, int ntiles, int N, int steps, int stagger) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, gq = lane >> 4;
+  float* const img = reinterpret_cast<float*>(smem + wave * 4096);
+  const int per_xcd = gridDim.x >> 3;
+  union { unsigned u[4]; bf16x8_t v; } fa, fb;
+  for (int q = 0; q < 4; ++q) { fa.u[q] = 0x3F803C00u + lane * 0x00010001u + q; fb.u[q] = 0x3E803D00u + lane * 0x00030001u + 7 * q; }
+  if (stagger > 0) {      // start the workgroups of an XCD in four phase groups, `stagger` MFMA steps apart (so that the CUs' store bursts do not coincide)
+    f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ((blockIdx.x >> 3) & 3) * stagger * 64; ++s) w = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb.v, fa.v, w, 0, 0, 0);
+    if (w[0] == 12345.678f) c32[lane] = w[0];
+  }
+  for (int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3); id < ntiles; id += gridDim.x) {
+    const int m0 = (id / tiles_n) * 256, n0 = (id % tiles_n) * 256;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < steps; ++s) {
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb.v, fa.v, acc[i][j], 0, 0, 0);
+      fa.u[0] ^= 0x00010001u; fb.u[1] ^= 0x00010001u;
+    }
+    const int row0 = m0 + wr * 128;
+    if (V == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (s == 12345.678f) c32[lane] = s;
+    } else if (V == 1 || V == 4) {
+      const int col = n0 + wc * 64 + 4 * l15;
+      const float4 b4 = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float4 in[4];
+        if (V == 4) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it) in[it] = *reinterpret_cast<const float4*>(resid + (long)(row0 + i * 16 + it * 4 + gq) * N + col);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(img + l15 * 64 + (((4 * j + gq) ^ l15) << 2)) = acc[i][j];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int lr = it * 4 + gq;
+          float4 v = *reinterpret_cast<const float4*>(img + lr * 64 + ((l15 ^ lr) << 2));
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          const long o = (long)(row0 + i * 16 + lr) * N + col;
+          if (V == 1) {
+            uint2 h, l;
+            split2(v.x, v.y, h.x, l.x); split2(v.z, v.w, h.y, l.y);
+            *reinterpret_cast<uint2*>(hi + o) = h;
+            *reinterpret_cast<uint2*>(lo + o) = l;
+          } else {
+            v.x += in[it].x; v.y += in[it].y; v.z += in[it].z; v.w += in[it].w;
+            *reinterpret_cast<float4*>(c32 + o) = v;
+          }
+        }
+      }
+    } else if (V == 2) {
+      // MFMA block j, lane group gq, element e  <->  column 32 (j >> 1) + 8 gq + 4 ((j ^ gq) & 1) + e
+      const int odd = gq & 1;
+      float4 bs[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bs[u][0] = *reinterpret_cast<const float4*>(bias + n0 + wc * 64 + 32 * u + 8 * gq);
+        bs[u][1] = *reinterpret_cast<const float4*>(bias + n0 + wc * 64 + 32 * u + 8 * gq + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const long orow = (long)(row0 + i * 16 + l15) * N + n0 + wc * 64 + 8 * gq;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x4 a = odd ? acc[i][2 * u + 1] : acc[i][2 * u], b = odd ? acc[i][2 * u] : acc[i][2 * u + 1];
+          uint4 h, l;
+          split2(a[0] + bs[u][0].x, a[1] + bs[u][0].y, h.x, l.x); split2(a[2] + bs[u][0].z, a[3] + bs[u][0].w, h.y, l.y);
+          split2(b[0] + bs[u][1].x, b[1] + bs[u][1].y, h.z, l.z); split2(b[2] + bs[u][1].z, b[3] + bs[u][1].w, h.w, l.w);
+          *reinterpret_cast<uint4*>(hi + orow + 32 * u) = h;
+          *reinterpret_cast<uint4*>(lo + orow + 32 * u) = l;
+        }
+      }
+    } else if (V == 3 || V == 5) {
+      float4 bs[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bs[j] = *reinterpret_cast<const float4*>(bias + n0 + wc * 64 + 16 * j + 4 * gq);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const long orow = (long)(row0 + i * 16 + l15) * N + n0 + wc * 64 + 4 * gq;
+        float4 in[4];
+        if (V == 5) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) in[j] = *reinterpret_cast<const float4*>(resid + orow + 16 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float4 v = make_float4(acc[i][j][0] + bs[j].x, acc[i][j][1] + bs[j].y, acc[i][j][2] + bs[j].z, acc[i][j][3] + bs[j].w);
+          if (V == 3) {
+            uint2 h, l;
+            split2(v.x, v.y, h.x, l.x); split2(v.z, v.w, h.y, l.y);
+            *reinterpret_cast<uint2*>(hi + orow + 16 * j) = h;
+            *reinterpret_cast<uint2*>(lo + orow + 16 * j) = l;
+          } else {
+            v.x += in[j].x; v.y += in[j].y; v.z += in[j].z; v.w += in[j].w;
+            *reinterpret_cast<float4*>(c32 + orow + 16 * j) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+template <int V>
+static float run(unsigned short* hi, unsigned short* lo, float* c32, const float* resid, const float* bias, int M, int N, int steps, int stagger = 0) {
+  const int tiles_n = N / 256, ntiles = tiles_n * (M / 256);
+  hipFuncSetAttribute((const void*)epi_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; ++rep) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((epi_kernel<V>), dim3(256), dim3(512), 160 * 1024, 0, hi, lo, c32, resid, bias, tiles_n, ntiles, N, steps, stagger);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  return best;
+}
+
+int main(int argc, char** argv) {
+  const int M = 256 * 1275;
+  const int steps = argc > 1 ? atoi(argv[1]) : 24;
+  const int stagger = argc > 2 ? atoi(argv[2]) : 0;
+  unsigned short *hi, *lo;
+  float *c32, *resid, *bias;
+  CK(hipMalloc(&hi, (size_t)M * 1536 * 2)); CK(hipMalloc(&lo, (size_t)M * 1536 * 2));
+  CK(hipMalloc(&c32, (size_t)M * 512 * 4)); CK(hipMalloc(&resid, (size_t)M * 512 * 4)); CK(hipMalloc(&bias, 2048 * 4));
+  CK(hipMemset(resid, 0, (size_t)M * 512 * 4)); CK(hipMemset(bias, 0, 2048 * 4));
+  printf("steps per tile %d (64 MFMAs per wave and step), start stagger %d steps per phase group\n", steps, stagger);
+  {
+    const int N = 1536; const double rounds = (double)(N / 256) * (M / 256) / 256.0;
+    const float t0 = run<0>(hi, lo, c32, resid, bias, M, N, steps, stagger);
+    const float t1 = run<1>(hi, lo, c32, resid, bias, M, N, steps, stagger);
+    const float t2 = run<2>(hi, lo, c32, resid, bias, M, N, steps, stagger);
+    const float t3 = run<3>(hi, lo, c32, resid, bias, M, N, steps, stagger);
+    printf("planar bf16, N = 1536 (%.1f tiles per workgroup): none %.3f ms | LDS image 4 rows x 128 B %.3f ms (+%.2f us / tile) | permuted 16 rows x 64 B %.3f ms (+%.2f) | natural 16 rows x 32 B %.3f ms (+%.2f)\n",
+           rounds, t0, t1, (t1 - t0) * 1e3 / rounds, t2, (t2 - t0) * 1e3 / rounds, t3, (t3 - t0) * 1e3 / rounds);
+  }
+  {
+    const int N = 512; const double rounds = (double)(N / 256) * (M / 256) / 256.0;
+    const float t0 = run<0>(hi, lo, c32, resid, bias, M, N, steps, stagger);
+    const float t4 = run<4>(hi, lo, c32, resid, bias, M, N, steps, stagger);
+    const float t5 = run<5>(hi, lo, c32, resid, bias, M, N, steps, stagger);
+    printf("fp32 + residual, N = 512 (%.1f tiles per workgroup): none %.3f ms | LDS image 4 rows x 256 B %.3f ms (+%.2f us / tile) | natural 16 rows x 64 B %.3f ms (+%.2f)\n",
+           rounds, t0, t4, (t4 - t0) * 1e3 / rounds, t5, (t5 - t0) * 1e3 / rounds);
+  }
+  return 0;
+}
