@@ -160,7 +160,10 @@ int ln_fwd(const LnFwdArgs& a_in, int out_mode, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 // saturation / non-finite counters of the scaled-fp16 gradient stores (common.h sat_f16x4): 4 floats behind the scale (mp_model::gsc)
 __device__ __forceinline__ unsigned* gs_cnt(const float* gsc) { return reinterpret_cast<unsigned*>(const_cast<float*>(gsc)) + 4; }
-constexpr int LNB_GRID = 1024;   // 4 workgroups (16 waves) per CU
+#ifndef LNB_GRID_N
+#define LNB_GRID_N 1024
+#endif
+constexpr int LNB_GRID = LNB_GRID_N;   // 4 workgroups (16 waves) per CU
 
 // V float4 per lane (C <= 256 V); R rows in flight per wave: every load of the R rows (x, dy, skip gradient, statistics, DropPath
 // scale) is issued before the first row is reduced.
@@ -331,14 +334,15 @@ int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, cons
 }
 
 #ifndef LNB2_R
-#define LNB2_R 2
-#endif
+#define LNB2_R 1      // rows in flight per wave.  Round 4 (tools/probes/ln_bwd_probe.hip, profiles/r04_probes/ln_bwd_variants1.log): isolated at the bench's token
+#endif                // count 576 us with two rows (168 VGPRs, 3 waves per SIMD), 530 us with one (ln_bwd_kernel: 528 us for the same 16 B per element); in the step the
+                      // LayerNorm class 28.17 -> 27.57 ms with every kernel on one queue, 168.0 -> 166.1 ms per step (same box, alternating, two rounds)
 // Fused pair of LayerNorm backwards across a block boundary (precision-independent, C <= 512):
 //   t  = dskip + LN1'(dy1; x1, stats1, gamma1)        (norm1 of block l+1, plus the residual skip gradient)
 //   dx = LN0'(t; x0, stats0, gamma0)                  (shared post-norm behind block l)
 // saving one fp32 write + read of the gradient stream per block.  Partials: [dgamma1 | dbeta1 | dgamma0 | dbeta0].
-// R rows in flight per wave: every load of the R rows is issued before the first row is reduced (one row per wave left ~60 KB in flight per
-// CU and the kernel at 4.2 TB/s of its 16 B per element, against 5.8 TB/s for ln_bwd_kernel with its two rows).
+// R rows in flight per wave: every load of the R rows is issued before the first row is reduced.  (Round 3 measured one row per wave slower - on a
+// fixed grid of 1024 workgroups; with the grid taken from the occupancy query below the register-lighter one-row form puts more waves on a CU and wins.)
 template <typename TDY, int R>
 __global__ __launch_bounds__(256) void ln_bwd2_kernel(const TDY* __restrict__ dy1,
                                                        const float* __restrict__ stats1, const float* __restrict__ gamma1,
@@ -490,7 +494,11 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
       slots[dy_bf16 ? 1 : 0] = LNB_GRID;
     } else slots[dy_bf16 ? 1 : 0] = min(cus * per_cu, LNB_GRID);
   }
+#ifdef LNB2_GRID
+  const int grid = max(1, min(cdiv(M, 4), LNB2_GRID));      // probe builds (tools/probes/ln_bwd_probe.hip)
+#else
   const int grid = max(1, min(cdiv(M, 4), slots[dy_bf16 ? 1 : 0]));
+#endif
   MP_CHECK(scratch_floats >= (long)grid * 4 * C, MP_ERR_ARG, "ln_bwd2: scratch too small");
   if (dy_bf16)
     hipLaunchKernelGGL((ln_bwd2_kernel<bf16, LNB2_R>), dim3(grid), dim3(256), 0, st, (const bf16*)dy1, stats1, gamma1, dskip, x0, stats0, gamma0,

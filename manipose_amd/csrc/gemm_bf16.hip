@@ -809,6 +809,12 @@ __device__ __forceinline__ void persist_epilogue_bf16_packed(const GemmB16Args& 
   }
 }
 
+// (Round 4, tools/probes/epi_shapes.hip + profiles/r04_probes/: what an epilogue costs is set by the CU's store path and by every CU storing at
+// once - the same 256 KiB of planar output cost 6.5 us per tile as dwordx2 stores of 4 rows x 128 B (this epilogue), 4.4 us as dwordx4 stores
+// of 8 rows x 128 B, 8 us with the MFMA columns permuted so that no LDS transposition is needed (16 rows x 64 B per instruction), 13 us in the
+// natural accumulator layout (16 rows x 32 B), 3 us as contiguous 16 KiB blocks; one CU in 32 storing: 4.2 / 2.1 / 5.7 / 11.6 / 0.2 us.  The
+// dwordx4 form of this epilogue for the planar outputs was built and measured in the real kernels: qkv 1356 / 1344 -> 1338 / 1341 us, fc1
+// unchanged, the step unchanged - not kept.)
 // SPLIT: see gemm_bf16_glds_kernel (three steps per k-tile, the DMA source planes rotate)
 template <int TRB, typename TC, int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, int tiles_n, int ntiles) {
@@ -820,6 +826,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
   const int per_xcd = gridDim.x >> 3;                       // gridDim.x is a multiple of 8
+  // (Round 4: giving every XCD ONE contiguous range of whole tile rows for the whole launch - so that no activation row panel is shared between
+  // two L2s - changes nothing: block of four split-precision GEMMs 3898 / 3856 us -> 3899 / 3875 us, profiles/r04_probes/gemm_block_ab.log.)
   int id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (id >= ntiles) return;
   const int nk = g.K / GBK;                                 // K % 64 == 0, nk >= 2 (launcher)

@@ -9,7 +9,8 @@
 //   fp32 with an fp32 residual read (proj / fc2):
 //     4  as shipped: LDS image, dwordx4 loads / stores of 4 rows x 256 B per instruction
 //     5  no LDS, natural columns: dwordx4 loads / stores of 16 rows x 64 B per instruction
-// hipcc --offload-arch=gfx950 -O3 tools/probes/epi_shapes.hip -o /tmp/epi_shapes && /tmp/epi_shapes [steps per tile]
+//   (6 / 7: contiguous 16 KiB blocks; 8: form 1 with dwordx4 stores of 8 rows x 128 B; 9: form 4 with the residual requested two passes ahead)
+// hipcc --offload-arch=gfx950 -O3 tools/probes/epi_shapes.hip -o /tmp/epi_shapes && /tmp/epi_shapes [steps per tile] [start stagger] [one in F workgroups stores] [wave mode]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -28,7 +29,7 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 
 template <int V>
 __global__ __launch_bounds__(512) void epi_kernel(unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, float* __restrict__ c32,
-                                                  const float* __restrict__ resid, const float* __restrict__ bias, int tiles_n, int ntiles, int N, int steps, int stagger) {
+                                                  const float* __restrict__ resid, const float* __restrict__ bias, int tiles_n, int ntiles, int N, int steps, int stagger, int cufrac, int wmode) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -60,7 +61,9 @@ __global__ __launch_bounds__(512) void epi_kernel(unsigned short* __restrict__ h
       fa.u[0] ^= 0x00010001u; fb.u[1] ^= 0x00010001u;
     }
     const int row0 = m0 + wr * 128;
-    if (V == 0) {
+    // cufrac F: only one in F workgroups of every XCD stores; wmode 1: only waves 0-3 store, 2: only the even waves (the others keep their accumulators alive like form 0)
+    const bool skip = (cufrac > 1 && ((blockIdx.x >> 3) % cufrac) != 0) || (wmode == 1 && wave >= 4) || (wmode == 2 && (wave & 1));
+    if (V == 0 || skip) {
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -118,6 +121,71 @@ __global__ __launch_bounds__(512) void epi_kernel(unsigned short* __restrict__ h
           *reinterpret_cast<uint4*>(lo + orow + 32 * u) = l;
         }
       }
+    } else if (V == 8) {
+      // the LDS image of form 1 read back with 8 lanes per row (two ds_read_b128 per lane): dwordx4 stores, 8 rows x 128 B per instruction
+      const int c8 = lane & 7, r8 = lane >> 3;
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + n0 + wc * 64 + 8 * c8), b1 = *reinterpret_cast<const float4*>(bias + n0 + wc * 64 + 8 * c8 + 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(img + l15 * 64 + (((4 * j + gq) ^ l15) << 2)) = acc[i][j];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int lr = it * 8 + r8;
+          const float4 v0 = *reinterpret_cast<const float4*>(img + lr * 64 + (((2 * c8) ^ lr) << 2));
+          const float4 v1 = *reinterpret_cast<const float4*>(img + lr * 64 + (((2 * c8 + 1) ^ lr) << 2));
+          const long o = (long)(row0 + i * 16 + lr) * N + n0 + wc * 64 + 8 * c8;
+          uint4 h, l;
+          split2(v0.x + b0.x, v0.y + b0.y, h.x, l.x); split2(v0.z + b0.z, v0.w + b0.w, h.y, l.y);
+          split2(v1.x + b1.x, v1.y + b1.y, h.z, l.z); split2(v1.z + b1.z, v1.w + b1.w, h.w, l.w);
+          *reinterpret_cast<uint4*>(hi + o) = h;
+          *reinterpret_cast<uint4*>(lo + o) = l;
+        }
+      }
+    } else if (V == 9) {
+      // form 4 with the residual rows requested TWO passes ahead of their use instead of one
+      const int col = n0 + wc * 64 + 4 * l15;
+      const float4 b4 = *reinterpret_cast<const float4*>(bias + col);
+      float4 in[3][4];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) in[p][it] = *reinterpret_cast<const float4*>(resid + (long)(row0 + p * 16 + it * 4 + gq) * N + col);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(img + l15 * 64 + (((4 * j + gq) ^ l15) << 2)) = acc[i][j];
+        if (i + 2 < 8) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it) in[(i + 2) % 3][it] = *reinterpret_cast<const float4*>(resid + (long)(row0 + (i + 2) * 16 + it * 4 + gq) * N + col);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int lr = it * 4 + gq;
+          float4 v = *reinterpret_cast<const float4*>(img + lr * 64 + ((l15 ^ lr) << 2));
+          const float4 r = in[i % 3][it];
+          v.x += b4.x + r.x; v.y += b4.y + r.y; v.z += b4.z + r.z; v.w += b4.w + r.w;
+          *reinterpret_cast<float4*>(c32 + (long)(row0 + i * 16 + lr) * N + col) = v;
+        }
+      }
+    } else if (V == 6 || V == 7) {
+      // same bytes, but the wave's 128 x 64 sub-tile is one CONTIGUOUS 16 KiB block per plane (every store instruction writes 1 KiB of consecutive
+      // addresses): what the memory system does with the tile's bytes when their placement is ideal.  7: the same with non-temporal stores
+      const long blk = ((long)id * 8 + wave) * 8192;      // elements per wave and plane
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x4 a = acc[i][2 * u], b = acc[i][2 * u + 1];
+          uint4 h, l;
+          split2(a[0], a[1], h.x, l.x); split2(a[2], a[3], h.y, l.y);
+          split2(b[0], b[1], h.z, l.z); split2(b[2], b[3], h.w, l.w);
+          typedef unsigned u4 __attribute__((ext_vector_type(4)));
+          u4* ph = reinterpret_cast<u4*>(hi + blk + (i * 2 + u) * 512 + lane * 8);
+          u4* pl = reinterpret_cast<u4*>(lo + blk + (i * 2 + u) * 512 + lane * 8);
+          if (V == 7) { __builtin_nontemporal_store(u4{h.x, h.y, h.z, h.w}, ph); __builtin_nontemporal_store(u4{l.x, l.y, l.z, l.w}, pl); }
+          else { *ph = u4{h.x, h.y, h.z, h.w}; *pl = u4{l.x, l.y, l.z, l.w}; }
+        }
     } else if (V == 3 || V == 5) {
       float4 bs[4];
 #pragma unroll
@@ -151,7 +219,7 @@ __global__ __launch_bounds__(512) void epi_kernel(unsigned short* __restrict__ h
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 template <int V>
-static float run(unsigned short* hi, unsigned short* lo, float* c32, const float* resid, const float* bias, int M, int N, int steps, int stagger = 0) {
+static float run(unsigned short* hi, unsigned short* lo, float* c32, const float* resid, const float* bias, int M, int N, int steps, int stagger = 0, int cufrac = 1, int wmode = 0) {
   const int tiles_n = N / 256, ntiles = tiles_n * (M / 256);
   hipFuncSetAttribute((const void*)epi_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipEvent_t e0, e1;
@@ -159,7 +227,7 @@ static float run(unsigned short* hi, unsigned short* lo, float* c32, const float
   float best = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((epi_kernel<V>), dim3(256), dim3(512), 160 * 1024, 0, hi, lo, c32, resid, bias, tiles_n, ntiles, N, steps, stagger);
+    hipLaunchKernelGGL((epi_kernel<V>), dim3(256), dim3(512), 160 * 1024, 0, hi, lo, c32, resid, bias, tiles_n, ntiles, N, steps, stagger, cufrac, wmode);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0.f;
@@ -173,26 +241,34 @@ int main(int argc, char** argv) {
   const int M = 256 * 1275;
   const int steps = argc > 1 ? atoi(argv[1]) : 24;
   const int stagger = argc > 2 ? atoi(argv[2]) : 0;
+  const int cufrac = argc > 3 ? atoi(argv[3]) : 1, wmode = argc > 4 ? atoi(argv[4]) : 0;
   unsigned short *hi, *lo;
   float *c32, *resid, *bias;
   CK(hipMalloc(&hi, (size_t)M * 1536 * 2)); CK(hipMalloc(&lo, (size_t)M * 1536 * 2));
   CK(hipMalloc(&c32, (size_t)M * 512 * 4)); CK(hipMalloc(&resid, (size_t)M * 512 * 4)); CK(hipMalloc(&bias, 2048 * 4));
   CK(hipMemset(resid, 0, (size_t)M * 512 * 4)); CK(hipMemset(bias, 0, 2048 * 4));
-  printf("steps per tile %d (64 MFMAs per wave and step), start stagger %d steps per phase group\n", steps, stagger);
+  printf("steps per tile %d (64 MFMAs per wave and step), start stagger %d steps per phase group, one in %d workgroups stores, wave mode %d\n", steps, stagger, cufrac, wmode);
   {
     const int N = 1536; const double rounds = (double)(N / 256) * (M / 256) / 256.0;
-    const float t0 = run<0>(hi, lo, c32, resid, bias, M, N, steps, stagger);
-    const float t1 = run<1>(hi, lo, c32, resid, bias, M, N, steps, stagger);
-    const float t2 = run<2>(hi, lo, c32, resid, bias, M, N, steps, stagger);
-    const float t3 = run<3>(hi, lo, c32, resid, bias, M, N, steps, stagger);
+    const float t0 = run<0>(hi, lo, c32, resid, bias, M, N, steps, stagger, cufrac, wmode);
+    const float t1 = run<1>(hi, lo, c32, resid, bias, M, N, steps, stagger, cufrac, wmode);
+    const float t2 = run<2>(hi, lo, c32, resid, bias, M, N, steps, stagger, cufrac, wmode);
+    const float t3 = run<3>(hi, lo, c32, resid, bias, M, N, steps, stagger, cufrac, wmode);
+    const float t8 = run<8>(hi, lo, c32, resid, bias, M, N, steps, stagger, cufrac, wmode);
+    printf("  LDS image read back 8 lanes per row, dwordx4 stores 8 rows x 128 B: %.3f ms (+%.2f us / tile)\n", t8, (t8 - t0) * 1e3 / rounds);
+    const float t6 = run<6>(hi, lo, c32, resid, bias, M, N, steps, stagger, cufrac, wmode);
+    const float t7 = run<7>(hi, lo, c32, resid, bias, M, N, steps, stagger, cufrac, wmode);
+    printf("  the same bytes as one contiguous 16 KiB block per wave and plane: %.3f ms (+%.2f us / tile), with non-temporal stores %.3f ms (+%.2f)\n", t6, (t6 - t0) * 1e3 / rounds, t7, (t7 - t0) * 1e3 / rounds);
     printf("planar bf16, N = 1536 (%.1f tiles per workgroup): none %.3f ms | LDS image 4 rows x 128 B %.3f ms (+%.2f us / tile) | permuted 16 rows x 64 B %.3f ms (+%.2f) | natural 16 rows x 32 B %.3f ms (+%.2f)\n",
            rounds, t0, t1, (t1 - t0) * 1e3 / rounds, t2, (t2 - t0) * 1e3 / rounds, t3, (t3 - t0) * 1e3 / rounds);
   }
   {
     const int N = 512; const double rounds = (double)(N / 256) * (M / 256) / 256.0;
-    const float t0 = run<0>(hi, lo, c32, resid, bias, M, N, steps, stagger);
-    const float t4 = run<4>(hi, lo, c32, resid, bias, M, N, steps, stagger);
-    const float t5 = run<5>(hi, lo, c32, resid, bias, M, N, steps, stagger);
+    const float t0 = run<0>(hi, lo, c32, resid, bias, M, N, steps, stagger, cufrac, wmode);
+    const float t4 = run<4>(hi, lo, c32, resid, bias, M, N, steps, stagger, cufrac, wmode);
+    const float t5 = run<5>(hi, lo, c32, resid, bias, M, N, steps, stagger, cufrac, wmode);
+    const float t9 = run<9>(hi, lo, c32, resid, bias, M, N, steps, stagger, cufrac, wmode);
+    printf("  LDS image, residual rows requested two passes ahead: %.3f ms (+%.2f us / tile)\n", t9, (t9 - t0) * 1e3 / rounds);
     printf("fp32 + residual, N = 512 (%.1f tiles per workgroup): none %.3f ms | LDS image 4 rows x 256 B %.3f ms (+%.2f us / tile) | natural 16 rows x 64 B %.3f ms (+%.2f)\n",
            rounds, t0, t4, (t4 - t0) * 1e3 / rounds, t5, (t5 - t0) * 1e3 / rounds);
   }
