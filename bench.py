@@ -446,9 +446,10 @@ def main():
                 k = sub
                 kname = ("gemm_bf16_persist_kernel (forward + dgrad Linear GEMMs: persistent, direct-to-LDS 256x256x64 tiles, "
                          "v_mfma_f32_16x16x32_bf16; all instantiations" +
-                         ("; the split-precision forward instantiations read two planes per operand and issue 3 bf16 products per k-tile "
-                          "(proj, fc2) or one fp16 + one double-depth fp8 product (qkv, fc1: v_mfma_f32_16x16x32_f16 + "
-                          "v_mfma_scale_f32_16x16x128_f8f6f4); flops = 2 M N K, bytes = both planes)" if args.precision == "bf16x3" else ")"))
+                         ("; the split-precision forward instantiations read two planes per operand and issue 3 bf16 products per k-tile"
+                          + (" (proj, fc2) or one fp16 + one double-depth fp8 product (qkv, fc1: v_mfma_f32_16x16x32_f16 + "
+                             "v_mfma_scale_f32_16x16x128_f8f6f4)" if args.f16f8 >= 1 else "")
+                          + "; flops = 2 M N K, bytes = both planes)" if args.precision == "bf16x3" else ")"))
             else:
                 k = prof["gemm_fwd"]
                 kname = ("gemm_bf16_glds_kernel (forward Linear GEMMs)" if args.precision != "fp32"

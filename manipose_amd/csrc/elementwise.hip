@@ -163,7 +163,9 @@ __device__ __forceinline__ unsigned* gs_cnt(const float* gsc) { return reinterpr
 #ifndef LNB_GRID_N
 #define LNB_GRID_N 1024
 #endif
-constexpr int LNB_GRID = LNB_GRID_N;   // 4 workgroups (16 waves) per CU
+constexpr int LNB_GRID = LNB_GRID_N;
+// (Round 4: walking the rows last-written-first, so that a kernel starts on what its producer left in the 256 MB Infinity Cache, moves nothing:
+// LayerNorm class 27.65 / 27.73 -> 27.57 / 27.58 ms with every kernel on one queue, profiles/r04_probes/ab_step3.log.)   // 4 workgroups (16 waves) per CU
 
 // V float4 per lane (C <= 256 V); R rows in flight per wave: every load of the R rows (x, dy, skip gradient, statistics, DropPath
 // scale) is issued before the first row is reduced.
@@ -317,12 +319,26 @@ int ln_bwd(const void* dy, int dy_bf16, const float* x, const float* stats, cons
            const float* mask, int mask_mode, int T, int J, float* dgamma, float* dbeta, int M, int C, float* scratch,
            long scratch_floats, hipStream_t st, hipStream_t st_param, hipEvent_t ev, float rs, const float* dy_scale, const float* b16_gs) {
   MP_CHECK(C % 4 == 0 && C <= 1024, MP_ERR_ARG, "ln_bwd: C=%d unsupported", C);
-  const int grid = max(1, min(cdiv(M, 4), LNB_GRID));
+#ifndef LNB_R
+#define LNB_R 1      // rows in flight per wave: 499 -> 490 us isolated with one (92 VGPRs, the 1024 workgroups of the scratch rows all resident); profiles/r04_probes/ln_bwd_variants2.log
+#endif
+  // persistent grid = the workgroups resident at once (occupancy query x CUs, at most LNB_GRID: the partial-sum scratch has LNB_GRID rows)
+  static int slots[2] = {0, 0};
+  if (C <= 512 && slots[dy_bf16 ? 1 : 0] == 0) {
+    int dev = 0, cus = 0, per_cu = 0;
+    const void* fn = dy_bf16 ? (const void*)ln_bwd_kernel<bf16, 2, LNB_R> : (const void*)ln_bwd_kernel<float, 2, LNB_R>;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || cus <= 0 || per_cu <= 0) {
+      (void)hipGetLastError();
+      slots[dy_bf16 ? 1 : 0] = LNB_GRID;
+    } else slots[dy_bf16 ? 1 : 0] = min(cus * per_cu, LNB_GRID);
+  }
+  const int grid = max(1, min(cdiv(M, 4), C <= 512 ? slots[dy_bf16 ? 1 : 0] : LNB_GRID));
   MP_CHECK(scratch_floats >= (long)grid * 2 * C, MP_ERR_ARG, "ln_bwd: scratch too small");
 #define MP_LN_BWD(TDY, V, R)                                                                                                             \
   hipLaunchKernelGGL((ln_bwd_kernel<TDY, V, R>), dim3(grid), dim3(256), 0, st, (const TDY*)dy, x, stats, gamma, dskip, dx, (bf16*)dx_b16, \
                      mask, mask ? mask_mode : 0, T, J, scratch, M, C, rs, dy_scale, b16_gs)
-  if (C <= 512) { if (dy_bf16) MP_LN_BWD(bf16, 2, 2); else MP_LN_BWD(float, 2, 2); }
+  if (C <= 512) { if (dy_bf16) MP_LN_BWD(bf16, 2, LNB_R); else MP_LN_BWD(float, 2, LNB_R); }
   else          { if (dy_bf16) MP_LN_BWD(bf16, 4, 1); else MP_LN_BWD(float, 4, 1); }
 #undef MP_LN_BWD
   MP_LAUNCH_CHECK();

@@ -674,12 +674,9 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
         const float dscale = dp.scale(row);
         float4 r = ld4(g.R + o);
         if (g.rstats != nullptr) {               // the residual is LayerNorm(R), recomputed (ln_fwd stage-1 expression)
-          // (mean, rstd) of this row out of the wave's prefetched statistics.  NOT a per-row float2 load consumed on the spot: that
-          // form compiled to `global_load_dwordx2 v[n:n+1]; s_waitcnt vmcnt(0); ... v_pk_mul_f32 .., v[n:n+1] op_sel:[0,1]` (the low
-          // lane of the packed multiply takes the pair's HIGH register), and on gfx950 its low-lane results came out wrong for lanes
-          // 48-63 in ~1e-4 of the rows - run-to-run different, caught by tools/gemm_determinism.py in round 3 (an empty asm that only
-          // forces the two values into separate registers made it disappear).  The shuffle above delivers them long after the
-          // load; lone() (common.h) puts each into a VALU-written register of its own.
+          // (mean, rstd) of this row out of the wave's prefetched statistics (one coalesced load per 64 rows, handed out by the shuffles
+          // above), not a per-row float2 load consumed on the spot: that form - compiled to a v_pk_mul_f32 with op_sel on the loaded pair -
+          // was the site of round 3's wrong rows (common.h, "packed-fp32 guard": cause not identified; the form no longer exists)
           mean = lone(mean); rstd = lone(rstd);
           r = make_float4((r.x - mean) * rstd * rg4.x + rb4.x, (r.y - mean) * rstd * rg4.y + rb4.y, (r.z - mean) * rstd * rg4.z + rb4.z,
                           (r.w - mean) * rstd * rg4.w + rb4.w);
@@ -1274,7 +1271,10 @@ static void wgrad_split_b16(int Mtok, int Nout, int Kin, int bt, int& splits, in
   const int tiles = cdiv(Nout, bt) * cdiv(Kin, bt);
   // 256^2 tiles run one workgroup per CU: fill the 256 CUs exactly once (a 257th workgroup would double the kernel time);
   // 128^2 tiles run 2-4 per CU.  Fewer splits also means fewer fp32 slabs to write and reduce.
-  splits = (bt == 256) ? max(1, min(64, 256 / tiles)) : max(1, min(64, (1024 + tiles - 1) / tiles));
+  // 128-wide tiles (the bones net): up to 128 splits - with 64 its one to three output tiles gave 64-192 workgroups for 512 slots (round 4: the
+  // weight-gradient class 22.54 -> 22.00 ms with every kernel on one queue, 256 splits the same; the three-queue step does not move, the bones
+  // net's backward runs beside the main queue: profiles/r04_probes/ab_step2.log)
+  splits = (bt == 256) ? max(1, min(64, 256 / tiles)) : max(1, min(128, (1024 + tiles - 1) / tiles));
   kper = ((cdiv(Mtok, splits) + GBK - 1) / GBK) * GBK;
   splits = cdiv(Mtok, kper);
 }

@@ -191,7 +191,7 @@ long wgrad_f32_slab_floats(int Mtok, int Nout, int Kin) {
   (void)Mtok;   // upper bound over every token count: the split count never exceeds the tile-derived target
   const int tiles = cdiv(Nout, BM) * cdiv(Kin, BN);                  // 128x128 tiles (fp32 and narrow bf16 layers)
   const int tiles256 = cdiv(Nout, 256) * cdiv(Kin, 256);             // 256x256 tiles of the bf16 direct-to-LDS kernel
-  const int s128 = max(1, min(64, (1024 + tiles - 1) / tiles)), s256 = max(1, min(64, (512 + tiles256 - 1) / tiles256));
+  const int s128 = max(1, min(256, (1024 + tiles - 1) / tiles)), s256 = max(1, min(64, (512 + tiles256 - 1) / tiles256));      // (bounds of wgrad_split / wgrad_split_b16)
   return ((long)Nout * Kin + Nout) * max(s128, s256);
 }
 

@@ -1163,8 +1163,8 @@ def test_rccl_backend_single_rank_collectives_on_the_flat_gradient_buffer(lib):
                 time.sleep(0.5)
         out.seek(0); err.seek(0)
         so, se = out.read(), err.read()
-    log_dir = os.path.join(root, "gpurun_out")
-    if os.path.isdir(log_dir):                 # keep RCCL's log of this run next to the other GPU-side logs
+    log_dir = os.environ.get("MANIPOSE_TEST_LOG_DIR")      # (optional) keep RCCL's log of this run; the test writes nothing into the repo by itself
+    if log_dir and os.path.isdir(log_dir):
         with open(os.path.join(log_dir, "rccl_single_rank.log"), "w") as f:
             f.write(so + "\n--- stderr ---\n" + se)
     assert not timed_out, "the single-rank RCCL process did not finish within 180 s (killed); its output:\n" + so[-500:] + "\n" + se[-3000:]

@@ -455,10 +455,11 @@ def test_gradient_buckets_cover_the_layers_of_the_rotations_net():
 
 
 def test_generated_code_has_no_packed_op_reading_a_freshly_loaded_high_register():
-    """Audit of the gfx950 assembly of every kernel source for the hazard described in csrc/common.h (lone()): a packed fp32 op whose low
-    lane takes the high register of a pair that a vector-memory load wrote.  Round 3 traced run-to-run different results (2 mm on the
-    segment lengths at the benchmark's batch, non-reproducible gradients) to exactly that pattern; tools/scan_pk_opsel.py compiles the
-    sources with hipcc (cross-compilation, no GPU needed) and must find none."""
+    """Audit of the gfx950 assembly of every kernel source (csrc/common.h, "packed-fp32 guard"): no packed fp32 op at all, in particular none
+    whose low lane takes the high register of a pair.  Round 3 saw run-to-run different results (2 mm on the segment lengths at the
+    benchmark's batch, non-reproducible gradients) at two sites with that operand form; the form alone is not faulty (round-4 probe), the cause
+    is unknown, and the library keeps the whole instruction class out.  tools/scan_pk_opsel.py compiles the sources with hipcc
+    (cross-compilation, no GPU needed) and must find none."""
     import shutil, subprocess
     if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")

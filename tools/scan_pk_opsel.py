@@ -1,7 +1,7 @@
-"""Build-time audit for a gfx950 hazard found in round 3 (csrc/common.h, "gfx950 hazard guard"): a packed fp32 VALU op
-(v_pk_mul/add/fma_f32) whose LOW lane reads the HIGH register of a VGPR pair (op_sel bit = 1 on that source) produced wrong low-lane
-results for lanes 48-63, rarely and differently in every run.  The SLP vectoriser is the only producer of that operand form in this
-code base, so the library is built with -fno-slp-vectorize; this script compiles every csrc/*.hip to gfx950 assembly with the flags of
+"""Build-time audit (csrc/common.h, "packed-fp32 guard"): round 3 saw run-to-run different results at two sites whose generated code had a
+packed fp32 VALU op (v_pk_mul/add/fma_f32) taking the HIGH register of a VGPR pair for its LOW lane (op_sel bit = 1 on that source).  The
+isolating probe of round 4 (tools/probes/pk_opsel.hip) shows that operand form to be correct by itself, so the cause is unknown; the form - and
+every other packed fp32 op - is simply kept out of the device code (-fno-slp-vectorize, -packed-fp32-ops), and this script compiles every csrc/*.hip to gfx950 assembly with the flags of
 build.sh and lists every packed fp32 op that still has the form (and, as a second class, those whose selected register was last
 written by a vector-memory load).  Exit status 1 if any is found.      python tools/scan_pk_opsel.py [file.s ...]"""
 import glob, os, re, subprocess, sys, tempfile
