@@ -1159,6 +1159,12 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3p_kernel(const bf16* __r
   }
 }
 
+// (Round 4, the idea round 3 left open - matrix work of one part of a wave's unit under the softmax arithmetic of another: the cheap form of it,
+// taking the exponentials tile pair by tile pair inside phase 2, ahead of that pair's P V products (same arithmetic, same order, bit-identical
+// outputs; where this wave's and its SIMD partner's matrix instructions are in flight instead of in a block of their own) was built and measured:
+// 909.7 / 878.1 us -> 887.3 / 879.4 us per layer at the benchmark's batch (alternating, same box; profiles/r04_probes/attn_exp_ab.log) - nothing.
+// Where the vector work is issued does not matter to this kernel; with the SQ counters of round 3 (waves parked 32 %, issue-stalled 34 %) that
+// leaves the two barriers per unit and the exposed LDS / DMA round trips, not the instruction mix.  Not kept.)
 // (A two-phase form of the bf16 temporal BACKWARD - (K, V) and (Q, dO) regions by DMA behind the other pass, eight waves with two strips
 // each so that every LDS fragment serves both - was built and measured in round 3: bit-compatible, half the LDS fragment traffic, and no
 // faster: 1100-1130 us against 1123 us isolated at the benchmark's batch, 178.9 against 177.7 ms per step.  The SQ counters of both
