@@ -30,9 +30,20 @@ constexpr int NTILE = TP / 16;
 // MI355X_MICROARCH.md, "price of one filler beside MFMAs").  Plain C, not inline asm: hipcc inserts the wait states an MFMA result needs
 // before a VALU instruction reads it only for instructions it knows (an asm v_fma_f32 on an accumulator read stale data).
 __device__ __forceinline__ float sfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ float sadd(float a, float b) { return a + b; }
-__device__ __forceinline__ float smul(float a, float b) { return a * b; }
-__device__ __forceinline__ float ssub(float a, float b) { return a - b; }
+// (contraction off INSIDE the helpers: the flag travels with the instruction when it is inlined, so a product and a sum written through them are never
+// fused into one rounding, whatever ends up in one basic block - the kernels of this file stay bit-compatible with one another)
+__device__ __forceinline__ float sadd(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float smul(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float ssub(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
 
 __device__ __forceinline__ float4 bf16x4_to_float4(const uint2& r) {
   return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
@@ -809,7 +820,7 @@ __device__ __forceinline__ int img_off(int img, int img_bytes) { return img * im
 // PREFETCHED INTO REGISTERS while unit u is computed (the loads are issued right after the images of u were written to LDS), so the
 // HBM / L2 latency of the staging - as long as the compute of a unit when it is not overlapped - is hidden behind the MFMAs of the
 // previous unit.  (The bf16 kernel above overlaps staging and compute by running two 64 KiB workgroups per CU instead.)
-template <int D>
+template <int D, bool FULL>      // FULL: all NTILE key tiles are in the window (T > 240): compile-time tile count, no per-tile branches
 __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __restrict__ qkv_hi, const bf16* __restrict__ qkv_lo,
                                                                  bf16* __restrict__ out_hi, bf16* __restrict__ out_lo,
                                                                  float* __restrict__ lse, int nunits, int T, int J, int C, int H, float scale, int debug) {
@@ -823,10 +834,10 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __re
 #define MP_ADBG(bit) 0
 #endif
   constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB, CH = ACfg<D>::CH, PER = 4;
-  const int rows = (T + 31) & ~31, nw = (int)(blockDim.x >> 6), nthreads = (int)blockDim.x;
+  const int rows = FULL ? TP : (T + 31) & ~31, nw = (int)(blockDim.x >> 6), nthreads = (int)blockDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const long rs3 = (long)J * 3 * C;
-  const int ntile = (T + 15) >> 4;
+  const int ntile = FULL ? NTILE : (T + 15) >> 4;
   const int img_bytes = rows * ROWB, nchunk = rows * CH;      // per image; nchunk <= PER * nthreads (launcher)
   ImgRd<D> Khr, Vhr;
   Khr.init(sm, lane);
@@ -999,16 +1010,22 @@ __device__ __forceinline__ void tm_dma_region(char* __restrict__ region, const b
   }
 }
 
+// FULL: the window fills all NTILE key tiles (T > 240: the benchmark's 243 frames) - the tile count is a compile-time constant, so the unrolled
+// tile loops carry no wave-uniform branches and each phase is one basic block for the instruction scheduler
+template <bool FULL>
 __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3p_kernel(const bf16* __restrict__ qkv_hi, const bf16* __restrict__ qkv_lo,
                                                                   bf16* __restrict__ out_hi, bf16* __restrict__ out_lo,
                                                                   float* __restrict__ lse, int nunits, int T, int J, int C, int H, float scale) {
+  // no contraction across statements: with the whole phase in one basic block (FULL) hipcc would fuse the score scaling into the subtraction of the
+  // row maximum (one rounding less); kept off so that this kernel, its FULL = false form and the one-strip kernel stay bit-compatible (tested)
+#pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int D = 64, ROWB = 128, KS = 2, DB = 4, NW = 8, OPITCH = 144;
-  const int rows = (T + 31) & ~31;
+  const int rows = FULL ? TP : (T + 31) & ~31;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long rs3 = (long)J * 3 * C;
-  const int ntile = (T + 15) >> 4;
+  const int ntile = FULL ? NTILE : (T + 15) >> 4;
   const int img_bytes = rows * ROWB;
   char* const regA = sm;                              // K_hi | K_lo
   char* const regB = sm + 2 * img_bytes;              // V_hi | V_lo
@@ -1345,6 +1362,12 @@ int attn_spatial_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf
   return MP_OK;
 }
 
+// (-DATTN_X3P_NO_FULL: A/B builds without the full-window specialisations)
+#ifdef ATTN_X3P_NO_FULL
+#define ATTN_X3P_FULL_GUARD && false
+#else
+#define ATTN_X3P_FULL_GUARD
+#endif
 template <int D>
 static int launch_tmfma_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* lse, int units, int T, int J, int C,
                                int H, float scale, hipStream_t st) {
@@ -1355,7 +1378,8 @@ static int launch_tmfma_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out
   const size_t lds = 4 * (size_t)rows * ACfg<D>::ROWB;
   static bool attr_set = false;
   if (!attr_set) {
-    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * ACfg<D>::ROWB)));
+    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * ACfg<D>::ROWB)));
+    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * ACfg<D>::ROWB)));
     attr_set = true;
   }
   const int per_cu = (int)max((size_t)1, min((size_t)4, (size_t)(160 * 1024) / lds));
@@ -1365,7 +1389,10 @@ static int launch_tmfma_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out
 #else
   constexpr int dbg = 0;
 #endif
-  hipLaunchKernelGGL((attn_tmfma_fwd_x3_kernel<D>), dim3(grid), dim3(64 * waves), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, dbg);
+  if (ntile == NTILE ATTN_X3P_FULL_GUARD)
+    hipLaunchKernelGGL((attn_tmfma_fwd_x3_kernel<D, true>), dim3(grid), dim3(64 * waves), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, dbg);
+  else
+    hipLaunchKernelGGL((attn_tmfma_fwd_x3_kernel<D, false>), dim3(grid), dim3(64 * waves), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, dbg);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
@@ -1390,11 +1417,15 @@ int attn_temporal_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, b
     const size_t lds = 4 * (size_t)rows * 128 + 8 * 16 * 144;
     static bool attr_set = false;
     if (!attr_set) {
-      MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * 128 + 8 * 16 * 144)));
+      MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * 128 + 8 * 16 * 144)));
+      MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * 128 + 8 * 16 * 144)));
       attr_set = true;
     }
     const int grid = min(units, num_cus());
-    hipLaunchKernelGGL(attn_tmfma_fwd_x3p_kernel, dim3(grid), dim3(512), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale);
+    if (((T + 15) >> 4) == NTILE ATTN_X3P_FULL_GUARD)
+      hipLaunchKernelGGL(attn_tmfma_fwd_x3p_kernel<true>, dim3(grid), dim3(512), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale);
+    else
+      hipLaunchKernelGGL(attn_tmfma_fwd_x3p_kernel<false>, dim3(grid), dim3(512), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale);
     MP_LAUNCH_CHECK();
     return MP_OK;
   }
