@@ -806,6 +806,11 @@ __device__ __forceinline__ void persist_epilogue_bf16_packed(const GemmB16Args& 
   }
 }
 
+// (Round 4: the residual epilogue below executes ~2700 instructions per tile and wave - the planar bias epilogue ~1100 - a third of them 64-bit
+// row-offset multiplies and the two scalar branches of each of its 32 DropPath mask lookups.  A form with running row offsets and the mask kind /
+// recomputed-LayerNorm flag as template parameters of the kernel (378 -> 54 branches, 5800 -> 3200-4300 instructions in the kernel) was built,
+// passed the parity tests and moved nothing: proj 543 / 544 vs 546 / 553 us, forward-GEMM class 63.8 / 64.1 vs 63.9 / 64.1 ms, step 162.7 vs
+// 162.6 ms (profiles/r04_probes/ab_step5_resid_epilogue_special.log).  The epilogue is not bound by its instruction stream.  Not kept.)
 // (Round 4, tools/probes/epi_shapes.hip + profiles/r04_probes/: what an epilogue costs is set by the CU's store path and by every CU storing at
 // once - the same 256 KiB of planar output cost 6.5 us per tile as dwordx2 stores of 4 rows x 128 B (this epilogue), 4.4 us as dwordx4 stores
 // of 8 rows x 128 B, 8 us with the MFMA columns permuted so that no LDS transposition is needed (16 rows x 64 B per instruction), 13 us in the
