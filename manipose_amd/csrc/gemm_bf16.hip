@@ -708,12 +708,15 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
 // (lane = row, 4 consecutive columns; 16-byte chunks XOR-swizzled by the row) and read back row-major, so residual / gelu'
 // loads and the stores are full lines, 16 lanes per row.  FULL = the tile has no rows past M: no predicates, and the
 // loads of a pass are issued together ahead of its stores.
-template <typename TC, int EPI, bool FULL>
+// F16G (gelu'-multiplying dgrad): dz leaves as saturating scaled fp16 (GemmB16Args::gout) - a template parameter, not a run-time branch: inlined 64 times,
+// the saturating store with its slow path and counters made this kernel 11 600 instructions (93 KB, more than the 64 KB instruction cache) and left
+// its matrix cores 29 % busy where the plain dgrad reaches 47 % (profiles/r04_bf16x3_B79_pmc_mfma_util.csv), although the default backward never takes it
+template <typename TC, int EPI, bool FULL, bool F16G = false>
 __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32x4 (&acc)[8][4], float* __restrict__ img, int row0, int col,
                                                  const float4& bias4, TC* __restrict__ C, typename ZType<TC>::type* __restrict__ Z, int l15, int gq) {
   constexpr bool LOADS = (EPI == EPI_BIAS_RESID || EPI == EPI_DGELU);
   const long lo_off = c_lo_off<TC>(g);
-  const float gout_v = (EPI == EPI_DGELU && g.gout != nullptr) ? *g.gout : 0.f;      // this backward's gradient scale (a device scalar)
+  const float gout_v = (EPI == EPI_DGELU && F16G) ? *g.gout : 0.f;      // this backward's gradient scale (a device scalar)
   float4 in_nxt[4];
   float ds_nxt[4];
   // residual = LayerNorm(R) recomputed from R and its row statistics (GemmB16Args::rstats): per-lane gamma / beta of its 4 columns
@@ -770,10 +773,8 @@ __device__ __forceinline__ void persist_epilogue(const GemmB16Args& g, const f32
         v = make_float4(v.x * in[it].x, v.y * in[it].y, v.z * in[it].z, v.w * in[it].w);      // Z holds gelu'(pre-activation)
       }
       if (FULL || row < g.M) {
-        if constexpr (EPI == EPI_DGELU && sizeof(TC) == 2) {      // dz: bf16, or scaled fp16 for an fc1 layer whose backward GEMMs run on fp16 operands
-          if (g.gout != nullptr) st4_f16(C + o, v, gout_v, g.gsat);
-          else st4(C + o, v, lo_off);
-        } else st4(C + o, v, lo_off);
+        if constexpr (EPI == EPI_DGELU && sizeof(TC) == 2 && F16G) st4_f16(C + o, v, gout_v, g.gsat);      // dz as scaled fp16 for an fc1 layer whose backward GEMMs run on fp16 operands
+        else st4(C + o, v, lo_off);
       }
     }
   }
@@ -818,7 +819,7 @@ __device__ __forceinline__ void persist_epilogue_bf16_packed(const GemmB16Args& 
 // dwordx4 form of this epilogue for the planar outputs was built and measured in the real kernels: qkv 1356 / 1344 -> 1338 / 1341 us, fc1
 // unchanged, the step unchanged - not kept.)
 // SPLIT: see gemm_bf16_glds_kernel (three steps per k-tile, the DMA source planes rotate)
-template <int TRB, typename TC, int EPI, int SPLIT = 0>
+template <int TRB, typename TC, int EPI, int SPLIT = 0, bool F16G = false>
 __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, int tiles_n, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BT = 256, WN = 4, MI = 8, OPB = BT * 128, STAGE = 2 * OPB;
@@ -1026,8 +1027,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
         }
       }
       if (!done) {
-        if (m0 + BT <= g.M) persist_epilogue<TC, EPI, true>(g, acc, img, m0 + wr * 128, col, bias4, C, Z, e15, eq);
-        else persist_epilogue<TC, EPI, false>(g, acc, img, m0 + wr * 128, col, bias4, C, Z, e15, eq);
+        if (m0 + BT <= g.M) persist_epilogue<TC, EPI, true, F16G>(g, acc, img, m0 + wr * 128, col, bias4, C, Z, e15, eq);
+        else persist_epilogue<TC, EPI, false, F16G>(g, acc, img, m0 + wr * 128, col, bias4, C, Z, e15, eq);
       }
     }
 #ifdef MP_GEMM_DIAG
@@ -1070,6 +1071,19 @@ static int persist_workgroups() {
 static thread_local int g_last_persist = 0;
 int gemm_bf16_take_last_persist() { const int v = g_last_persist; g_last_persist = 0; return v; }
 
+template <int TRB, typename TC, int EPI, int SPLIT, bool F16G>
+static int persist_go(const GemmB16Args& g, int wgs, int tiles_n, int ntiles, hipStream_t st) {
+  constexpr size_t lds = 2 * 2 * 256 * 128 + 8 * 4096;     // two operand stages + the epilogue images = 160 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    MP_HIP(hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<TRB, TC, EPI, SPLIT, F16G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_persist_kernel<TRB, TC, EPI, SPLIT, F16G>), dim3(wgs), dim3(512), lds, st, g, tiles_n, ntiles);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
 template <int TRB, typename TC, int EPI, int SPLIT = 0>
 static int launch_persist(const GemmB16Args& g_in, int wgs, hipStream_t st) {
   g_last_persist = 1;
@@ -1083,16 +1097,11 @@ static int launch_persist(const GemmB16Args& g_in, int wgs, hipStream_t st) {
     g.stagger = stagger;
   }
 #endif
-  constexpr size_t lds = 2 * 2 * 256 * 128 + 8 * 4096;     // two operand stages + the epilogue images = 160 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
-    MP_HIP(hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<TRB, TC, EPI, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
   const int tiles_n = cdiv(g.N, 256), ntiles = tiles_n * cdiv(g.M, 256);
-  hipLaunchKernelGGL((gemm_bf16_persist_kernel<TRB, TC, EPI, SPLIT>), dim3(wgs), dim3(512), lds, st, g, tiles_n, ntiles);
-  MP_LAUNCH_CHECK();
-  return MP_OK;
+  if constexpr (EPI == EPI_DGELU && sizeof(TC) == 2) {
+    if (g.gout != nullptr) return persist_go<TRB, TC, EPI, SPLIT, true>(g, wgs, tiles_n, ntiles, st);
+  }
+  return persist_go<TRB, TC, EPI, SPLIT, false>(g, wgs, tiles_n, ntiles, st);
 }
 
 static bool g_force_small_tile = false;    // test hook: exercise the 128x128 instantiation on big shapes too
