@@ -183,8 +183,12 @@ __device__ __forceinline__ void store4(bf16* p, const f32x4& v, float s) {
 
 // gradient outputs (dQ, dK, dV) of the backward kernels: bf16, or - gout != 0 - fp16 of gout * value (a layer whose dgrad / weight-gradient GEMMs
 // run on fp16 operands: kernels.h GemmB16Args::f16; gout is a power of two that lifts the gradients into fp16's normal range)
+// F16G is a template parameter of the backward kernels, not a run-time branch: the saturating store (slow path, counters: common.h) is inlined
+// at every one of their 12-24 store sites, and the default bf16 backward should not carry it (round 4: the same construct had pushed a GEMM
+// kernel past the instruction cache)
+template <bool F16G>
 __device__ __forceinline__ void store4g(bf16* p, const f32x4& v, float s, float gout, unsigned* __restrict__ cnt) {
-  if (gout != 0.f) {
+  if constexpr (F16G) {
     s *= gout;
     *reinterpret_cast<uint2*>(p) = sat_f16x4(v[0] * s, v[1] * s, v[2] * s, v[3] * s, cnt);      // saturating: common.h
   } else store4(p, v, s);
@@ -301,15 +305,15 @@ __global__ __launch_bounds__(512, 4) void attn_tmfma_fwd_kernel(const bf16* __re
 // one workgroup per CU); wave w owns the 16-query strip w in pass A (dQ) and the 16-key strip w in pass B (dK, dV) and takes
 // its own strip's fragments from the LDS images like everyone else's.  16 waves (instead of 8 with two strips each) cover the
 // MFMA -> exp -> MFMA dependency chain of a strip with other strips' work.
-template <int D, int NTC>
+template <int D, int NTC, bool F16G>
 __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                                const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                bf16* __restrict__ dqkv, int T, int J, int C, int H, float scale,
                                                                int debug, const float* __restrict__ gout_p) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB, NW = 16, UNR = NTC ? NTC / 2 : 1;
-  const float gout = gout_p != nullptr ? *gout_p : 0.f;      // this backward's gradient scale (engine: grad_scale_kernel), or bf16 outputs
-  unsigned* const gcnt = gout_p != nullptr ? reinterpret_cast<unsigned*>(const_cast<float*>(gout_p)) + 4 : nullptr;      // its saturation counters
+  const float gout = F16G ? *gout_p : 0.f;      // this backward's gradient scale (engine: grad_scale_kernel); F16G false: bf16 outputs
+  unsigned* const gcnt = F16G ? reinterpret_cast<unsigned*>(const_cast<float*>(gout_p)) + 4 : nullptr;      // its saturation counters
   const int rows = NTC ? TP : (T + 31) & ~31, nw = NTC ? NW : (int)(blockDim.x >> 6);     // short windows: see the forward kernel
   char* Qs = sm;
   char* Ks = Qs + rows * ROWB;
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
     }
     if (tq < T) {
 #pragma unroll
-      for (int db = 0; db < DB; ++db) store4g(dq_base + (long)tq * rs3 + 16 * db + 4 * g, dq[db], scale, gout, gcnt);
+      for (int db = 0; db < DB; ++db) store4g<F16G>(dq_base + (long)tq * rs3 + 16 * db + 4 * g, dq[db], scale, gout, gcnt);
     }
   }
 #ifdef MP_GEMM_DIAG
@@ -473,8 +477,8 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
     if (tk < T) {
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        store4g(dq_base + C + (long)tk * rs3 + 16 * db + 4 * g, dk[db], scale, gout, gcnt);
-        store4g(dq_base + 2 * C + (long)tk * rs3 + 16 * db + 4 * g, dv[db], 1.0f, gout, gcnt);
+        store4g<F16G>(dq_base + C + (long)tk * rs3 + 16 * db + 4 * g, dk[db], scale, gout, gcnt);
+        store4g<F16G>(dq_base + 2 * C + (long)tk * rs3 + 16 * db + 4 * g, dv[db], 1.0f, gout, gcnt);
       }
     }
   }
@@ -617,11 +621,11 @@ __global__ __launch_bounds__(512) void attn_smfma_fwd_kernel(const bf16* __restr
   }
 }
 
-template <int D>
+template <int D, bool F16G>
 __global__ __launch_bounds__(512) void attn_smfma_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                                bf16* __restrict__ dqkv, int N, int C, int H, float scale, const float* __restrict__ gout_p) {
-  const float gout = gout_p != nullptr ? *gout_p : 0.f;
-  unsigned* const gcnt = gout_p != nullptr ? reinterpret_cast<unsigned*>(const_cast<float*>(gout_p)) + 4 : nullptr;
+  const float gout = F16G ? *gout_p : 0.f;
+  unsigned* const gcnt = F16G ? reinterpret_cast<unsigned*>(const_cast<float*>(gout_p)) + 4 : nullptr;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int KS = ACfg<D>::KS, DB = ACfg<D>::DB;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(512) void attn_smfma_bwd_kernel(const bf16* __restr
     for (int db = 0; db < DB; ++db) {
       f32x4 dq = {0.f, 0.f, 0.f, 0.f};
       dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokT<D>(sm, pitch, ok, db, lane, N), bds, dq, 0, 0, 0);
-      if (tq < N) store4g(dbase + (long)tq * 3 * C + 16 * db + 4 * g, dq, scale, gout, gcnt);
+      if (tq < N) store4g<F16G>(dbase + (long)tq * 3 * C + 16 * db + 4 * g, dq, scale, gout, gcnt);
     }
   }
   // ---- pass B ([query][key] orientation): dK, dV.  Row statistics come from pass A's column statistics by shuffle ----
@@ -739,8 +743,8 @@ __global__ __launch_bounds__(512) void attn_smfma_bwd_kernel(const bf16* __restr
       dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokT<D>(gs, gpitch, og, db, lane, N), bp, dv, 0, 0, 0);
       dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tokT<D>(sm, pitch, oq, db, lane, N), bds, dk, 0, 0, 0);
       if (tk < N) {
-        store4g(dbase + C + (long)tk * 3 * C + 16 * db + 4 * g, dk, scale, gout, gcnt);
-        store4g(dbase + 2 * C + (long)tk * 3 * C + 16 * db + 4 * g, dv, 1.0f, gout, gcnt);
+        store4g<F16G>(dbase + C + (long)tk * 3 * C + 16 * db + 4 * g, dk, scale, gout, gcnt);
+        store4g<F16G>(dbase + 2 * C + (long)tk * 3 * C + 16 * db + 4 * g, dv, 1.0f, gout, gcnt);
       }
     }
   }
@@ -777,12 +781,15 @@ int attn_smfma_bwd(const bf16* qkv, const bf16* dout, bf16* dqkv, int B, int T, 
   if (D == 64) {
     static bool attr_set = false;
     if (!attr_set) {
-      MP_HIP(hipFuncSetAttribute((const void*)attn_smfma_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MP_HIP(hipFuncSetAttribute((const void*)attn_smfma_bwd_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MP_HIP(hipFuncSetAttribute((const void*)attn_smfma_bwd_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
-    hipLaunchKernelGGL(attn_smfma_bwd_kernel<64>, dim3(B * T), dim3(H * 64), lds, st, qkv, dout, dqkv, J, C, H, scale, g_grad_f16);
+    if (g_grad_f16 != nullptr) hipLaunchKernelGGL((attn_smfma_bwd_kernel<64, true>), dim3(B * T), dim3(H * 64), lds, st, qkv, dout, dqkv, J, C, H, scale, g_grad_f16);
+    else hipLaunchKernelGGL((attn_smfma_bwd_kernel<64, false>), dim3(B * T), dim3(H * 64), lds, st, qkv, dout, dqkv, J, C, H, scale, g_grad_f16);
   } else {
-    hipLaunchKernelGGL(attn_smfma_bwd_kernel<16>, dim3(B * T), dim3(H * 64), lds, st, qkv, dout, dqkv, J, C, H, scale, g_grad_f16);
+    if (g_grad_f16 != nullptr) hipLaunchKernelGGL((attn_smfma_bwd_kernel<16, true>), dim3(B * T), dim3(H * 64), lds, st, qkv, dout, dqkv, J, C, H, scale, g_grad_f16);
+    else hipLaunchKernelGGL((attn_smfma_bwd_kernel<16, false>), dim3(B * T), dim3(H * 64), lds, st, qkv, dout, dqkv, J, C, H, scale, g_grad_f16);
   }
   MP_LAUNCH_CHECK();
   return MP_OK;
@@ -1473,11 +1480,16 @@ static int launch_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, 
   const size_t lds = 4 * (size_t)rows * ACfg<D>::ROWB + 2 * rows * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_bwd_kernel<D, NTC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_bwd_kernel<D, NTC, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(4 * TP * ACfg<D>::ROWB + 2 * TP * sizeof(float))));
+    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_bwd_kernel<D, NTC, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(4 * TP * ACfg<D>::ROWB + 2 * TP * sizeof(float))));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_tmfma_bwd_kernel<D, NTC>), dim3(units), dim3(64 * waves), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg, g_grad_f16);
+  if (g_grad_f16 != nullptr)
+    hipLaunchKernelGGL((attn_tmfma_bwd_kernel<D, NTC, true>), dim3(units), dim3(64 * waves), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg, g_grad_f16);
+  else
+    hipLaunchKernelGGL((attn_tmfma_bwd_kernel<D, NTC, false>), dim3(units), dim3(64 * waves), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg, g_grad_f16);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
