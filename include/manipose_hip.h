@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 7
+#define MP_ABI_VERSION 8
 
 int mp_abi_version(void);
 const char* mp_last_error(void);
@@ -222,6 +222,9 @@ typedef struct mp_model_config {
   int f16f8;
   int f16_backward;
   int streams;
+  /* ABI v8.  debug: bit 0 = the stream-hazard check (below): every launch of mp_model_forward / mp_model_backward is declared to a host-side
+   * tracker together with the events the engine records and waits on; costs host time only, changes no launch.  0 = off. */
+  int debug;
 } mp_model_config;
 
 int mp_model_create(const mp_model_config* cfg, mp_model** out);
@@ -266,9 +269,31 @@ int mp_model_grad_bucket_wait(mp_model* m, int index, void* stream);
 /* Health of the scaled-fp16 gradient operands of the LAST mp_model_backward (f16_backward models; zeros otherwise): copies 4 floats to the
  * HOST after synchronising `stream`: out[0] = S, the power-of-two scale of that backward; out[1] = number of fp16 gradient elements that
  * hit the +-65504 clamp (stores saturate, they never write inf); out[2] = number of non-finite gradient elements met at those stores
- * (written as 0); out[3] = largest |S x value| stored.  A trainer that sees out[1] + out[2] > 0 should redo the step with f16_backward
- * off or skip it. */
+ * (written as 0); out[3] = 1 / S (what consumers of the scaled operands multiply by).  A trainer that sees out[1] + out[2] > 0 should redo
+ * the step with f16_backward off or skip it (manipose_amd/training.py does the latter).  MP_ERR_STATE unless a completed mp_model_backward is
+ * the last engine call (a forward, or a backward that failed midway, has overwritten what the counters described).
+ * mp_model_grad_health_async: the same four values as floats into a DEVICE (or pinned host) buffer by an asynchronous copy on `stream`, no
+ * host synchronisation - for a trainer that looks at the counters every N steps. */
 int mp_model_grad_health(mp_model* m, float* out4_host, void* stream);
+int mp_model_grad_health_async(mp_model* m, float* out4_device, void* stream);
+/* Which of the engine's two extra streams the NEXT forward / backward calls use: the `streams` bit set of mp_model_config, changed on a live
+ * model (bench.py times the kernel classes of the same model with every kernel on one queue).  Synchronises the engine's streams first. */
+int mp_model_set_streams(mp_model* m, int streams);
+/* Stream-hazard check (mp_model_config::debug bit 0; csrc/hazard.h): the engine runs its rotations net, its segments net and its weight-gradient
+ * GEMMs on three streams ordered by events.  With the check on, every launch declares the byte ranges of the workspace / gradient buffers it
+ * reads and writes and its stream, every event record / wait is mirrored, and a vector clock per stream decides for each pair of launches on
+ * different streams that touch the same bytes (at least one writing) whether an event path orders them.  out4 = {launches declared, conflicting
+ * cross-stream pairs found ORDERED, pairs found UNORDERED (violations), events recorded}; the first violations are written to `msg` as lines
+ * of text (may be NULL).  Returns MP_ERR_STATE when the model was created without the debug bit. */
+int mp_model_hazard_report(const mp_model* m, int64_t* out4, char* msg, int msg_cap);
+/* The tracker by itself (no device involved; used by the CPU tests): streams and events are small integers. */
+typedef struct mp_hazard mp_hazard;
+mp_hazard* mp_hazard_create(void);
+void mp_hazard_destroy(mp_hazard* h);
+int mp_hazard_launch(mp_hazard* h, int stream, const char* name, int n, const int64_t* addr, const int64_t* bytes, const int* is_write);
+int mp_hazard_record(mp_hazard* h, int event, int stream);
+int mp_hazard_wait(mp_hazard* h, int stream, int event);
+int mp_hazard_report(const mp_hazard* h, int64_t* out4, char* msg, int msg_cap);
 /* intermediate outputs of the last forward (device pointers owned by the model): 0 = head output
  * (K, B*T*17, O), 1 = segment lengths (B, 16), 2 = the DropPath multipliers of the last train-mode forward (layout: mp_model_mask_info);
  * the fp32 residual stream block by block (blocks in execution order STE0, TTE0, STE1, ...; (B*T*N, C) each): 100 + 2 l = after the

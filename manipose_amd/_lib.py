@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MANIPOSE_HIP_LIB") or os.path.join(_HERE, "libmanipos
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "manipose_hip.h")
 
 _lib: Optional[C.CDLL] = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 vp, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
@@ -33,7 +33,7 @@ class ModelConfig(C.Structure):
                 ("n_hyp", i32), ("drop_path_rate", f32), ("max_batch", i32), ("precision", i32), ("rot_rep_dim", i32),
                 ("qk_scale_rot", f32), ("resid_scale_rot", f32), ("readout_mult_rot", f32),
                 ("qk_scale_seg", f32), ("resid_scale_seg", f32), ("readout_mult_seg", f32),
-                ("f16f8", i32), ("f16_backward", i32), ("streams", i32)]
+                ("f16f8", i32), ("f16_backward", i32), ("streams", i32), ("debug", i32)]
 
 
 _SIGNATURES = {
@@ -84,6 +84,15 @@ _SIGNATURES = {
     "mp_model_grad_bucket_info": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
     "mp_model_grad_bucket_wait": (i32, [vp, i32, vp]),
     "mp_model_grad_health": (i32, [vp, C.POINTER(f32), vp]),
+    "mp_model_grad_health_async": (i32, [vp, vp, vp]),
+    "mp_model_set_streams": (i32, [vp, i32]),
+    "mp_model_hazard_report": (i32, [vp, C.POINTER(i64), C.c_char_p, i32]),
+    "mp_hazard_create": (vp, []),
+    "mp_hazard_destroy": (None, [vp]),
+    "mp_hazard_launch": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]),
+    "mp_hazard_record": (i32, [vp, i32, i32]),
+    "mp_hazard_wait": (i32, [vp, i32, i32]),
+    "mp_hazard_report": (i32, [vp, C.POINTER(i64), C.c_char_p, i32]),
     "mp_model_peek": (i32, [vp, i32, C.POINTER(vp), C.POINTER(i64)]),
     "mp_model_peek_copy": (i32, [vp, i32, vp, i64, vp]),
     "mp_gather_windows": (i32, [vp, vp, vp, i32, vp, vp, vp, C.POINTER(i32), vp, vp, i32, i32, i32, vp, vp, vp]),

@@ -77,11 +77,13 @@ class FusedLiftingMixin:
         self.f16_backward = False
         self.side_stream = True
         self.wgrad_stream = True
+        self.hazard_check = False         # mp_model_config::debug bit 0: the engine's host-side stream-hazard check (engine.hazard_report())
         self.max_batch_hint = 0
 
     # -- engine / flat storage -----------------------------------------------------------------
     def _engine_options(self) -> dict:
-        return dict(f16f8=int(self.f16f8), f16_backward=bool(self.f16_backward), side_stream=bool(self.side_stream), wgrad_stream=bool(self.wgrad_stream))
+        return dict(f16f8=int(self.f16f8), f16_backward=bool(self.f16_backward), side_stream=bool(self.side_stream), wgrad_stream=bool(self.wgrad_stream),
+                    hazard_check=bool(self.hazard_check))
 
     def _ensure_engine(self, B: int, device: torch.device):
         if device.type != "cuda":

@@ -20,9 +20,11 @@ class LiftEngine:
                  num_heads_rot: int, embed_dim_seg: int, depth_seg: int, num_heads_seg: int, n_hyp: int,
                  drop_path_rate: float, max_batch: int, precision: str = "fp32", rot_rep_dim: int = 6, qk_scale_rot: float = 0.0,
                  resid_scale_rot: float = 0.0, readout_mult_rot: float = 0.0, qk_scale_seg: float = 0.0, resid_scale_seg: float = 0.0,
-                 readout_mult_seg: float = 0.0, f16f8: int = 0, f16_backward: bool = False, side_stream: bool = True, wgrad_stream: bool = True):
+                 readout_mult_seg: float = 0.0, f16f8: int = 0, f16_backward: bool = False, side_stream: bool = True, wgrad_stream: bool = True,
+                 hazard_check: bool = False):
         """f16f8 / f16_backward / side_stream / wgrad_stream: mp_model_config::f16f8, f16_backward, streams (include/manipose_hip.h) - the
-        operand form of the qkv / fc1 (/ fc2) Linear layers of a bf16x3 model, and which of the engine's two extra streams it uses."""
+        operand form of the qkv / fc1 (/ fc2) Linear layers of a bf16x3 model, and which of the engine's two extra streams it uses.
+        hazard_check: mp_model_config::debug bit 0, the host-side stream-hazard check (hazard_report())."""
         self.lib = _lib.load()
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {list(PRECISIONS)}, got {precision}")
@@ -35,7 +37,7 @@ class LiftEngine:
                                     resid_scale_rot=resid_scale_rot, readout_mult_rot=readout_mult_rot, qk_scale_seg=qk_scale_seg,
                                     resid_scale_seg=resid_scale_seg, readout_mult_seg=readout_mult_seg,
                                     f16f8=int(f16f8), f16_backward=int(bool(f16_backward)),
-                                    streams=(0 if side_stream else 1) | (0 if wgrad_stream else 2))
+                                    streams=(0 if side_stream else 1) | (0 if wgrad_stream else 2), debug=int(bool(hazard_check)))
         self.arch = arch
         self.K = max(1, n_hyp) if arch == "rmcl_manifold" else 1
         self.max_batch = max_batch
@@ -128,6 +130,24 @@ class LiftEngine:
         out = (C.c_float * 4)()
         _lib.check(self.lib.mp_model_grad_health(self.handle, out, _lib.stream_ptr()), "mp_model_grad_health")
         return {"scale": out[0], "saturated": int(out[1]), "non_finite": int(out[2]), "inv_scale": out[3]}
+
+    def grad_health_async(self, out: torch.Tensor) -> None:
+        """The same four values (scale, saturated, non_finite, inv_scale) as floats into the device tensor `out` (4 floats), enqueued on the
+        current stream without a host synchronisation."""
+        _lib.check(self.lib.mp_model_grad_health_async(self.handle, _lib.ptr(out), _lib.stream_ptr()), "mp_model_grad_health_async")
+
+    def set_streams(self, side_stream: bool = True, wgrad_stream: bool = True) -> None:
+        """Which of the engine's two extra streams the next forward / backward calls use (mp_model_set_streams)."""
+        _lib.check(self.lib.mp_model_set_streams(self.handle, (0 if side_stream else 1) | (0 if wgrad_stream else 2)), "mp_model_set_streams")
+
+    def hazard_report(self) -> Dict[str, object]:
+        """Stream-hazard check (hazard_check=True): launches declared, conflicting cross-stream pairs found ordered by an event path, pairs
+        found UNORDERED (violations) with their descriptions, events recorded."""
+        out = (C.c_int64 * 4)()
+        buf = C.create_string_buffer(1 << 15)
+        _lib.check(self.lib.mp_model_hazard_report(self.handle, out, buf, len(buf)), "mp_model_hazard_report")
+        return {"launches": int(out[0]), "ordered_pairs": int(out[1]), "violations": int(out[2]), "events": int(out[3]),
+                "messages": [l for l in buf.value.decode().splitlines() if l]}
 
     def prof_enable(self, on: bool = True) -> None:
         _lib.check(self.lib.mp_prof_enable(self.handle, int(on)), "mp_prof_enable")

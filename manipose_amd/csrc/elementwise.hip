@@ -572,6 +572,17 @@ int grad_scale(const float* d_poses, long n_poses, const float* d_scores, long n
   return MP_OK;
 }
 
+// mp_model_grad_health_async: {S, 1 / S, scratch, 1, clamped (u32), non-finite (u32)} -> {S, clamped, non-finite, 1 / S} as floats, on the device
+__global__ void grad_health_pack_kernel(const float* __restrict__ gsc, float* __restrict__ out) {
+  const unsigned* c = reinterpret_cast<const unsigned*>(gsc + 4);
+  out[0] = gsc[0]; out[1] = (float)c[0]; out[2] = (float)c[1]; out[3] = gsc[1];
+}
+int grad_health_pack(const float* gsc, float* out4, hipStream_t st) {
+  hipLaunchKernelGGL(grad_health_pack_kernel, dim3(1), dim3(1), 0, st, gsc, out4);
+  MP_LAUNCH_CHECK();
+  return MP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // rotation backbone input embedding: Linear(2, C) + Spatial_pos_embed (mix_ste.py:134-138)
 // ---------------------------------------------------------------------------------------------

@@ -4,10 +4,12 @@
 // (manipose_amd/architectures) only hands over device pointers.
 #include <stdlib.h>
 #include <string.h>
+#include <memory>
 #include <string>
 #include <vector>
 #include "common.h"
 #include "kernels.h"
+#include "hazard.h"
 #include "../../include/manipose_hip.h"
 
 namespace mp {
@@ -118,6 +120,7 @@ struct mp_model {
   std::vector<double> ev_flops, ev_bytes, ev_mflops;   // issued matrix-core flops, algorithmic bytes, flops of the mathematical product (2 M N K)
   std::vector<char> ev_tag;              // 1: the launch ran gemm_bf16_persist_kernel
   std::vector<signed char> ev_kind;      // Linear GEMM launches: module * 12 + direction * 4 + layer (mp_prof_kinds), -1 otherwise
+  std::unique_ptr<mp::HazardTracker> hz; // mp_model_config::debug bit 0: the stream-hazard check (hazard.h); null otherwise
   int cur_kind = -1;                     // kind of the GEMM being enqueued (set by the backbone code around linear_fwd / dgrad / wgrad)
   double kind_ms[MP_PROF_KINDS] = {}, kind_flops[MP_PROF_KINDS] = {}, kind_bytes[MP_PROF_KINDS] = {}, kind_mflops[MP_PROF_KINDS] = {};
   int64_t kind_launches[MP_PROF_KINDS] = {}, kind_persist[MP_PROF_KINDS] = {};
@@ -205,6 +208,10 @@ static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int prec
   auto act = [&](long n) -> void* { return bp.take(half ? (n + 1) / 2 : n); };   // bf16 activations take half the floats
   auto lo = [&](long n) -> void* { return precision == 2 ? bp.take((n + 1) / 2) : nullptr; };   // lo plane of a planar activation
   md.ws.resize(2 * md.depth);
+  // The lo planes (and, with f8, the 8-bit correction planes that take the place of a1l / a2l) are read by the forward consumer of their own block
+  // only - the backward runs on the hi planes - and a module's kernels are enqueued on one stream in block order: ONE set per module, shared
+  // by all its blocks (16 C bytes per token instead of 16 C x 2 depth: 124 -> 84 GiB at the bench's B = 79).
+  void* const a1l = lo(M * C); void* const qkvl = lo(M * 3 * C); void* const aol = lo(M * C); void* const a2l = lo(M * C); void* const fl = lo(M * 2 * C);
   for (size_t l = 0; l < md.ws.size(); ++l) {
     BlockWS& w = md.ws[l];
     const bool lazy_in = half && l >= 2 && C <= 512;         // lazy_block_input(): recomputed where it is used, never stored
@@ -213,7 +220,7 @@ static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int prec
     w.lse = bp.take((long)Bmax * md.N * md.H * T);
     w.ao = act(M * C);         w.x_mid = bp.take(M * C);   w.st2 = bp.take(M * 2);  w.a2 = act(M * C);
     w.z = act(M * 2 * C);      w.f = act(M * 2 * C);       w.x_out = bp.take(M * C); w.stp = bp.take(M * 2);
-    w.a1l = lo(M * C); w.qkvl = lo(M * 3 * C); w.aol = lo(M * C); w.a2l = lo(M * C); w.fl = lo(M * 2 * C);
+    w.a1l = a1l; w.qkvl = qkvl; w.aol = aol; w.a2l = a2l; w.fl = fl;
     // f8g: nobody reads a bf16 a1 / a2 (the backward runs on the fp16 planes): the fp16 planes take their place
     w.a1h = md.f8 ? (md.f8g ? w.a1 : bp.take((M * C + 1) / 2)) : nullptr;
     w.a2h = md.f8 ? (md.f8g ? w.a2 : bp.take((M * C + 1) / 2)) : nullptr;
@@ -344,6 +351,33 @@ struct ProfScope {
     if (rc__) return rc__;                             \
   } while (0)
 
+// ---- stream-hazard check (hazard.h): every launch declares its stream and the byte ranges it reads (HR) / writes (HW); the engine's event
+// records and waits go through ev_record / ev_wait so that the tracker sees the same ordering edges HIP does ----
+#define HR(p, bytes) mp::hz_r((p), (double)(bytes))
+#define HW(p, bytes) mp::hz_w((p), (double)(bytes))
+#define HZ(st_, name_, ...)                                                                                                  \
+  do {                                                                                                                       \
+    if (m->hz) {                                                                                                             \
+      const mp::HzAccess hz_a__[] = {__VA_ARGS__};                                                                           \
+      m->hz->launch(m->hz->stream_id((const void*)(st_)), (name_), hz_a__, (int)(sizeof(hz_a__) / sizeof(hz_a__[0])));       \
+    }                                                                                                                        \
+  } while (0)
+static hipError_t ev_record(mp_model* m, hipEvent_t ev, hipStream_t st) {
+  if (m->hz) m->hz->record((const void*)ev, m->hz->stream_id((const void*)st));
+  return hipEventRecord(ev, st);
+}
+static hipError_t ev_wait(mp_model* m, hipStream_t st, hipEvent_t ev) {
+  if (m->hz) m->hz->wait(m->hz->stream_id((const void*)st), (const void*)ev);
+  return hipStreamWaitEvent(st, ev, 0);
+}
+// a kernel wrapper that moves its parameter-gradient tail to (st_param, ev) records ev on st and makes st_param wait for it (param_stream(),
+// elementwise.hip; scores_bwd, heads.hip): the same edge for the tracker; returns the stream the tail runs on
+static hipStream_t hz_param_edge(mp_model* m, hipStream_t st, hipStream_t st_param, hipEvent_t ev) {
+  if (st_param == nullptr || ev == nullptr) return st;
+  if (m->hz) { m->hz->record((const void*)ev, m->hz->stream_id((const void*)st)); m->hz->wait(m->hz->stream_id((const void*)st_param), (const void*)ev); }
+  return st_param;
+}
+
 static const float* P(const mp_model* m, const float* flat, int idx) { return flat + m->params[idx].offset; }
 static float* G(const mp_model* m, float* flat, int idx) { return flat + m->params[idx].offset; }
 
@@ -354,6 +388,15 @@ static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* 
                       int epi, void* Z, const float* R, const float* mask, int mask_mode, int T, int J, const float* rstats = nullptr,
                       const float* rgamma = nullptr, const float* rbeta = nullptr, const void* A_lo = nullptr, void* C_lo = nullptr,
                       bool f8in = false, bool f8out = false) {
+  {      // stream-hazard check: operands of this launch (element sizes by precision; the weight shadow, not the fp32 parameters, is the B operand from precision 1 on)
+    const int p = m->cfg.precision;
+    const double ea = p == 0 ? 4.0 : 2.0, ec = (p == 0 || epi == EPI_BIAS_RESID) ? 4.0 : 2.0;
+    const long woff = m->params[widx].offset;
+    HZ(st, "linear_fwd", HR(A, ea * M * K), HR(A_lo, ea * M * K), HR(p == 0 ? (const void*)P(m, fp, widx) : (const void*)(m->wbf + woff), ea * N * K),
+       HR(p == 2 ? (const void*)(m->wbf_lo + woff) : nullptr, 2.0 * N * K), HR(f8in ? (const char*)m->w16 + woff * 2 : nullptr, 2.0 * N * K),
+       HR(f8in ? m->w8 + woff * 2 : nullptr, 2.0 * N * K), HW(Cc, ec * M * N), HW(C_lo, ec * M * N), HW(Z, ec * M * N), HR(R, 4.0 * M * N), HR(rstats, 8.0 * M),
+       HR(mask, 4.0 * (mask_mode == 1 ? M / J : (M / ((long)T * J)) * J)));
+  }
   if (m->cfg.precision == 0) {
     GemmF32Args g = {};
     g.A = (const float*)A; g.lda = K; g.B = P(m, fp, widx); g.ldb = K; g.C = (float*)Cc; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
@@ -397,6 +440,12 @@ static int linear_fwd(mp_model* m, hipStream_t st, const float* fp, const void* 
 // dX[M,K] = dY[M,N] W[N,K]  (optionally * gelu'(Z)).  dy_f32 / dx_f32: storage of dY / dX in bf16 mode.
 static int linear_dgrad(mp_model* m, hipStream_t st, const float* fp, const void* dY, int dy_f32, int widx, void* dX, int dx_f32,
                         long M, int N, int K, void* Z, bool f16 = false, const float* gout = nullptr) {
+  {
+    const int p = m->cfg.precision;
+    const long woff = m->params[widx].offset;
+    HZ(st, "linear_dgrad", HR(dY, (p == 0 || dy_f32 ? 4.0 : 2.0) * M * N), HR(p == 0 ? (const void*)P(m, fp, widx) : (f16 ? (const void*)((const char*)m->w16 + woff * 2) : (const void*)(m->wbf + woff)), (p == 0 ? 4.0 : 2.0) * N * K),
+       HW(dX, (p == 0 || dx_f32 ? 4.0 : 2.0) * M * K), HR(Z, (p == 0 ? 4.0 : 2.0) * M * K), HR(gout, 4));
+  }
   if (m->cfg.precision == 0) {
     GemmF32Args g = {};
     g.A = (const float*)dY; g.lda = N; g.B = P(m, fp, widx); g.ldb = K; g.C = (float*)dX; g.ldc = K; g.M = (int)M; g.N = K; g.K = N;
@@ -418,6 +467,8 @@ static int linear_dgrad(mp_model* m, hipStream_t st, const float* fp, const void
 }
 static int linear_wgrad(mp_model* m, hipStream_t st, const void* dY, int dy_f32, const void* X, float* dW, float* db, long M, int N,
                         int K, bool f16 = false) {
+  HZ(st, "linear_wgrad", HR(dY, (m->cfg.precision == 0 || dy_f32 ? 4.0 : 2.0) * M * N), HR(X, (m->cfg.precision == 0 ? 4.0 : 2.0) * M * K), HW(dW, 4.0 * N * K), HW(db, 4.0 * N),
+     HW(m->slab, 4.0 * m->slab_floats));
   if (m->cfg.precision == 0)
     RUN(PC_GEMM_WGRAD, 2.0 * M * N * K, wgrad_f32((const float*)dY, N, (const float*)X, K, (int)M, N, K, dW, db, m->slab, m->slab_floats, st));
   else
@@ -471,6 +522,11 @@ static int backbone_bwd(mp_model* m, Module& md, const float* fp, float* fg, int
   return rc;
 }
 
+static void hz_ln_fwd(mp_model* m, hipStream_t st, const LnFwdArgs& a, int out_mode) {
+  const double MC = (double)a.M * a.C, eo = out_mode == 0 ? 4.0 : 2.0;
+  HZ(st, "ln_fwd", HR(a.x, 4.0 * MC), HW(a.x1, 4.0 * MC), HW(a.stats1, 8.0 * a.M), HW(a.y2, eo * MC), HW(a.y2_lo, 2.0 * MC), HW(a.y2_b16, 2.0 * MC),
+     HW(a.stats2, 8.0 * a.M));
+}
 static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hipStream_t st) {
   const int T = m->cfg.num_frame, N = md.N, C = md.C, H = md.H, L = 2 * md.depth;
   const int half = md.f8 ? 3 : m->cfg.precision;          // LayerNorm output mode: 0 fp32, 1 bf16, 2 planar hi/lo bf16, 3 f16f8 planes + bf16 copy
@@ -483,6 +539,7 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     a.x = md.ws[0].x_in; a.M = (int)M; a.C = C;
     a.g2 = P(m, fp, md.bp[0].n1w); a.b2 = P(m, fp, md.bp[0].n1b); a.eps2 = 1e-6f; a.y2 = md.ws[0].a1; a.y2_lo = md.ws[0].a1l; a.stats2 = md.ws[0].st1;
     if (md.f8) { a.y2 = md.ws[0].a1h; a.y2_b16 = (m->infer || md.f8g) ? nullptr : md.ws[0].a1; }
+    hz_ln_fwd(m, st, a, half);
     RUN(PC_LN, 0, ln_fwd(a, half, st));
   }
   for (int l = 0; l < L; ++l) {
@@ -494,6 +551,11 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     int rc = linear_fwd(m, st, fp, md.f8 ? w.a1h : w.a1, q.qkvw, q.qkvb, w.qkv, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr,
                         w.a1l, w.qkvl, md.f8);
     if (rc) return rc;
+    {
+      const double eb = m->cfg.precision == 0 ? 4.0 : 2.0;
+      HZ(st, "attention_fwd", HR(w.qkv, eb * M * 3 * C), HR(x3 ? w.qkvl : nullptr, eb * M * 3 * C), HW(w.ao, eb * M * C), HW(x3 ? w.aol : nullptr, eb * M * C),
+         HW(spatial ? nullptr : w.lse, 4.0 * B * N * H * T), HW(xattn, xattn ? 16.0 * M * C : 0.0));
+    }
     if (x3) {
       if (spatial) RUN(PC_ATTN, 12.0 * B * T * N * N * C, attn_spatial_fwd_x3((const bf16*)w.qkv, (const bf16*)w.qkvl, (bf16*)w.ao, (bf16*)w.aol, xattn, B, T, N, C, H, st));
       else RUN(PC_ATTN, 12.0 * B * N * (double)T * T * C, attn_temporal_fwd_x3((const bf16*)w.qkv, (const bf16*)w.qkvl, (bf16*)w.ao, (bf16*)w.aol, w.lse, xattn, B, T, N, C, H, st));
@@ -519,7 +581,8 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
       a.x = w.x_mid; a.M = (int)M; a.C = C;
       a.g2 = P(m, fp, q.n2w); a.b2 = P(m, fp, q.n2b); a.eps2 = 1e-6f; a.y2 = w.a2; a.y2_lo = w.a2l; a.stats2 = w.st2;
       if (md.f8) { a.y2 = w.a2h; a.y2_b16 = (m->infer || md.f8g) ? nullptr : w.a2; }
-      RUN(PC_LN, 0, ln_fwd(a, half, st));
+      hz_ln_fwd(m, st, a, half);
+    RUN(PC_LN, 0, ln_fwd(a, half, st));
     }
     // (inference, precision >= 1: gelu' - read by the fc2 dgrad only - is not written)
     m->cur_kind = (md.is_rot ? 0 : 12) + 0 * 4 + LK_FC1;
@@ -543,11 +606,25 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
       a.y2 = md.ws[l + 1].a1; a.y2_lo = md.ws[l + 1].a1l; a.stats2 = md.ws[l + 1].st1;
       if (md.f8) { a.y2 = md.ws[l + 1].a1h; a.y2_b16 = (m->infer || md.f8g) ? nullptr : md.ws[l + 1].a1; }
     }
+    hz_ln_fwd(m, st, a, half);
     RUN(PC_LN, 0, ln_fwd(a, half, st));
   }
   return MP_OK;
 }
 
+// LayerNorm backward (ln_bwd / ln_bwd2): the row kernel on st reads dy, x (or, recomputed input: x0 + stats0), the statistics, the skip gradient g
+// (read-modify-write: dx = dskip + ...) and writes dx, the 2-byte copy and the per-workgroup partial sums; the reduction of the partials into the
+// parameter gradients runs on st_param behind `ev` when given (param_stream(), elementwise.hip), else on st
+static void hz_ln_bwd(mp_model* m, hipStream_t st, hipStream_t st_param, hipEvent_t ev, const char* name, const void* dy, double dy_elem, const float* x,
+                      const float* stats, float* g, void* g_b16, const float* mask, const float* x0, const float* stats0, long M, int C, float* scratch,
+                      long scratch_floats, float* dg1, float* db1, float* dg0, float* db0) {
+  if (!m->hz) return;
+  const double MC = (double)M * C;
+  HZ(st, name, HR(dy, dy_elem * MC), HR(x, 4.0 * MC), HR(stats, 8.0 * M), HR(x0, 4.0 * MC), HR(stats0, 8.0 * M), HW(g, 4.0 * MC), HW(g_b16, 2.0 * MC),
+     HR(mask, 4), HW(scratch, 4.0 * scratch_floats));
+  const hipStream_t sp = hz_param_edge(m, st, st_param, ev);
+  HZ(sp, "ln_bwd.param_reduce", HR(scratch, 4.0 * scratch_floats), HW(dg1, 4.0 * C), HW(db1, 4.0 * C), HW(dg0, 4.0 * C), HW(db0, 4.0 * C));
+}
 // on entry m->g holds dL/d x_final; on exit m->g holds dL/d (embedding output)
 static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg, int B, hipStream_t st) {
   const int T = m->cfg.num_frame, N = md.N, C = md.C, H = md.H, L = 2 * md.depth;
@@ -566,9 +643,9 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
   hipEvent_t lev = wasync ? m->ev_heads : nullptr;
   auto ln_scratch = [&]() -> float* { return (wasync && ln_call < m->lnpart_n) ? m->lnpart + (long)(ln_call++) * m->lnpart_slice : m->small; };
   auto ln_floats = [&](float* p) -> long { return p == m->small ? m->small_floats : m->lnpart_slice; };
-#define E_READY(i) do { if (wasync) { MP_HIP(hipEventRecord(m->evE[par][i], st)); MP_HIP(hipStreamWaitEvent(sw, m->evE[par][i], 0)); } } while (0)
-#define W_DONE(i) do { if (wasync) MP_HIP(hipEventRecord(m->evW[par][i], sw)); } while (0)
-#define WAIT_W(p, i) do { if (wasync) MP_HIP(hipStreamWaitEvent(st, m->evW[p][i], 0)); } while (0)
+#define E_READY(i) do { if (wasync) { MP_HIP(ev_record(m, m->evE[par][i], st)); MP_HIP(ev_wait(m, sw, m->evE[par][i])); } } while (0)
+#define W_DONE(i) do { if (wasync) MP_HIP(ev_record(m, m->evW[par][i], sw)); } while (0)
+#define WAIT_W(p, i) do { if (wasync) MP_HIP(ev_wait(m, st, m->evW[p][i])); } while (0)
   for (int l = L - 1; l >= 0; --l, par ^= 1) {
     const BlockP& q = md.bp[l];
     BlockWS& w = md.ws[l];
@@ -578,8 +655,13 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
     // norm1/post-norm backward (h) has already produced dL/d x_out[l]
     const float* mk2 = branch_mask(m, md, l, 1, B, m->train);
     if (!post_done) {
-      if (l == 0) RUN(PC_OTHER, 0, tpos_grad(g, G(m, fg, md.tpos), B, T, N, C, st));
+      if (l == 0) {
+        HZ(st, "tpos_grad", HR(g, 4.0 * M * C), HW(G(m, fg, md.tpos), 4.0 * T * C));
+        RUN(PC_OTHER, 0, tpos_grad(g, G(m, fg, md.tpos), B, T, N, C, st));
+      }
       float* lsc = ln_scratch();
+      hz_ln_bwd(m, st, lsc == m->small ? nullptr : lst, lev, "ln_bwd.postnorm", g, 4.0, w.x_out, w.stp, g, m->g_b16, mk2, nullptr, nullptr, M, C, lsc, ln_floats(lsc),
+                G(m, fg, spatial ? md.sn_w : md.tn_w), G(m, fg, spatial ? md.sn_b : md.tn_b), nullptr, nullptr);
       RUN(PC_LN, 0, ln_bwd(g, 0, w.x_out, w.stp, P(m, fp, spatial ? md.sn_w : md.tn_w), nullptr, g, m->g_b16, mk2, mode, T, N,
                            G(m, fg, spatial ? md.sn_w : md.tn_w), G(m, fg, spatial ? md.sn_b : md.tn_b), (int)M, C, lsc,
                            ln_floats(lsc), st, lsc == m->small ? nullptr : lst, lev, 1.0f, nullptr, md.f8m ? m->gsc : nullptr));
@@ -588,6 +670,7 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
     // (b) mlp branch: fc2 (gb = DropPath-scaled branch gradient; a bf16 copy emitted by the LN backward in precision 1)
     const void* gb = half ? (const void*)m->g_b16 : (const void*)g;
     if (mk2 && !half) {
+      HZ(st, "scale_rows", HR(g, 4.0 * M * C), HW(m->tmpMask, 4.0 * M * C));
       RUN(PC_OTHER, 0, scale_rows(g, mk2, mode, m->tmpMask, 0, (int)M, C, T, N, st));
       gb = m->tmpMask;
     }
@@ -614,12 +697,15 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
     // (d) norm2 + skip
     const float* mk1 = branch_mask(m, md, l, 0, B, m->train);
     float* lsc2 = ln_scratch();
+    hz_ln_bwd(m, st, lsc2 == m->small ? nullptr : lst, lev, "ln_bwd.norm2", m->tmpC, half ? 2.0 : 4.0, w.x_mid, w.st2, g, m->g_b16, mk1, nullptr, nullptr, M, C, lsc2,
+              ln_floats(lsc2), G(m, fg, q.n2w), G(m, fg, q.n2b), nullptr, nullptr);
     RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_mid, w.st2, P(m, fp, q.n2w), g, g, m->g_b16, mk1, mode, T, N, G(m, fg, q.n2w),
                          G(m, fg, q.n2b), (int)M, C, lsc2, ln_floats(lsc2), st, lsc2 == m->small ? nullptr : lst, lev, md.rs,
                          md.f8g ? m->gsc + 1 : nullptr));
     // (e) attention branch: proj
     gb = half ? (const void*)m->g_b16 : (const void*)g;
     if (mk1 && !half) {
+      HZ(st, "scale_rows", HR(g, 4.0 * M * C), HW(m->tmpMask, 4.0 * M * C));
       RUN(PC_OTHER, 0, scale_rows(g, mk1, mode, m->tmpMask, 0, (int)M, C, T, N, st));
       gb = m->tmpMask;
     }
@@ -634,6 +720,9 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
     if (have_prev) WAIT_W(par ^ 1, 3);                             // previous block's qkv wgrad still reads tmp3C
     // (f) attention core
     {
+      const double eb = half ? 2.0 : 4.0;
+      HZ(st, "attention_bwd", HR(w.qkv, eb * M * 3 * C), HR(spatial ? nullptr : w.ao, eb * M * C), HR(m->tmpC, eb * M * C), HR(spatial ? nullptr : w.lse, 4.0 * B * N * H * T),
+         HW(spatial ? nullptr : m->delta, 4.0 * B * N * H * T), HW(m->tmp3C, eb * M * 3 * C));
       AttnGradF16Scope f16_out(md.f8g ? m->gsc : nullptr);      // f8g: dqkv leaves as scaled fp16 (its two consumers below run on fp16 operands)
       if (spatial) RUN(PC_ATTN, 10.0 * B * T * N * N * C, attn_spatial_bwd(w.qkv, m->tmpC, m->tmp3C, half, B, T, N, C, H, st));
       else RUN(PC_ATTN, 10.0 * B * N * (double)T * T * C, attn_temporal_bwd(w.qkv, w.ao, m->tmpC, w.lse, m->delta, m->tmp3C, half, B, T, N, C, H, st));
@@ -657,6 +746,8 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
       const bool pspatial = ((l - 1) % 2 == 0);
       const float* mkp = branch_mask(m, md, l - 1, 1, B, m->train);
       float* lsc3 = ln_scratch();
+      hz_ln_bwd(m, st, lsc3 == m->small ? nullptr : lst, lev, "ln_bwd2.norm1+postnorm", m->tmpC, half ? 2.0 : 4.0, w.x_in, w.st1, g, m->g_b16, mkp, wp.x_out, wp.stp, M, C,
+                lsc3, ln_floats(lsc3), G(m, fg, q.n1w), G(m, fg, q.n1b), G(m, fg, pspatial ? md.sn_w : md.tn_w), G(m, fg, pspatial ? md.sn_b : md.tn_b));
       RUN(PC_LN, 0, ln_bwd2(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, wp.x_out, wp.stp, P(m, fp, pspatial ? md.sn_w : md.tn_w),
                             P(m, fp, pspatial ? md.sn_b : md.tn_b), g, m->g_b16, mkp, pspatial ? 1 : 2, T, N, G(m, fg, q.n1w), G(m, fg, q.n1b),
                             G(m, fg, pspatial ? md.sn_w : md.tn_w), G(m, fg, pspatial ? md.sn_b : md.tn_b), (int)M, C, lsc3,
@@ -665,6 +756,8 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
       post_done = true;
     } else {
       float* lsc4 = ln_scratch();
+      hz_ln_bwd(m, st, lsc4 == m->small ? nullptr : lst, lev, "ln_bwd.norm1", m->tmpC, half ? 2.0 : 4.0, w.x_in, w.st1, g, nullptr, nullptr, nullptr, nullptr, M, C, lsc4,
+                ln_floats(lsc4), G(m, fg, q.n1w), G(m, fg, q.n1b), nullptr, nullptr);
       RUN(PC_LN, 0, ln_bwd(m->tmpC, half, w.x_in, w.st1, P(m, fp, q.n1w), g, g, nullptr, nullptr, 0, T, N, G(m, fg, q.n1w),
                            G(m, fg, q.n1b), (int)M, C, lsc4, ln_floats(lsc4), st, lsc4 == m->small ? nullptr : lst, lev, md.rs,
                            md.f8g ? m->gsc + 1 : nullptr));
@@ -673,10 +766,10 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
     // enqueued - the weight-gradient stream first waits for the main stream's position, then carries the event
     if (md.is_rot && (l % 2 == 0) && (size_t)(l / 2) < m->ev_bucket.size()) {
       if (sw != st) {
-        MP_HIP(hipEventRecord(m->ev_sync, st));
-        MP_HIP(hipStreamWaitEvent(sw, m->ev_sync, 0));
+        MP_HIP(ev_record(m, m->ev_sync, st));
+        MP_HIP(ev_wait(m, sw, m->ev_sync));
       }
-      MP_HIP(hipEventRecord(m->ev_bucket[l / 2], sw));
+      MP_HIP(ev_record(m, m->ev_bucket[l / 2], sw));
     }
   }
   if (wasync && have_prev) {    // the last block's fc1 / qkv weight gradients
@@ -704,6 +797,13 @@ static void head_grads(const mp_model* m, const Module& md, float* fg, HeadGrads
     hg.gamma[k] = G(m, fg, md.hg[k]); hg.beta[k] = G(m, fg, md.hb[k]); hg.b[k] = G(m, fg, md.hbias[k]);
     hg.W[k] = md.hdw != nullptr ? md.hdw + k * WC : G(m, fg, md.hw[k]);
   }
+}
+// floats of the flat buffer from the first head parameter of a module to the end of its last one (the heads' slots are contiguous)
+static long head_param_floats(const mp_model* m, const Module& md) {
+  const bool rmcl = md.is_rot && m->cfg.arch == 0;
+  const ParamDesc& first = m->params[md.hg[0]];
+  const ParamDesc& last = m->params[rmcl ? md.sb[md.K - 1] : md.hbias[0]];
+  return last.offset + (last.numel + 63) / 64 * 64 - first.offset;
 }
 static int refresh_head_weights(mp_model* m, const Module& md, const float* fp, hipStream_t st) {
   if (md.hw_eff == nullptr) return MP_OK;
@@ -751,6 +851,7 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
            "mp_model_create: rot_rep_dim %d (4 or 6; 0 = 6)", cfg->rot_rep_dim);
   MP_CHECK(cfg->f16f8 >= 0 && cfg->f16f8 <= 2 && (cfg->f16_backward == 0 || cfg->f16_backward == 1) && cfg->streams >= 0 && cfg->streams <= 3, MP_ERR_ARG,
            "mp_model_create: f16f8 %d (0..2), f16_backward %d (0/1), streams %d (bit set 0..3)", cfg->f16f8, cfg->f16_backward, cfg->streams);
+  MP_CHECK(cfg->debug >= 0 && cfg->debug <= 1, MP_ERR_ARG, "mp_model_create: debug %d (bit 0 = stream-hazard check)", cfg->debug);
   MP_CHECK(cfg->f16f8 == 0 || cfg->precision == 2, MP_ERR_ARG, "mp_model_create: f16f8 operands belong to precision 2 (bf16x3)");
   MP_CHECK(cfg->f16_backward == 0 || cfg->f16f8 >= 1, MP_ERR_ARG, "mp_model_create: f16_backward needs f16f8 >= 1");
   MP_CHECK(cfg->f16f8 < 2 || cfg->f16_backward == 1, MP_ERR_ARG, "mp_model_create: f16f8 = 2 (the fc2 layer) needs f16_backward");
@@ -826,6 +927,7 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
       return MP_ERR_HIP;
     }
   }
+  if (cfg->debug & 1) m->hz.reset(new HazardTracker());
   e = hipMemset(m->dscore_zero, 0, sizeof(float) * (size_t)cfg->max_batch * m->rot.K * cfg->num_frame);
   if (e != hipSuccess) {
     set_error("mp_model_create: hipMemset failed: %s", hipGetErrorString(e));
@@ -917,6 +1019,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
   m->x_in = x;
   if (m->train) {
     if (masks_override) {
+      HZ(st, "masks.copy", HW(m->maskbuf, 4.0 * mp_model_mask_floats(m, B)));
       MP_HIP(hipMemcpyAsync(m->maskbuf, masks_override, sizeof(float) * mp_model_mask_floats(m, B), hipMemcpyDeviceToDevice, st));
     } else {
       std::vector<MaskDesc> ds;
@@ -928,19 +1031,23 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
           ds.push_back({(int)off, cnt, b.keep});
           off += cnt;
         }
+      HZ(st, "droppath_masks", HW(m->maskbuf, 4.0 * off));
       RUN(PC_OTHER, 0, droppath_masks(m->maskbuf, ds.data(), (int)ds.size(), seed, step, st));
     }
   }
+  if (m->cfg.precision >= 1) HZ(st, "weight_shadow", HW(m->wbf, 2.0 * m->flat_size), HW(m->wbf_lo, 2.0 * m->flat_size), HW(m->w16, 2.0 * m->flat_size), HW(m->w8, 2.0 * m->flat_size));
   if (m->cfg.precision == 1) RUN(PC_OTHER, 0, cast_to_bf16(fp, m->wbf, m->flat_size, st));
   if (m->cfg.precision == 2) RUN(PC_OTHER, 0, cast_to_bf16x2(fp, m->wbf, m->wbf_lo, m->flat_size, st));
   if (m->w16 != nullptr) RUN(PC_OTHER, 0, cast_to_f16f8(fp, m->w16, m->w8, m->flat_size, 1, st));
   // fork: the side stream may start once the masks / bf16 weights above are in place
   const hipStream_t side = (m->cfg.streams & 1) ? st : m->st2;
-  MP_HIP(hipEventRecord(m->ev_fork, st));
-  MP_HIP(hipStreamWaitEvent(side, m->ev_fork, 0));
+  MP_HIP(ev_record(m, m->ev_fork, st));
+  MP_HIP(ev_wait(m, side, m->ev_fork));
   use_scratch(m, 0);
   // rotations backbone (mix_ste.py:128-173)
   const long Mr = (long)B * T * J, Ms = (long)B * T * S;
+  if (m->hz) m->hz->prune();      // drop the records every stream has synchronised past (the previous steps)
+  HZ(st, "embed_fwd", HW(m->rot.ws[0].x_in, 4.0 * Mr * m->rot.C));
   RUN(PC_OTHER, 0, embed_fwd(x, P(m, fp, m->rot.emb_w), P(m, fp, m->rot.emb_b), P(m, fp, m->rot.spos), m->rot.ws[0].x_in, (int)Mr,
                              m->rot.C, J, st));
   int rc = backbone_fwd(m, m->rot, fp, B, st);
@@ -949,6 +1056,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
   head_params(m, m->rot, fp, hp);
   rc = refresh_head_weights(m, m->rot, fp, st);
   if (rc) return rc;
+  HZ(st, "heads_fwd", HR(m->rot.x_final, 4.0 * Mr * m->rot.C), HW(m->rot.headout, 4.0 * K * Mr * m->rot.O), HW(m->rot.hstats, 8.0 * Mr), HW(m->rot.hfold, 4.0 * heads_fold_floats(m->rot.C)));
   if (heads_use_mfma(K, m->rot.O, m->rot.C))
     RUN(PC_OTHER, 0, heads_fwd_mfma(m->rot.x_final, hp, K, m->rot.O, m->rot.headout, m->rot.hstats, (int)Mr, m->rot.C, m->rot.hfold, st));
   else
@@ -956,6 +1064,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
   if (m->cfg.arch == 0) {
     ScoreParams sp;
     for (int k = 0; k < K; ++k) { sp.w[k] = P(m, fp, m->rot.sw[k]); sp.b[k] = P(m, fp, m->rot.sb[k]); }
+    HZ(st, "scores_fwd", HR(m->rot.headout, 4.0 * K * Mr * m->rot.O), HW(scores, 4.0 * B * K * T));
     RUN(PC_OTHER, 0, scores_fwd(m->rot.headout, sp, K, m->rot.O, scores, B, T, J, st));
   }
   if (!m->has_seg) {   // MixSTE.forward (mix_ste.py:175-191): the head output IS the pose, rows (b, t, j) = the (B, 1, T, J, 3) layout
@@ -967,6 +1076,7 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
     hipStream_t main_st = st;
     st = side;
     use_scratch(m, 1);
+    HZ(st, "bones_embed_fwd", HW(m->seg.ws[0].x_in, 4.0 * Ms * m->seg.C));
     RUN(PC_OTHER, 0, bones_embed_fwd(x, P(m, fp, m->seg.emb_w), P(m, fp, m->seg.emb_b), P(m, fp, m->seg.spos), m->seg.ws[0].x_in,
                                      B * T, J * 2, S * m->seg.C, st));
     rc = backbone_fwd(m, m->seg, fp, B, st);
@@ -975,17 +1085,20 @@ int mp_model_forward(mp_model* m, const float* fp, const float* x, int B, float*
     head_params(m, m->seg, fp, hs);
     rc = refresh_head_weights(m, m->seg, fp, st);
     if (rc) return rc;
+    HZ(st, "heads_fwd.seg", HR(m->seg.x_final, 4.0 * Ms * m->seg.C), HW(m->seg.headout, 4.0 * Ms), HW(m->seg.hstats, 8.0 * Ms), HW(m->seg.hfold, 4.0 * heads_fold_floats(m->seg.C)));
     if (heads_use_mfma(1, 1, m->seg.C))
       RUN(PC_OTHER, 0, heads_fwd_mfma(m->seg.x_final, hs, 1, 1, m->seg.headout, m->seg.hstats, (int)Ms, m->seg.C, m->seg.hfold, st));
     else
       RUN(PC_OTHER, 0, heads_fwd(m->seg.x_final, hs, 1, 1, m->seg.headout, m->seg.hstats, (int)Ms, m->seg.C, st));
+    HZ(st, "bones_mean_fwd", HR(m->seg.headout, 4.0 * Ms), HW(m->lengths, 4.0 * B * S));
     RUN(PC_OTHER, 0, bones_mean_fwd(m->seg.headout, m->lengths, B, T, S, st));
-    MP_HIP(hipEventRecord(m->ev_join, side));
+    MP_HIP(ev_record(m, m->ev_join, side));
     st = main_st;
     use_scratch(m, 0);
-    MP_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
+    MP_HIP(ev_wait(m, st, m->ev_join));
   }
   // manifold decoder (pose_decoder.py:32-55)
+  HZ(st, "fk_decode_fwd", HR(m->rot.headout, 4.0 * K * Mr * m->rot.O), HR(m->lengths, 4.0 * B * S), HW(poses, 12.0 * B * K * T * J));
   RUN(PC_OTHER, 0, fk_decode_fwd(m->rot.headout, m->rot.O, m->cfg.rot_rep_dim, m->lengths, poses, B, K, T, st));
   return MP_OK;
 }
@@ -1004,6 +1117,8 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   hipStream_t pst = m->wgrad_async ? m->st3 : nullptr;
   { int rz = zero_head_grad_scratch(m->rot, st); if (rz) return rz; }
   // decoder
+  HZ(st, "fk_decode_bwd", HR(m->rot.headout, 4.0 * K * Mr * m->rot.O), HR(m->lengths, 4.0 * B * S), HR(d_poses, 12.0 * B * K * T * J), HW(m->rot.dheadout, 4.0 * K * Mr * m->rot.O),
+     HW(m->has_seg ? m->dlen_pose : nullptr, 4.0 * B * K * T * S));
   if (m->has_seg) RUN(PC_OTHER, 0, fk_decode_bwd(m->rot.headout, m->rot.O, m->cfg.rot_rep_dim, m->lengths, d_poses, m->rot.dheadout, m->dlen_pose, B, K, T, st));
   else MP_HIP(hipMemcpyAsync(m->rot.dheadout, d_poses, sizeof(float) * Mr * 3, hipMemcpyDeviceToDevice, st));
   if (m->cfg.arch == 0) {
@@ -1015,23 +1130,40 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     }
     // scores are recomputed into tmpC-sized scratch? no: softmax outputs are cheap to recompute from the head output
     float* sc = m->tmpC;    // (B,K,T) scratch, free at this point of the backward
+    HZ(st, "scores_fwd.recompute", HR(m->rot.headout, 4.0 * K * Mr * m->rot.O), HW(sc, 4.0 * B * K * T));
     RUN(PC_OTHER, 0, scores_fwd(m->rot.headout, sp, K, m->rot.O, sc, B, T, J, st));
+    {
+      float* const ssc = pst ? m->sc_dlogit : m->small;
+      const double sscb = 4.0 * (pst ? scores_bwd_scratch_floats(K, B, T) : m->small_floats);
+      HZ(st, "scores_bwd", HR(m->rot.headout, 4.0 * K * Mr * m->rot.O), HR(sc, 4.0 * B * K * T), HW(m->rot.dheadout, 4.0 * K * Mr * m->rot.O), HW(ssc, sscb));
+      const hipStream_t sp_st = hz_param_edge(m, st, pst, pst ? m->ev_heads : nullptr);
+      HZ(sp_st, "scores_bwd.params", HR(m->rot.headout, 4.0 * K * Mr * m->rot.O), HW(ssc, sscb), HW(G(m, fg, m->rot.hg[0]), 4.0 * head_param_floats(m, m->rot)));
+    }
     RUN(PC_OTHER, 0, scores_bwd(m->rot.headout, sc, d_scores ? d_scores : m->dscore_zero, sp, sg, K, m->rot.O, m->rot.dheadout, B, T, J,
                                 pst ? m->sc_dlogit : m->small, pst ? scores_bwd_scratch_floats(K, B, T) : m->small_floats, st, pst, pst ? m->ev_heads : nullptr));
   } else if (pst) {
-    MP_HIP(hipEventRecord(m->ev_heads, st));             // dheadout is final: the head parameter gradients may start on the other stream
-    MP_HIP(hipStreamWaitEvent(pst, m->ev_heads, 0));
+    MP_HIP(ev_record(m, m->ev_heads, st));             // dheadout is final: the head parameter gradients may start on the other stream
+    MP_HIP(ev_wait(m, pst, m->ev_heads));
   }
   // fork: the bones-net backward only needs the per-pose length gradients of the decoder backward
   const hipStream_t side = (m->cfg.streams & 1) ? st : m->st2;
-  MP_HIP(hipEventRecord(m->ev_fork, st));
-  MP_HIP(hipStreamWaitEvent(side, m->ev_fork, 0));
+  MP_HIP(ev_record(m, m->ev_fork, st));
+  MP_HIP(ev_wait(m, side, m->ev_fork));
   use_scratch(m, 0);
   // rotations module
   HeadParams hp;
   HeadGrads hg;
   head_params(m, m->rot, fp, hp);
   head_grads(m, m->rot, fg, hg);
+  {
+    float* const hsc = pst ? m->hsmall : m->small;
+    const double hscb = 4.0 * (pst ? m->hsmall_floats : m->small_floats);
+    HZ(st, "heads_bwd.dx", HR(m->rot.x_final, 4.0 * Mr * m->rot.C), HR(m->rot.hstats, 8.0 * Mr), HR(m->rot.hfold, 4.0 * heads_fold_floats(m->rot.C)), HR(m->rot.headout, 4.0 * K * Mr * m->rot.O),
+       HR(m->rot.dheadout, 4.0 * K * Mr * m->rot.O), HW(m->g, 4.0 * Mr * m->rot.C), HW(pst ? nullptr : hsc, hscb));
+    // (the parameter kernels go to pst WITHOUT an event of their own: they read what the dx kernel reads, all final since ev_heads above)
+    HZ(pst ? pst : st, "heads_bwd.params", HR(m->rot.x_final, 4.0 * Mr * m->rot.C), HR(m->rot.hstats, 8.0 * Mr), HR(m->rot.headout, 4.0 * K * Mr * m->rot.O),
+       HR(m->rot.dheadout, 4.0 * K * Mr * m->rot.O), HW(hsc, hscb), HW(G(m, fg, m->rot.hg[0]), 4.0 * head_param_floats(m, m->rot)));
+  }
   if (heads_use_mfma(K, m->rot.O, m->rot.C))
     RUN(PC_OTHER, 0, heads_bwd_mfma(m->rot.x_final, m->rot.hstats, m->rot.hfold, m->rot.headout, hp, hg, K, m->rot.O, m->rot.dheadout, m->g, (int)Mr, m->rot.C,
                                     pst ? m->hsmall : m->small, pst ? m->hsmall_floats : m->small_floats, st, pst));
@@ -1043,9 +1175,11 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   // starts from - NOT from d_poses: the WTA loss gradient is a unit vector per joint whatever the error, so its maximum is a constant of the
   // batch shape while the interior gradients shrank by four orders of magnitude over 200 optimisation steps (measured, round 4: 38 % of
   // dz's true values would have been fp16-subnormal at an S taken from d_poses).  One read of g (M x C floats, ~0.13 ms at full size).
+  if (m->rot.f8g) HZ(st, "grad_scale", HR(m->g, 4.0 * Mr * m->rot.C), HW(m->gsc, 32));
   if (m->rot.f8g) RUN(PC_OTHER, 0, grad_scale(m->g, Mr * m->rot.C, nullptr, 0, m->gsc, st));
   int rc = backbone_bwd(m, m->rot, fp, fg, B, st);
   if (rc) return rc;
+  HZ(st, "embed_bwd", HR(m->g, 4.0 * Mr * m->rot.C), HW(m->small, 4.0 * m->small_floats), HW(G(m, fg, m->rot.emb_w), 4.0 * m->rot.C * 2), HW(G(m, fg, m->rot.spos), 4.0 * J * m->rot.C));
   RUN(PC_OTHER, 0, embed_bwd(m->g, m->x_in, G(m, fg, m->rot.emb_w), G(m, fg, m->rot.emb_b), G(m, fg, m->rot.spos), (int)Mr, m->rot.C, J,
                              m->small, m->small_floats, st));
   // segments module, on the side stream with its own scratch set
@@ -1053,12 +1187,15 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     hipStream_t main_st = st;
     st = side;
     use_scratch(m, 1);
+    HZ(st, "bones_mean_bwd", HR(m->dlen_pose, 4.0 * B * K * T * S), HW(m->seg.dheadout, 4.0 * Ms));
     RUN(PC_OTHER, 0, bones_mean_bwd(m->dlen_pose, K * T, nullptr, m->seg.dheadout, B, T, S, st));
     HeadParams hs;
     HeadGrads hgs;
     head_params(m, m->seg, fp, hs);
     head_grads(m, m->seg, fg, hgs);
     { int rz = zero_head_grad_scratch(m->seg, st); if (rz) return rz; }
+    HZ(st, "heads_bwd.seg", HR(m->seg.x_final, 4.0 * Ms * m->seg.C), HR(m->seg.hstats, 8.0 * Ms), HR(m->seg.headout, 4.0 * Ms), HR(m->seg.dheadout, 4.0 * Ms), HW(m->g, 4.0 * Ms * m->seg.C),
+       HW(m->small, 4.0 * m->small_floats), HW(hgs.W[0], 4.0 * m->seg.C), HW(hgs.gamma[0], 4.0 * m->seg.C), HW(hgs.beta[0], 4.0 * m->seg.C));
     if (heads_use_mfma(1, 1, m->seg.C))
       RUN(PC_OTHER, 0, heads_bwd_mfma(m->seg.x_final, m->seg.hstats, m->seg.hfold, m->seg.headout, hs, hgs, 1, 1, m->seg.dheadout, m->g, (int)Ms,
                                       m->seg.C, m->small, m->small_floats, st, nullptr));
@@ -1068,32 +1205,100 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     { int rf = flush_head_grads(m, m->seg, fg, st); if (rf) return rf; }
     rc = backbone_bwd(m, m->seg, fp, fg, B, st);
     if (rc) return rc;
+    HZ(st, "bones_embed_bwd", HR(m->g, 4.0 * Ms * m->seg.C), HW(m->small, 4.0 * m->small_floats), HW(G(m, fg, m->seg.emb_w), 4.0 * S * m->seg.C * J * 2), HW(G(m, fg, m->seg.spos), 4.0 * S * m->seg.C));
     RUN(PC_OTHER, 0, bones_embed_bwd(m->g, m->x_in, G(m, fg, m->seg.emb_w), G(m, fg, m->seg.emb_b), G(m, fg, m->seg.spos), B * T, J * 2,
                                      S * m->seg.C, m->small, m->small_floats, st));
-    MP_HIP(hipEventRecord(m->ev_join, side));
+    MP_HIP(ev_record(m, m->ev_join, side));
     st = main_st;
     use_scratch(m, 0);
-    MP_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
+    MP_HIP(ev_wait(m, st, m->ev_join));
   }
   if (pst) {                                              // everything queued on the weight-gradient stream belongs to this backward
-    MP_HIP(hipEventRecord(m->ev_heads, pst));
-    MP_HIP(hipStreamWaitEvent(st, m->ev_heads, 0));
+    MP_HIP(ev_record(m, m->ev_heads, pst));
+    MP_HIP(ev_wait(m, st, m->ev_heads));
   }
   m->buckets_recorded = true;
   return MP_OK;
 }
 
+static int hazard_report(const HazardTracker* hz, int64_t* out4, char* msg, int msg_cap) {
+  if (out4) { out4[0] = hz->launches(); out4[1] = hz->ordered_pairs(); out4[2] = hz->violations(); out4[3] = hz->events(); }
+  if (msg && msg_cap > 0) {
+    std::string t;
+    for (const std::string& l : hz->messages()) { t += l; t += '\n'; }
+    snprintf(msg, (size_t)msg_cap, "%s", t.c_str());
+  }
+  return MP_OK;
+}
+int mp_model_hazard_report(const mp_model* m, int64_t* out4, char* msg, int msg_cap) {
+  MP_CHECK(m != nullptr, MP_ERR_ARG, "mp_model_hazard_report: null model");
+  MP_CHECK(m->hz != nullptr, MP_ERR_STATE, "mp_model_hazard_report: the model was created without mp_model_config::debug bit 0");
+  return hazard_report(m->hz.get(), out4, msg, msg_cap);
+}
+struct mp_hazard { HazardTracker t; };
+mp_hazard* mp_hazard_create(void) { return new mp_hazard(); }
+void mp_hazard_destroy(mp_hazard* h) { delete h; }
+int mp_hazard_launch(mp_hazard* h, int stream, const char* name, int n, const int64_t* addr, const int64_t* bytes, const int* is_write) {
+  MP_CHECK(h && stream >= 0 && stream < HazardTracker::MAXS && n >= 0 && (n == 0 || (addr && bytes && is_write)), MP_ERR_ARG, "mp_hazard_launch: bad argument");
+  std::vector<HzAccess> acc;
+  for (int i = 0; i < n; ++i) acc.push_back(HzAccess{(const void*)(uintptr_t)addr[i], (size_t)bytes[i], is_write[i] != 0});
+  // (streams are named by small integers here: id i is the i-th distinct handle, so register them in order)
+  for (int i = 0; i <= stream; ++i) (void)h->t.stream_id((const void*)(uintptr_t)(i + 1));
+  h->t.launch(stream, name, acc.data(), n);
+  return MP_OK;
+}
+int mp_hazard_record(mp_hazard* h, int event, int stream) {
+  MP_CHECK(h && stream >= 0 && stream < HazardTracker::MAXS, MP_ERR_ARG, "mp_hazard_record: bad argument");
+  for (int i = 0; i <= stream; ++i) (void)h->t.stream_id((const void*)(uintptr_t)(i + 1));
+  h->t.record((const void*)(uintptr_t)(event + 1), stream);
+  return MP_OK;
+}
+int mp_hazard_wait(mp_hazard* h, int stream, int event) {
+  MP_CHECK(h && stream >= 0 && stream < HazardTracker::MAXS, MP_ERR_ARG, "mp_hazard_wait: bad argument");
+  for (int i = 0; i <= stream; ++i) (void)h->t.stream_id((const void*)(uintptr_t)(i + 1));
+  h->t.wait(stream, (const void*)(uintptr_t)(event + 1));
+  return MP_OK;
+}
+int mp_hazard_report(const mp_hazard* h, int64_t* out4, char* msg, int msg_cap) {
+  MP_CHECK(h != nullptr, MP_ERR_ARG, "mp_hazard_report: null tracker");
+  return hazard_report(&h->t, out4, msg, msg_cap);
+}
+
+int mp_model_set_streams(mp_model* m, int streams) {
+  MP_CHECK(m != nullptr && streams >= 0 && streams <= 3, MP_ERR_ARG, "mp_model_set_streams: streams %d (bit set 0..3)", streams);
+  MP_CHECK(m->cfg.max_batch > 0, MP_ERR_STATE, "mp_model_set_streams: a layout-only handle has no streams");
+  MP_HIP(hipStreamSynchronize(m->st2));
+  MP_HIP(hipStreamSynchronize(m->st3));
+  m->cfg.streams = streams;
+  m->wgrad_async = (streams & 2) == 0;
+  return MP_OK;
+}
+
+// {S, 1 / S, scratch, 1, clamped (u32), non-finite (u32)} of mp_model::gsc -> {S, clamped, non-finite, 1 / S} as floats
+static void grad_health_values(const float* h, float* out) {
+  unsigned c[2];
+  memcpy(c, h + 4, sizeof(c));
+  out[0] = h[0]; out[1] = (float)c[0]; out[2] = (float)c[1]; out[3] = h[1];
+}
 int mp_model_grad_health(mp_model* m, float* out, void* stream) {
   MP_CHECK(m && out, MP_ERR_ARG, "mp_model_grad_health: null argument");
   out[0] = out[1] = out[2] = out[3] = 0.f;
   if (m->gsc == nullptr || !m->rot.f8g) return MP_OK;
+  MP_CHECK(m->buckets_recorded, MP_ERR_STATE, "mp_model_grad_health: no completed mp_model_backward since the last mp_model_forward");
   float h[8];
   MP_HIP(hipMemcpyAsync(h, m->gsc, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
   MP_HIP(hipStreamSynchronize((hipStream_t)stream));
-  unsigned c[2];
-  memcpy(c, h + 4, sizeof(c));
-  out[0] = h[0]; out[1] = (float)c[0]; out[2] = (float)c[1]; out[3] = h[1];
+  grad_health_values(h, out);
   return MP_OK;
+}
+int mp_model_grad_health_async(mp_model* m, float* out, void* stream) {
+  MP_CHECK(m && out, MP_ERR_ARG, "mp_model_grad_health_async: null argument");
+  if (m->gsc == nullptr || !m->rot.f8g) {
+    MP_HIP(hipMemsetAsync(out, 0, 4 * sizeof(float), (hipStream_t)stream));
+    return MP_OK;
+  }
+  MP_CHECK(m->buckets_recorded, MP_ERR_STATE, "mp_model_grad_health_async: no completed mp_model_backward since the last mp_model_forward");
+  return grad_health_pack(m->gsc, out, (hipStream_t)stream);
 }
 
 // (the bucket LAYOUT is a property of the parameter layout and also answered by a layout-only handle; waiting needs a device model, whose
@@ -1115,7 +1320,7 @@ int mp_model_grad_bucket_info(const mp_model* m, int index, int64_t* offset, int
 int mp_model_grad_bucket_wait(mp_model* m, int index, void* stream) {
   MP_CHECK(m && index >= 0 && index < (int)m->ev_bucket.size(), MP_ERR_ARG, "mp_model_grad_bucket_wait: bad index %d (a layout-only handle has no events)", index);
   MP_CHECK(m->buckets_recorded, MP_ERR_STATE, "mp_model_grad_bucket_wait: no completed mp_model_backward since the last mp_model_forward");
-  MP_HIP(hipStreamWaitEvent((hipStream_t)stream, m->ev_bucket[index], 0));
+  MP_HIP(ev_wait(m, (hipStream_t)stream, m->ev_bucket[index]));
   return MP_OK;
 }
 

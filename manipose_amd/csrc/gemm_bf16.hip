@@ -445,6 +445,81 @@ __device__ __forceinline__ void persist_dma(char* __restrict__ S, const char* __
   for (int n4 = 0; n4 < 4; ++n4) __builtin_amdgcn_global_load_lds((gptr)(base + off[n4]), (lptr)(S + (wave * 4 + n4) * 1024), 16, 0, 0);
 }
 
+// ---- hand-scheduled k-step (MP_KLOOP_ASM; tools/gen_kloop_asm.py -> kloop_asm.inc) -------------------------------------------------------
+// One 64-wide step of a wave's 128 x 64 sub-tile as a single inline-asm block: the 64 MFMAs, the 24 fragment requests (two groups of 8 MFMAs
+// ahead, counted lgkmcnt waits, fragments in the fixed registers v[200:255]) and the wave's share of the step's operand DMA.  What hipcc makes
+// of mma_stage above: requests one group ahead behind lgkmcnt(0) waits, the DMA instructions (and ~60 scalar instructions of address and
+// predicate arithmetic) in front of the step's first fragment request.
+#ifndef MP_KLOOP_ASM
+#define MP_KLOOP_ASM 0      // round 5: every schedule variant measured slower than hipcc's own; kept as a build option
+#endif
+#include "kloop_asm.inc"
+#ifndef MP_KSTEP_VARIANT
+#define MP_KSTEP_VARIANT 0      // schedule variant of the generated step (tools/gen_kloop_asm.py, VARIANTS)
+#endif
+#define MP_KSTEP_CAT2(t, v) MP_KSTEP_ASM_TRB##t##_V##v
+#define MP_KSTEP_CAT(t, v) MP_KSTEP_CAT2(t, v)
+#define MP_KSTEP_CLOB2(v) MP_KSTEP_CLOBBERS_V##v
+#define MP_KSTEP_CLOB(v) MP_KSTEP_CLOB2(v)
+// A DMA job of a step, all wave-uniform: 4 x 1 KiB pieces (this wave's rows of a 256-row operand tile) from base + per-lane offsets to LDS
+struct KJob { int en; unsigned lds; const char* base; };
+__device__ __forceinline__ unsigned lds_u32(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
+}
+// Pins a wave-uniform value into a scalar register AT THIS POINT of the program (a real s_mov: an empty asm with a tied "+s" operand is refused
+// when the compiler has chosen the vector ALU for the value's arithmetic): the jobs of a step are computed in front of its wait + barrier.
+__device__ __forceinline__ unsigned sgpr_pin(unsigned v) { unsigned r; asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "s"(v)); return r; }
+__device__ __forceinline__ void kjob_pin(KJob& j) {
+  int en; unsigned lds; const char* base;
+  asm volatile("s_mov_b32 %0, %3\n s_mov_b32 %1, %4\n s_mov_b64 %2, %5" : "=&s"(en), "=&s"(lds), "=&s"(base) : "s"(__builtin_amdgcn_readfirstlane(j.en)), "s"(j.lds), "s"(j.base));      // (the flag arithmetic may sit in the vector ALU)
+  j.en = en; j.lds = lds; j.base = base;
+}
+// per-lane parts of the fragment addresses (loop-invariant): A / "N" B image: row r = block rows + (lane & 15), 16-byte chunk
+// (4 ks + (lane >> 4)) ^ (r & 7) of the 128-byte row (read_frag2<0>); "T" B image: read_frag2<1, 256> for the four 16-column blocks
+struct KFragAddr { unsigned a[2]; unsigned b[4]; };
+template <int TRB>
+__device__ __forceinline__ void kfrag_addr(KFragAddr& fa, int wr, int wc, int lane) {
+  const int l15 = lane & 15, gq = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) fa.a[ks] = (unsigned)((wr * 128 + l15) * 128 + (((ks * 4 + gq) ^ (lane & 7)) << 4));
+  if (TRB == 0) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) fa.b[ks] = (unsigned)((wc * 64 + l15) * 128 + (((ks * 4 + gq) ^ (lane & 7)) << 4));
+    fa.b[2] = fa.b[3] = 0;
+  } else {
+    const int q = l15 >> 2, p = l15 & 3, r = gq * 8 + q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = wc * 64 + j * 16 + 4 * p;
+      fa.b[j] = (unsigned)(r * 512 + (((col >> 3) ^ t_swz(r)) << 4) + ((col >> 2) & 1) * 8);
+    }
+  }
+}
+template <int TRB>
+__device__ __forceinline__ void kstep_asm(f32x4 (&acc)[8][4], const KFragAddr& fa, unsigned As, unsigned Bs, const KJob& ja, const unsigned (&aoff)[4],
+                                          const KJob& jb, const unsigned (&boff)[4], const KJob& jc, unsigned coff) {
+  const unsigned aa0 = As + fa.a[0], aa1 = As + fa.a[1];
+  if constexpr (TRB == 0) {
+    const unsigned ba0 = Bs + fa.b[0], ba1 = Bs + fa.b[1];
+    asm volatile(MP_KSTEP_CAT(0, MP_KSTEP_VARIANT)
+                 : MP_KSTEP_ACC_OPERANDS
+                 : [aa0] "v"(aa0), [aa1] "v"(aa1), [ba0] "v"(ba0), [ba1] "v"(ba1),
+                   [ena] "s"(ja.en), [ldsa] "s"(ja.lds), [gba] "s"(ja.base), [ao0] "v"(aoff[0]), [ao1] "v"(aoff[1]), [ao2] "v"(aoff[2]), [ao3] "v"(aoff[3]),
+                   [enb] "s"(jb.en), [ldsb] "s"(jb.lds), [gbb] "s"(jb.base), [bo0] "v"(boff[0]), [bo1] "v"(boff[1]), [bo2] "v"(boff[2]), [bo3] "v"(boff[3]),
+                   [enc] "s"(jc.en), [ldsc] "s"(jc.lds), [gbc] "s"(jc.base), [co] "v"(coff)
+                 : MP_KSTEP_CLOB(MP_KSTEP_VARIANT));
+  } else {
+    const unsigned bt0 = Bs + fa.b[0], bt1 = Bs + fa.b[1], bt2 = Bs + fa.b[2], bt3 = Bs + fa.b[3];
+    asm volatile(MP_KSTEP_CAT(1, MP_KSTEP_VARIANT)
+                 : MP_KSTEP_ACC_OPERANDS
+                 : [aa0] "v"(aa0), [aa1] "v"(aa1), [bt0] "v"(bt0), [bt1] "v"(bt1), [bt2] "v"(bt2), [bt3] "v"(bt3),
+                   [ena] "s"(ja.en), [ldsa] "s"(ja.lds), [gba] "s"(ja.base), [ao0] "v"(aoff[0]), [ao1] "v"(aoff[1]), [ao2] "v"(aoff[2]), [ao3] "v"(aoff[3]),
+                   [enb] "s"(jb.en), [ldsb] "s"(jb.lds), [gbb] "s"(jb.base), [bo0] "v"(boff[0]), [bo1] "v"(boff[1]), [bo2] "v"(boff[2]), [bo3] "v"(boff[3]),
+                   [enc] "s"(jc.en), [ldsc] "s"(jc.lds), [gbc] "s"(jc.base), [co] "v"(coff)
+                 : MP_KSTEP_CLOB(MP_KSTEP_VARIANT));
+  }
+}
+
 // The same with an UNEVEN split of a tile's 32 DMA pieces over the waves (weight-gradient kernel): the waves of group 0 (0-3) take P0 pieces
 // each, those of group 1 (4-7) 8 - P0.  Measured, not derived: group 0 - the older wave of every SIMD - with ONE piece per operand and group 1
 // with seven is 3 % faster than the even split on the weight-gradient shapes; the same split does nothing for the persistent kernels.
@@ -838,6 +913,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   unsigned aoff[4], boff[4];
   persist_offsets<0>(aoff, g.lda, m0, g.M, lane, wave);
   persist_offsets<TRB>(boff, g.ldb, 0, BT, lane, wave);     // N % 256 == 0: the same for every tile
+  constexpr bool KASM = MP_KLOOP_ASM && (SPLIT == 0 || SPLIT == 1);      // the hand-scheduled k-step (bf16 MFMA; plain and three-product loops)
+  KFragAddr kfa;
+  if constexpr (KASM) kfrag_addr<TRB>(kfa, wr, wc, lane);
+  const unsigned smem_l = lds_u32(smem), dma_l = smem_l + wave * 4096;   // LDS addresses: the stages' origin, this wave's 4 KiB of an operand tile
+  const unsigned img_l = smem_l + 2 * STAGE + wave * 4096;               // this wave's epilogue image (the step's bias DMA lands there)
   // byte address of (tile origin, reduction index k) of each operand
   // byte address of (tile origin, k-tile kt) of each operand plane
   auto a_base = [&](int mm, int kt) { return A + ((long)mm * g.lda + kt * GBK) * 2; };
@@ -870,6 +950,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
     const int idn = id + gridDim.x;
     const bool has_next = idn < ntiles;
     const int m0n = (idn / tiles_n) * BT, n0n = (idn % tiles_n) * BT;
+    // (hand-scheduled k-step) hi-plane byte addresses of this tile's and the next tile's first k-tile, and the B operand's step per k-tile
+    const char* const tile_a = a_base(m0, 0);
+    const char* const tile_b = b_base(n0, 0);
+    const char* const tile_an = a_base(m0n, 0);
+    const char* const tile_bn = b_base(n0n, 0);
+    const long kstep_b = TRB ? (long)GBK * g.ldb * 2 : GBK * 2;
+    const int has_next_i = __builtin_amdgcn_readfirstlane(has_next ? 1 : 0), has_bias_i = __builtin_amdgcn_readfirstlane(has_bias ? 1 : 0);
     f32x4 acc[MI][4];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -915,6 +1002,47 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       // vmcnt(4): requests retire in order, so B_lo has landed while the four A_lo requests issued behind it may still be in flight -
       // one of the two tiles the next step 0 needs has two steps to arrive instead of one.
       bool early = false;
+      if constexpr (KASM) {
+        // hand-scheduled form: the same buffers, DMA schedule and waits; a step's DMA is handed to its asm block as jobs (b before a: step 2's
+        // vmcnt(4) counts on B_lo preceding A_lo), and the jobs' scalar arithmetic is done BEFORE the step's wait + barrier (pinned by the
+        // empty asm), so that behind the barrier a wave's first instructions are its fragment requests
+        // (flags as wave-uniform INTEGERS: a bool that lives across blocks is a lane mask to the compiler, and its use as an asm "s" operand
+        // then goes through the vector ALU)
+        int early_i = 0;
+        for (int kt = 0, term = 0; kt < nk;) {
+          const int last_i = (kt + 1 == nk) ? 1 : 0, more_i = (last_i ^ 1) | has_next_i;
+          if (term == 1 && (last_i & more_i)) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+          const char* const a_nxt = (last_i ? tile_an : tile_a + (long)(kt + 1) * (GBK * 2)) + a_lo;         // A_lo of the next k-tile / tile
+          const char* const b_nxt = last_i ? tile_bn : tile_b + (long)(kt + 1) * kstep_b;                    // B_hi of the next k-tile / tile
+          KJob ja = {term == 0 ? 1 : (term == 1 ? more_i : 0), dma_l + (term == 0 ? STAGE : 0),
+                     term == 0 ? tile_a + (long)kt * (GBK * 2) : a_nxt};                                     // A_hi[kt] -> A1 | A_lo' -> A0
+          KJob jb = {term == 1 ? 1 : (term == 2 ? more_i : 0), dma_l + OPB + (term == 1 ? STAGE : 0),
+                     term == 1 ? tile_b + (long)kt * kstep_b + b_lo : b_nxt};                                // B_lo[kt] -> B1 | B_hi' -> B0
+          KJob jc = {term == 2 ? (last_i & has_bias_i) : 0, img_l, reinterpret_cast<const char*>(g.bias + n0 + wc * 64)};
+          unsigned As_l = smem_l + (term == 0 ? 0 : STAGE), Bs_l = smem_l + OPB + (term == 2 ? STAGE : 0);
+          kjob_pin(ja); kjob_pin(jb); kjob_pin(jc); As_l = sgpr_pin(As_l); Bs_l = sgpr_pin(Bs_l);
+#ifdef MP_GEMM_DIAG
+          const unsigned long long tk0 = __builtin_readcyclecounter();
+#endif
+          if (kt == 0 && term == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only: (A_lo, B_hi) of this tile were waited for before the previous epilogue
+          else if (term == 2 && early_i) __builtin_amdgcn_s_waitcnt(0x0074);           // vmcnt(4) lgkmcnt(0)
+          else __builtin_amdgcn_s_waitcnt(0x0070);
+#ifdef MP_GEMM_DIAG
+          const unsigned long long tk1 = __builtin_readcyclecounter();
+#endif
+          __builtin_amdgcn_s_barrier();
+#ifdef MP_GEMM_DIAG
+          const unsigned long long tk2 = __builtin_readcyclecounter();
+          dg_wait += tk1 - tk0; dg_bar += tk2 - tk1;
+#endif
+          if (term == 1) early_i = more_i;
+          kstep_asm<TRB>(acc, kfa, As_l, Bs_l, ja, aoff, jb, boff, jc, 4u * lane);
+#ifdef MP_GEMM_DIAG
+          dg_mma += __builtin_readcyclecounter() - tk2;
+#endif
+          if (++term == 3) { term = 0; ++kt; }
+        }
+      } else
       for (int kt = 0, term = 0; kt < nk;) {
 #ifdef MP_GEMM_DIAG
         const unsigned long long tk0 = __builtin_readcyclecounter();
@@ -957,6 +1085,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
         if (++term == 3) { term = 0; ++kt; }
       }
       (void)stage;
+    } else if constexpr (KASM) {
+      // plain loop, hand-scheduled form (see above): one job per operand into the other stage
+      for (int ks = 0; ks < nk; ++ks, stage ^= 1) {
+        const int last_i = (ks + 1 == nk) ? 1 : 0;
+        const int fetch_i = MP_DBG(g, 2) ? 0 : ((last_i ^ 1) | has_next_i);
+        if (fetch_i & last_i) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+        KJob ja = {fetch_i, dma_l + (stage ^ 1) * STAGE, last_i ? tile_an : tile_a + (long)(ks + 1) * (GBK * 2)};
+        KJob jb = {fetch_i, dma_l + (stage ^ 1) * STAGE + OPB, last_i ? tile_bn : tile_b + (long)(ks + 1) * kstep_b};
+        KJob jc = {last_i & has_bias_i, img_l, reinterpret_cast<const char*>(g.bias + n0 + wc * 64)};
+        unsigned As_l = smem_l + stage * STAGE, Bs_l = As_l + OPB;
+        kjob_pin(ja); kjob_pin(jb); kjob_pin(jc); As_l = sgpr_pin(As_l); Bs_l = sgpr_pin(Bs_l);
+#ifdef MP_GEMM_DIAG
+        const unsigned long long tk0 = __builtin_readcyclecounter();
+#endif
+        if (ks == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only
+        else __builtin_amdgcn_s_waitcnt(0x0070);                        // vmcnt(0) lgkmcnt(0)
+#ifdef MP_GEMM_DIAG
+        const unsigned long long tk1 = __builtin_readcyclecounter();
+#endif
+        __builtin_amdgcn_s_barrier();
+#ifdef MP_GEMM_DIAG
+        const unsigned long long tk2 = __builtin_readcyclecounter();
+        dg_wait += tk1 - tk0; dg_bar += tk2 - tk1;
+#endif
+        if (!MP_DBG(g, 1)) kstep_asm<TRB>(acc, kfa, As_l, Bs_l, ja, aoff, jb, boff, jc, 4u * lane);
+#ifdef MP_GEMM_DIAG
+        dg_mma += __builtin_readcyclecounter() - tk2;
+#endif
+      }
     } else {
     for (int ks = 0; ks < nk; ++ks, stage ^= 1) {
       // k-tile ks has landed for every wave and nobody still reads the other stage.  On a tile's first k-tile the DMA was

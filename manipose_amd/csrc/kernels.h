@@ -108,6 +108,7 @@ int ln_bwd2(const void* dy1, int dy_bf16, const float* x1, const float* stats1, 
             const float* b16_gs = nullptr);      // as in ln_bwd (dy_scale applies to dy1)
 // gsc (8 floats on the device) <- {S, 1 / S, scratch, 1, 0u, 0u (saturation / non-finite counters of this backward's fp16 stores)} with S the power of two that brings the largest |element| of the two tensors (the second may be null) into [2^11, 2^12) (elementwise.hip)
 int grad_scale(const float* d_poses, long n_poses, const float* d_scores, long n_scores, float* gsc, hipStream_t st);
+int grad_health_pack(const float* gsc, float* out4, hipStream_t st);      // mp_model_grad_health_async: the four health values as floats (device to device)
 // dst = s * src ; dst += s * src  (muP readout multiplier on the head weights / their gradients)
 int scale_copy(float* dst, const float* src, float s, long n, hipStream_t st);
 int axpy_scaled(float* dst, const float* src, float s, long n, hipStream_t st);

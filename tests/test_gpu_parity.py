@@ -2319,3 +2319,41 @@ def test_config2_T27_K1_single_hypothesis_full_width_vs_oracle(lib, precision):
         cs = [_cos(p.grad.cpu(), req[k].grad) for k, p in model.named_parameters() if req[k].grad.abs().max() > 0]
         print(f"\n[bf16x3 drift] config #2: worst gradient cosine {min(cs):.6f}")
         assert min(cs) > 0.9995, min(cs)
+
+
+def test_stream_hazard_check_of_the_three_stream_engine(lib):
+    """mp_model_config::debug bit 0 (csrc/hazard.h): every launch of a forward + backward declares its stream and the bytes it reads / writes, the
+    engine's event records / waits are mirrored, and a vector clock per stream must find every conflicting cross-stream pair ordered - for the
+    rotations net on the caller's stream, the segments net on the side stream and the weight gradients / parameter reductions on the third
+    stream, in every precision, over two training steps (the second step's forward meets the first step's backward), with DropPath masks.
+    Results are those of a model without the check."""
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    from manipose_amd.metrics import rmcl_training_loss
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = (0.3 * torch.randn(3, 27, 17, 2, device="cuda", generator=g)).clamp(-1, 1)
+    y = 0.3 * torch.randn(3, 27, 17, 3, device="cuda", generator=g)
+    for precision in ("bf16x3", "bf16", "fp32"):
+        grads = {}
+        for check in (True, False):
+            torch.manual_seed(11)
+            m = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=27, embed_dim_rot=128, depth_rot=3, num_heads_rot=8, embed_dim_seg=64, depth_seg=2,
+                                   num_heads_seg=4, n_hyp=3, drop_path_rate=0.1)
+            m.precision, m.hazard_check = precision, check
+            m = m.cuda().train()
+            for step in range(2):
+                m.zero_grad(set_to_none=True)
+                poses, scores = m(X)
+                total, _ = rmcl_training_loss(poses, scores, y)
+                total.backward()
+            torch.cuda.synchronize()
+            grads[check] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+            if check:
+                rep = m._engine.hazard_report()
+                assert rep["violations"] == 0, "\n".join(rep["messages"][:8])
+                # the check did see the engine's concurrency: hundreds of launches, event edges, and conflicting cross-stream pairs that ARE ordered
+                assert rep["launches"] > 300 and rep["events"] > 40 and rep["ordered_pairs"] > 100, rep
+                print(precision, {k: v for k, v in rep.items() if k != "messages"})
+            else:
+                with pytest.raises(RuntimeError, match="debug bit 0"):
+                    m._engine.hazard_report()
+        assert torch.equal(grads[True], grads[False])

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/manipose_hip.h but not exported"
         assert n in _lib._SIGNATURES, f"{n} has no ctypes signature in manipose_amd/_lib.py"
-    assert lib.mp_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.mp_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_state_dict_layout_matches_reference(golden_dir):
@@ -509,7 +509,7 @@ def test_model_config_carries_the_engine_options():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = [n for decl in re.findall(r"(?:int|float)\s+([^;]+);", body) for n in re.split(r"\s*,\s*", decl.strip())]
     assert fields == [n for n, _ in _lib.ModelConfig._fields_], (fields, [n for n, _ in _lib.ModelConfig._fields_])
-    assert fields[-3:] == ["f16f8", "f16_backward", "streams"]
+    assert fields[-4:] == ["f16f8", "f16_backward", "streams", "debug"]
     base = dict(arch="rmcl_manifold", num_frame=27, num_joints=17, num_bones=16, embed_dim_rot=256, depth_rot=2, num_heads_rot=4, embed_dim_seg=32,
                 depth_seg=1, num_heads_seg=4, n_hyp=2, drop_path_rate=0.0, max_batch=0, precision="bf16x3")
     e0 = LiftEngine(**base)
@@ -521,9 +521,72 @@ def test_model_config_carries_the_engine_options():
         LiftEngine(**base, f16f8=2, f16_backward=False)
     m = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=27, embed_dim_rot=256, depth_rot=2, num_heads_rot=4, embed_dim_seg=32, depth_seg=1,
                            num_heads_seg=4, n_hyp=2)
-    assert m._engine_options() == dict(f16f8=0, f16_backward=False, side_stream=True, wgrad_stream=True)
-    m.f16f8, m.f16_backward, m.wgrad_stream = 1, True, False
-    assert m._engine_options() == dict(f16f8=1, f16_backward=True, side_stream=True, wgrad_stream=False)
+    assert m._engine_options() == dict(f16f8=0, f16_backward=False, side_stream=True, wgrad_stream=True, hazard_check=False)
+    m.f16f8, m.f16_backward, m.wgrad_stream, m.hazard_check = 1, True, False, True
+    assert m._engine_options() == dict(f16f8=1, f16_backward=True, side_stream=True, wgrad_stream=False, hazard_check=True)
+    e2 = LiftEngine(**base, hazard_check=True)
+    assert e2.cfg.debug == 1 and e0.cfg.debug == 0
+
+
+def test_stream_hazard_tracker_finds_missing_events():
+    """csrc/hazard.h through its own C entry points (no device): vector clocks per stream, events carry the recording stream's clock.  The
+    scenarios are the engine's patterns: fork / join of a side stream, an operand handed to the weight-gradient stream and rewritten after
+    its 'done' event, and each of them with the event left out."""
+    import ctypes as C
+    from manipose_amd import _lib
+    lib = _lib.load()
+
+    def run(ops):
+        h = lib.mp_hazard_create()
+        try:
+            for op in ops:
+                if op[0] == "L":
+                    _, stream, name, acc = op
+                    n = len(acc)
+                    addr = (C.c_int64 * n)(*[a for a, _, _ in acc]); nb = (C.c_int64 * n)(*[b for _, b, _ in acc]); wr = (C.c_int * n)(*[w for _, _, w in acc])
+                    assert lib.mp_hazard_launch(h, stream, name.encode(), n, addr, nb, wr) == 0
+                elif op[0] == "R":
+                    assert lib.mp_hazard_record(h, op[1], op[2]) == 0
+                else:
+                    assert lib.mp_hazard_wait(h, op[1], op[2]) == 0
+            out = (C.c_int64 * 4)()
+            buf = C.create_string_buffer(8192)
+            assert lib.mp_hazard_report(h, out, buf, len(buf)) == 0
+            return list(out), buf.value.decode()
+        finally:
+            lib.mp_hazard_destroy(h)
+
+    X, G, TMP = 0x1000, 0x9000, 0x20000
+    # fork / join: main writes X, side reads it behind the fork event, writes G; main reads G behind the join event
+    ok = [("L", 0, "produce", [(X, 256, 1)]), ("R", 0, 0), ("W", 1, 0), ("L", 1, "side", [(X, 256, 0), (G, 64, 1)]), ("R", 1, 1), ("W", 0, 1),
+          ("L", 0, "consume", [(G, 64, 0)])]
+    out, msg = run(ok)
+    assert out == [3, 2, 0, 2] and msg == ""                     # 3 launches, 2 conflicting cross-stream pairs, both ordered, 2 events
+    out, msg = run([o for o in ok if o != ("W", 1, 0)])          # the side stream does not wait for the fork event
+    assert out[2] == 1 and "RAW" in msg and "'side'" in msg and "'produce'" in msg
+    out, msg = run([o for o in ok if o != ("W", 0, 1)])          # main does not wait for the join event
+    assert out[2] == 1 and "RAW" in msg and "'consume'" in msg
+    # the weight-gradient pattern: main writes TMP, the other stream reads it (E event), main rewrites TMP only behind the W event
+    wg = [("L", 0, "dgrad", [(TMP, 1024, 1)]), ("R", 0, 0), ("W", 2, 0), ("L", 2, "wgrad", [(TMP, 1024, 0)]), ("R", 1, 2), ("W", 0, 1),
+          ("L", 0, "next dgrad", [(TMP + 512, 1024, 1)])]
+    out, msg = run(wg)
+    assert out[2] == 0 and out[1] == 2
+    out, msg = run([o for o in wg if o != ("W", 0, 1)])          # the rewrite does not wait for the reader: write after read
+    assert out[2] == 1 and msg.startswith("WAR") and "next dgrad" in msg
+    # transitivity: 0 -> 1 -> 2 orders 0 before 2; an event that was never recorded orders nothing; disjoint bytes never conflict
+    out, msg = run([("L", 0, "a", [(X, 16, 1)]), ("R", 0, 0), ("W", 1, 0), ("L", 1, "b", [(G, 16, 1)]), ("R", 1, 1), ("W", 2, 1), ("L", 2, "c", [(X, 16, 1)])])
+    assert out[2] == 0 and out[1] == 1
+    out, msg = run([("L", 0, "a", [(X, 16, 1)]), ("W", 1, 5), ("L", 1, "c", [(X + 8, 16, 1)])])
+    assert out[2] == 1 and msg.startswith("WAW")
+    out, msg = run([("L", 0, "a", [(X, 16, 1)]), ("L", 1, "c", [(X + 16, 16, 1)]), ("L", 1, "d", [(X, 16, 0)]), ("L", 2, "e", [(X + 16, 4, 0)])])
+    assert out[2] == 2                                           # d reads a's bytes, e reads c's bytes; a and c do not overlap
+
+
+def test_generated_k_step_is_up_to_date():
+    """manipose_amd/csrc/kloop_asm.inc is the output of tools/gen_kloop_asm.py (the hand-scheduled k-step of the persistent GEMM)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_kloop_asm.py"), "--check"])
+    assert r.returncode == 0, "run python tools/gen_kloop_asm.py"
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

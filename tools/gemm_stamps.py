@@ -6,7 +6,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-diag = os.path.join(ROOT, "manipose_amd", "libmanipose_hip_diag.so")
+diag = os.environ.get("MANIPOSE_DIAG_LIB") or os.path.join(ROOT, "manipose_amd", "libmanipose_hip_diag.so")      # MANIPOSE_DIAG_LIB: another diagnostics build (A/B of schedule variants)
 assert os.path.exists(diag), "build the diagnostics library first: MP_DIAG=1 bash manipose_amd/csrc/build.sh"
 os.environ["MANIPOSE_HIP_LIB"] = diag
 stamps = torch.zeros(256 * 64 * 2 + 256 * 8 * 4, dtype=torch.int64, device="cuda")

@@ -1,0 +1,195 @@
+"""Generates manipose_amd/csrc/kloop_asm.inc: the hand-scheduled 64-wide k-step of gemm_bf16_persist_kernel (gemm_bf16.hip) as ONE inline-asm
+block per step - 64 v_mfma_f32_16x16x32_bf16 of a wave's 128 x 64 sub-tile, the 24 LDS fragment reads (ds_read_b128; the "T" operand of the
+dgrad through ds_read_b64_tr_b16), and the step's share of the operand DMA (global_load_lds_dwordx4), in a written-out order:
+
+  * fragments are requested TWO groups of 8 MFMAs ahead (hipcc's schedule: one group ahead, every wait an lgkmcnt(0)), into a ring of three A
+    slots and two B sets held in FIXED registers v[200:255] (clobbers of the block: sub-registers of an asm operand cannot be named, and the
+    transpose reads fill a fragment in two 64-bit halves); every wait is a counted lgkmcnt(N) that leaves the younger requests in flight;
+  * the first fragments of the step are requested BEFORE the step's DMA instructions are issued (hipcc: after), and the DMA instructions are
+    spread over the first four MFMA groups, one behind the third and one behind the sixth MFMA of a group (job b in groups 0-1, job a in 2-3);
+  * no VALU / SALU instruction except the DMA's m0 set-up stands between the MFMAs.
+
+    python tools/gen_kloop_asm.py            # rewrites the .inc
+    python tools/gen_kloop_asm.py --check    # exit 1 if the committed .inc differs (CPU test)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "manipose_amd", "csrc", "kloop_asm.inc")
+
+FA0, FB0 = 200, 224          # A ring: 3 slots x 2 fragments x 4 registers; B: 2 sets (k-step parity) x 4 fragments x 4 registers (set per variant: `base`)
+NGROUP = 8                   # groups of 8 MFMAs: group g = (k-step g / 4, A fragments 2 (g % 4), 2 (g % 4) + 1) against the four B fragments
+
+
+def vr(base, n=4):
+    return f"v[{base}:{base + n - 1}]"
+
+
+def fa(slot, f):             # A fragment f (0 / 1) of ring slot `slot`
+    return FA0 + (slot * 2 + f) * 4
+
+
+def fb(ks, j):
+    return FB0 + (ks * 4 + j) * 4
+
+
+def reads_a(g):
+    """requests of the two A fragments of group g (k-step g / 4, 16-row blocks 2 (g % 4), + 1) into ring slot g % 3"""
+    ks, p = g // 4, g % 4
+    return [f"ds_read_b128 {vr(fa(g % 3, f))}, %[aa{ks}] offset:{(2 * p + f) * 2048}" for f in range(2)], 2
+
+
+def reads_b(ks, trb):
+    """requests of the four B fragments of k-step ks"""
+    out = []
+    if trb == 0:
+        for j in range(4):
+            out.append(f"ds_read_b128 {vr(fb(ks, j))}, %[ba{ks}] offset:{j * 2048}")
+        return out, 4
+    for j in range(4):       # "T" image (256 output columns per reduction row, 512-byte rows): two transpose reads, 4 rows apart, per fragment
+        for h in range(2):
+            out.append(f"ds_read_b64_tr_b16 {vr(fb(ks, j) + 2 * h, 2)}, %[bt{j}] offset:{ks * 16384 + h * 2048}")
+    return out, 8
+
+
+def dma(job, n, guarded=True):
+    """DMA instruction n (0..3) of job 'a' / 'b': 1 KiB = 64 lanes x 16 bytes from (SGPR base + per-lane offset) to the LDS address in m0"""
+    L = f".Lkd{job}{n}_%="
+    body = [f"s_add_u32 m0, %[lds{job}], {n * 1024}",
+            "s_nop 0",
+            f"global_load_lds_dwordx4 %[{job}o{n}], %[gb{job}]"]
+    if not guarded:
+        return body
+    return [f"s_cmp_eq_u32 %[en{job}], 0", f"s_cbranch_scc1 {L}"] + body + [f"{L}:"]
+
+
+def dma_job(job):
+    """all four instructions of a job behind ONE test of its enable flag"""
+    L = f".Lkj{job}_%="
+    out = [f"s_cmp_eq_u32 %[en{job}], 0", f"s_cbranch_scc1 {L}"]
+    for n in range(4):
+        out += dma(job, n, guarded=False)
+    return out + [f"{L}:"]
+
+
+def bias_dma():
+    return ["s_cmp_eq_u32 %[enc], 0",
+            "s_cbranch_scc1 .Lkdc_%=",
+            "s_mov_b32 m0, %[ldsc]",
+            "s_nop 0",
+            "global_load_lds_dword %[co], %[gbc]",
+            ".Lkdc_%=:"]
+
+
+# Variants (MP_KSTEP_VARIANT selects one at compile time; the A/B of round 5 is in DESIGN.md section 5):
+#   dma    'spread'       one DMA instruction behind the third and the sixth MFMA of groups 0-3 (job b in groups 0-1, job a in 2-3)
+#          'head_before'  both jobs in front of the step's first fragment request (what hipcc makes of the HIP source)
+#          'head_after'   both jobs behind the step's first fragment requests, in front of the first wait (their issue overlaps the LDS latency)
+#   ahead  1 / 2          fragment requests one / two groups of 8 MFMAs ahead of their use
+VARIANTS = {
+    0: dict(dma="spread", ahead=2),
+    1: dict(dma="head_before", ahead=2),
+    2: dict(dma="head_after", ahead=2),
+    3: dict(dma="head_before", ahead=1),
+    4: dict(dma="head_after", ahead=1),
+    5: dict(dma="head_before", ahead=1, base=198),      # the fragment tuples start at a register = 2 mod 4 (hipcc's own allocation does)
+    6: dict(dma="head_before", ahead=1, pad=True),      # a lone 4-byte s_waitcnt between MFMA groups is followed by an s_nop: every MFMA starts at 0 mod 8
+    7: dict(dma="head_before", ahead=2, base=198, pad=True),
+}
+
+
+def step(trb, dma="spread", ahead=2, base=200, pad=False):
+    """the instruction list of one step; `pend` = request batches in flight, oldest first, as (group that needs them, count)"""
+    global FA0, FB0
+    FA0, FB0 = base, base + 24
+    ins = []
+    pend = []
+
+    def request(lines, n, needed_by):
+        ins.extend(lines)
+        pend.append((needed_by, n))
+
+    def wait_for(g):          # everything group g needs has landed; younger batches stay in flight
+        younger = sum(n for need, n in pend if need > g)
+        ins.append(f"s_waitcnt lgkmcnt({younger})")
+        if pad:
+            ins.append("s_nop 0")
+        pend[:] = [(need, n) for need, n in pend if need > g]
+
+    if dma == "head_before":
+        ins.extend(dma_job("b") + dma_job("a"))
+    rb, nb = reads_b(0, trb)
+    request(rb, nb, 0)
+    r, n = reads_a(0)
+    request(r, n, 0)
+    if ahead >= 2:
+        r, n = reads_a(1)
+        request(r, n, 1)
+    if dma == "head_after":
+        ins.extend(dma_job("b") + dma_job("a"))
+    wait_for(0)
+    for g in range(NGROUP):
+        ks, p = g // 4, g % 4
+        slot = g % 3
+        mf = []
+        for f in range(2):
+            for j in range(4):
+                c = f"%[c{2 * p + f}{j}]"
+                mf.append(f"v_mfma_f32_16x16x32_bf16 {c}, {vr(fb(ks, j))}, {vr(fa(slot, f))}, {c}")
+        ins.append(mf[0])
+        # requests issued behind the first MFMA of the group: the fragments of group g + ahead (B of the next k-step with its first A)
+        t = g + ahead
+        if t < NGROUP:
+            if t % 4 == 0:
+                rb, nb = reads_b(t // 4, trb)
+                request(rb, nb, t)
+            r, n = reads_a(t)
+            request(r, n, t)
+        ins.extend(mf[1:3])
+        if dma == "spread" and g < 4:
+            ins.extend(globals()["dma"]("ba"[g // 2], 2 * (g % 2)))
+        ins.extend(mf[3:6])
+        if dma == "spread" and g < 4:
+            ins.extend(globals()["dma"]("ba"[g // 2], 2 * (g % 2) + 1))
+        if g == 4:
+            ins.extend(bias_dma())
+        ins.extend(mf[6:8])
+        if g + 1 < NGROUP:
+            wait_for(g + 1)
+    assert not pend, pend
+    return ins
+
+
+HEADER = """// GENERATED by tools/gen_kloop_asm.py - do not edit (tests/test_host_cpu.py checks that it is up to date).
+// One 64-wide k-step of a wave's 128 x 64 sub-tile as a single inline-asm block: see the generator's docstring for the schedule.
+// Registers v[200:255] hold the fragment ring (clobbered); operands: the 32 accumulator tuples, the LDS fragment addresses, the DMA jobs.
+"""
+
+
+def emit():
+    out = [HEADER]
+    for v, opt in sorted(VARIANTS.items()):
+        for trb in (0, 1):
+            lines = step(trb, **opt)
+            out.append(f"#define MP_KSTEP_ASM_TRB{trb}_V{v} \\")
+            for i, l in enumerate(lines):
+                out.append(f'  "{l}\\n"' + (" \\" if i + 1 < len(lines) else ""))
+            out.append("")
+    acc = ", ".join(f'[c{i}{j}] "+v"(acc[{i}][{j}])' for i in range(8) for j in range(4))
+    out.append(f"#define MP_KSTEP_ACC_OPERANDS {acc}")
+    for v, opt in sorted(VARIANTS.items()):
+        b = opt.get("base", 200)
+        clob = ", ".join(f'"v{r}"' for r in range(b, b + 56))
+        out.append(f'#define MP_KSTEP_CLOBBERS_V{v} "memory", "scc", {clob}')
+    out.append("")
+    return "\n".join(out)
+
+
+if __name__ == "__main__":
+    text = emit()
+    if "--check" in sys.argv:
+        sys.exit(0 if os.path.exists(OUT) and open(OUT).read() == text else 1)
+    with open(OUT, "w") as f:
+        f.write(text)
+    print("wrote", OUT)
