@@ -28,6 +28,7 @@ class _LiftFunction(torch.autograd.Function):
         ctx.save_for_backward(x) if masks is None else ctx.save_for_backward(x, masks)   # x is read again by the embedding backward
         ctx.has_scores = scores is not None
         ctx.fwd = (model._step_counter, bool(train), model._seed)
+        ctx.param_token = model._param_token()                                   # the parameter bits this graph node was computed from
         if scores is None:
             return poses
         return poses, scores
@@ -37,6 +38,11 @@ class _LiftFunction(torch.autograd.Function):
         model = ctx.model
         eng = model._engine
         step, train, seed = ctx.fwd
+        if ctx.param_token != model._param_token():
+            # (what autograd's saved-tensor version check says for an ordinary module: the engine reads the parameters again in the backward -
+            # and in the re-run forward of the branch below - so gradients taken now would belong to a different graph)
+            raise RuntimeError("manipose_amd: the model's parameters were modified in place (optimizer step, load_state_dict, ...) between this "
+                               "forward and its backward; run the backward before updating the parameters")
         if eng is None or ctx.held != [id(eng), eng.forward_serial]:         # some other forward (of any caller) has run on the engine since
             x, *mk = ctx.saved_tensors
             if eng is None or eng.max_batch < x.shape[0]:
@@ -124,6 +130,11 @@ class FusedLiftingMixin:
             m = mults.pop()
             out[f"readout_mult_{tag}"] = 0.0 if m == 1.0 else float(m)
         return out
+
+    def _param_token(self):
+        """Changes whenever the parameter bits may have: the autograd version counter of the flat buffer (shared by every parameter view:
+        torch-side in-place updates, load_state_dict) and the count of fused optimizer steps (the Adam kernel writes through raw pointers)."""
+        return (self._flat._version if self._flat is not None else -1, getattr(self, "_fused_updates", 0))
 
     def _views_intact(self) -> bool:
         base = self._flat.data_ptr()

@@ -56,6 +56,7 @@ class FusedAdam:
             self.exp_avg = torch.zeros_like(flat)
             self.exp_avg_sq = torch.zeros_like(flat)
         self.step_count += 1
+        self.model._fused_updates = getattr(self.model, "_fused_updates", 0) + 1      # _fused.py: the parameter bits change (the kernel writes through raw pointers)
         lr = self.param_groups[0]["lr"]
         if self.lr_mult is not None:
             if self.lr_mult.device != flat.device:

@@ -20,7 +20,12 @@ from .optim import FusedAdam
 class LiftingTrainer:
     def __init__(self, model, lr: float = 4e-5, weight_decay: float = 1e-6, w_loss: bool = True, vel_loss: float = 2.0,
                  smooth_reg: float = 0.5, rmcl_score_reg: float = 0.1, seed: int = 42, process_group=None,
-                 sq_loss: bool = False, rigid_seg_reg: float = 0.0, grad_buckets: bool = False):
+                 sq_loss: bool = False, rigid_seg_reg: float = 0.0, grad_buckets: bool = False, health_interval: int = 25,
+                 on_saturation: str = "raise"):
+        """health_interval / on_saturation: a model with f16_backward carries some gradient operands as fp16 of S x value; stores that hit
+        the +-65504 clamp (or met a non-finite value, written as 0) are counted on the device (mp_model_grad_health).  The trainer sums the
+        two counters of every backward on the device (no synchronisation) and reads the sums every `health_interval` steps: a non-zero sum
+        raises RuntimeError ("raise": the steps since the last check trained on clamped operands) or warns ("warn")."""
         self.model = model
         self.lib = _lib.load()
         self.opt = FusedAdam(model, lr=lr, weight_decay=weight_decay)
@@ -46,6 +51,11 @@ class LiftingTrainer:
         self.time_exchange = False
         self._xev = []
         self.flat_grads: Optional[torch.Tensor] = None
+        if on_saturation not in ("raise", "warn"):
+            raise ValueError("on_saturation must be 'raise' or 'warn'")
+        self.health_interval, self.on_saturation = max(1, int(health_interval)), on_saturation
+        self._health = self._health_sum = None            # device: this backward's four health values; running sum of (clamped, non-finite)
+        self.saturation_events = 0                        # gradient elements found clamped / non-finite so far ("warn" mode keeps counting)
         self.rmcl = model._arch == "rmcl_manifold"
         self._bufs = {}
 
@@ -95,6 +105,8 @@ class LiftingTrainer:
         eng.backward(m._flat, self.flat_grads, bf["d_poses"], bf["d_scores"])
         if ev:
             ev[1].record()
+        if getattr(m, "f16_backward", False):
+            self._check_grad_health(eng, X.device)
         if self.world > 1:
             # one collective per step over the single flat gradient buffer (137.8 MB fp32 at full size); RCCL picks the
             # all-links algorithm over the xGMI mesh.  Averaging is folded into the Adam kernel (grad_scale).
@@ -109,6 +121,26 @@ class LiftingTrainer:
             self._xev.append(ev)
         self.opt.step(self.flat_grads, grad_scale=1.0 / self.world)
         return bf["terms"]
+
+    def _check_grad_health(self, eng, device) -> None:
+        """f16_backward models: add this backward's saturation counters to a device-side sum (asynchronous), look at the sum every
+        health_interval steps (one small device-to-host copy then)."""
+        if self._health is None:
+            self._health = torch.zeros(4, device=device)
+            self._health_sum = torch.zeros(2, device=device)
+        eng.grad_health_async(self._health)
+        self._health_sum += self._health[1:3]
+        if self.step_no % self.health_interval == 0:
+            clamped, bad = (int(v) for v in self._health_sum.tolist())
+            self._health_sum.zero_()
+            if clamped or bad:
+                self.saturation_events += clamped + bad
+                msg = (f"manipose_amd: the fp16 gradient operands of the last {self.health_interval} steps saturated ({clamped} elements clamped at "
+                       f"+-65504, {bad} non-finite): those steps trained on clamped gradients; rebuild the model with f16_backward=False")
+                if self.on_saturation == "raise":
+                    raise RuntimeError(msg)
+                import warnings
+                warnings.warn(msg)
 
     def exchange_times(self):
         """Mean device times (ms) over the steps recorded since the last call (time_exchange): `backward_ms` = the backward on the caller's

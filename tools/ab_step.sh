@@ -11,6 +11,6 @@ for r in $(seq 1 "$ROUNDS"); do
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$which', 'step', round(d['ms_per_step'],2), 'ms', round(d['value']), 'poses/s')"
     timeout -k 10 200 python bench.py --single-queue --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-extra 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_classes']
-print('$which', 'one queue', round(d['ms_per_step'],2), 'ms', ' '.join(f'{n}={v[\"ms_per_step\"]:.2f}' for n,v in k.items()))"
+print('$which', 'one queue', round(d['ms_per_step'],2), 'ms', ' '.join(f'{n}={v[\"isolated_ms_per_step\"]:.2f}' for n,v in k.items()))"
   done
 done

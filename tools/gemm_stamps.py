@@ -66,5 +66,7 @@ tot = cyc.sum(-1, keepdim=True)
 fr = (cyc / tot).mean((0, 1))
 print(f"per-wave cycle split over the launch (mean of 256 x 8 waves): parked on s_waitcnt (operand DMA) {fr[0]:.3f}, on the barrier {fr[1]:.3f}, MFMA stage {fr[2]:.3f}, "
       f"epilogue {fr[3]:.3f}; cycles per wave {tot.mean():.0f}")
+ab = cyc.mean(0)      # absolute shader-clock cycles per wave index (what an A/B of two builds compares: the fractions hide a category that grows)
+print("  absolute k-cycles by wave index (wait / barrier / mma / epilogue): " + "  ".join(f"w{i}: {ab[i, 0] / 1e3:.0f}/{ab[i, 1] / 1e3:.0f}/{ab[i, 2] / 1e3:.0f}/{ab[i, 3] / 1e3:.0f}" for i in range(8)))
 w = cyc / tot
 print("  by wave index (wait / barrier / mma / epilogue): " + "  ".join(f"w{i}: {w[:, i, 0].mean():.2f}/{w[:, i, 1].mean():.2f}/{w[:, i, 2].mean():.2f}/{w[:, i, 3].mean():.2f}" for i in range(8)))
