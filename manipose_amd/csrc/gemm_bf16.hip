@@ -451,72 +451,87 @@ __device__ __forceinline__ void persist_dma(char* __restrict__ S, const char* __
 // of mma_stage above: requests one group ahead behind lgkmcnt(0) waits, the DMA instructions (and ~60 scalar instructions of address and
 // predicate arithmetic) in front of the step's first fragment request.
 #ifndef MP_KLOOP_ASM
-#define MP_KLOOP_ASM 0      // round 5: every schedule variant measured slower than hipcc's own; kept as a build option
+#define MP_KLOOP_ASM 1      // round 5: block of four split-precision forward GEMMs 3.81 -> 3.61 ms, block of four dgrads 1.235 -> 1.215 ms
 #endif
 #include "kloop_asm.inc"
+// schedule variant of the generated step (tools/gen_kloop_asm.py, VARIANTS), for the split-precision loop and the plain loop.  Measured (same box,
+// alternating, block of four GEMMs): split 0: 3626-3635, 1: 3629-3656, 2: 3608-3615, 3: 3677-3688 us (hipcc's own schedule 3803-3812);
+// dgrad 0: 1213-1218, 1: 1206-1219, 2: 1222, 3: 1244-1246 us (hipcc 1231-1240) - profiles/r05_probes/kstep_variants.log
 #ifndef MP_KSTEP_VARIANT
-#define MP_KSTEP_VARIANT 0      // schedule variant of the generated step (tools/gen_kloop_asm.py, VARIANTS)
+#define MP_KSTEP_VARIANT 2
 #endif
-#define MP_KSTEP_CAT2(t, v) MP_KSTEP_ASM_TRB##t##_V##v
-#define MP_KSTEP_CAT(t, v) MP_KSTEP_CAT2(t, v)
+#ifndef MP_KSTEP_VARIANT_P
+#define MP_KSTEP_VARIANT_P 0
+#endif
 #define MP_KSTEP_CLOB2(v) MP_KSTEP_CLOBBERS_V##v
 #define MP_KSTEP_CLOB(v) MP_KSTEP_CLOB2(v)
-// A DMA job of a step, all wave-uniform: 4 x 1 KiB pieces (this wave's rows of a 256-row operand tile) from base + per-lane offsets to LDS
-struct KJob { int en; unsigned lds; const char* base; };
 __device__ __forceinline__ unsigned lds_u32(const void* p) {
   return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
 }
-// Pins a wave-uniform value into a scalar register AT THIS POINT of the program (a real s_mov: an empty asm with a tied "+s" operand is refused
-// when the compiler has chosen the vector ALU for the value's arithmetic): the jobs of a step are computed in front of its wait + barrier.
-__device__ __forceinline__ unsigned sgpr_pin(unsigned v) { unsigned r; asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "s"(v)); return r; }
-__device__ __forceinline__ void kjob_pin(KJob& j) {
-  int en; unsigned lds; const char* base;
-  asm volatile("s_mov_b32 %0, %3\n s_mov_b32 %1, %4\n s_mov_b64 %2, %5" : "=&s"(en), "=&s"(lds), "=&s"(base) : "s"(__builtin_amdgcn_readfirstlane(j.en)), "s"(j.lds), "s"(j.base));      // (the flag arithmetic may sit in the vector ALU)
-  j.en = en; j.lds = lds; j.base = base;
-}
 // per-lane parts of the fragment addresses (loop-invariant): A / "N" B image: row r = block rows + (lane & 15), 16-byte chunk
-// (4 ks + (lane >> 4)) ^ (r & 7) of the 128-byte row (read_frag2<0>); "T" B image: read_frag2<1, 256> for the four 16-column blocks
-struct KFragAddr { unsigned a[2]; unsigned b[4]; };
-template <int TRB>
-__device__ __forceinline__ void kfrag_addr(KFragAddr& fa, int wr, int wc, int lane) {
+// (4 ks + (lane >> 4)) ^ (r & 7) of the 128-byte row (read_frag2<0>); "T" B image: read_frag2<1, 256> for the four 16-column blocks.
+// Held per LDS buffer (base + per-lane part), so that a step needs no address arithmetic behind its barrier.
+struct KFragA { unsigned a[2]; };
+struct KFragB { unsigned b[4]; };
+__device__ __forceinline__ void kfrag_a(KFragA& f, unsigned base, int wr, int lane) {
   const int l15 = lane & 15, gq = lane >> 4;
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) fa.a[ks] = (unsigned)((wr * 128 + l15) * 128 + (((ks * 4 + gq) ^ (lane & 7)) << 4));
+  for (int ks = 0; ks < 2; ++ks) f.a[ks] = base + (unsigned)((wr * 128 + l15) * 128 + (((ks * 4 + gq) ^ (lane & 7)) << 4));
+}
+template <int TRB>
+__device__ __forceinline__ void kfrag_b(KFragB& f, unsigned base, int wc, int lane) {
+  const int l15 = lane & 15, gq = lane >> 4;
   if (TRB == 0) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) fa.b[ks] = (unsigned)((wc * 64 + l15) * 128 + (((ks * 4 + gq) ^ (lane & 7)) << 4));
-    fa.b[2] = fa.b[3] = 0;
+    for (int ks = 0; ks < 2; ++ks) f.b[ks] = base + (unsigned)((wc * 64 + l15) * 128 + (((ks * 4 + gq) ^ (lane & 7)) << 4));
+    f.b[2] = f.b[3] = 0;
   } else {
     const int q = l15 >> 2, p = l15 & 3, r = gq * 8 + q;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = wc * 64 + j * 16 + 4 * p;
-      fa.b[j] = (unsigned)(r * 512 + (((col >> 3) ^ t_swz(r)) << 4) + ((col >> 2) & 1) * 8);
+      f.b[j] = base + (unsigned)(r * 512 + (((col >> 3) ^ t_swz(r)) << 4) + ((col >> 2) & 1) * 8);
     }
   }
 }
-template <int TRB>
-__device__ __forceinline__ void kstep_asm(f32x4 (&acc)[8][4], const KFragAddr& fa, unsigned As, unsigned Bs, const KJob& ja, const unsigned (&aoff)[4],
+// Job configuration of a step = which DMA jobs its asm block can carry (tools/gen_kloop_asm.py, CONFIGS): X0 / X1 / X2 = the three steps of a
+// k-tile of the split-precision loop, P = a step of the plain loop.  ONE block per step type, the jobs that are not always there behind a
+// wave-uniform flag in a scalar register: two blocks on the two sides of a C++ branch make hipcc reconcile the 128 accumulator registers
+// through 500-800 bytes of scratch memory per lane.
+// The flags are made by the SCALAR ALU from scalar sources (kflag_*): an asm "s" operand takes nothing else, hipcc keeps wave-uniform bools as
+// lane masks + v_cndmask and folds __builtin_amdgcn_readfirstlane of a value it knows to be uniform, and a hand-written v_readfirstlane of such
+// a value was observed stale (round 5: one tile in a few fetched the tile behind the workgroup's last one).  If hipcc ever holds one of the
+// sources in a vector register the assembler refuses the operand - a build error, not a wrong flag.
+struct KJob { int en; unsigned lds; const char* base; };      // wave-uniform: enable flag (conditional jobs), LDS address of the wave's 4 KiB of the destination tile, source address
+__device__ __forceinline__ int kflag_lt(int a, int b) { int r; asm volatile("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+__device__ __forceinline__ int kflag_nonnull(const void* p) { int r; asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(p) : "scc"); return r; }
+// (a != b) ? 1 : x   -   "more work follows this k-tile": not the tile's last k-tile, or a next tile exists
+__device__ __forceinline__ int kflag_more(int a, int b, int x) { int r; asm volatile("s_cmp_lg_u32 %1, %2\n\ts_cselect_b32 %0, 1, %3" : "=s"(r) : "s"(a), "s"(b), "s"(x) : "scc"); return r; }
+// (a == b) ? x : 0
+__device__ __forceinline__ int kflag_last(int a, int b, int x) { int r; asm volatile("s_cmp_eq_u32 %1, %2\n\ts_cselect_b32 %0, %3, 0" : "=s"(r) : "s"(a), "s"(b), "s"(x) : "scc"); return r; }
+enum { KC_X0 = 0, KC_X1 = 1, KC_X2 = 2, KC_P = 3 };
+#define MP_KSTEP_SEL2(c, t, v) MP_KSTEP_ASM_##c##_TRB##t##_V##v
+#define MP_KSTEP_SEL(c, t, v) MP_KSTEP_SEL2(c, t, v)
+#define MP_KSTEP_JOBS                                                                                                                                     \
+  [ena] "s"(ja.en), [ldsa] "s"(ja.lds), [gba] "s"(ja.base), [ao0] "v"(aoff[0]), [ao1] "v"(aoff[1]), [ao2] "v"(aoff[2]), [ao3] "v"(aoff[3]),                 \
+  [enb] "s"(jb.en), [ldsb] "s"(jb.lds), [gbb] "s"(jb.base), [bo0] "v"(boff[0]), [bo1] "v"(boff[1]), [bo2] "v"(boff[2]), [bo3] "v"(boff[3]),                 \
+  [enc] "s"(jc.en), [ldsc] "s"(jc.lds), [gbc] "s"(jc.base), [co] "v"(coff)
+#define MP_KSTEP_OPS_0 [aa0] "v"(fa.a[0]), [aa1] "v"(fa.a[1]), [ba0] "v"(fb.b[0]), [ba1] "v"(fb.b[1]), MP_KSTEP_JOBS
+#define MP_KSTEP_OPS_1 [aa0] "v"(fa.a[0]), [aa1] "v"(fa.a[1]), [bt0] "v"(fb.b[0]), [bt1] "v"(fb.b[1]), [bt2] "v"(fb.b[2]), [bt3] "v"(fb.b[3]), MP_KSTEP_JOBS
+#define MP_KSTEP_EMIT(c, t, v) asm volatile(MP_KSTEP_SEL(c, t, v) : MP_KSTEP_ACC_OPERANDS : MP_KSTEP_OPS_##t : MP_KSTEP_CLOB(v))
+template <int TRB, int CFG>
+__device__ __forceinline__ void kstep_asm(f32x4 (&acc)[8][4], const KFragA& fa, const KFragB& fb, const KJob& ja, const unsigned (&aoff)[4],
                                           const KJob& jb, const unsigned (&boff)[4], const KJob& jc, unsigned coff) {
-  const unsigned aa0 = As + fa.a[0], aa1 = As + fa.a[1];
   if constexpr (TRB == 0) {
-    const unsigned ba0 = Bs + fa.b[0], ba1 = Bs + fa.b[1];
-    asm volatile(MP_KSTEP_CAT(0, MP_KSTEP_VARIANT)
-                 : MP_KSTEP_ACC_OPERANDS
-                 : [aa0] "v"(aa0), [aa1] "v"(aa1), [ba0] "v"(ba0), [ba1] "v"(ba1),
-                   [ena] "s"(ja.en), [ldsa] "s"(ja.lds), [gba] "s"(ja.base), [ao0] "v"(aoff[0]), [ao1] "v"(aoff[1]), [ao2] "v"(aoff[2]), [ao3] "v"(aoff[3]),
-                   [enb] "s"(jb.en), [ldsb] "s"(jb.lds), [gbb] "s"(jb.base), [bo0] "v"(boff[0]), [bo1] "v"(boff[1]), [bo2] "v"(boff[2]), [bo3] "v"(boff[3]),
-                   [enc] "s"(jc.en), [ldsc] "s"(jc.lds), [gbc] "s"(jc.base), [co] "v"(coff)
-                 : MP_KSTEP_CLOB(MP_KSTEP_VARIANT));
+    if constexpr (CFG == KC_X0) MP_KSTEP_EMIT(X0, 0, MP_KSTEP_VARIANT);
+    else if constexpr (CFG == KC_X1) MP_KSTEP_EMIT(X1, 0, MP_KSTEP_VARIANT);
+    else if constexpr (CFG == KC_X2) MP_KSTEP_EMIT(X2, 0, MP_KSTEP_VARIANT);
+    else MP_KSTEP_EMIT(P, 0, MP_KSTEP_VARIANT_P);
   } else {
-    const unsigned bt0 = Bs + fa.b[0], bt1 = Bs + fa.b[1], bt2 = Bs + fa.b[2], bt3 = Bs + fa.b[3];
-    asm volatile(MP_KSTEP_CAT(1, MP_KSTEP_VARIANT)
-                 : MP_KSTEP_ACC_OPERANDS
-                 : [aa0] "v"(aa0), [aa1] "v"(aa1), [bt0] "v"(bt0), [bt1] "v"(bt1), [bt2] "v"(bt2), [bt3] "v"(bt3),
-                   [ena] "s"(ja.en), [ldsa] "s"(ja.lds), [gba] "s"(ja.base), [ao0] "v"(aoff[0]), [ao1] "v"(aoff[1]), [ao2] "v"(aoff[2]), [ao3] "v"(aoff[3]),
-                   [enb] "s"(jb.en), [ldsb] "s"(jb.lds), [gbb] "s"(jb.base), [bo0] "v"(boff[0]), [bo1] "v"(boff[1]), [bo2] "v"(boff[2]), [bo3] "v"(boff[3]),
-                   [enc] "s"(jc.en), [ldsc] "s"(jc.lds), [gbc] "s"(jc.base), [co] "v"(coff)
-                 : MP_KSTEP_CLOB(MP_KSTEP_VARIANT));
+    if constexpr (CFG == KC_X0) MP_KSTEP_EMIT(X0, 1, MP_KSTEP_VARIANT);
+    else if constexpr (CFG == KC_X1) MP_KSTEP_EMIT(X1, 1, MP_KSTEP_VARIANT);
+    else if constexpr (CFG == KC_X2) MP_KSTEP_EMIT(X2, 1, MP_KSTEP_VARIANT);
+    else MP_KSTEP_EMIT(P, 1, MP_KSTEP_VARIANT_P);
   }
 }
 
@@ -914,9 +929,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   persist_offsets<0>(aoff, g.lda, m0, g.M, lane, wave);
   persist_offsets<TRB>(boff, g.ldb, 0, BT, lane, wave);     // N % 256 == 0: the same for every tile
   constexpr bool KASM = MP_KLOOP_ASM && (SPLIT == 0 || SPLIT == 1);      // the hand-scheduled k-step (bf16 MFMA; plain and three-product loops)
-  KFragAddr kfa;
-  if constexpr (KASM) kfrag_addr<TRB>(kfa, wr, wc, lane);
   const unsigned smem_l = lds_u32(smem), dma_l = smem_l + wave * 4096;   // LDS addresses: the stages' origin, this wave's 4 KiB of an operand tile
+  KFragA kfa[2];      // fragment addresses in the A buffer of stage 0 / 1 (split loop: A0 = A_lo, A1 = A_hi)
+  KFragB kfb[2];      // ... in the B buffer of stage 0 / 1 (split loop: B0 = B_hi, B1 = B_lo)
+  if constexpr (KASM) {
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) { kfrag_a(kfa[sg], smem_l + sg * STAGE, wr, lane); kfrag_b<TRB>(kfb[sg], smem_l + sg * STAGE + OPB, wc, lane); }
+  }
   const unsigned img_l = smem_l + 2 * STAGE + wave * 4096;               // this wave's epilogue image (the step's bias DMA lands there)
   // byte address of (tile origin, reduction index k) of each operand
   // byte address of (tile origin, k-tile kt) of each operand plane
@@ -956,7 +975,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
     const char* const tile_an = a_base(m0n, 0);
     const char* const tile_bn = b_base(n0n, 0);
     const long kstep_b = TRB ? (long)GBK * g.ldb * 2 : GBK * 2;
-    const int has_next_i = __builtin_amdgcn_readfirstlane(has_next ? 1 : 0), has_bias_i = __builtin_amdgcn_readfirstlane(has_bias ? 1 : 0);
+    const int has_next_i = KASM ? kflag_lt(idn, ntiles) : 0, has_bias_i = (KASM && EPI != EPI_DGELU) ? kflag_nonnull(g.bias) : 0;
     f32x4 acc[MI][4];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -1003,44 +1022,53 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       // one of the two tiles the next step 0 needs has two steps to arrive instead of one.
       bool early = false;
       if constexpr (KASM) {
-        // hand-scheduled form: the same buffers, DMA schedule and waits; a step's DMA is handed to its asm block as jobs (b before a: step 2's
-        // vmcnt(4) counts on B_lo preceding A_lo), and the jobs' scalar arithmetic is done BEFORE the step's wait + barrier (pinned by the
-        // empty asm), so that behind the barrier a wave's first instructions are its fragment requests
-        // (flags as wave-uniform INTEGERS: a bool that lives across blocks is a lane mask to the compiler, and its use as an asm "s" operand
-        // then goes through the vector ALU)
-        int early_i = 0;
-        for (int kt = 0, term = 0; kt < nk;) {
-          const int last_i = (kt + 1 == nk) ? 1 : 0, more_i = (last_i ^ 1) | has_next_i;
-          if (term == 1 && (last_i & more_i)) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
-          const char* const a_nxt = (last_i ? tile_an : tile_a + (long)(kt + 1) * (GBK * 2)) + a_lo;         // A_lo of the next k-tile / tile
-          const char* const b_nxt = last_i ? tile_bn : tile_b + (long)(kt + 1) * kstep_b;                    // B_hi of the next k-tile / tile
-          KJob ja = {term == 0 ? 1 : (term == 1 ? more_i : 0), dma_l + (term == 0 ? STAGE : 0),
-                     term == 0 ? tile_a + (long)kt * (GBK * 2) : a_nxt};                                     // A_hi[kt] -> A1 | A_lo' -> A0
-          KJob jb = {term == 1 ? 1 : (term == 2 ? more_i : 0), dma_l + OPB + (term == 1 ? STAGE : 0),
-                     term == 1 ? tile_b + (long)kt * kstep_b + b_lo : b_nxt};                                // B_lo[kt] -> B1 | B_hi' -> B0
-          KJob jc = {term == 2 ? (last_i & has_bias_i) : 0, img_l, reinterpret_cast<const char*>(g.bias + n0 + wc * 64)};
-          unsigned As_l = smem_l + (term == 0 ? 0 : STAGE), Bs_l = smem_l + OPB + (term == 2 ? STAGE : 0);
-          kjob_pin(ja); kjob_pin(jb); kjob_pin(jc); As_l = sgpr_pin(As_l); Bs_l = sgpr_pin(Bs_l);
+        // hand-scheduled form: the same buffers, DMA schedule and waits, the three steps of a k-tile written out (one asm block each, with the
+        // DMA jobs that step can carry: KC_X0 / X1 / X2); running operand addresses, fragment addresses per buffer: a step's scalar set-up
+        // is a handful of instructions
+        const char* pa = tile_a;                           // A_hi of k-tile kt
+        const char* pb = tile_b;                           // B_hi of k-tile kt
+        const KJob none = {0, 0u, nullptr};
+        const unsigned coff = 4u * lane;
+        for (int kt = 0; kt < nk; ++kt, pa += GBK * 2, pb += kstep_b) {
+          const bool last = kt + 1 == nk;
+          const int more_i = kflag_more(kt + 1, nk, has_next_i);
 #ifdef MP_GEMM_DIAG
-          const unsigned long long tk0 = __builtin_readcyclecounter();
+          unsigned long long tk0 = __builtin_readcyclecounter(), tk1, tk2;
+#define MP_KDIAG_A() tk1 = __builtin_readcyclecounter()
+#define MP_KDIAG_B() tk2 = __builtin_readcyclecounter(); dg_wait += tk1 - tk0; dg_bar += tk2 - tk1
+#define MP_KDIAG_C() tk0 = __builtin_readcyclecounter(); dg_mma += tk0 - tk2
+#else
+#define MP_KDIAG_A()
+#define MP_KDIAG_B()
+#define MP_KDIAG_C()
 #endif
-          if (kt == 0 && term == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only: (A_lo, B_hi) of this tile were waited for before the previous epilogue
-          else if (term == 2 && early_i) __builtin_amdgcn_s_waitcnt(0x0074);           // vmcnt(4) lgkmcnt(0)
+          // step 0: (A0 = A_lo, B0 = B_hi); requests A_hi[kt] -> A1
+          if (kt == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only: (A_lo, B_hi) of this tile were waited for before the previous epilogue
           else __builtin_amdgcn_s_waitcnt(0x0070);
-#ifdef MP_GEMM_DIAG
-          const unsigned long long tk1 = __builtin_readcyclecounter();
-#endif
+          MP_KDIAG_A();
           __builtin_amdgcn_s_barrier();
-#ifdef MP_GEMM_DIAG
-          const unsigned long long tk2 = __builtin_readcyclecounter();
-          dg_wait += tk1 - tk0; dg_bar += tk2 - tk1;
-#endif
-          if (term == 1) early_i = more_i;
-          kstep_asm<TRB>(acc, kfa, As_l, Bs_l, ja, aoff, jb, boff, jc, 4u * lane);
-#ifdef MP_GEMM_DIAG
-          dg_mma += __builtin_readcyclecounter() - tk2;
-#endif
-          if (++term == 3) { term = 0; ++kt; }
+          MP_KDIAG_B();
+          kstep_asm<TRB, KC_X0>(acc, kfa[0], kfb[0], KJob{1, dma_l + STAGE, pa}, aoff, none, boff, none, coff);
+          MP_KDIAG_C();
+          // step 1: (A1 = A_hi, B0 = B_hi); requests B_lo[kt] -> B1, then A_lo of the next k-tile / tile -> A0
+          if (last && more_i) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+          __builtin_amdgcn_s_waitcnt(0x0070);
+          MP_KDIAG_A();
+          __builtin_amdgcn_s_barrier();
+          MP_KDIAG_B();
+          kstep_asm<TRB, KC_X1>(acc, kfa[1], kfb[0], KJob{more_i, dma_l, (last ? tile_an : pa + GBK * 2) + a_lo}, aoff, KJob{1, dma_l + STAGE + OPB, pb + b_lo}, boff,
+                                none, coff);
+          MP_KDIAG_C();
+          // step 2: (A1 = A_hi, B1 = B_lo); requests B_hi of the next k-tile / tile -> B0, and the bias behind the tile's last step.  It waits with
+          // vmcnt(4): B_lo has landed, the four A_lo requests issued behind it may still be in flight
+          if (more_i) __builtin_amdgcn_s_waitcnt(0x0074);
+          else __builtin_amdgcn_s_waitcnt(0x0070);
+          MP_KDIAG_A();
+          __builtin_amdgcn_s_barrier();
+          MP_KDIAG_B();
+          kstep_asm<TRB, KC_X2>(acc, kfa[1], kfb[1], none, aoff, KJob{more_i, dma_l + OPB, last ? tile_bn : pb + kstep_b}, boff,
+                                KJob{kflag_last(kt + 1, nk, has_bias_i), img_l, reinterpret_cast<const char*>(g.bias + n0 + wc * 64)}, coff);
+          MP_KDIAG_C();
         }
       } else
       for (int kt = 0, term = 0; kt < nk;) {
@@ -1086,33 +1114,32 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       }
       (void)stage;
     } else if constexpr (KASM) {
-      // plain loop, hand-scheduled form (see above): one job per operand into the other stage
-      for (int ks = 0; ks < nk; ++ks, stage ^= 1) {
-        const int last_i = (ks + 1 == nk) ? 1 : 0;
-        const int fetch_i = MP_DBG(g, 2) ? 0 : ((last_i ^ 1) | has_next_i);
-        if (fetch_i & last_i) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
-        KJob ja = {fetch_i, dma_l + (stage ^ 1) * STAGE, last_i ? tile_an : tile_a + (long)(ks + 1) * (GBK * 2)};
-        KJob jb = {fetch_i, dma_l + (stage ^ 1) * STAGE + OPB, last_i ? tile_bn : tile_b + (long)(ks + 1) * kstep_b};
-        KJob jc = {last_i & has_bias_i, img_l, reinterpret_cast<const char*>(g.bias + n0 + wc * 64)};
-        unsigned As_l = smem_l + stage * STAGE, Bs_l = As_l + OPB;
-        kjob_pin(ja); kjob_pin(jb); kjob_pin(jc); As_l = sgpr_pin(As_l); Bs_l = sgpr_pin(Bs_l);
+      // plain loop, hand-scheduled form (see above): both operands of the next k-tile / tile into the other stage
+      const char* pa = tile_a + GBK * 2;                   // A of k-tile ks + 1
+      const char* pb = tile_b + kstep_b;
+      const unsigned coff = 4u * lane;
+      for (int ks = 0; ks < nk; ++ks, stage ^= 1, pa += GBK * 2, pb += kstep_b) {
+        const bool last = ks + 1 == nk;
+        const int fetch_i = MP_DBG(g, 2) ? 0 : kflag_more(ks + 1, nk, has_next_i);
+        if (last && fetch_i) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+        // this stage's fragment addresses (stage 0's + 64 KiB): a few vector adds in front of the barrier - NOT kfa[stage], which makes the
+        // arrays scratch memory
+        const unsigned so = (unsigned)stage * STAGE;
+        const KFragA fa = {{kfa[0].a[0] + so, kfa[0].a[1] + so}};
+        const KFragB fb = {{kfb[0].b[0] + so, kfb[0].b[1] + so, kfb[0].b[2] + so, kfb[0].b[3] + so}};
 #ifdef MP_GEMM_DIAG
-        const unsigned long long tk0 = __builtin_readcyclecounter();
+        unsigned long long tk0 = __builtin_readcyclecounter(), tk1, tk2;
 #endif
         if (ks == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only
         else __builtin_amdgcn_s_waitcnt(0x0070);                        // vmcnt(0) lgkmcnt(0)
-#ifdef MP_GEMM_DIAG
-        const unsigned long long tk1 = __builtin_readcyclecounter();
-#endif
+        MP_KDIAG_A();
         __builtin_amdgcn_s_barrier();
-#ifdef MP_GEMM_DIAG
-        const unsigned long long tk2 = __builtin_readcyclecounter();
-        dg_wait += tk1 - tk0; dg_bar += tk2 - tk1;
-#endif
-        if (!MP_DBG(g, 1)) kstep_asm<TRB>(acc, kfa, As_l, Bs_l, ja, aoff, jb, boff, jc, 4u * lane);
-#ifdef MP_GEMM_DIAG
-        dg_mma += __builtin_readcyclecounter() - tk2;
-#endif
+        MP_KDIAG_B();
+        const unsigned nx = dma_l + (stage ^ 1) * STAGE;
+        if (!MP_DBG(g, 1))
+          kstep_asm<TRB, KC_P>(acc, fa, fb, KJob{fetch_i, nx, last ? tile_an : pa}, aoff, KJob{fetch_i, nx + OPB, last ? tile_bn : pb}, boff,
+                               KJob{kflag_last(ks + 1, nk, has_bias_i), img_l, reinterpret_cast<const char*>(g.bias + n0 + wc * 64)}, coff);
+        MP_KDIAG_C();
       }
     } else {
     for (int ks = 0; ks < nk; ++ks, stage ^= 1) {

@@ -64,23 +64,36 @@ def dma(job, n, guarded=True):
     return [f"s_cmp_eq_u32 %[en{job}], 0", f"s_cbranch_scc1 {L}"] + body + [f"{L}:"]
 
 
-def dma_job(job):
-    """all four instructions of a job behind ONE test of its enable flag"""
-    L = f".Lkj{job}_%="
-    out = [f"s_cmp_eq_u32 %[en{job}], 0", f"s_cbranch_scc1 {L}"]
+def dma_job(job, mode="cond"):
+    """all four instructions of a job: mode 'always' (unconditional), 'cond' (behind ONE test of its enable flag), 'none' (nothing)"""
+    if mode == "none":
+        return []
+    out = []
     for n in range(4):
         out += dma(job, n, guarded=False)
-    return out + [f"{L}:"]
+    if mode == "always":
+        return out
+    L = f".Lkj{job}_%="
+    return [f"s_cmp_eq_u32 %[en{job}], 0", f"s_cbranch_scc1 {L}"] + out + [f"{L}:"]
 
 
-def bias_dma():
-    return ["s_cmp_eq_u32 %[enc], 0",
-            "s_cbranch_scc1 .Lkdc_%=",
-            "s_mov_b32 m0, %[ldsc]",
-            "s_nop 0",
-            "global_load_lds_dword %[co], %[gbc]",
-            ".Lkdc_%=:"]
+def bias_dma(mode="always"):
+    if mode == "none":
+        return []
+    out = ["s_mov_b32 m0, %[ldsc]", "s_nop 0", "global_load_lds_dword %[co], %[gbc]"]
+    if mode == "always":
+        return out
+    return ["s_cmp_eq_u32 %[enc], 0", "s_cbranch_scc1 .Lkdc_%="] + out + [".Lkdc_%=:"]
 
+
+# Job configurations of a step: which DMA jobs it can carry (a / b = the four pieces of an A / B operand tile, c = the bias row); a job is
+# 'always' there, 'none', or 'cond' = behind one test of a wave-uniform flag in a scalar register (%[ena] / %[enb] / %[enc]):
+#   X0 / X1 / X2  the three steps of a k-tile of the split-precision loop: (A_lo, B_hi) requests A_hi; (A_hi, B_hi) requests B_lo and - unless
+#                 this is the launch's last k-tile - the next A_lo; (A_hi, B_lo) requests the next B_hi likewise, and the bias behind the tile's last step
+#   P             a step of the plain loop: both operands of the next k-tile unless it is the launch's last, the bias behind a tile's last step
+# ONE asm block per step type: two blocks on the two sides of a branch make hipcc reconcile the 128 accumulator registers through scratch memory.
+CONFIGS = {"X0": dict(a="always", b="none", c="none"), "X1": dict(a="cond", b="always", c="none"), "X2": dict(a="none", b="cond", c="cond"),
+           "P": dict(a="cond", b="cond", c="cond")}
 
 # Variants (MP_KSTEP_VARIANT selects one at compile time; the A/B of round 5 is in DESIGN.md section 5):
 #   dma    'spread'       one DMA instruction behind the third and the sixth MFMA of groups 0-3 (job b in groups 0-1, job a in 2-3)
@@ -88,23 +101,20 @@ def bias_dma():
 #          'head_after'   both jobs behind the step's first fragment requests, in front of the first wait (their issue overlaps the LDS latency)
 #   ahead  1 / 2          fragment requests one / two groups of 8 MFMAs ahead of their use
 VARIANTS = {
-    0: dict(dma="spread", ahead=2),
+    0: dict(dma="head_before", ahead=1),     # hipcc's own order, written out
     1: dict(dma="head_before", ahead=2),
     2: dict(dma="head_after", ahead=2),
-    3: dict(dma="head_before", ahead=1),
-    4: dict(dma="head_after", ahead=1),
-    5: dict(dma="head_before", ahead=1, base=198),      # the fragment tuples start at a register = 2 mod 4 (hipcc's own allocation does)
-    6: dict(dma="head_before", ahead=1, pad=True),      # a lone 4-byte s_waitcnt between MFMA groups is followed by an s_nop: every MFMA starts at 0 mod 8
-    7: dict(dma="head_before", ahead=2, base=198, pad=True),
+    3: dict(dma="spread", ahead=2),
 }
 
 
-def step(trb, dma="spread", ahead=2, base=200, pad=False):
+def step(trb, cfg, dma="spread", ahead=2, base=200, pad=False):
     """the instruction list of one step; `pend` = request batches in flight, oldest first, as (group that needs them, count)"""
     global FA0, FB0
     FA0, FB0 = base, base + 24
     ins = []
     pend = []
+    jm = CONFIGS[cfg]
 
     def request(lines, n, needed_by):
         ins.extend(lines)
@@ -118,7 +128,7 @@ def step(trb, dma="spread", ahead=2, base=200, pad=False):
         pend[:] = [(need, n) for need, n in pend if need > g]
 
     if dma == "head_before":
-        ins.extend(dma_job("b") + dma_job("a"))
+        ins.extend(dma_job("b", jm["b"]) + dma_job("a", jm["a"]))
     rb, nb = reads_b(0, trb)
     request(rb, nb, 0)
     r, n = reads_a(0)
@@ -127,7 +137,7 @@ def step(trb, dma="spread", ahead=2, base=200, pad=False):
         r, n = reads_a(1)
         request(r, n, 1)
     if dma == "head_after":
-        ins.extend(dma_job("b") + dma_job("a"))
+        ins.extend(dma_job("b", jm["b"]) + dma_job("a", jm["a"]))
     wait_for(0)
     for g in range(NGROUP):
         ks, p = g // 4, g % 4
@@ -147,13 +157,13 @@ def step(trb, dma="spread", ahead=2, base=200, pad=False):
             r, n = reads_a(t)
             request(r, n, t)
         ins.extend(mf[1:3])
-        if dma == "spread" and g < 4:
-            ins.extend(globals()["dma"]("ba"[g // 2], 2 * (g % 2)))
+        if dma == "spread" and g < 4 and jm["ba"[g // 2]] != "none":
+            ins.extend(globals()["dma"]("ba"[g // 2], 2 * (g % 2), guarded=jm["ba"[g // 2]] == "cond"))
         ins.extend(mf[3:6])
-        if dma == "spread" and g < 4:
-            ins.extend(globals()["dma"]("ba"[g // 2], 2 * (g % 2) + 1))
+        if dma == "spread" and g < 4 and jm["ba"[g // 2]] != "none":
+            ins.extend(globals()["dma"]("ba"[g // 2], 2 * (g % 2) + 1, guarded=jm["ba"[g // 2]] == "cond"))
         if g == 4:
-            ins.extend(bias_dma())
+            ins.extend(bias_dma(jm["c"]))
         ins.extend(mf[6:8])
         if g + 1 < NGROUP:
             wait_for(g + 1)
@@ -170,12 +180,13 @@ HEADER = """// GENERATED by tools/gen_kloop_asm.py - do not edit (tests/test_hos
 def emit():
     out = [HEADER]
     for v, opt in sorted(VARIANTS.items()):
-        for trb in (0, 1):
-            lines = step(trb, **opt)
-            out.append(f"#define MP_KSTEP_ASM_TRB{trb}_V{v} \\")
-            for i, l in enumerate(lines):
-                out.append(f'  "{l}\\n"' + (" \\" if i + 1 < len(lines) else ""))
-            out.append("")
+        for cfg in CONFIGS:
+            for trb in (0, 1):
+                lines = step(trb, cfg, **opt)
+                out.append(f"#define MP_KSTEP_ASM_{cfg}_TRB{trb}_V{v} \\")
+                for i, l in enumerate(lines):
+                    out.append(f'  "{l}\\n"' + (" \\" if i + 1 < len(lines) else ""))
+                out.append("")
     acc = ", ".join(f'[c{i}{j}] "+v"(acc[{i}][{j}])' for i in range(8) for j in range(4))
     out.append(f"#define MP_KSTEP_ACC_OPERANDS {acc}")
     for v, opt in sorted(VARIANTS.items()):
