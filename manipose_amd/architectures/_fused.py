@@ -132,9 +132,10 @@ class FusedLiftingMixin:
         return out
 
     def _param_token(self):
-        """Changes whenever the parameter bits may have: the autograd version counter of the flat buffer (shared by every parameter view:
-        torch-side in-place updates, load_state_dict) and the count of fused optimizer steps (the Adam kernel writes through raw pointers)."""
-        return (self._flat._version if self._flat is not None else -1, getattr(self, "_fused_updates", 0))
+        """Changes whenever the parameter bits may have: the autograd version counters of the flat buffer and of every parameter (each
+        nn.Parameter is re-pointed at its slice through `.data`, so it counts its own in-place writes: load_state_dict, p.mul_(...)) and the
+        count of fused optimizer steps (the Adam kernel writes through raw pointers).  ~300 integer reads per call."""
+        return (self._flat._version if self._flat is not None else -1, sum(p._version for p in self._plist), getattr(self, "_fused_updates", 0))
 
     def _views_intact(self) -> bool:
         base = self._flat.data_ptr()
