@@ -35,21 +35,23 @@ def fb(ks, j):
 
 
 def reads_a(g):
-    """requests of the two A fragments of group g (k-step g / 4, 16-row blocks 2 (g % 4), + 1) into ring slot g % 3"""
-    ks, p = g // 4, g % 4
+    """requests of the two A fragments of group g (k-step (g % 8) / 4, 16-row blocks 2 (g % 4), + 1) into ring slot g % 3"""
+    ks, p = (g % NGROUP) // 4, g % 4
     return [f"ds_read_b128 {vr(fa(g % 3, f))}, %[aa{ks}] offset:{(2 * p + f) * 2048}" for f in range(2)], 2
 
 
-def reads_b(ks, trb):
-    """requests of the four B fragments of k-step ks"""
+def reads_b(kidx, trb, img="ba"):
+    """requests of the four B fragments of the k-step with running index kidx (register set kidx % 2, address operands of image `img`)"""
     out = []
+    ks = kidx % 2
     if trb == 0:
         for j in range(4):
-            out.append(f"ds_read_b128 {vr(fb(ks, j))}, %[ba{ks}] offset:{j * 2048}")
+            out.append(f"ds_read_b128 {vr(fb(ks, j))}, %[{img}{ks}] offset:{j * 2048}")
         return out, 4
+    t = {"ba": "bt", "bb": "bu"}[img]
     for j in range(4):       # "T" image (256 output columns per reduction row, 512-byte rows): two transpose reads, 4 rows apart, per fragment
         for h in range(2):
-            out.append(f"ds_read_b64_tr_b16 {vr(fb(ks, j) + 2 * h, 2)}, %[bt{j}] offset:{ks * 16384 + h * 2048}")
+            out.append(f"ds_read_b64_tr_b16 {vr(fb(ks, j) + 2 * h, 2)}, %[{t}{j}] offset:{ks * 16384 + h * 2048}")
     return out, 8
 
 
@@ -93,7 +95,12 @@ def bias_dma(mode="always"):
 #   P             a step of the plain loop: both operands of the next k-tile unless it is the launch's last, the bias behind a tile's last step
 # ONE asm block per step type: two blocks on the two sides of a branch make hipcc reconcile the 128 accumulator registers through scratch memory.
 CONFIGS = {"X0": dict(a="always", b="none", c="none"), "X1": dict(a="cond", b="always", c="none"), "X2": dict(a="none", b="cond", c="cond"),
-           "P": dict(a="cond", b="cond", c="cond")}
+           "P": dict(a="cond", b="cond", c="cond"),
+           # five-buffer form of the split-precision loop (A_lo | A_hi | B_lo | B_hi even | B_hi odd k-tile: B_hi is double-buffered, so nothing
+           # that a k-tile still reads is overwritten inside it) - TWO barriers per k-tile:
+           #   Y0  (A_lo, B_hi): requests A_hi and B_lo of this k-tile
+           #   Y1  (A_hi, B_hi) and then (A_hi, B_lo) in ONE block of 128 MFMAs (images "ba" then "bb"): requests the next A_lo and B_hi
+           "Y0": dict(a="always", b="always", c="none"), "Y1": dict(a="cond", b="cond", c="none", images=("ba", "bb"))}
 
 # Variants (MP_KSTEP_VARIANT selects one at compile time; the A/B of round 5 is in DESIGN.md section 5):
 #   dma    'spread'       one DMA instruction behind the third and the sixth MFMA of groups 0-3 (job b in groups 0-1, job a in 2-3)
@@ -127,9 +134,15 @@ def step(trb, cfg, dma="spread", ahead=2, base=200, pad=False):
             ins.append("s_nop 0")
         pend[:] = [(need, n) for need, n in pend if need > g]
 
+    images = jm.get("images", ("ba",))
+    ng = NGROUP * len(images)             # groups of 8 MFMAs in this block: 8 per (A image, B image) pair
+
+    def img_of(g):
+        return images[g // NGROUP]
+
     if dma == "head_before":
         ins.extend(dma_job("b", jm["b"]) + dma_job("a", jm["a"]))
-    rb, nb = reads_b(0, trb)
+    rb, nb = reads_b(0, trb, img_of(0))
     request(rb, nb, 0)
     r, n = reads_a(0)
     request(r, n, 0)
@@ -139,20 +152,20 @@ def step(trb, cfg, dma="spread", ahead=2, base=200, pad=False):
     if dma == "head_after":
         ins.extend(dma_job("b", jm["b"]) + dma_job("a", jm["a"]))
     wait_for(0)
-    for g in range(NGROUP):
-        ks, p = g // 4, g % 4
+    for g in range(ng):
+        kidx, p = g // 4, g % 4           # running k-step index (two per image pair), A fragment pair inside it
         slot = g % 3
         mf = []
         for f in range(2):
             for j in range(4):
                 c = f"%[c{2 * p + f}{j}]"
-                mf.append(f"v_mfma_f32_16x16x32_bf16 {c}, {vr(fb(ks, j))}, {vr(fa(slot, f))}, {c}")
+                mf.append(f"v_mfma_f32_16x16x32_bf16 {c}, {vr(fb(kidx % 2, j))}, {vr(fa(slot, f))}, {c}")
         ins.append(mf[0])
         # requests issued behind the first MFMA of the group: the fragments of group g + ahead (B of the next k-step with its first A)
         t = g + ahead
-        if t < NGROUP:
+        if t < ng:
             if t % 4 == 0:
-                rb, nb = reads_b(t // 4, trb)
+                rb, nb = reads_b(t // 4, trb, img_of(t))
                 request(rb, nb, t)
             r, n = reads_a(t)
             request(r, n, t)
@@ -165,7 +178,7 @@ def step(trb, cfg, dma="spread", ahead=2, base=200, pad=False):
         if g == 4:
             ins.extend(bias_dma(jm["c"]))
         ins.extend(mf[6:8])
-        if g + 1 < NGROUP:
+        if g + 1 < ng:
             wait_for(g + 1)
     assert not pend, pend
     return ins
