@@ -463,12 +463,10 @@ __device__ __forceinline__ void persist_dma(char* __restrict__ S, const char* __
 #ifndef MP_KSTEP_VARIANT_P
 #define MP_KSTEP_VARIANT_P 0
 #endif
-// Five-buffer form of the split-precision loop (1, with MP_KLOOP_ASM): LDS = A_lo | A_hi | B_lo | B_hi (even k-tiles) | B_hi (odd k-tiles), the
-// epilogue images inside the A_hi buffer.  B_hi double-buffered means no buffer that a k-tile still reads is overwritten inside it, so a k-tile
-// needs TWO barriers instead of three: (A_lo, B_hi) | barrier | (A_hi, B_hi) and (A_hi, B_lo) as one block of 128 MFMAs.
-#ifndef MP_X3_FIVEBUF
-#define MP_X3_FIVEBUF 0      // measured slower: block of four 3941-3951 us against 3875 us for the three-barrier form (profiles/r05_probes/x3_five_buffer_ab.log)
-#endif
+// (Round 5: a five-buffer form of the split-precision loop - A_lo | A_hi | B_lo | B_hi even | B_hi odd k-tile, the epilogue images inside A_hi, TWO
+// barriers per k-tile with (A_hi, B_hi) and (A_hi, B_lo) as one block of 128 MFMAs - was built, passed the parity tests and measured 1.8 % SLOWER
+// (block of four 3941-3951 us against 3875 us, profiles/r05_probes/x3_five_buffer_ab.log): A_hi and B_lo can only be requested behind the k-tile's
+// first barrier and are then both needed 64 MFMAs later.  Removed; the code is in the history, commit "five-buffer / two-barrier form".)
 #define MP_KSTEP_CLOB2(v) MP_KSTEP_CLOBBERS_V##v
 #define MP_KSTEP_CLOB(v) MP_KSTEP_CLOB2(v)
 __device__ __forceinline__ unsigned lds_u32(const void* p) {
@@ -515,7 +513,7 @@ __device__ __forceinline__ int kflag_nonnull(const void* p) { int r; asm volatil
 __device__ __forceinline__ int kflag_more(int a, int b, int x) { int r; asm volatile("s_cmp_lg_u32 %1, %2\n\ts_cselect_b32 %0, 1, %3" : "=s"(r) : "s"(a), "s"(b), "s"(x) : "scc"); return r; }
 // (a == b) ? x : 0
 __device__ __forceinline__ int kflag_last(int a, int b, int x) { int r; asm volatile("s_cmp_eq_u32 %1, %2\n\ts_cselect_b32 %0, %3, 0" : "=s"(r) : "s"(a), "s"(b), "s"(x) : "scc"); return r; }
-enum { KC_X0 = 0, KC_X1 = 1, KC_X2 = 2, KC_P = 3, KC_Y0 = 4, KC_Y1 = 5 };
+enum { KC_X0 = 0, KC_X1 = 1, KC_X2 = 2, KC_P = 3 };
 #define MP_KSTEP_SEL2(c, t, v) MP_KSTEP_ASM_##c##_TRB##t##_V##v
 #define MP_KSTEP_SEL(c, t, v) MP_KSTEP_SEL2(c, t, v)
 #define MP_KSTEP_JOBS                                                                                                                                     \
@@ -525,18 +523,10 @@ enum { KC_X0 = 0, KC_X1 = 1, KC_X2 = 2, KC_P = 3, KC_Y0 = 4, KC_Y1 = 5 };
 #define MP_KSTEP_OPS_0 [aa0] "v"(fa.a[0]), [aa1] "v"(fa.a[1]), [ba0] "v"(fb.b[0]), [ba1] "v"(fb.b[1]), MP_KSTEP_JOBS
 #define MP_KSTEP_OPS_1 [aa0] "v"(fa.a[0]), [aa1] "v"(fa.a[1]), [bt0] "v"(fb.b[0]), [bt1] "v"(fb.b[1]), [bt2] "v"(fb.b[2]), [bt3] "v"(fb.b[3]), MP_KSTEP_JOBS
 #define MP_KSTEP_EMIT(c, t, v) asm volatile(MP_KSTEP_SEL(c, t, v) : MP_KSTEP_ACC_OPERANDS : MP_KSTEP_OPS_##t : MP_KSTEP_CLOB(v))
-// the two-image block (Y1): the fragment addresses of the second B image as well ("N" images only: the split-precision forward)
-#define MP_KSTEP_EMIT2(c, v) asm volatile(MP_KSTEP_SEL(c, 0, v) : MP_KSTEP_ACC_OPERANDS : MP_KSTEP_OPS_0, [bb0] "v"(fb2.b[0]), [bb1] "v"(fb2.b[1]) : MP_KSTEP_CLOB(v))
 template <int TRB, int CFG>
 __device__ __forceinline__ void kstep_asm(f32x4 (&acc)[8][4], const KFragA& fa, const KFragB& fb, const KJob& ja, const unsigned (&aoff)[4],
-                                          const KJob& jb, const unsigned (&boff)[4], const KJob& jc, unsigned coff, const KFragB& fb2 = KFragB()) {
-  if constexpr (CFG == KC_Y0) {
-    static_assert(TRB == 0, "the five-buffer loop is the split-precision forward (\"N\" images)");
-    MP_KSTEP_EMIT(Y0, 0, MP_KSTEP_VARIANT);
-  } else if constexpr (CFG == KC_Y1) {
-    static_assert(TRB == 0, "the five-buffer loop is the split-precision forward (\"N\" images)");
-    MP_KSTEP_EMIT2(Y1, MP_KSTEP_VARIANT);
-  } else if constexpr (TRB == 0) {
+                                          const KJob& jb, const unsigned (&boff)[4], const KJob& jc, unsigned coff) {
+  if constexpr (TRB == 0) {
     if constexpr (CFG == KC_X0) MP_KSTEP_EMIT(X0, 0, MP_KSTEP_VARIANT);
     else if constexpr (CFG == KC_X1) MP_KSTEP_EMIT(X1, 0, MP_KSTEP_VARIANT);
     else if constexpr (CFG == KC_X2) MP_KSTEP_EMIT(X2, 0, MP_KSTEP_VARIANT);
@@ -950,15 +940,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) { kfrag_a(kfa[sg], smem_l + sg * STAGE, wr, lane); kfrag_b<TRB>(kfb[sg], smem_l + sg * STAGE + OPB, wc, lane); }
   }
-  // five-buffer split-precision layout (MP_X3_FIVEBUF): A_lo | A_hi | B_lo | B_hi[0] | B_hi[1], 32 KiB each; the epilogue images lie in A_hi
-  constexpr bool FIVE = KASM && SPLIT == 1 && TRB == 0 && MP_X3_FIVEBUF;
-  KFragB kfb5[2];     // FIVE: fragment addresses in B_lo and in B_hi[0] (B_hi[1] = + 32 KiB)
-  if constexpr (FIVE) {
-    kfrag_a(kfa[0], smem_l, wr, lane); kfrag_a(kfa[1], smem_l + OPB, wr, lane);
-    kfrag_b<TRB>(kfb5[0], smem_l + 2 * OPB, wc, lane); kfrag_b<TRB>(kfb5[1], smem_l + 3 * OPB, wc, lane);
-  }
-  int bpar = 0;       // FIVE: which B_hi buffer the current k-tile reads (alternates per k-tile, across tiles)
-  const unsigned img_l = smem_l + (FIVE ? OPB : 2 * STAGE) + wave * 4096;      // this wave's epilogue image (not FIVE: the step's bias DMA lands there)
+  const unsigned img_l = smem_l + 2 * STAGE + wave * 4096;               // this wave's epilogue image (the step's bias DMA lands there)
   // byte address of (tile origin, reduction index k) of each operand
   // byte address of (tile origin, k-tile kt) of each operand plane
   auto a_base = [&](int mm, int kt) { return A + ((long)mm * g.lda + kt * GBK) * 2; };
@@ -967,12 +949,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   constexpr bool PLANES = (SPLIT & 1) || SPLIT == 8;        // two planes per operand (SPLIT 0 / 16: one, bf16 / fp16)
   const long a_lo = PLANES ? reinterpret_cast<const char*>(g.A_lo) - A : 0, b_lo = PLANES ? reinterpret_cast<const char*>(g.B_lo) - B : 0;
   persist_dma(smem, a_base(m0, 0) + (SPLIT == 8 ? 0 : a_lo), aoff, wave);       // SPLIT 1: the first step multiplies (A_lo, B_hi); 8: the fp16 planes
-  persist_dma(smem + (FIVE ? 3 * OPB : OPB), b_base(n0, 0), boff, wave);
+  persist_dma(smem + OPB, b_base(n0, 0), boff, wave);
   int stage = 0;
   bool landed = false;                                      // this tile's first k-tile was already waited for (before the previous epilogue)
   TC* const C = reinterpret_cast<TC*>(g.C);
   typename ZType<TC>::type* const Z = reinterpret_cast<typename ZType<TC>::type*>(g.Z);
-  float* const img = reinterpret_cast<float*>(smem + (FIVE ? OPB : 2 * STAGE) + wave * 4096);
+  float* const img = reinterpret_cast<float*>(smem + 2 * STAGE + wave * 4096);
   const bool has_bias = EPI != EPI_DGELU && g.bias != nullptr;
 #ifdef MP_GEMM_DIAG                                          // diagnostics build (MP_DIAG=1 build.sh -> libmanipose_hip_diag.so, tools/gemm_stamps.py)
   int tile_no = 0;
@@ -1043,49 +1025,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       // vmcnt(4): requests retire in order, so B_lo has landed while the four A_lo requests issued behind it may still be in flight -
       // one of the two tiles the next step 0 needs has two steps to arrive instead of one.
       bool early = false;
-      if constexpr (FIVE) {
-        // five buffers, two barriers per k-tile (see MP_X3_FIVEBUF):
-        //   barrier 0: (A_lo, B_hi[bpar]) of this k-tile have landed; everybody is done with the previous k-tile (A_hi, B_lo free)
-        //     block Y0: A_lo x B_hi; requests A_hi -> buffer 1, B_lo -> buffer 2   (needed one block later)
-        //   barrier 1: they have landed; everybody is done with A_lo
-        //     block Y1: A_hi x B_hi, A_hi x B_lo (128 MFMAs, no bubble between the products); requests the next A_lo -> buffer 0 and the next
-        //     B_hi -> the OTHER B_hi buffer (needed two products later)
-        const char* pa = tile_a;                           // A_hi of k-tile kt
-        const char* pb = tile_b;                           // B_hi of k-tile kt
-        const KJob none = {0, 0u, nullptr};
-        const unsigned coff = 4u * lane;
-        for (int kt = 0; kt < nk; ++kt, pa += GBK * 2, pb += kstep_b, bpar ^= 1) {
-          const bool last = kt + 1 == nk;
-          const int more_i = kflag_more(kt + 1, nk, has_next_i);
-          const unsigned bo = (unsigned)bpar * OPB;
-          const KFragB fbh = {{kfb5[1].b[0] + bo, kfb5[1].b[1] + bo, 0u, 0u}};      // B_hi[bpar]
-#ifdef MP_GEMM_DIAG
-          unsigned long long tk0 = __builtin_readcyclecounter(), tk1, tk2;
-#define MP_KDIAG_A() tk1 = __builtin_readcyclecounter()
-#define MP_KDIAG_B() tk2 = __builtin_readcyclecounter(); dg_wait += tk1 - tk0; dg_bar += tk2 - tk1
-#define MP_KDIAG_C() tk0 = __builtin_readcyclecounter(); dg_mma += tk0 - tk2
-#else
-#define MP_KDIAG_A()
-#define MP_KDIAG_B()
-#define MP_KDIAG_C()
-#endif
-          if (kt == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only: (A_lo, B_hi) of this tile were waited for before the previous epilogue
-          else __builtin_amdgcn_s_waitcnt(0x0070);
-          MP_KDIAG_A();
-          __builtin_amdgcn_s_barrier();
-          MP_KDIAG_B();
-          kstep_asm<TRB, KC_Y0>(acc, kfa[0], fbh, KJob{1, dma_l + OPB, pa}, aoff, KJob{1, dma_l + 2 * OPB, pb + b_lo}, boff, none, coff);
-          MP_KDIAG_C();
-          if (last && more_i) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
-          __builtin_amdgcn_s_waitcnt(0x0070);
-          MP_KDIAG_A();
-          __builtin_amdgcn_s_barrier();
-          MP_KDIAG_B();
-          kstep_asm<TRB, KC_Y1>(acc, kfa[1], fbh, KJob{more_i, dma_l, (last ? tile_an : pa + GBK * 2) + a_lo}, aoff,
-                                KJob{more_i, dma_l + 3 * OPB + (unsigned)(bpar ^ 1) * OPB, last ? tile_bn : pb + kstep_b}, boff, none, coff, kfb5[0]);
-          MP_KDIAG_C();
-        }
-      } else if constexpr (KASM) {
+      if constexpr (KASM) {
         // hand-scheduled form: the same buffers, DMA schedule and waits, the three steps of a k-tile written out (one asm block each, with the
         // DMA jobs that step can carry: KC_X0 / X1 / X2); running operand addresses, fragment addresses per buffer: a step's scalar set-up
         // is a handful of instructions
@@ -1096,9 +1036,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
         for (int kt = 0; kt < nk; ++kt, pa += GBK * 2, pb += kstep_b) {
           const bool last = kt + 1 == nk;
           const int more_i = kflag_more(kt + 1, nk, has_next_i);
-#undef MP_KDIAG_A
-#undef MP_KDIAG_B
-#undef MP_KDIAG_C
 #ifdef MP_GEMM_DIAG
           unsigned long long tk0 = __builtin_readcyclecounter(), tk1, tk2;
 #define MP_KDIAG_A() tk1 = __builtin_readcyclecounter()
@@ -1252,7 +1189,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): the next tile's first k-tile (issued one k-tile ago)
     landed = true;
-    if constexpr (FIVE) __builtin_amdgcn_s_barrier();                 // the epilogue images lie in the A_hi buffer: everybody has read its last fragments
 
     // ---- epilogue, 16 rows of the wave's 128 x 64 sub-tile per pass through the wave-private image ----
 #ifdef MP_GEMM_DIAG
@@ -1267,7 +1203,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       asm volatile("" : "+v"(e15), "+v"(eq));
       const int col = n0 + wc * 64 + 4 * e15;               // < N: N % 256 == 0
       float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (has_bias) bias4 = FIVE ? ld4(g.bias + col) : *reinterpret_cast<const float4*>(img + 4 * e15);      // (FIVE: no LDS left for a bias row)
+      if (has_bias) bias4 = *reinterpret_cast<const float4*>(img + 4 * e15);
       bool done = false;
       if constexpr (sizeof(TC) == 2 && EPI == EPI_BIAS && (SPLIT == 0 || SPLIT == 16)) {      // plain bf16 output (bf16p is the planar tag: SPLIT kernels only)
         if (!has_bias) {

@@ -95,12 +95,7 @@ def bias_dma(mode="always"):
 #   P             a step of the plain loop: both operands of the next k-tile unless it is the launch's last, the bias behind a tile's last step
 # ONE asm block per step type: two blocks on the two sides of a branch make hipcc reconcile the 128 accumulator registers through scratch memory.
 CONFIGS = {"X0": dict(a="always", b="none", c="none"), "X1": dict(a="cond", b="always", c="none"), "X2": dict(a="none", b="cond", c="cond"),
-           "P": dict(a="cond", b="cond", c="cond"),
-           # five-buffer form of the split-precision loop (A_lo | A_hi | B_lo | B_hi even | B_hi odd k-tile: B_hi is double-buffered, so nothing
-           # that a k-tile still reads is overwritten inside it) - TWO barriers per k-tile:
-           #   Y0  (A_lo, B_hi): requests A_hi and B_lo of this k-tile
-           #   Y1  (A_hi, B_hi) and then (A_hi, B_lo) in ONE block of 128 MFMAs (images "ba" then "bb"): requests the next A_lo and B_hi
-           "Y0": dict(a="always", b="always", c="none"), "Y1": dict(a="cond", b="cond", c="none", images=("ba", "bb"))}
+           "P": dict(a="cond", b="cond", c="cond")}
 
 # Variants (MP_KSTEP_VARIANT selects one at compile time; the A/B of round 5 is in DESIGN.md section 5):
 #   dma    'spread'       one DMA instruction behind the third and the sixth MFMA of groups 0-3 (job b in groups 0-1, job a in 2-3)
