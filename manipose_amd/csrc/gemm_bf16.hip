@@ -438,6 +438,22 @@ __device__ __forceinline__ void persist_offsets(unsigned (&off)[4], long ld, int
     }
   }
 }
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// the same for NP consecutive pieces starting at piece `first` (MP_KSTEP_YOUNG: waves 4-7 take 8 pieces of a tile each)
+template <int TR, int NP>
+__device__ __forceinline__ void persist_offsets_n(unsigned (&off)[NP], long ld, int out0, int OUT, int lane, int first) {
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = 64 * (first + i) + lane;
+    if (TR == 0) {
+      const int row = c >> 3, kg = (c & 7) ^ (row & 7);
+      off[i] = (unsigned)(min(row, OUT - 1 - out0) * (int)ld * 2 + kg * 16);
+    } else {
+      const int rr = c >> 5, oc = (c & 31) ^ t_swz(rr);
+      off[i] = (unsigned)(rr * (int)ld * 2 + oc * 16);
+    }
+  }
+}
 __device__ __forceinline__ void persist_dma(char* __restrict__ S, const char* __restrict__ base, const unsigned (&off)[4], int wave) {
   typedef __attribute__((address_space(3))) void* lptr;
   typedef const __attribute__((address_space(1))) void* gptr;
@@ -498,6 +514,11 @@ __device__ __forceinline__ void kfrag_b(KFragB& f, unsigned base, int wc, int la
     }
   }
 }
+// MP_KSTEP_YOUNG (with MP_KLOOP_ASM): the operand DMA of the hand-scheduled loops is issued by waves 4-7 only - the younger wave of every SIMD, 8
+// pieces per tile each - instead of 4 pieces by every wave (configurations Z0 / Z1 / Z2 / ZP of the generator)
+#ifndef MP_KSTEP_YOUNG
+#define MP_KSTEP_YOUNG 1
+#endif
 // Job configuration of a step = which DMA jobs its asm block can carry (tools/gen_kloop_asm.py, CONFIGS): X0 / X1 / X2 = the three steps of a
 // k-tile of the split-precision loop, P = a step of the plain loop.  ONE block per step type, the jobs that are not always there behind a
 // wave-uniform flag in a scalar register: two blocks on the two sides of a C++ branch make hipcc reconcile the 128 accumulator registers
@@ -516,26 +537,47 @@ __device__ __forceinline__ int kflag_last(int a, int b, int x) { int r; asm vola
 enum { KC_X0 = 0, KC_X1 = 1, KC_X2 = 2, KC_P = 3 };
 #define MP_KSTEP_SEL2(c, t, v) MP_KSTEP_ASM_##c##_TRB##t##_V##v
 #define MP_KSTEP_SEL(c, t, v) MP_KSTEP_SEL2(c, t, v)
-#define MP_KSTEP_JOBS                                                                                                                                     \
-  [ena] "s"(ja.en), [ldsa] "s"(ja.lds), [gba] "s"(ja.base), [ao0] "v"(aoff[0]), [ao1] "v"(aoff[1]), [ao2] "v"(aoff[2]), [ao3] "v"(aoff[3]),                 \
-  [enb] "s"(jb.en), [ldsb] "s"(jb.lds), [gbb] "s"(jb.base), [bo0] "v"(boff[0]), [bo1] "v"(boff[1]), [bo2] "v"(boff[2]), [bo3] "v"(boff[3]),                 \
+#if MP_KSTEP_YOUNG
+constexpr int KNP = 8;      // DMA pieces (1 KiB each) per operand tile and issuing wave
+#define MP_KSTEP_OFFS(o, arr) [o##0] "v"(arr[0]), [o##1] "v"(arr[1]), [o##2] "v"(arr[2]), [o##3] "v"(arr[3]), [o##4] "v"(arr[4]), [o##5] "v"(arr[5]), [o##6] "v"(arr[6]), [o##7] "v"(arr[7])
+#else
+constexpr int KNP = 4;
+#define MP_KSTEP_OFFS(o, arr) [o##0] "v"(arr[0]), [o##1] "v"(arr[1]), [o##2] "v"(arr[2]), [o##3] "v"(arr[3])
+#endif
+#define MP_KSTEP_JOBS                                                                                    \
+  [ena] "s"(ja.en), [ldsa] "s"(ja.lds), [gba] "s"(ja.base), MP_KSTEP_OFFS(ao, aoff),                       \
+  [enb] "s"(jb.en), [ldsb] "s"(jb.lds), [gbb] "s"(jb.base), MP_KSTEP_OFFS(bo, boff),                       \
   [enc] "s"(jc.en), [ldsc] "s"(jc.lds), [gbc] "s"(jc.base), [co] "v"(coff)
 #define MP_KSTEP_OPS_0 [aa0] "v"(fa.a[0]), [aa1] "v"(fa.a[1]), [ba0] "v"(fb.b[0]), [ba1] "v"(fb.b[1]), MP_KSTEP_JOBS
 #define MP_KSTEP_OPS_1 [aa0] "v"(fa.a[0]), [aa1] "v"(fa.a[1]), [bt0] "v"(fb.b[0]), [bt1] "v"(fb.b[1]), [bt2] "v"(fb.b[2]), [bt3] "v"(fb.b[3]), MP_KSTEP_JOBS
 #define MP_KSTEP_EMIT(c, t, v) asm volatile(MP_KSTEP_SEL(c, t, v) : MP_KSTEP_ACC_OPERANDS : MP_KSTEP_OPS_##t : MP_KSTEP_CLOB(v))
 template <int TRB, int CFG>
-__device__ __forceinline__ void kstep_asm(f32x4 (&acc)[8][4], const KFragA& fa, const KFragB& fb, const KJob& ja, const unsigned (&aoff)[4],
-                                          const KJob& jb, const unsigned (&boff)[4], const KJob& jc, unsigned coff) {
+__device__ __forceinline__ void kstep_asm(f32x4 (&acc)[8][4], const KFragA& fa, const KFragB& fb, const KJob& ja, const unsigned (&aoff)[KNP],
+                                          const KJob& jb, const unsigned (&boff)[KNP], const KJob& jc, unsigned coff) {
   if constexpr (TRB == 0) {
+#if MP_KSTEP_YOUNG
+    if constexpr (CFG == KC_X0) MP_KSTEP_EMIT(Z0, 0, MP_KSTEP_VARIANT);
+    else if constexpr (CFG == KC_X1) MP_KSTEP_EMIT(Z1, 0, MP_KSTEP_VARIANT);
+    else if constexpr (CFG == KC_X2) MP_KSTEP_EMIT(Z2, 0, MP_KSTEP_VARIANT);
+    else MP_KSTEP_EMIT(ZP, 0, MP_KSTEP_VARIANT_P);
+#else
     if constexpr (CFG == KC_X0) MP_KSTEP_EMIT(X0, 0, MP_KSTEP_VARIANT);
     else if constexpr (CFG == KC_X1) MP_KSTEP_EMIT(X1, 0, MP_KSTEP_VARIANT);
     else if constexpr (CFG == KC_X2) MP_KSTEP_EMIT(X2, 0, MP_KSTEP_VARIANT);
     else MP_KSTEP_EMIT(P, 0, MP_KSTEP_VARIANT_P);
+#endif
   } else {
+#if MP_KSTEP_YOUNG
+    if constexpr (CFG == KC_X0) MP_KSTEP_EMIT(Z0, 1, MP_KSTEP_VARIANT);
+    else if constexpr (CFG == KC_X1) MP_KSTEP_EMIT(Z1, 1, MP_KSTEP_VARIANT);
+    else if constexpr (CFG == KC_X2) MP_KSTEP_EMIT(Z2, 1, MP_KSTEP_VARIANT);
+    else MP_KSTEP_EMIT(ZP, 1, MP_KSTEP_VARIANT_P);
+#else
     if constexpr (CFG == KC_X0) MP_KSTEP_EMIT(X0, 1, MP_KSTEP_VARIANT);
     else if constexpr (CFG == KC_X1) MP_KSTEP_EMIT(X1, 1, MP_KSTEP_VARIANT);
     else if constexpr (CFG == KC_X2) MP_KSTEP_EMIT(X2, 1, MP_KSTEP_VARIANT);
     else MP_KSTEP_EMIT(P, 1, MP_KSTEP_VARIANT_P);
+#endif
   }
 }
 
@@ -929,11 +971,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   if (id >= ntiles) return;
   const int nk = g.K / GBK;                                 // K % 64 == 0, nk >= 2 (launcher)
   int m0 = (id / tiles_n) * BT, n0 = (id % tiles_n) * BT;
-  unsigned aoff[4], boff[4];
-  persist_offsets<0>(aoff, g.lda, m0, g.M, lane, wave);
-  persist_offsets<TRB>(boff, g.ldb, 0, BT, lane, wave);     // N % 256 == 0: the same for every tile
   constexpr bool KASM = MP_KLOOP_ASM && (SPLIT == 0 || SPLIT == 1);      // the hand-scheduled k-step (bf16 MFMA; plain and three-product loops)
-  const unsigned smem_l = lds_u32(smem), dma_l = smem_l + wave * 4096;   // LDS addresses: the stages' origin, this wave's 4 KiB of an operand tile
+  constexpr bool YOUNG = KASM && MP_KSTEP_YOUNG;                         // its operand DMA comes from waves 4-7 only (8 pieces of a tile each)
+  constexpr int NP = YOUNG ? 8 : 4;
+  const int dma_first = YOUNG ? (wave >= 4 ? (wave - 4) * 8 : 0) : wave * 4;      // this wave's first piece of an operand tile
+  unsigned aoff[NP], boff[NP];
+  persist_offsets_n<0, NP>(aoff, g.lda, m0, g.M, lane, dma_first);
+  persist_offsets_n<TRB, NP>(boff, g.ldb, 0, BT, lane, dma_first);       // N % 256 == 0: the same for every tile
+  const unsigned smem_l = lds_u32(smem), dma_l = smem_l + dma_first * 1024;   // LDS addresses: the stages' origin, this wave's pieces of an operand tile
+  const int dma_wave = YOUNG ? kflag_lt(3, wave) : 1;                    // does this wave issue operand DMA (a scalar-register flag)
   KFragA kfa[2];      // fragment addresses in the A buffer of stage 0 / 1 (split loop: A0 = A_lo, A1 = A_hi)
   KFragB kfb[2];      // ... in the B buffer of stage 0 / 1 (split loop: B0 = B_hi, B1 = B_lo)
   if constexpr (KASM) {
@@ -948,8 +994,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   // SPLIT: A / B above are the hi planes; the lo planes lie at these byte distances
   constexpr bool PLANES = (SPLIT & 1) || SPLIT == 8;        // two planes per operand (SPLIT 0 / 16: one, bf16 / fp16)
   const long a_lo = PLANES ? reinterpret_cast<const char*>(g.A_lo) - A : 0, b_lo = PLANES ? reinterpret_cast<const char*>(g.B_lo) - B : 0;
-  persist_dma(smem, a_base(m0, 0) + (SPLIT == 8 ? 0 : a_lo), aoff, wave);       // SPLIT 1: the first step multiplies (A_lo, B_hi); 8: the fp16 planes
-  persist_dma(smem + OPB, b_base(n0, 0), boff, wave);
+  if constexpr (YOUNG) {
+    if (wave >= 4) {
+      uneven_dma<NP>(smem, a_base(m0, 0) + a_lo, aoff, dma_first, NP);
+      uneven_dma<NP>(smem + OPB, b_base(n0, 0), boff, dma_first, NP);
+    }
+  } else {
+    persist_dma(smem, a_base(m0, 0) + (SPLIT == 8 ? 0 : a_lo), aoff, wave);       // SPLIT 1: the first step multiplies (A_lo, B_hi); 8: the fp16 planes
+    persist_dma(smem + OPB, b_base(n0, 0), boff, wave);
+  }
   int stage = 0;
   bool landed = false;                                      // this tile's first k-tile was already waited for (before the previous epilogue)
   TC* const C = reinterpret_cast<TC*>(g.C);
@@ -999,7 +1052,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
         char* nx = smem + (par ^ 1) * STAGE;
         const bool last = v + 1 == 2 * nk;
         if (!last || has_next) {
-          if (last) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+          if (last) persist_offsets_n<0, NP>(aoff, g.lda, m0n, g.M, opaque(lane), dma_first);      // (opaque: the rows are recomputed here, not kept - spilled - across the tile)
           const int ktn = last ? 0 : (v + 1) >> 1;
           persist_dma(nx, a_base(last ? m0n : m0, ktn) + (par ? 0 : a_lo), aoff, wave);
           persist_dma(nx + OPB, b_base(last ? n0n : n0, ktn) + (par ? 0 : b_lo), boff, wave);
@@ -1052,15 +1105,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
           MP_KDIAG_A();
           __builtin_amdgcn_s_barrier();
           MP_KDIAG_B();
-          kstep_asm<TRB, KC_X0>(acc, kfa[0], kfb[0], KJob{1, dma_l + STAGE, pa}, aoff, none, boff, none, coff);
+          kstep_asm<TRB, KC_X0>(acc, kfa[0], kfb[0], KJob{dma_wave, dma_l + STAGE, pa}, aoff, none, boff, none, coff);
           MP_KDIAG_C();
           // step 1: (A1 = A_hi, B0 = B_hi); requests B_lo[kt] -> B1, then A_lo of the next k-tile / tile -> A0
-          if (last && more_i) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+          if (last && more_i) persist_offsets_n<0, NP>(aoff, g.lda, m0n, g.M, opaque(lane), dma_first);      // (opaque: the rows are recomputed here, not kept - spilled - across the tile)
           __builtin_amdgcn_s_waitcnt(0x0070);
           MP_KDIAG_A();
           __builtin_amdgcn_s_barrier();
           MP_KDIAG_B();
-          kstep_asm<TRB, KC_X1>(acc, kfa[1], kfb[0], KJob{more_i, dma_l, (last ? tile_an : pa + GBK * 2) + a_lo}, aoff, KJob{1, dma_l + STAGE + OPB, pb + b_lo}, boff,
+          kstep_asm<TRB, KC_X1>(acc, kfa[1], kfb[0], KJob{more_i & dma_wave, dma_l, (last ? tile_an : pa + GBK * 2) + a_lo}, aoff, KJob{dma_wave, dma_l + STAGE + OPB, pb + b_lo}, boff,
                                 none, coff);
           MP_KDIAG_C();
           // step 2: (A1 = A_hi, B1 = B_lo); requests B_hi of the next k-tile / tile -> B0, and the bias behind the tile's last step.  It waits with
@@ -1070,7 +1123,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
           MP_KDIAG_A();
           __builtin_amdgcn_s_barrier();
           MP_KDIAG_B();
-          kstep_asm<TRB, KC_X2>(acc, kfa[1], kfb[1], none, aoff, KJob{more_i, dma_l + OPB, last ? tile_bn : pb + kstep_b}, boff,
+          kstep_asm<TRB, KC_X2>(acc, kfa[1], kfb[1], none, aoff, KJob{more_i & dma_wave, dma_l + OPB, last ? tile_bn : pb + kstep_b}, boff,
                                 KJob{kflag_last(kt + 1, nk, has_bias_i), img_l, reinterpret_cast<const char*>(g.bias + n0 + wc * 64)}, coff);
           MP_KDIAG_C();
         }
@@ -1099,7 +1152,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
           persist_dma(B1, b_base(n0, kt) + b_lo, boff, wave);             // B_lo[kt]
           early = !last || has_next;
           if (early) {
-            if (last) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+            if (last) persist_offsets_n<0, NP>(aoff, g.lda, m0n, g.M, opaque(lane), dma_first);      // (opaque: the rows are recomputed here, not kept - spilled - across the tile)
             persist_dma(A0, a_base(last ? m0n : m0, last ? 0 : kt + 1) + a_lo, aoff, wave);      // A_lo of the next k-tile / tile
           }
         } else {
@@ -1125,7 +1178,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
       for (int ks = 0; ks < nk; ++ks, stage ^= 1, pa += GBK * 2, pb += kstep_b) {
         const bool last = ks + 1 == nk;
         const int fetch_i = MP_DBG(g, 2) ? 0 : kflag_more(ks + 1, nk, has_next_i);
-        if (last && fetch_i) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+        if (last && fetch_i) persist_offsets_n<0, NP>(aoff, g.lda, m0n, g.M, opaque(lane), dma_first);      // (opaque: the rows are recomputed here, not kept - spilled - across the tile)
         // this stage's fragment addresses (stage 0's + 64 KiB): a few vector adds in front of the barrier - NOT kfa[stage], which makes the
         // arrays scratch memory
         const unsigned so = (unsigned)stage * STAGE;
@@ -1141,7 +1194,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
         MP_KDIAG_B();
         const unsigned nx = dma_l + (stage ^ 1) * STAGE;
         if (!MP_DBG(g, 1))
-          kstep_asm<TRB, KC_P>(acc, fa, fb, KJob{fetch_i, nx, last ? tile_an : pa}, aoff, KJob{fetch_i, nx + OPB, last ? tile_bn : pb}, boff,
+          kstep_asm<TRB, KC_P>(acc, fa, fb, KJob{fetch_i & dma_wave, nx, last ? tile_an : pa}, aoff, KJob{fetch_i & dma_wave, nx + OPB, last ? tile_bn : pb}, boff,
                                KJob{kflag_last(ks + 1, nk, has_bias_i), img_l, reinterpret_cast<const char*>(g.bias + n0 + wc * 64)}, coff);
         MP_KDIAG_C();
       }
@@ -1173,7 +1226,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
         persist_dma(nx + OPB, b_base(last ? n0n : n0, last ? 0 : ks + 1), boff, wave);
       };
       if (fetch) {
-        if (last) persist_offsets<0>(aoff, g.lda, m0n, g.M, lane, wave);
+        if (last) persist_offsets_n<0, NP>(aoff, g.lda, m0n, g.M, opaque(lane), dma_first);      // (opaque: the rows are recomputed here, not kept - spilled - across the tile)
         if (!late) issue();
       }
       if (last && has_bias) {      // this wave's 64 bias values -> its (idle) epilogue image, 4 bytes per lane; covered by the vmcnt(0) below

@@ -56,7 +56,7 @@ def reads_b(kidx, trb, img="ba"):
 
 
 def dma(job, n, guarded=True):
-    """DMA instruction n (0..3) of job 'a' / 'b': 1 KiB = 64 lanes x 16 bytes from (SGPR base + per-lane offset) to the LDS address in m0"""
+    """DMA instruction n of job 'a' / 'b': 1 KiB = 64 lanes x 16 bytes from (SGPR base + per-lane offset) to the LDS address in m0"""
     L = f".Lkd{job}{n}_%="
     body = [f"s_add_u32 m0, %[lds{job}], {n * 1024}",
             "s_nop 0",
@@ -66,12 +66,12 @@ def dma(job, n, guarded=True):
     return [f"s_cmp_eq_u32 %[en{job}], 0", f"s_cbranch_scc1 {L}"] + body + [f"{L}:"]
 
 
-def dma_job(job, mode="cond"):
-    """all four instructions of a job: mode 'always' (unconditional), 'cond' (behind ONE test of its enable flag), 'none' (nothing)"""
+def dma_job(job, mode="cond", pieces=4):
+    """all instructions of a job: mode 'always' (unconditional), 'cond' (behind ONE test of its enable flag), 'none' (nothing)"""
     if mode == "none":
         return []
     out = []
-    for n in range(4):
+    for n in range(pieces):
         out += dma(job, n, guarded=False)
     if mode == "always":
         return out
@@ -95,7 +95,12 @@ def bias_dma(mode="always"):
 #   P             a step of the plain loop: both operands of the next k-tile unless it is the launch's last, the bias behind a tile's last step
 # ONE asm block per step type: two blocks on the two sides of a branch make hipcc reconcile the 128 accumulator registers through scratch memory.
 CONFIGS = {"X0": dict(a="always", b="none", c="none"), "X1": dict(a="cond", b="always", c="none"), "X2": dict(a="none", b="cond", c="cond"),
-           "P": dict(a="cond", b="cond", c="cond")}
+           "P": dict(a="cond", b="cond", c="cond"),
+           # the same steps with the operand DMA issued by the YOUNGER wave of every SIMD only (waves 4-7: eight pieces per tile each, every job
+           # behind a flag that is 0 in waves 0-3): the older wave wins the matrix pipe's arbitration, so DMA instructions in ITS head delay the
+           # SIMD's first MFMA of the step, while the younger wave waits for the pipe anyway
+           "Z0": dict(a="cond", b="none", c="none", pieces=8), "Z1": dict(a="cond", b="cond", c="none", pieces=8),
+           "Z2": dict(a="none", b="cond", c="cond", pieces=8), "ZP": dict(a="cond", b="cond", c="cond", pieces=8)}
 
 # Variants (MP_KSTEP_VARIANT selects one at compile time; the A/B of round 5 is in DESIGN.md section 5):
 #   dma    'spread'       one DMA instruction behind the third and the sixth MFMA of groups 0-3 (job b in groups 0-1, job a in 2-3)
@@ -103,10 +108,8 @@ CONFIGS = {"X0": dict(a="always", b="none", c="none"), "X1": dict(a="cond", b="a
 #          'head_after'   both jobs behind the step's first fragment requests, in front of the first wait (their issue overlaps the LDS latency)
 #   ahead  1 / 2          fragment requests one / two groups of 8 MFMAs ahead of their use
 VARIANTS = {
-    0: dict(dma="head_before", ahead=1),     # hipcc's own order, written out
-    1: dict(dma="head_before", ahead=2),
-    2: dict(dma="head_after", ahead=2),
-    3: dict(dma="spread", ahead=2),
+    0: dict(dma="head_before", ahead=1),     # hipcc's own order, written out (measured: best for the plain loop)
+    2: dict(dma="head_after", ahead=2),      # (measured: best for the split-precision loop; 1 = head_before / ahead 2 and 3 = spread / ahead 2 were slower)
 }
 
 
@@ -130,13 +133,14 @@ def step(trb, cfg, dma="spread", ahead=2, base=200, pad=False):
         pend[:] = [(need, n) for need, n in pend if need > g]
 
     images = jm.get("images", ("ba",))
+    npc = jm.get("pieces", 4)
     ng = NGROUP * len(images)             # groups of 8 MFMAs in this block: 8 per (A image, B image) pair
 
     def img_of(g):
         return images[g // NGROUP]
 
     if dma == "head_before":
-        ins.extend(dma_job("b", jm["b"]) + dma_job("a", jm["a"]))
+        ins.extend(dma_job("b", jm["b"], npc) + dma_job("a", jm["a"], npc))
     rb, nb = reads_b(0, trb, img_of(0))
     request(rb, nb, 0)
     r, n = reads_a(0)
@@ -145,7 +149,7 @@ def step(trb, cfg, dma="spread", ahead=2, base=200, pad=False):
         r, n = reads_a(1)
         request(r, n, 1)
     if dma == "head_after":
-        ins.extend(dma_job("b", jm["b"]) + dma_job("a", jm["a"]))
+        ins.extend(dma_job("b", jm["b"], npc) + dma_job("a", jm["a"], npc))
     wait_for(0)
     for g in range(ng):
         kidx, p = g // 4, g % 4           # running k-step index (two per image pair), A fragment pair inside it
