@@ -1,7 +1,8 @@
 """Where the persistent GEMM's workgroups are in time: every workgroup stamps the start and end of each tile's epilogue (MANIPOSE_GEMM_STAMPS,
 10 ns ticks of the constant clock).  Prints, for one launch of the split-precision qkv shape, the epilogue durations and how the epilogues of
 the 256 workgroups line up (all at once = a chip-wide burst of stores, or spread over the tile time).  Needs the diagnostics build of the
-library (MP_DIAG=1 bash manipose_amd/csrc/build.sh).   [MANIPOSE_GEMM_STAGGER=ticks] python tools/gemm_stamps.py [x3|bf16|dgrad [N K]]"""
+library (MP_DIAG=1 bash manipose_amd/csrc/build.sh).   [MANIPOSE_GEMM_STAGGER=ticks] python tools/gemm_stamps.py [x3|x3gelu|x3res|bf16|dgrad [N K]]
+(x3gelu / x3res: the split-precision forward with the GELU epilogue of fc1 / the fp32 residual epilogue of proj and fc2)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,6 +24,8 @@ Wh, Wl = torch.empty_like(W, dtype=torch.bfloat16), torch.empty_like(W, dtype=to
 lib.mp_split_bf16(x.data_ptr(), xh.data_ptr(), xl.data_ptr(), x.numel(), st); lib.mp_split_bf16(W.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), W.numel(), st)
 b = torch.randn(N, device="cuda")
 yh, yl = torch.empty(M, N, device="cuda", dtype=torch.bfloat16), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+if mode == "x3gelu": zz = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+if mode == "x3res": y32, rr = torch.empty(M, N, device="cuda"), torch.randn(M, N, device="cuda")
 if mode == "dgrad":
     # (the call also runs the weight-gradient GEMM, which is not a persistent kernel and writes no stamps: the "launch us" line includes it)
     dy = torch.randn(M, N, device="cuda").bfloat16(); dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
@@ -33,6 +36,10 @@ def run():
         _lib.check(lib.mp_linear_bwd_bf16(dy.data_ptr(), 0, xh.data_ptr(), Wh.data_ptr(), dx.data_ptr(), 0, dW.data_ptr(), db.data_ptr(), M, N, K, slab.data_ptr(), slab.numel(), st))
     elif mode == "x3":
         _lib.check(lib.mp_linear_fwd_bf16x3(xh.data_ptr(), xl.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), b.data_ptr(), yh.data_ptr(), yl.data_ptr(), None, None, M, N, K, 0, st))
+    elif mode == "x3gelu":
+        _lib.check(lib.mp_linear_fwd_bf16x3(xh.data_ptr(), xl.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), b.data_ptr(), yh.data_ptr(), yl.data_ptr(), zz.data_ptr(), None, M, N, K, 1, st))
+    elif mode == "x3res":
+        _lib.check(lib.mp_linear_fwd_bf16x3(xh.data_ptr(), xl.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), b.data_ptr(), y32.data_ptr(), None, None, rr.data_ptr(), M, N, K, 2, st))
     else:
         _lib.check(lib.mp_linear_fwd_bf16(xh.data_ptr(), Wh.data_ptr(), b.data_ptr(), yh.data_ptr(), None, None, M, N, K, 0, st))
 for _ in range(3): run()
