@@ -482,7 +482,8 @@ __device__ __forceinline__ void persist_dma(char* __restrict__ S, const char* __
 // (Round 5: a five-buffer form of the split-precision loop - A_lo | A_hi | B_lo | B_hi even | B_hi odd k-tile, the epilogue images inside A_hi, TWO
 // barriers per k-tile with (A_hi, B_hi) and (A_hi, B_lo) as one block of 128 MFMAs - was built, passed the parity tests and measured 1.8 % SLOWER
 // (block of four 3941-3951 us against 3875 us, profiles/r05_probes/x3_five_buffer_ab.log): A_hi and B_lo can only be requested behind the k-tile's
-// first barrier and are then both needed 64 MFMAs later.  Removed; the code is in the history, commit "five-buffer / two-barrier form".)
+// first barrier and are then both needed 64 MFMAs later.  With the operand DMA moved to the younger waves (MP_KSTEP_YOUNG) the two forms are equal
+// (3793-3805 against 3781-3787 us, x3_five_buffer_young_ab.log).  Removed; the code is in the history, commit "five-buffer / two-barrier form".)
 #define MP_KSTEP_CLOB2(v) MP_KSTEP_CLOBBERS_V##v
 #define MP_KSTEP_CLOB(v) MP_KSTEP_CLOB2(v)
 __device__ __forceinline__ unsigned lds_u32(const void* p) {
