@@ -1,10 +1,12 @@
-// Isolating probe for the hazard csrc/common.h describes ("gfx950 hazard guard"): does a packed fp32 multiply whose LOW lane takes the HIGH
+// Isolating probe for the hazard csrc/common.h describes ("packed-fp32 guard"): does a packed fp32 multiply whose LOW lane takes the HIGH
 // register of a VGPR pair (op_sel:[0,1]) return wrong low-lane results on gfx950?  The kernel's ONLY arithmetic is that instruction, on
 //   mode 0: a pair that global_load_dwordx2 has just written (load; s_waitcnt vmcnt(0); v_pk_mul_f32 - the sequence of the faulty epilogue)
 //   mode 1: a pair written by two v_mov_b32 (VALU-written)
 // checked bit for bit against two v_mul_f32 of the same operands, ~1e9 lane-operations per mode, with a bandwidth-bound kernel busy on a
 // second stream (modes 2 / 3 further down: the whole instruction sequence of the faulty epilogue).  Mismatches are counted per lane group
-// (lanes 0-47 / 48-63).  Build + run ONCE on the GPU box:
+// (lanes 0-47 / 48-63).  RESULT: modes 0-3 are clean (round 4, profiles/r04_pk_opsel_probe.log) - and mode 4, added in round 5 (the same
+// sequence with MFMAs running in the SIMD's other wave), is NOT: ~8e5 wrong values, all in lanes 48-63 (profiles/r05_defect_isa/).
+// tools/probes/pk_mfma.hip takes it apart from there.  Build + run ONCE on the GPU box:
 //   hipcc --offload-arch=gfx950 -O2 tools/probes/pk_opsel.hip -o /tmp/pk_opsel && /tmp/pk_opsel
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -89,6 +91,64 @@ __global__ __launch_bounds__(512) void probe_seq(const f2* __restrict__ R, const
   if (nbad) atomicAdd(bad + ((threadIdx.x & 63) >= 48), nbad);
 }
 
+// Modes 4 / 5 (round 5): what the modes above leave out and both defect sites had - MFMA work on the SAME SIMD while the packed ops run (the faulty
+// epilogue's wave shares its SIMD with other workgroups' waves inside their k loops, accumulators in AGPRs; LayerNorm d gamma went wrong "more often
+// with other streams busy", and those streams run GEMMs).  512-thread workgroups, two waves per SIMD:
+//   mode 4: waves 0-3 run the epilogue sequence of mode 2, waves 4-7 issue back-to-back v_mfma_f32_32x32x16_bf16 until the first four are done
+//   mode 5: every wave issues four independent MFMAs itself right in front of each epilogue sequence (MFMA -> packed-op issue in one wave)
+typedef __attribute__((ext_vector_type(8))) __bf16 mf_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float mf_f32x16;
+template <int SAME>
+__global__ __launch_bounds__(512) void probe_mfma(const f2* __restrict__ R, const f2* __restrict__ st, long n, int iters, unsigned* __restrict__ bad, float* __restrict__ sink) {
+  __shared__ int done;
+  if (threadIdx.x == 0) done = 0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  mf_f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  mf_bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)((threadIdx.x + i) & 7); b[i] = (__bf16)(0.125f * (float)((threadIdx.x ^ i) & 3)); }
+  if (!SAME && wave >= 4) {                    // the MFMA neighbours: every wave leaves as soon as the four probing waves have (they always finish)
+    int guard = 0;
+    while (__hip_atomic_load(&done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 && ++guard < (1 << 22)) {
+      for (int r = 0; r < 16; ++r) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+      }
+    }
+    if (c0[0] + c1[1] + c2[2] + c3[3] == 12345.f) sink[threadIdx.x] = c0[5];
+    return;
+  }
+  const int nprobe = SAME ? 512 : 256;
+  const long tid = (long)blockIdx.x * nprobe + threadIdx.x, nthr = (long)gridDim.x * nprobe;
+  unsigned nbad = 0;
+  for (int it = 0; it < iters; ++it) {
+    const long row = (tid + (long)it * nthr * 5) % n;
+    const f2* rp = R + 2 * (row % (n / 2));
+    unsigned long long sa = (unsigned long long)(st + row);
+    f2 r01, r23;
+    if (SAME) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+    }
+    asm volatile("global_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %3, off offset:8\n\tglobal_load_dwordx2 %2, %2, off\n\ts_waitcnt vmcnt(0)\n\t"
+                 "v_pk_add_f32 %0, %0, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 %0, %0, %2 op_sel:[0,1]\n\tv_pk_mul_f32 %1, %1, %2 op_sel:[0,1]"
+                 : "=&v"(r01), "=&v"(r23), "+v"(sa) : "v"(rp) : "memory");
+    float mean, rstd, e0, e1, e2, e3;
+    const f2 av = rp[0], bv = rp[1];
+    asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:4\n\ts_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7"
+                 : "=&v"(mean), "=&v"(rstd) : "v"(st + row) : "memory");
+    asm volatile("v_sub_f32 %0, %4, %8\n\tv_sub_f32 %1, %5, %8\n\tv_sub_f32 %2, %6, %8\n\tv_sub_f32 %3, %7, %8\n\t"
+                 "v_mul_f32 %0, %0, %9\n\tv_mul_f32 %1, %1, %9\n\tv_mul_f32 %2, %2, %9\n\tv_mul_f32 %3, %3, %9"
+                 : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3) : "v"(av[0]), "v"(av[1]), "v"(bv[0]), "v"(bv[1]), "v"(mean), "v"(rstd));
+    nbad += (__float_as_uint(r01[0]) != __float_as_uint(e0)) + (__float_as_uint(r01[1]) != __float_as_uint(e1)) +
+            (__float_as_uint(r23[0]) != __float_as_uint(e2)) + (__float_as_uint(r23[1]) != __float_as_uint(e3));
+  }
+  if (nbad) atomicAdd(bad + ((threadIdx.x & 63) >= 48), nbad);
+  if (SAME && c0[0] + c1[1] + c2[2] + c3[3] == 12345.f) sink[threadIdx.x] = c0[5];
+  if (!SAME && (threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 int main() {
   const long n = 1L << 24;                    // 16 M pairs = 128 MB per array: beyond the L2s
   std::vector<f2> hx(n), hs(n);
@@ -127,5 +187,14 @@ int main() {
       printf("epilogue sequence%s, neighbour stream %-4s: %.3g rows x 4 values; wrong values: lanes 0-47 %u, lanes 48-63 %u\n",
              nops ? " + 16 idle cycles behind the wait" : "", busy ? "busy" : "idle", (double)512 * 512 * iters, h[0], h[1]);
     }
+  for (int same = 0; same < 2; ++same) {
+    CK(hipMemset(dbad, 0, 16 * sizeof(unsigned)));
+    if (same) hipLaunchKernelGGL(probe_mfma<1>, dim3(512), dim3(512), 0, s1, dx, ds, n, iters / 2, dbad, sink);
+    else hipLaunchKernelGGL(probe_mfma<0>, dim3(512), dim3(512), 0, s1, dx, ds, n, iters, dbad, sink);
+    CK(hipDeviceSynchronize());
+    unsigned h[2]; CK(hipMemcpy(h, dbad, sizeof(h), hipMemcpyDeviceToHost));
+    printf("epilogue sequence with MFMAs %s: %.3g rows x 4 values; wrong values: lanes 0-47 %u, lanes 48-63 %u\n",
+           same ? "issued by the same wave in front of it" : "running in the SIMD's other wave", (double)512 * 256 * iters, h[0], h[1]);
+  }
   return 0;
 }
