@@ -10,7 +10,7 @@ EXTRA=""
 if [ "${MP_DIAG:-0}" = "1" ]; then OUT="$HERE/../libmanipose_hip_diag.so"; OBJ="$HERE/_obj_diag"; EXTRA="-DMP_GEMM_DIAG"; fi
 mkdir -p "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-# -fno-slp-vectorize and -packed-fp32-ops: no v_pk_*_f32 in the device code.  Two round-3 wrong-result defects sat at SLP-made packed ops with op_sel (cause not identified: common.h, "packed-fp32 guard")
+# -fno-slp-vectorize and -packed-fp32-ops: no v_pk_*_f32 in the device code.  Two round-3 wrong-result defects sat at SLP-made packed ops with op_sel (cause: common.h, "packed-fp32 guard"; reproduced in round 5, profiles/r05_defect_isa/)
 # (DESIGN sections 2 and 5), and packed fp32 is slower than the plain instructions it replaces on this chip (same-box A/B of the whole
 # library: 171.6 / 170.9 -> 170.2 / 169.9 ms per step).  The feature flag also reaches the host pass, which says it does not know it: filtered.
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops -Wall -Wno-unused-function $EXTRA"

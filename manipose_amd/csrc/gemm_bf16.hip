@@ -535,6 +535,12 @@ __device__ __forceinline__ int kflag_nonnull(const void* p) { int r; asm volatil
 __device__ __forceinline__ int kflag_more(int a, int b, int x) { int r; asm volatile("s_cmp_lg_u32 %1, %2\n\ts_cselect_b32 %0, 1, %3" : "=s"(r) : "s"(a), "s"(b), "s"(x) : "scc"); return r; }
 // (a == b) ? x : 0
 __device__ __forceinline__ int kflag_last(int a, int b, int x) { int r; asm volatile("s_cmp_eq_u32 %1, %2\n\ts_cselect_b32 %0, %3, 0" : "=s"(r) : "s"(a), "s"(b), "s"(x) : "scc"); return r; }
+// MP_KLOOP_PIPE (with MP_KLOOP_ASM and MP_KSTEP_YOUNG): k-tiles 0 .. nk-2 of a tile of the split-precision forward loop run as ONE asm block with the
+// loop inside and the fragment pipeline continuing across the steps - every step's barrier stands two MFMA groups before its end instead of in front
+// of it (tools/gen_kloop_asm.py, pipe_loop_x3); the tile's last k-tile keeps the block-per-step form.
+#ifndef MP_KLOOP_PIPE
+#define MP_KLOOP_PIPE 1
+#endif
 enum { KC_X0 = 0, KC_X1 = 1, KC_X2 = 2, KC_P = 3 };
 #define MP_KSTEP_SEL2(c, t, v) MP_KSTEP_ASM_##c##_TRB##t##_V##v
 #define MP_KSTEP_SEL(c, t, v) MP_KSTEP_SEL2(c, t, v)
@@ -581,6 +587,27 @@ __device__ __forceinline__ void kstep_asm(f32x4 (&acc)[8][4], const KFragA& fa, 
 #endif
   }
 }
+#if MP_KSTEP_YOUNG
+// k-tiles 0 .. n-1 (n = nk - 1 >= 1) of a split-precision forward tile, behind the tile's first barrier (A_lo[0], B_hi[0] landed in A0, B0; A1, B1 free).
+// pa / pb: the hi planes' addresses of the tile's k-tile 0.  aoff / boff come back advanced by n k-tiles (128 bytes each) in the waves that issue DMA.
+__device__ __forceinline__ void kpipe_x3(f32x4 (&acc)[8][4], const KFragA (&kfa)[2], const KFragB (&kfb)[2], unsigned (&aoff)[KNP], unsigned (&boff)[KNP],
+                                         int dma_wave, unsigned dma_l, const char* pa, const char* pb, long a_lo, long b_lo, int n) {
+  const char* const pahi0 = pa;                    // A_hi[0], B_lo[0]: the entry's requests
+  const char* const pblo0 = pb + b_lo;
+  const char* const pahi1 = pa + 128;              // "the next k-tile" of each plane: the offsets advance, these stay
+  const char* const palo1 = pa + 128 + a_lo;
+  const char* const pbhi1 = pb + 128;
+  const char* const pblo1 = pb + 128 + b_lo;
+  asm volatile(MP_KPIPE_X3_ASM
+               : MP_KSTEP_ACC_OPERANDS, [cnt] "+s"(n),
+                 [ao0] "+v"(aoff[0]), [ao1] "+v"(aoff[1]), [ao2] "+v"(aoff[2]), [ao3] "+v"(aoff[3]), [ao4] "+v"(aoff[4]), [ao5] "+v"(aoff[5]), [ao6] "+v"(aoff[6]), [ao7] "+v"(aoff[7]),
+                 [bo0] "+v"(boff[0]), [bo1] "+v"(boff[1]), [bo2] "+v"(boff[2]), [bo3] "+v"(boff[3]), [bo4] "+v"(boff[4]), [bo5] "+v"(boff[5]), [bo6] "+v"(boff[6]), [bo7] "+v"(boff[7])
+               : [a0k0] "v"(kfa[0].a[0]), [a0k1] "v"(kfa[0].a[1]), [a1k0] "v"(kfa[1].a[0]), [a1k1] "v"(kfa[1].a[1]),
+                 [b0k0] "v"(kfb[0].b[0]), [b0k1] "v"(kfb[0].b[1]), [b1k0] "v"(kfb[1].b[0]), [b1k1] "v"(kfb[1].b[1]),
+                 [dmaw] "s"(dma_wave), [lds] "s"(dma_l), [pahi0] "s"(pahi0), [pblo0] "s"(pblo0), [pahi1] "s"(pahi1), [palo1] "s"(palo1), [pbhi1] "s"(pbhi1), [pblo1] "s"(pblo1)
+               : MP_KSTEP_CLOB(MP_KSTEP_VARIANT));
+}
+#endif
 
 // The same with an UNEVEN split of a tile's 32 DMA pieces over the waves (weight-gradient kernel): the waves of group 0 (0-3) take P0 pieces
 // each, those of group 1 (4-7) 8 - P0.  Measured, not derived: group 0 - the older wave of every SIMD - with ONE piece per operand and group 1
@@ -1087,11 +1114,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
         const char* pb = tile_b;                           // B_hi of k-tile kt
         const KJob none = {0, 0u, nullptr};
         const unsigned coff = 4u * lane;
-        for (int kt = 0; kt < nk; ++kt, pa += GBK * 2, pb += kstep_b) {
-          const bool last = kt + 1 == nk;
-          const int more_i = kflag_more(kt + 1, nk, has_next_i);
 #ifdef MP_GEMM_DIAG
-          unsigned long long tk0 = __builtin_readcyclecounter(), tk1, tk2;
 #define MP_KDIAG_A() tk1 = __builtin_readcyclecounter()
 #define MP_KDIAG_B() tk2 = __builtin_readcyclecounter(); dg_wait += tk1 - tk0; dg_bar += tk2 - tk1
 #define MP_KDIAG_C() tk0 = __builtin_readcyclecounter(); dg_mma += tk0 - tk2
@@ -1099,6 +1122,48 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
 #define MP_KDIAG_A()
 #define MP_KDIAG_B()
 #define MP_KDIAG_C()
+#endif
+        constexpr bool PIPE = MP_KLOOP_PIPE && YOUNG && TRB == 0;
+        if constexpr (PIPE) {
+          // k-tiles 0 .. nk-2 in one block (pipeline across the steps, barriers inside), then the last k-tile block by block: its step 0 needs no
+          // barrier (A0, B0 landed before the block's last barrier; it requests nothing - A_hi, B_lo of this k-tile are on their way since then)
+          if (landed) __builtin_amdgcn_s_waitcnt(0xC07F);
+          else __builtin_amdgcn_s_waitcnt(0x0070);
+          __builtin_amdgcn_s_barrier();
+#ifdef MP_GEMM_DIAG
+          const unsigned long long tp0 = __builtin_readcyclecounter();
+#endif
+          kpipe_x3(acc, kfa, kfb, aoff, boff, dma_wave, dma_l, pa, pb, a_lo, b_lo, nk - 1);
+#pragma unroll
+          for (int i = 0; i < NP; ++i) boff[i] -= (unsigned)(nk - 1) * (GBK * 2);      // (the B offsets are the same for every tile: back to k-tile 0)
+          pa += (long)(nk - 1) * GBK * 2; pb += (long)(nk - 1) * kstep_b;
+          const int more_i = has_next_i;
+          kstep_asm<TRB, KC_X0>(acc, kfa[0], kfb[0], none, aoff, none, boff, none, coff);
+          if (more_i) persist_offsets_n<0, NP>(aoff, g.lda, m0n, g.M, opaque(lane), dma_first);
+#ifdef MP_GEMM_DIAG
+          unsigned long long tk0 = __builtin_readcyclecounter(), tk1, tk2;
+          dg_mma += tk0 - tp0;
+#endif
+          __builtin_amdgcn_s_waitcnt(0x0078);               // vmcnt(8): A_hi has landed, B_lo behind it may still be in flight
+          MP_KDIAG_A();
+          __builtin_amdgcn_s_barrier();
+          MP_KDIAG_B();
+          kstep_asm<TRB, KC_X1>(acc, kfa[1], kfb[0], KJob{more_i & dma_wave, dma_l, tile_an + a_lo}, aoff, none, boff, none, coff);
+          MP_KDIAG_C();
+          if (more_i) __builtin_amdgcn_s_waitcnt(0x0078);   // B_lo has landed, the next tile's A_lo may still be in flight
+          else __builtin_amdgcn_s_waitcnt(0x0070);
+          MP_KDIAG_A();
+          __builtin_amdgcn_s_barrier();
+          MP_KDIAG_B();
+          kstep_asm<TRB, KC_X2>(acc, kfa[1], kfb[1], none, aoff, KJob{more_i & dma_wave, dma_l + OPB, tile_bn}, boff,
+                                KJob{has_bias_i, img_l, reinterpret_cast<const char*>(g.bias + n0 + wc * 64)}, coff);
+          MP_KDIAG_C();
+        } else
+        for (int kt = 0; kt < nk; ++kt, pa += GBK * 2, pb += kstep_b) {
+          const bool last = kt + 1 == nk;
+          const int more_i = kflag_more(kt + 1, nk, has_next_i);
+#ifdef MP_GEMM_DIAG
+          unsigned long long tk0 = __builtin_readcyclecounter(), tk1, tk2;
 #endif
           // step 0: (A0 = A_lo, B0 = B_hi); requests A_hi[kt] -> A1
           if (kt == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only: (A_lo, B_hi) of this tile were waited for before the previous epilogue

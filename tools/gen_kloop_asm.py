@@ -183,6 +183,104 @@ def step(trb, cfg, dma="spread", ahead=2, base=200, pad=False):
     return ins
 
 
+def pipe_loop_x3(ahead=2):
+    """The split-precision loop's k-tiles 0 .. nk-2 of a tile as ONE asm block with the loop inside (MP_KLOOP_PIPE): the fragment pipeline runs
+    ACROSS the steps.  A step's barrier does not stand in front of it but two groups of 8 MFMAs before its end, in front of the first
+    request that reads the NEXT step's buffers: behind `s_waitcnt vmcnt(V) lgkmcnt(0); s_barrier` every wave has finished reading this
+    step's buffers (so the DMA into them may be issued at once) and the next step's tiles have landed for every wave; each wave still holds
+    the fragments of two groups, whose 16 MFMAs (and the SIMD partner's) cover the latency of the next step's first requests - the ~300 idle
+    cycles at the head of every step of the block-per-step form.  Buffers and DMA schedule per k-tile kt (A0 | B0 | A1 | B1):
+      step 0 (A0 = A_lo, B0 = B_hi): behind its barrier A0 is free  -> A_lo[kt + 1];   needs A1 = A_hi[kt] landed: vmcnt(8) (B_lo[kt] may fly)
+      step 1 (A1 = A_hi, B0):        behind its barrier B0 is free  -> B_hi[kt + 1];   needs B1 = B_lo[kt]: vmcnt(8) (A_lo[kt + 1] may fly)
+      step 2 (A1, B1 = B_lo):        behind its barrier A1, B1 free -> A_hi[kt + 1], B_lo[kt + 1];   needs A0, B0 of kt + 1: vmcnt(0)
+    Entry (behind the tile's first barrier): the head requests, then A_hi[0], B_lo[0].  DMA by waves 4-7 only (8 pieces of a tile each);
+    source = a constant base per plane (+ 128 bytes: "the next k-tile") + the per-lane offsets, which advance by 128 bytes per k-tile.
+    The tile's last k-tile runs in the block-per-step form (its jobs depend on the next tile).  "N" operand layout only (forward)."""
+    global FA0, FB0
+    FA0, FB0 = 200, 224
+    OPB, STAGE = 32768, 65536
+    ins, pend = [], []
+    A = {0: ("a0k0", "a0k1"), 1: ("a1k0", "a1k1")}
+    B = {0: ("b0k0", "b0k1"), 1: ("b1k0", "b1k1")}
+    bufs = [(0, 0), (1, 0), (1, 1)]                  # (A buffer, B buffer) of steps 0 / 1 / 2
+
+    def rd_a(G, abuf):
+        g = G % 8
+        return [f"ds_read_b128 {vr(fa(G % 3, f))}, %[{A[abuf][g // 4]}] offset:{(2 * (g % 4) + f) * 2048}" for f in range(2)], 2
+
+    def rd_b(G, bbuf):
+        ks = (G % 8) // 4
+        return [f"ds_read_b128 {vr(fb(ks, j))}, %[{B[bbuf][ks]}] offset:{j * 2048}" for j in range(4)], 4
+
+    def request(lines, n, needed_by):
+        ins.extend(lines)
+        pend.append((needed_by, n))
+
+    def wait_for(G):
+        if not any(need <= G for need, n in pend):
+            return
+        younger = sum(n for need, n in pend if need > G)
+        ins.append(f"s_waitcnt lgkmcnt({younger})")
+        pend[:] = [(need, n) for need, n in pend if need > G]
+
+    def job(lds_const, base, offs, imm=0):
+        out = []
+        for n in range(8):
+            out += [f"s_add_u32 m0, %[lds], {lds_const + n * 1024}", "s_nop 0",
+                    f"global_load_lds_dwordx4 %[{offs}{n}], %[{base}]" + (f" offset:{imm}" if imm else "")]
+        return out
+
+    def young(tag, body):
+        return [f"s_cmp_eq_u32 %[dmaw], 0", f"s_cbranch_scc1 .Lkp{tag}_%="] + body + [f".Lkp{tag}_%=:"]
+
+    # entry: the head requests of step 0, then A_hi[0] -> A1 and B_lo[0] -> B1
+    r, n = rd_b(0, 0); request(r, n, 0)
+    r, n = rd_a(0, 0); request(r, n, 0)
+    r, n = rd_a(1, 0); request(r, n, 1)
+    ins.extend(young("e", job(STAGE, "pahi0", "ao") + job(STAGE + OPB, "pblo0", "bo")))      # (an instruction offset would also move the LDS address)
+    ins.append(".Lkploop_%=:")
+    head_pend = list(pend)
+    VM = [8, 8, 0]
+    for S in range(3):
+        abuf, bbuf = bufs[S]
+        nabuf, nbbuf = bufs[(S + 1) % 3]
+        for g in range(8):
+            G = 8 * S + g
+            if g == 8 - ahead:
+                ins.append(f"s_waitcnt vmcnt({VM[S]}) lgkmcnt(0)")
+                ins.append("s_barrier")
+                pend[:] = []
+            else:
+                wait_for(G)
+            slot, ks, p = G % 3, g // 4, g % 4
+            mf = []
+            for f in range(2):
+                for j in range(4):
+                    c = f"%[c{2 * p + f}{j}]"
+                    mf.append(f"v_mfma_f32_16x16x32_bf16 {c}, {vr(fb(ks, j))}, {vr(fa(slot, f))}, {c}")
+            ins.append(mf[0])
+            t = G + ahead
+            nxt = t >= 8 * (S + 1)                   # a request into the next step's buffers (behind this step's barrier)
+            # step 1 multiplies the B tile of step 0 again: its B fragments are still in the two register sets, no request
+            if t % 4 == 0 and (t % 24) // 8 != 1:
+                r, n = rd_b(t, nbbuf if nxt else bbuf); request(r, n, t)
+            r, n = rd_a(t, nabuf if nxt else abuf); request(r, n, t)
+            if g == 8 - ahead:
+                if S == 0:
+                    ins.extend(young("a", job(0, "palo1", "ao")))
+                elif S == 1:
+                    ins.extend(young("b", job(OPB, "pbhi1", "bo")))
+                else:
+                    adv = [f"v_add_u32 %[ao{n}], 128, %[ao{n}]" for n in range(8)] + [f"v_add_u32 %[bo{n}], 128, %[bo{n}]" for n in range(8)]
+                    ins.extend(young("c", job(STAGE, "pahi1", "ao") + job(STAGE + OPB, "pblo1", "bo") + adv))
+            ins.extend(mf[1:])
+    # the requests in flight at the back edge are those in flight at the loop's head (same counts, group numbers modulo 24)
+    assert [(need - 24, n) for need, n in pend] == head_pend, (pend, head_pend)
+    ins += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 .Lkploop_%=",
+            "s_waitcnt lgkmcnt(0)"]                  # (the last iteration's requests for a step 0 that runs in the block-per-step form: let them land)
+    return ins
+
+
 HEADER = """// GENERATED by tools/gen_kloop_asm.py - do not edit (tests/test_host_cpu.py checks that it is up to date).
 // One 64-wide k-step of a wave's 128 x 64 sub-tile as a single inline-asm block: see the generator's docstring for the schedule.
 // Registers v[200:255] hold the fragment ring (clobbered); operands: the 32 accumulator tuples, the LDS fragment addresses, the DMA jobs.
@@ -199,6 +297,11 @@ def emit():
                 for i, l in enumerate(lines):
                     out.append(f'  "{l}\\n"' + (" \\" if i + 1 < len(lines) else ""))
                 out.append("")
+    lines = pipe_loop_x3()
+    out.append("#define MP_KPIPE_X3_ASM \\")
+    for i, l in enumerate(lines):
+        out.append(f'  "{l}\\n"' + (" \\" if i + 1 < len(lines) else ""))
+    out.append("")
     acc = ", ".join(f'[c{i}{j}] "+v"(acc[{i}][{j}])' for i in range(8) for j in range(4))
     out.append(f"#define MP_KSTEP_ACC_OPERANDS {acc}")
     for v, opt in sorted(VARIANTS.items()):
