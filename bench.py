@@ -125,6 +125,50 @@ PARITY_WINDOWS = 3             # parity windows per run (oracle forward on the h
 EXTRA_BATCH = {"fp32": 16, "bf16": 79, "bf16x3": 79}
 
 
+def _power_pass(step, seconds=3.0):
+    """socket power (W) and shader clock (MHz) sampled through rocm-smi every ~0.2 s while `step` runs back to back; None if rocm-smi is not usable"""
+    import re, shutil, subprocess, threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                out = subprocess.run([smi, "--showclocks", "--showpower", "--csv"], capture_output=True, text=True, timeout=5).stdout
+                row = [l for l in out.splitlines() if l.startswith("card0")]
+                if row:
+                    f = row[0].split(",")
+                    samples.append((int(re.sub(r"\D", "", f[5])), float(f[9])))
+            except Exception:
+                return
+            stop.wait(0.2)
+
+    cap = None
+    try:
+        out = subprocess.run([smi, "--showmaxpower", "--csv"], capture_output=True, text=True, timeout=5).stdout
+        row = [l for l in out.splitlines() if l.startswith("card0")]
+        nums = re.findall(r"\d+(?:\.\d+)?", row[0].split(",", 1)[1]) if row else []
+        cap = float(nums[0]) if nums else None
+    except Exception:
+        pass
+    th = threading.Thread(target=poll)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        step()
+        torch.cuda.synchronize()
+    stop.set()
+    th.join()
+    busy = samples[2:] if len(samples) > 4 else samples      # (the first samples still see the ramp)
+    if not busy:
+        return None
+    return {"mean_w": sum(w for _, w in busy) / len(busy), "max_w": max(w for _, w in busy), "cap_w": cap,
+            "mean_sclk_mhz": sum(c for c, _ in busy) / len(busy), "part_max_sclk_mhz": 2400, "samples": len(busy),
+            "note": "rocm-smi (socket graphics package power, sclk) sampled every ~0.2 s over ~3 s of the timed configuration's steps, behind the timed region"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +194,7 @@ def main():
                          "stream) instead of one all-reduce of the flat buffer behind it; off by default (never measured on a multi-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock samples behind the timed region (N=1 only)")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity measurement (profiling passes)")
     ap.add_argument("--no-extra", action="store_true", help="skip the few-step runs of the other precisions (N=1 only)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) CPU child: time the CPU oracle and print its JSON")
@@ -388,6 +433,14 @@ def main():
                     "classes_sum_ms_per_step": sum(v["ms"] for v in pi.values()) / ni}
         log(f"one-queue pass: {isolated['ms_per_step']:.1f} ms per step, kernel classes sum {isolated['classes_sum_ms_per_step']:.1f} ms")
 
+    # N=1: socket power and shader clock while the same steps run (behind the timed region; rocm-smi child processes, read-only).  Round 5 found the
+    # GEMMs and the step as a whole at the board's power cap ("power"): the kernel times then follow energy, not the schedule.
+    power = None
+    if rank == 0 and world == 1 and not args.no_power:
+        power = _power_pass(lambda: trainer.train_step(X, y), seconds=3.0)
+        if power:
+            log(f"power pass: {power['mean_w']:.0f} W mean of a {power.get('cap_w')} W cap, shader clock {power['mean_sclk_mhz']:.0f} MHz, {power['samples']} samples")
+
     # N=1: the other precisions on the same workload, a few steps each (their own batch sizes), with the same parity measurement
     other = {}
     if rank == 0 and world == 1 and not args.no_extra:
@@ -556,6 +609,8 @@ def main():
                          "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}
                 kc[n] = e
             out["kernel_classes"] = kc
+            if power:
+                out["power"] = power
             if isolated:
                 out["kernel_classes_basis"] = {"isolated_sum_ms_per_step": isolated["classes_sum_ms_per_step"], "one_queue_ms_per_step": isolated["ms_per_step"],
                                                "one_queue_steps": isolated["steps"], "three_queue_ms_per_step": 1e3 * dt / args.steps,

@@ -8,7 +8,7 @@ timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "hea
 tail -n 3 gpurun_out/heads_tests.log
 cd /tmp && export TMPDIR=/tmp
 for v in 0 1; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/hm$v -- python /root/repo/bench.py --option heads_mfma=$v --steps 4 --warmup 2 --no-cpu-baseline --no-parity --no-extra > /root/repo/gpurun_out/hm$v.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/hm$v -- python /root/repo/bench.py --option heads_mfma=$v --steps 4 --warmup 2 --no-cpu-baseline --no-parity --no-extra --no-power > /root/repo/gpurun_out/hm$v.log 2>&1
   tail -n 1 /root/repo/gpurun_out/hm$v.log | cut -c1-200
   f=$(find /root/repo/gpurun_out/hm$v -name "*kernel_stats.csv" | head -n 1)
   grep -i "heads\|scores" $f | cut -c1-160

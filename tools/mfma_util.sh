@@ -6,7 +6,7 @@ set -eu
 TAG="${1:-r03_bf16x3_B79}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/profiles_new; mkdir -p "$O"; rm -rf "$O/mf"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O/mf" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra --no-prof > "$O/mfma.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O/mf" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra --no-power --no-prof > "$O/mfma.log" 2>&1
 python - "$(find "$O/mf" -name '*counter_collection.csv' | head -1)" "$O/${TAG}_pmc_mfma_util.csv" <<'PY'
 import collections, csv, sys
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -5,7 +5,7 @@ set -eu
 TAG="$1"; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/sq_$TAG; rm -rf "$O"; mkdir -p "$O"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python bench.py --single-queue --steps 3 --warmup 2 --no-cpu-baseline --no-parity --no-extra --no-prof "$@" > "$O/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python bench.py --single-queue --steps 3 --warmup 2 --no-cpu-baseline --no-parity --no-extra --no-power --no-prof "$@" > "$O/stats.log" 2>&1
 find "$O/stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$O/kernel_stats.csv"
 rm -rf "$O/stats"
 python - "$O/kernel_stats.csv" <<'PY'
