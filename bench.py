@@ -128,6 +128,7 @@ EXTRA_BATCH = {"fp32": 16, "bf16": 79, "bf16x3": 79}
 def _power_pass(step, seconds=3.0):
     """socket power (W) and shader clock (MHz) sampled through rocm-smi every ~0.2 s while `step` runs back to back; None if rocm-smi is not usable"""
     import re, shutil, subprocess, threading
+    import torch
     smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     if not os.path.exists(smi):
         return None
@@ -153,14 +154,16 @@ def _power_pass(step, seconds=3.0):
         cap = float(nums[0]) if nums else None
     except Exception:
         pass
-    th = threading.Thread(target=poll)
+    th = threading.Thread(target=poll, daemon=True)
     th.start()
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        step()
-        torch.cuda.synchronize()
-    stop.set()
-    th.join()
+    try:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            step()
+            torch.cuda.synchronize()
+    finally:
+        stop.set()
+        th.join(timeout=10)
     busy = samples[2:] if len(samples) > 4 else samples      # (the first samples still see the ramp)
     if not busy:
         return None
