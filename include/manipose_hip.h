@@ -273,7 +273,9 @@ int mp_model_grad_bucket_wait(mp_model* m, int index, void* stream);
  * the step with f16_backward off or skip it (manipose_amd/training.py does the latter).  MP_ERR_STATE unless a completed mp_model_backward is
  * the last engine call (a forward, or a backward that failed midway, has overwritten what the counters described).
  * mp_model_grad_health_async: the same four values as floats into a DEVICE (or pinned host) buffer by an asynchronous copy on `stream`, no
- * host synchronisation - for a trainer that looks at the counters every N steps. */
+ * host synchronisation - for a trainer that looks at the counters every N steps.  Cost, accepted: a backward of an f16_backward model reads the
+ * residual-gradient stream of the heads once more on its main stream to choose S (one M x C fp32 pass, ~0.25 ms at the benchmark's batch) and
+ * resets the counters there; the synchronous form blocks the host until `stream` is idle. */
 int mp_model_grad_health(mp_model* m, float* out4_host, void* stream);
 int mp_model_grad_health_async(mp_model* m, float* out4_device, void* stream);
 /* Which of the engine's two extra streams the NEXT forward / backward calls use: the `streams` bit set of mp_model_config, changed on a live
