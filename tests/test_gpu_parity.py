@@ -1401,6 +1401,51 @@ def test_bf16x3_linear_forward_epilogues(lib, M, N, K):
     assert (y32.cpu().double() - (pre + r.double())).abs().max().item() / scale < 4e-5
 
 
+@pytest.mark.parametrize("M,N,K,wgs", [(300, 256, 128, 0), (1027, 768, 192, 8), (2049, 768, 320, 8), (777, 512, 1024, 0), (5000, 1536, 512, 16), (4131, 256, 128, 8)])
+def test_bf16x3_persistent_loop_shapes(lib, M, N, K, wgs):
+    """The persistent split-precision kernel's hand-scheduled loop (csrc/gemm_bf16.hip, MP_KLOOP_PIPE: k-tiles 0 .. nk-2 of a tile in one
+    pipelined asm block, the last k-tile block by block) forced on at small sizes: two k-tiles (one pass of the loop), odd k-tile counts, 16
+    k-tiles, one tile per workgroup (no next tile to prefetch) and several (few workgroups: the next tile's first k-tile is fetched during
+    the last), ragged last row panel; all three epilogues against the fp64 product and against the tiled kernels."""
+    from manipose_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    xd, Wd, bd, rd = x.cuda(), W.cuda(), b.cuda(), r.cuda()
+    xh, xl, Wh, Wl = (torch.empty(t.shape, device="cuda", dtype=torch.bfloat16) for t in (x, x, W, W))
+    _lib.check(lib.mp_split_bf16(xd.data_ptr(), xh.data_ptr(), xl.data_ptr(), xd.numel(), st()))
+    _lib.check(lib.mp_split_bf16(Wd.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), Wd.numel(), st()))
+    pre = x.double() @ W.double().t() + b.double()
+    scale = float(pre.abs().max())
+    res = {}
+    for min_tiles in (1, 1 << 30):                   # persistent kernel forced / tiled kernels only
+        _lib.check(lib.mp_set_option(b"gemm_persist_min_tiles", min_tiles))
+        if wgs: _lib.check(lib.mp_set_option(b"gemm_persist_wgs", wgs))
+        try:
+            yh, yl = torch.full((M, N), float("nan"), device="cuda").bfloat16(), torch.full((M, N), float("nan"), device="cuda").bfloat16()
+            _lib.check(lib.mp_linear_fwd_bf16x3(xh.data_ptr(), xl.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), bd.data_ptr(), yh.data_ptr(), yl.data_ptr(),
+                                                None, None, M, N, K, 0, st()))
+            zh, zl, z = torch.empty_like(yh), torch.empty_like(yh), torch.empty_like(yh)
+            _lib.check(lib.mp_linear_fwd_bf16x3(xh.data_ptr(), xl.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), bd.data_ptr(), zh.data_ptr(), zl.data_ptr(),
+                                                z.data_ptr(), None, M, N, K, 1, st()))
+            y32 = torch.full((M, N), float("nan"), device="cuda")
+            _lib.check(lib.mp_linear_fwd_bf16x3(xh.data_ptr(), xl.data_ptr(), Wh.data_ptr(), Wl.data_ptr(), bd.data_ptr(), y32.data_ptr(), None,
+                                                None, rd.data_ptr(), M, N, K, 2, st()))
+            torch.cuda.synchronize()
+        finally:
+            _lib.check(lib.mp_set_option(b"gemm_persist_min_tiles", 0))
+            if wgs: _lib.check(lib.mp_set_option(b"gemm_persist_wgs", 0))
+        assert (_join(yh, yl).cpu().double() - pre).abs().max().item() / scale < 4e-5, min_tiles
+        assert (_join(zh, zl).cpu().double() - torch.nn.functional.gelu(pre)).abs().max().item() / scale < 4e-5, min_tiles
+        assert (y32.cpu().double() - (pre + r.double())).abs().max().item() / scale < 4e-5, min_tiles
+        res[min_tiles] = (yh.cpu(), yl.cpu(), zh.cpu(), zl.cpu(), z.cpu(), y32.cpu())
+    p_, t_ = res[1], res[1 << 30]                    # (the 128-tile kernel sums in another order: agreement, not identity)
+    assert (_join(p_[0], p_[1]) - _join(t_[0], t_[1])).abs().max().item() <= 2e-5 * scale
+    assert (_join(p_[2], p_[3]) - _join(t_[2], t_[3])).abs().max().item() <= 2e-5 * scale
+    assert (p_[5] - t_[5]).abs().max().item() <= 2e-5 * scale
+
+
 def f16f8_planes(v, weight):
     """The "f16f8" operand format of include/manipose_hip.h (mp_linear_fwd_f16f8), built on the host: fp16 hi plane + the 8-bit correction
     plane (per four reduction indices: 4 e4m3 bytes | 4 e4m3 bytes).  Returns (hi, correction bytes, first half, second half)."""
