@@ -12,7 +12,7 @@ TAG="${1:-r04_bf16x3_B79}"
 EXTRA="${2:-}"          # extra bench flags of the configuration profiled, e.g. "--f16f8 1 --f16-backward"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/profiles_new; rm -rf "$O"; mkdir -p "$O"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-extra --no-power $EXTRA > "$O/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-extra --no-power --no-isolated $EXTRA > "$O/stats.log" 2>&1
 find "$O/stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$O/${TAG}_kernel_stats.csv"
 grep "^{" "$O/stats.log" > "$O/${TAG}_bench_under_rocprof.json"
 find "$O/stats" -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/stream_timeline.py {} > "$O/${TAG}_stream_timeline.txt"
