@@ -73,6 +73,10 @@ __device__ __forceinline__ void st4(bf16* p, float4 v) {
 // bf16 kernels can read a planar buffer unchanged.  `bf16p` tags a pointer to the hi plane of such a pair.
 struct bf16p { unsigned short v; };
 __device__ __forceinline__ void split_bf16x2(float a, float b, unsigned& hi, unsigned& lo) {
+  // What is split is the ROUNDED fp32 value.  Without the opaque move hipcc may fuse the multiply that produced it into the subtraction below
+  // (fma(x, y, -hi): the unrounded product) in some unrolled copies of an epilogue and not in others - round 5 found the lo plane of the GELU
+  // epilogue one ulp different in the last 4 of a wave's 128 rows, i.e. a token's result depending on its row position (tools/probes/half_batch_ops.py)
+  asm("" : "+v"(a), "+v"(b));
   hi = pack_bf16x2(a, b);
   lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
