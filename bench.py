@@ -570,6 +570,9 @@ def main():
                                "ridge_flop_per_byte": ridge,
                                "hbm_gbps": gbps, "hbm_frac": gbps / peak_bw,
                                "mfma_issue_tflops": issued_tflops, "mfma_issue_frac": issued_tflops / peak_tf,
+                               # what register-only bf16 MFMA loops sustain on toggling operands under this board's 1400 W cap (tools/probes/mfma_power.hip,
+                               # profiles/r05_probes/power_cap.log): the matrix roof that real data can reach; `peak` above stays the guide's dense figure
+                               "mfma_sustained_tflops_under_power_cap": 2070.0, "mfma_issue_frac_of_sustained": issued_tflops / 2070.0,
                                "issued_flops_per_launch": k["flops"] / nl,
                                "note": ("`bound` = intensity (2 M N K / algorithmic bytes, SURVEY 8d) against the ridge 2500 TF / 8 TB/s; `frac` = achieved / "
                                         "dense bf16 matrix peak, `frac_attainable` = achieved / min(peak, intensity x 8 TB/s). All instantiations of the "
