@@ -3,7 +3,7 @@
 # pipe is busy, summed over the chip's 1024 SIMDs) against GRBM_GUI_ACTIVE (busy clock cycles, summed over the 8 XCDs) of the same
 # dispatches -> utilisation = MFMA_BUSY / (1024 * GUI_ACTIVE / 8).  Writes gpurun_out/profiles_new/<tag>_pmc_mfma_util.csv
 set -eu
-TAG="${1:-r03_bf16x3_B79}"
+TAG="${1:-r05_bf16x3_B158}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/profiles_new; mkdir -p "$O"; rm -rf "$O/mf"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O/mf" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra --no-power --no-prof > "$O/mfma.log" 2>&1

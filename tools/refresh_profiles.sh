@@ -8,7 +8,7 @@
 #   pmc_traffic.json                  profiles/pmc_traffic.json with this configuration's entry replaced by the last row of that csv
 # The files are written under gpurun_out/ (merged back by gpurun); copy them into profiles/ afterwards.
 set -eu
-TAG="${1:-r04_bf16x3_B79}"
+TAG="${1:-r05_bf16x3_B158}"
 EXTRA="${2:-}"          # extra bench flags of the configuration profiled, e.g. "--f16f8 1 --f16-backward"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/profiles_new; rm -rf "$O"; mkdir -p "$O"
