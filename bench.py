@@ -17,7 +17,11 @@ Prints ONE JSON line on rank 0 with
                   (north star); the oracle forward runs in a CPU child process; at N>1 every rank checks its own replica;
   `rccl`          (N>1) backend name and the sum of a ones tensor all-reduced over the process group = the ranks RCCL really joined;
   `other_precisions`  (N=1) poses/s and the same parity figure of the other two precisions, a few steps each;
-  `cpu_baseline`  oracle/manipose_ref.py timed on the host cores (rank 0, N=1 only).
+  `other_configs`  (N=1) the other single-GPU BASELINE configurations in the timed precision, a few steps each with the same CPU-child parity:
+                  T27_K1_manifold_train (configs[1]), T81_K5_train and T81_K5_eval_tta (configs[4]'s shape: evaluation with flip-TTA, MPJPE / PCK@150 / AUC
+                  against the oracle's composition of the same procedure);  `small_batch`: the headline workload at the reference's batch sizes 3 and 25;
+  `cpu_baseline`  oracle/manipose_ref.py timed on the host cores (rank 0, N=1 only), B=1 and the reference's default B=3; `cores_limited_by` says which
+                  limit (cgroup quota / affinity mask / MANIPOSE_CPU_THREADS) set the thread count.
 Default precision: "bf16x3" (split operands, fp32 accumulate: every Linear and attention product as three bf16 matrix-core products of bf16
 hi / lo planes, bf16 backward) - the fastest precision whose drift stays inside the 1e-4 m bound; "bf16" (BASELINE config #3's wording) is
 faster but drifts ~3 mm.  `--f16f8 1 [--f16-backward]` runs the qkv / fc1 products as one fp16 + one block-scaled fp8 product instead
@@ -54,40 +58,54 @@ def pmc_traffic_per_launch(precision, batch, forms=""):
 
 
 
-def host_cores():
-    """CPU cores this job may actually use: cgroup quota (cpu.max) if set, else the affinity mask, else cpu_count."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+def host_cores(why=False):
+    """CPU cores this job may actually use: cgroup quota (cpu.max) if set, else the affinity mask, else cpu_count; capped by
+    MANIPOSE_CPU_THREADS (default 64).  why=True: (n, which of those limits decided)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n, reason = aff, f"affinity mask ({aff} of os.cpu_count()={os.cpu_count()})"
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
-            n = min(n, max(1, int(float(quota) / float(period))))
+            q = max(1, int(float(quota) / float(period)))
+            if q < n:
+                n, reason = q, f"cgroup cpu.max quota {quota}/{period} = {q} cores (affinity mask {aff}, os.cpu_count()={os.cpu_count()})"
     except Exception:
         pass
-    return max(1, min(n, int(os.environ.get("MANIPOSE_CPU_THREADS", "64"))))
+    cap = int(os.environ.get("MANIPOSE_CPU_THREADS", "64"))
+    if cap < n:
+        n, reason = cap, f"MANIPOSE_CPU_THREADS cap {cap} (the job could use {n})"
+    n = max(1, n)
+    return (n, reason) if why else n
 
 
 def cpu_baseline(T, K, steps=10):
     """Oracle (CPU restatement of the reference, fp32, torch autograd + torch.optim.Adam) on a bounded sample:
-    B=1 window of the same workload, 1 warm-up + `steps` timed training steps."""
+    B=1 window of the same workload, 3 warm-up + `steps` timed training steps; then the reference's default batch (B=3,
+    hpe/conf/config.yaml:26) for 1 warm-up + 3 timed steps."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import manipose_ref as orc
-    torch.set_num_threads(host_cores())
+    ncores, why = host_cores(why=True)
+    torch.set_num_threads(ncores)
     cfg = dict(orc.FULL_CFG, T=T, n_hyp=K)
     st = {k: v.requires_grad_(True) for k, v in orc.make_state(cfg, seed=0).items()}
     opt = torch.optim.Adam(list(st.values()), lr=4e-5, weight_decay=1e-6)
-    X, y = orc.synthetic_batch(1, T, seed=42)
+
+    def timed(B, warm, n):
+        X, y = orc.synthetic_batch(B, T, seed=42)
+        times = []
+        for i in range(n + warm):
+            t0 = time.perf_counter()
+            poses, scores = orc.rmcl_manifold_forward(X, st, orc.oracle_cfg(cfg))
+            total, _ = orc.rmcl_training_loss(poses, scores, y)
+            opt.zero_grad()
+            total.backward()
+            opt.step()
+            times.append(time.perf_counter() - t0)
+        return sorted(times[warm:])[len(times[warm:]) // 2]
     warm = 3
-    times = []
-    for i in range(steps + warm):
-        t0 = time.perf_counter()
-        poses, scores = orc.rmcl_manifold_forward(X, st, orc.oracle_cfg(cfg))
-        total, _ = orc.rmcl_training_loss(poses, scores, y)
-        opt.zero_grad()
-        total.backward()
-        opt.step()
-        times.append(time.perf_counter() - t0)
-    dt = sorted(times[warm:])[len(times[warm:]) // 2]
+    dt = timed(1, warm, steps)
+    dt3 = timed(3, 1, 3)
     model_name = "?"
     try:
         with open("/proc/cpuinfo") as f:
@@ -95,22 +113,40 @@ def cpu_baseline(T, K, steps=10):
     except OSError:
         pass
     return {"value": T / dt, "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cores_limited_by": why, "value_batch3": 3 * T / dt3,
             "sample": f"B=1 window T={T} K={K}, eval-mode DropPath off, {warm} warm-up + {steps} timed steps (median), "
                       f"fwd+loss+bwd+Adam, torch {torch.__version__} CPU fp32, {torch.get_num_threads()} threads of os.cpu_count()="
-                      f"{os.cpu_count()} ({model_name})"}
+                      f"{os.cpu_count()} ({model_name}); value_batch3 = the same at the reference's default batch of 3 windows "
+                      f"(1 warm-up + 3 timed steps)"}
 
 
 def parity_oracle(io_dir):
-    """(CPU child) fp32 oracle forward on the weights / input the parent saved; writes the poses and scores next to them."""
+    """(CPU child) fp32 oracle forwards on the weights / inputs the parent saved (parity_in.pt: a list of jobs, one per model configuration);
+    writes the poses and scores next to them.  A job with `y` also gets the oracle's composition of the evaluation procedure (flip test-time
+    augmentation, weighted-average aggregation, MPJPE / 3DPCK@150 mm / AUC: eval_utils.py:16-223, pck.py:92-199) on its windows."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import manipose_ref as orc
     torch.set_num_threads(host_cores())
-    blob = torch.load(os.path.join(io_dir, "parity_in.pt"))
-    cfg = dict(orc.FULL_CFG, T=blob["T"], n_hyp=blob["K"])
+    jobs = torch.load(os.path.join(io_dir, "parity_in.pt"))
+    out = {}
     with torch.no_grad():
-        poses, scores = orc.rmcl_manifold_forward(blob["X"], blob["state"], orc.oracle_cfg(cfg))
-    torch.save({"poses": poses, "scores": scores}, os.path.join(io_dir, "parity_out.pt"))
+        for job in jobs:
+            cfg = dict(orc.FULL_CFG, T=job["T"], n_hyp=job["K"] if job["arch"] == "rmcl" else 0)
+            ocfg = orc.oracle_cfg(cfg)
+            if job["arch"] == "rmcl":
+                poses, scores = orc.rmcl_manifold_forward(job["X"], job["state"], ocfg)
+                res = {"poses": poses, "scores": scores}
+                if job.get("y") is not None:
+                    y = job["y"]
+                    p1, s1 = orc.rmcl_manifold_forward(orc.flip_pose(job["X"]), job["state"], ocfg)
+                    agg = (orc.aggregate(poses, scores, "weighted_ave") + orc.aggregate(orc.flip_pose(p1), s1, "weighted_ave")) / 2
+                    pck, auc = orc.keypoint_3d_pck_auc(1000 * agg.reshape(-1, 17, 3), 1000 * y.reshape(-1, 17, 3))
+                    res["eval"] = {"mpjpe_mm": 1000 * orc.mpjpe_error(agg, y).item(), "pck150": pck.item(), "auc": auc.item()}
+            else:
+                res = {"poses": orc.manifold_forward(job["X"], job["state"], ocfg)}
+            out[job["name"]] = res
+    torch.save(out, os.path.join(io_dir, "parity_out.pt"))
 
 
 def free_port():
@@ -202,6 +238,9 @@ def main():
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock samples behind the timed region (N=1 only)")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity measurement (profiling passes)")
     ap.add_argument("--no-extra", action="store_true", help="skip the few-step runs of the other precisions (N=1 only)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the few-step runs of the other single-GPU BASELINE configurations (T=27 K=1 manifold train, T=81 K=5 train, T=81 K=5 "
+                         "evaluation with flip-TTA) and of the reference's own batch sizes (3, 25) behind the timed region (N=1 only)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) CPU child: time the CPU oracle and print its JSON")
     ap.add_argument("--parity-io", default=None, help="(internal) CPU child: directory with parity_in.pt; the oracle forward is written next to it")
     args = ap.parse_args()
@@ -229,9 +268,12 @@ def main():
     from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
     from manipose_amd.training import LiftingTrainer
 
-    def build_model(precision, batch):
+    def build_model(precision, batch, arch="rmcl", frames=None):
+        from manipose_amd import ManifoldMixSTE
         torch.manual_seed(42)
-        mdl = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=args.frames, n_hyp=args.hyp, drop_path_rate=0.1)
+        frames = frames or args.frames
+        mdl = (RMCLManifoldMixSTE(h36m_skeleton(), num_frame=frames, n_hyp=args.hyp, drop_path_rate=0.1) if arch == "rmcl"
+               else ManifoldMixSTE(h36m_skeleton(), num_frame=frames, drop_path_rate=0.1))
         with torch.no_grad():                      # exercise the (zero-initialised) positional tables too
             for n, p in mdl.named_parameters():
                 if n.endswith("pos_embed"):
@@ -248,7 +290,7 @@ def main():
         name, _, val = opt.partition("=")
         _l.check(_l.load().mp_set_option(name.encode(), int(val)), f"mp_set_option({name})")
     model = build_model(args.precision, args.batch)
-    cpu_json, oracle_out = None, None
+    cpu_json, oracle_out, oracle_all = None, None, {}
     # parity windows: the same on every rank (own generator), placed at the start, middle and end of the timed batch
     gp = torch.Generator().manual_seed(4242)
     npar = min(PARITY_WINDOWS, args.batch)
@@ -257,26 +299,44 @@ def main():
     def spread(nb):          # rows of an nb-window batch that carry the parity windows: first, middle, last
         return [min(nb - 1, (i * (nb - 1)) // max(1, npar - 1)) for i in range(npar)]
     want_cpu = world == 1 and args.gpus == 1 and not args.no_cpu_baseline
+    # N=1: the other single-GPU BASELINE configurations, a few steps each behind the timed region (BASELINE.json configs[1] and [4]; their
+    # token counts = 79 windows of 243 frames).  The models are built here, on the CPU, so that the CPU child can run the oracle on their weights.
+    OTHER = {"T27_K1_manifold_train": dict(arch="manifold", T=27, B=711), "T81_K5_train": dict(arch="rmcl", T=81, B=237)}
+    other_models, other_par = {}, {}
+    want_other = world == 1 and args.gpus == 1 and not args.no_other_configs and not args.no_parity and args.frames == 243 and args.hyp == 5
+    if want_other:
+        for name, oc in OTHER.items():
+            other_models[name] = build_model(args.precision, oc["B"], oc["arch"], oc["T"])
+            gq = torch.Generator().manual_seed(4243 + oc["T"])
+            Xq = (0.3 * torch.randn(PARITY_WINDOWS, oc["T"], 17, 2, generator=gq)).clamp(-1, 1)
+            yq = 0.075 * torch.randn(PARITY_WINDOWS, oc["T"], 17, 3, generator=gq)      # errors around the 150 mm threshold: PCK / AUC informative
+            yq[:, :, 0] = 0
+            other_par[name] = (Xq, yq)
     if rank == 0 and (want_cpu or not args.no_parity):
         io_dir = tempfile.mkdtemp(prefix="manipose_bench_")
         child = [sys.executable, os.path.abspath(__file__), "--frames", str(args.frames), "--hyp", str(args.hyp)]
         if not args.no_parity:
-            torch.save({"state": {k: v.detach().clone() for k, v in model.state_dict().items()}, "X": X_par, "T": args.frames, "K": args.hyp},
-                       os.path.join(io_dir, "parity_in.pt"))
+            jobs = [{"name": "main", "arch": "rmcl", "state": {k: v.detach().clone() for k, v in model.state_dict().items()}, "X": X_par, "T": args.frames, "K": args.hyp}]
+            for name, mdl in other_models.items():
+                jobs.append({"name": name, "arch": OTHER[name]["arch"], "state": {k: v.detach().clone() for k, v in mdl.state_dict().items()},
+                             "X": other_par[name][0], "y": other_par[name][1] if OTHER[name]["arch"] == "rmcl" else None, "T": OTHER[name]["T"], "K": args.hyp})
+            torch.save(jobs, os.path.join(io_dir, "parity_in.pt"))
+            del jobs
             child += ["--parity-io", io_dir]
         if want_cpu:
             child += ["--cpu-baseline-only"]
         try:
-            r = subprocess.run(child, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(child, capture_output=True, text=True, timeout=420)
             js = json.loads(r.stdout.strip().splitlines()[-1])
             if want_cpu:
                 cpu_json = js
             if not args.no_parity:
-                oracle_out = torch.load(os.path.join(io_dir, "parity_out.pt"))
+                oracle_all = torch.load(os.path.join(io_dir, "parity_out.pt"))
+                oracle_out = {k: oracle_all["main"][k] for k in ("poses", "scores")}
         except Exception as e:       # noqa: BLE001
             if want_cpu:
                 cpu_json = {"value": None, "unit": "poses/s", "cores": host_cores(), "kind": "port",
-                            "sample": f"CPU oracle did not finish inside its 300 s bound ({type(e).__name__})"}
+                            "sample": f"CPU oracle did not finish inside its 420 s bound ({type(e).__name__})"}
         import shutil
         shutil.rmtree(io_dir, ignore_errors=True)
 
@@ -328,26 +388,33 @@ def main():
     y = 0.3 * torch.randn(B, T, 17, 3, device="cuda", generator=g)
     y[:, :, 0] = 0
 
-    def parity_of(mdl, Xfull):
+    def parity_of(mdl, Xfull, ora=None, Xp=None):
         """MPJPE (m) of mdl's eval-mode forward against the oracle's poses on the parity windows, measured twice: with the windows embedded
         in the full batch Xfull at its first, middle and last row (the shapes - and therefore the kernels - of the timed steps) and as a
-        small stand-alone batch.  None without the oracle output."""
-        if oracle_out is None or Xfull.shape[0] < npar:
+        small stand-alone batch.  None without the oracle output.  ora / Xp: another configuration's oracle output and parity windows."""
+        ora = oracle_out if ora is None else ora
+        Xp = X_par if Xp is None else Xp
+        if ora is None or Xfull.shape[0] < npar:
             return None
         idx = spread(Xfull.shape[0])
         Xe = Xfull.clone()
-        Xe[idx] = X_par.cuda()
+        Xe[idx] = Xp.cuda()
         with torch.no_grad():
-            pf, sf = mdl.eval()(Xe)
-            pf, sf = pf[idx].clone(), sf[idx].clone()
-            p1, _ = mdl(X_par.cuda())
-        d = (pf - oracle_out["poses"]).norm(dim=-1)
-        d1 = (p1 - oracle_out["poses"]).norm(dim=-1)
+            of, o1 = mdl.eval()(Xe), mdl(Xp.cuda())
+        if "scores" not in ora:                     # single-hypothesis model: poses only
+            d = (of[idx] - ora["poses"].cuda()).norm(dim=-1)
+            d1 = (o1 - ora["poses"].cuda()).norm(dim=-1)
+            return {"mpjpe_m": d.mean().item(), "mpjpe_m_small_batch": d1.mean().item(), "batch": int(Xfull.shape[0]), "windows_checked": npar,
+                    "rows_in_batch": idx, "max_joint_err_m": d.max().item()}
+        pf, sf = of[0][idx].clone(), of[1][idx].clone()
+        p1 = o1[0]
+        d = (pf - ora["poses"].cuda()).norm(dim=-1)
+        d1 = (p1 - ora["poses"].cuda()).norm(dim=-1)
         # mean = MPJPE, the north-star metric; the tail is a handful of joints behind near-degenerate 6-D frames (two nearly colinear
         # 3-vectors: the Gram-Schmidt step divides by |a x b|), where ANY operand rounding is amplified
         return {"mpjpe_m": d.mean().item(), "mpjpe_m_small_batch": d1.mean().item(), "batch": int(Xfull.shape[0]), "windows_checked": npar, "rows_in_batch": idx,
                 "p999_joint_err_m": torch.quantile(d.flatten().float(), 0.999).item(), "max_joint_err_m": d.max().item(),
-                "score_max_abs_diff": (sf - oracle_out["scores"]).abs().max().item()}
+                "score_max_abs_diff": (sf - ora["scores"].cuda()).abs().max().item()}
 
     parity = parity_of(model, X)               # on the initial weights, before any optimisation step; every rank checks its own replica
     if world > 1 and parity is not None:
@@ -448,13 +515,15 @@ def main():
 
     # N=1: the other precisions on the same workload, a few steps each (their own batch sizes), with the same parity measurement
     other = {}
-    if rank == 0 and world == 1 and not args.no_extra:
+    run_other = rank == 0 and world == 1 and bool(other_models) and all(k in oracle_all for k in other_models)
+    if rank == 0 and world == 1 and (not args.no_extra or run_other):
         del trainer, terms, eng
         model._engine = None
         del model
         import gc
         gc.collect()
         torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_extra:
         for prec in ("bf16x3", "bf16", "fp32"):
             if prec == args.precision:
                 continue
@@ -482,6 +551,87 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:       # noqa: BLE001
                 other[prec] = {"error": f"{type(e).__name__}: {e}"}
+    # N=1: the other single-GPU BASELINE configurations and the reference's own batch sizes, a few steps each in the timed precision, with the same
+    # parity measurement (CPU-child oracle on the same weights; parity windows embedded at the first / middle / last row of the batch)
+    other_cfgs, small_batch = {}, {}
+    if run_other:
+        sys.path.insert(0, os.path.join(ROOT, "hpe"))
+        from _entry import evaluate
+
+        def time_train(mdl, Xb, yb, nst):
+            tr = LiftingTrainer(mdl.train(), lr=4e-5, weight_decay=1e-6, seed=42)
+            tr.train_step(Xb, yb)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(nst):
+                tr.train_step(Xb, yb)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / nst
+        for name, oc in OTHER.items():
+            try:
+                Bo, To = oc["B"], oc["T"]
+                mo = other_models.pop(name).cuda()
+                go = torch.Generator(device="cuda").manual_seed(43)
+                Xo = (0.3 * torch.randn(Bo, To, 17, 2, device="cuda", generator=go)).clamp(-1, 1)
+                yo = 0.3 * torch.randn(Bo, To, 17, 3, device="cuda", generator=go)
+                yo[:, :, 0] = 0
+                ora = oracle_all[name]
+                par = parity_of(mo, Xo, ora, other_par[name][0])
+                rp = None
+                if "eval" in ora:            # (the evaluation procedure against the oracle's, on the INITIAL weights - before the timed training steps move them)
+                    Xp, yp = (t.cuda() for t in other_par[name])
+                    rp = evaluate(mo, Xp, yp, batch=Xp.shape[0], tta=True, analytics=True)
+                dto = time_train(mo, Xo, yo, 4)
+                other_cfgs[name] = {"workload": f"H36M lifting T={To} J=17 K={args.hyp if oc['arch'] == 'rmcl' else 1} "
+                                                + ("ManiPose (RMCLManifoldMixSTE)" if oc["arch"] == "rmcl" else "single-hypothesis ManifoldMixSTE")
+                                                + " full width (C=512, depth 8), train step fwd+loss+bwd+Adam",
+                                    "poses_per_s": Bo * To / dto, "ms_per_step": 1e3 * dto, "windows_per_gpu": Bo, "steps": 4, "warmup": 1, "precision": args.precision,
+                                    "model_tflops": Bo * To / dto * TRAIN_GFLOP_PER_POSE[To] / 1e3,
+                                    "parity_mpjpe_m": par["mpjpe_m"], "parity_mpjpe_m_small_batch": par["mpjpe_m_small_batch"],
+                                    "within_bound": max(par["mpjpe_m"], par["mpjpe_m_small_batch"]) <= PARITY_BOUND_M}
+                log(f"{name}: {other_cfgs[name]['poses_per_s']:.0f} poses/s, parity {par['mpjpe_m']:.2e} m")
+                if "eval" in ora:
+                    # BASELINE config #5's procedure on this model: evaluation with flip test-time augmentation batched into one forward, aggregation,
+                    # MPJPE / 3DPCK@150 mm / AUC (hpe/_entry.py evaluate = eval_utils.py:16-223), (a) on the parity windows against the oracle's
+                    # composition of the same procedure, (b) timed over 4 batches of Be windows (forward of 2 Be windows each)
+                    Be = Bo // 2
+                    Xe4, ye4 = Xo[:Be].repeat(4, 1, 1, 1), 0.25 * yo[:Be].repeat(4, 1, 1, 1)
+                    evaluate(mo, Xe4[:Be], ye4[:Be], batch=Be, tta=True, analytics=True)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    evaluate(mo, Xe4, ye4, batch=Be, tta=True, analytics=True)
+                    torch.cuda.synchronize()
+                    dte = time.perf_counter() - t1
+                    oe = ora["eval"]
+                    other_cfgs[name.replace("_train", "_eval_tta")] = {
+                        "workload": f"MPI-INF-3DHP-shaped evaluation T={To} K={args.hyp}: flip-TTA in one forward of 2 x {Be} windows, weighted-average / best-score / "
+                                    f"oracle aggregation, MPJPE, 3DPCK@150 mm, AUC, P-MPJPE (analytics kernels), synthetic windows",
+                        "poses_per_s": 4 * Be * To / dte, "ms_per_batch": 1e3 * dte / 4, "windows_per_batch": Be, "batches": 4, "precision": args.precision,
+                        "mpjpe_mm": rp["mpjpe"], "mpjpe_mm_oracle": oe["mpjpe_mm"], "pck150": rp["analytics"]["pck"], "pck150_oracle": oe["pck150"],
+                        "auc": rp["analytics"]["auc"], "auc_oracle": oe["auc"], "windows_checked": int(Xp.shape[0]),
+                        "within_bound": abs(rp["mpjpe"] - oe["mpjpe_mm"]) <= 1e3 * PARITY_BOUND_M and abs(rp["analytics"]["pck"] - oe["pck150"]) <= 0.2
+                                        and abs(rp["analytics"]["auc"] - oe["auc"]) <= 0.2}
+                    log(f"{name} eval+TTA: {4 * Be * To / dte:.0f} poses/s, MPJPE {rp['mpjpe']:.3f} mm (oracle {oe['mpjpe_mm']:.3f})")
+                mo._engine = None
+                del mo, Xo, yo
+                gc.collect()
+                torch.cuda.empty_cache()
+            except Exception as e:       # noqa: BLE001
+                other_cfgs[name] = {"error": f"{type(e).__name__}: {e}"}
+        # the reference's own batch sizes at T=243 (hpe/conf/config.yaml:26: 3; hpe/conf/train/mix_ste.yaml:4: 25): what a drop-in user who keeps the
+        # recipe gets (the persistent GEMMs then have 49 / 404 row panels for 256 CUs)
+        try:
+            ms = build_model(args.precision, 25).cuda()
+            for Bs in (3, 25):
+                reps = (Bs + B - 1) // B
+                dts = time_train(ms, X.repeat(reps, 1, 1, 1)[:Bs].contiguous(), y.repeat(reps, 1, 1, 1)[:Bs].contiguous(), 10)
+                small_batch[str(Bs)] = {"poses_per_s": Bs * T / dts, "ms_per_step": 1e3 * dts, "steps": 10, "warmup": 1, "precision": args.precision}
+                log(f"T={T} B={Bs}: {Bs * T / dts:.0f} poses/s")
+            ms._engine = None
+            del ms
+            torch.cuda.empty_cache()
+        except Exception as e:       # noqa: BLE001
+            small_batch = {"error": f"{type(e).__name__}: {e}"}
     forms = "" if args.precision != "bf16x3" or args.f16f8 == 0 else f"+f16f8{args.f16f8}" + ("b" if args.f16_backward else "")
     if rank == 0:
         poses_per_s = world * B * T * args.steps / dt
@@ -520,6 +670,11 @@ def main():
                                             "wait between the end of the backward and the optimizer step; `value` is timed in the mode with timed_mode = true")
         if other:
             out["other_precisions"] = other
+        if other_cfgs:
+            out["other_configs"] = other_cfgs
+        if small_batch:
+            out["small_batch"] = dict(small_batch, note="train poses/s of the headline workload at the reference's own batch sizes (conf/config.yaml:26, conf/train/mix_ste.yaml:4)") \
+                if "error" not in small_batch else small_batch
         if prof is not None:
             # dominant kernel = the one with the largest share of the step: gemm_bf16_persist_kernel (forward + dgrad Linear GEMMs,
             # ~45 % of the kernel time) in the bf16 mode, the fp32 MFMA GEMM of the forward in the fp32 mode

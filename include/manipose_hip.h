@@ -270,7 +270,8 @@ int mp_model_grad_bucket_wait(mp_model* m, int index, void* stream);
  * HOST after synchronising `stream`: out[0] = S, the power-of-two scale of that backward; out[1] = number of fp16 gradient elements that
  * hit the +-65504 clamp (stores saturate, they never write inf); out[2] = number of non-finite gradient elements met at those stores
  * (written as 0); out[3] = 1 / S (what consumers of the scaled operands multiply by).  A trainer that sees out[1] + out[2] > 0 should redo
- * the step with f16_backward off or skip it (manipose_amd/training.py does the latter).  MP_ERR_STATE unless a completed mp_model_backward is
+ * the step with f16_backward off or skip it (manipose_amd/training.py sums the counters on the device, all-reduces the sum over the ranks and
+ * raises / warns every health_interval steps - the steps since the last check were applied; health_interval = 1 stops on the first).  MP_ERR_STATE unless a completed mp_model_backward is
  * the last engine call (a forward, or a backward that failed midway, has overwritten what the counters described).
  * mp_model_grad_health_async: the same four values as floats into a DEVICE (or pinned host) buffer by an asynchronous copy on `stream`, no
  * host synchronisation - for a trainer that looks at the counters every N steps.  Cost, accepted: a backward of an f16_backward model reads the

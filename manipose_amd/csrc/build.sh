@@ -17,7 +17,7 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-slp-vectorize -Xclang -ta
 pids=()
 for f in "$HERE"/*.hip; do
   o="$OBJ/$(basename "${f%.hip}").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$HERE/kernels.h" -nt "$o" ] || [ "$HERE/../../include/manipose_hip.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$HERE/kernels.h" -nt "$o" ] || [ "$HERE/hazard.h" -nt "$o" ] || [ "$HERE/kloop_asm.inc" -nt "$o" ] || [ "$HERE/../../include/manipose_hip.h" -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" 2> >(grep -v "is not a recognized feature for this target" >&2) &
     pids+=($!)
   fi

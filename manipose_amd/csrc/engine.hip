@@ -814,8 +814,9 @@ static int refresh_head_weights(mp_model* m, const Module& md, const float* fp, 
   }
   return MP_OK;
 }
-static int zero_head_grad_scratch(const Module& md, hipStream_t st) {
+static int zero_head_grad_scratch(mp_model* m, const Module& md, hipStream_t st) {
   if (md.hdw == nullptr) return MP_OK;
+  HZ(st, "heads.zero_dw_scratch", HW(md.hdw, 4.0 * md.K * md.O * md.C));
   MP_HIP(hipMemsetAsync(md.hdw, 0, sizeof(float) * (size_t)md.K * md.O * md.C, st));
   return MP_OK;
 }
@@ -823,6 +824,7 @@ static int flush_head_grads(mp_model* m, const Module& md, float* fg, hipStream_
   if (md.hdw == nullptr) return MP_OK;
   const long WC = (long)md.O * md.C;
   for (int k = 0; k < md.K; ++k) {
+    HZ(st, "heads.flush_dw", HR(md.hdw + k * WC, 4.0 * WC), HW(G(m, fg, md.hw[k]), 4.0 * WC));
     int rc = axpy_scaled(G(m, fg, md.hw[k]), md.hdw + k * WC, md.readout, WC, st);
     if (rc) return rc;
   }
@@ -1115,10 +1117,12 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
   // parameter gradients of the heads / score heads are needed by nobody downstream: with the weight-gradient stream on they run there,
   // at the start of the backward where that stream is idle (own scratch, ordered behind the last writer of dheadout)
   hipStream_t pst = m->wgrad_async ? m->st3 : nullptr;
-  { int rz = zero_head_grad_scratch(m->rot, st); if (rz) return rz; }
+  { int rz = zero_head_grad_scratch(m, m->rot, st); if (rz) return rz; }
   // decoder
-  HZ(st, "fk_decode_bwd", HR(m->rot.headout, 4.0 * K * Mr * m->rot.O), HR(m->lengths, 4.0 * B * S), HR(d_poses, 12.0 * B * K * T * J), HW(m->rot.dheadout, 4.0 * K * Mr * m->rot.O),
-     HW(m->has_seg ? m->dlen_pose : nullptr, 4.0 * B * K * T * S));
+  if (m->has_seg)
+    HZ(st, "fk_decode_bwd", HR(m->rot.headout, 4.0 * K * Mr * m->rot.O), HR(m->lengths, 4.0 * B * S), HR(d_poses, 12.0 * B * K * T * J), HW(m->rot.dheadout, 4.0 * K * Mr * m->rot.O),
+       HW(m->dlen_pose, 4.0 * B * K * T * S));
+  else HZ(st, "dposes_copy (no decoder)", HR(d_poses, 12.0 * Mr), HW(m->rot.dheadout, 12.0 * Mr));
   if (m->has_seg) RUN(PC_OTHER, 0, fk_decode_bwd(m->rot.headout, m->rot.O, m->cfg.rot_rep_dim, m->lengths, d_poses, m->rot.dheadout, m->dlen_pose, B, K, T, st));
   else MP_HIP(hipMemcpyAsync(m->rot.dheadout, d_poses, sizeof(float) * Mr * 3, hipMemcpyDeviceToDevice, st));
   if (m->cfg.arch == 0) {
@@ -1162,7 +1166,8 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
        HR(m->rot.dheadout, 4.0 * K * Mr * m->rot.O), HW(m->g, 4.0 * Mr * m->rot.C), HW(pst ? nullptr : hsc, hscb));
     // (the parameter kernels go to pst WITHOUT an event of their own: they read what the dx kernel reads, all final since ev_heads above)
     HZ(pst ? pst : st, "heads_bwd.params", HR(m->rot.x_final, 4.0 * Mr * m->rot.C), HR(m->rot.hstats, 8.0 * Mr), HR(m->rot.headout, 4.0 * K * Mr * m->rot.O),
-       HR(m->rot.dheadout, 4.0 * K * Mr * m->rot.O), HW(hsc, hscb), HW(G(m, fg, m->rot.hg[0]), 4.0 * head_param_floats(m, m->rot)));
+       HR(m->rot.dheadout, 4.0 * K * Mr * m->rot.O), HW(hsc, hscb), HW(G(m, fg, m->rot.hg[0]), 4.0 * head_param_floats(m, m->rot)),
+       HW(m->rot.hdw, m->rot.hdw ? 4.0 * K * m->rot.O * m->rot.C : 0.0));      // (MuReadout: the weight gradients land in the zeroed scratch, flushed below)
   }
   if (heads_use_mfma(K, m->rot.O, m->rot.C))
     RUN(PC_OTHER, 0, heads_bwd_mfma(m->rot.x_final, m->rot.hstats, m->rot.hfold, m->rot.headout, hp, hg, K, m->rot.O, m->rot.dheadout, m->g, (int)Mr, m->rot.C,
@@ -1193,7 +1198,7 @@ int mp_model_backward(mp_model* m, const float* fp, float* fg, const float* d_po
     HeadGrads hgs;
     head_params(m, m->seg, fp, hs);
     head_grads(m, m->seg, fg, hgs);
-    { int rz = zero_head_grad_scratch(m->seg, st); if (rz) return rz; }
+    { int rz = zero_head_grad_scratch(m, m->seg, st); if (rz) return rz; }
     HZ(st, "heads_bwd.seg", HR(m->seg.x_final, 4.0 * Ms * m->seg.C), HR(m->seg.hstats, 8.0 * Ms), HR(m->seg.headout, 4.0 * Ms), HR(m->seg.dheadout, 4.0 * Ms), HW(m->g, 4.0 * Ms * m->seg.C),
        HW(m->small, 4.0 * m->small_floats), HW(hgs.W[0], 4.0 * m->seg.C), HW(hgs.gamma[0], 4.0 * m->seg.C), HW(hgs.beta[0], 4.0 * m->seg.C));
     if (heads_use_mfma(1, 1, m->seg.C))

@@ -526,8 +526,10 @@ __device__ __forceinline__ void kfrag_b(KFragB& f, unsigned base, int wc, int la
 // through 500-800 bytes of scratch memory per lane.
 // The flags are made by the SCALAR ALU from scalar sources (kflag_*): an asm "s" operand takes nothing else, hipcc keeps wave-uniform bools as
 // lane masks + v_cndmask and folds __builtin_amdgcn_readfirstlane of a value it knows to be uniform, and a hand-written v_readfirstlane of such
-// a value was observed stale (round 5: one tile in a few fetched the tile behind the workgroup's last one).  If hipcc ever holds one of the
-// sources in a vector register the assembler refuses the operand - a build error, not a wrong flag.
+// a value was observed stale (round 5: one tile in a few fetched the tile behind the workgroup's last one; the mechanism was worked around, not
+// identified - a plausible one is the gfx9 hazard of a VALU-written SGPR read as m0 / by VMEM within a few wait states, which the hazard
+// recogniser does not see inside inline asm).  For a source hipcc holds in a vector register (e.g. `wave` below) it inserts its OWN
+// v_readfirstlane in front of the block, outside the asm, where its hazard recogniser does apply; nothing here relies on a build error.
 struct KJob { int en; unsigned lds; const char* base; };      // wave-uniform: enable flag (conditional jobs), LDS address of the wave's 4 KiB of the destination tile, source address
 __device__ __forceinline__ int kflag_lt(int a, int b) { int r; asm volatile("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
 __device__ __forceinline__ int kflag_nonnull(const void* p) { int r; asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(p) : "scc"); return r; }
@@ -540,6 +542,10 @@ __device__ __forceinline__ int kflag_last(int a, int b, int x) { int r; asm vola
 // of it (tools/gen_kloop_asm.py, pipe_loop_x3); the tile's last k-tile keeps the block-per-step form.
 #ifndef MP_KLOOP_PIPE
 #define MP_KLOOP_PIPE 1
+#endif
+// MP_KLOOP_ASM8 (with MP_KLOOP_ASM and MP_KSTEP_YOUNG): the "f16f8" loop (SPLIT = 8) in the hand-scheduled form, one block per step (0: hipcc's mma_stage_mix)
+#ifndef MP_KLOOP_ASM8
+#define MP_KLOOP_ASM8 1
 #endif
 enum { KC_X0 = 0, KC_X1 = 1, KC_X2 = 2, KC_P = 3 };
 #define MP_KSTEP_SEL2(c, t, v) MP_KSTEP_ASM_##c##_TRB##t##_V##v
@@ -558,6 +564,10 @@ constexpr int KNP = 4;
 #define MP_KSTEP_OPS_0 [aa0] "v"(fa.a[0]), [aa1] "v"(fa.a[1]), [ba0] "v"(fb.b[0]), [ba1] "v"(fb.b[1]), MP_KSTEP_JOBS
 #define MP_KSTEP_OPS_1 [aa0] "v"(fa.a[0]), [aa1] "v"(fa.a[1]), [bt0] "v"(fb.b[0]), [bt1] "v"(fb.b[1]), [bt2] "v"(fb.b[2]), [bt3] "v"(fb.b[3]), MP_KSTEP_JOBS
 #define MP_KSTEP_EMIT(c, t, v) asm volatile(MP_KSTEP_SEL(c, t, v) : MP_KSTEP_ACC_OPERANDS : MP_KSTEP_OPS_##t : MP_KSTEP_CLOB(v))
+// ("m0" is on the blocks' clobber lists - their DMA set-up writes it, and a compiler-made global_load_lds / readlane behind a block must
+// re-initialise it; clang accepts the reserved register and warns about it)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 template <int TRB, int CFG>
 __device__ __forceinline__ void kstep_asm(f32x4 (&acc)[8][4], const KFragA& fa, const KFragB& fb, const KJob& ja, const unsigned (&aoff)[KNP],
                                           const KJob& jb, const unsigned (&boff)[KNP], const KJob& jc, unsigned coff) {
@@ -588,6 +598,20 @@ __device__ __forceinline__ void kstep_asm(f32x4 (&acc)[8][4], const KFragA& fa, 
   }
 }
 #if MP_KSTEP_YOUNG
+// The two steps of a k-tile of the "f16f8" loop (SPLIT = 8) in the hand-scheduled form (round 6; generator: step(.., mfma = fp16) and step_f8):
+// F multiplies the fp16 tiles (64 v_mfma_f32_16x16x32_f16), E the 8-bit correction tiles (32 v_mfma_scale_f32_16x16x128_f8f6f4, block scales
+// 2^-15 x 1 in two vector registers); both carry the A / B jobs of the NEXT step's tiles behind scalar flags, E the bias behind a tile's last step.
+__device__ __forceinline__ void kstep_asm_f(f32x4 (&acc)[8][4], const KFragA& fa, const KFragB& fb, const KJob& ja, const unsigned (&aoff)[KNP],
+                                            const KJob& jb, const unsigned (&boff)[KNP]) {
+  const KJob jc = {0, 0u, nullptr};
+  const unsigned coff = 0;
+  MP_KSTEP_EMIT(ZF, 0, MP_KSTEP_VARIANT);
+}
+#define MP_KSTEP_OPS_E [aa0] "v"(fa.a[0]), [aa1] "v"(fa.a[1]), [ba0] "v"(fb.b[0]), [ba1] "v"(fb.b[1]), [sca] "v"(sca), [scb] "v"(scb), MP_KSTEP_JOBS
+__device__ __forceinline__ void kstep_asm_e(f32x4 (&acc)[8][4], const KFragA& fa, const KFragB& fb, const KJob& ja, const unsigned (&aoff)[KNP],
+                                            const KJob& jb, const unsigned (&boff)[KNP], const KJob& jc, unsigned coff, int sca, int scb) {
+  asm volatile(MP_KSTEP_SEL(ZE, 0, MP_KSTEP_VARIANT) : MP_KSTEP_ACC_OPERANDS : MP_KSTEP_OPS_E : MP_KSTEP_CLOB(MP_KSTEP_VARIANT));
+}
 // k-tiles 0 .. n-1 (n = nk - 1 >= 1) of a split-precision forward tile, behind the tile's first barrier (A_lo[0], B_hi[0] landed in A0, B0; A1, B1 free).
 // pa / pb: the hi planes' addresses of the tile's k-tile 0.  aoff / boff come back advanced by n k-tiles (128 bytes each) in the waves that issue DMA.
 __device__ __forceinline__ void kpipe_x3(f32x4 (&acc)[8][4], const KFragA (&kfa)[2], const KFragB (&kfb)[2], unsigned (&aoff)[KNP], unsigned (&boff)[KNP],
@@ -608,6 +632,7 @@ __device__ __forceinline__ void kpipe_x3(f32x4 (&acc)[8][4], const KFragA (&kfa)
                : MP_KSTEP_CLOB(MP_KSTEP_VARIANT));
 }
 #endif
+#pragma clang diagnostic pop
 
 // The same with an UNEVEN split of a tile's 32 DMA pieces over the waves (weight-gradient kernel): the waves of group 0 (0-3) take P0 pieces
 // each, those of group 1 (4-7) 8 - P0.  Measured, not derived: group 0 - the older wave of every SIMD - with ONE piece per operand and group 1
@@ -982,6 +1007,16 @@ __device__ __forceinline__ void persist_epilogue_bf16_packed(const GemmB16Args& 
 // natural accumulator layout (16 rows x 32 B), 3 us as contiguous 16 KiB blocks; one CU in 32 storing: 4.2 / 2.1 / 5.7 / 11.6 / 0.2 us.  The
 // dwordx4 form of this epilogue for the planar outputs was built and measured in the real kernels: qkv 1356 / 1344 -> 1338 / 1341 us, fc1
 // unchanged, the step unchanged - not kept.)
+// (diagnostics build: per-wave cycle totals of the hand-scheduled loops - wait, barrier, MFMA stage)
+#ifdef MP_GEMM_DIAG
+#define MP_KDIAG_A() tk1 = __builtin_readcyclecounter()
+#define MP_KDIAG_B() tk2 = __builtin_readcyclecounter(); dg_wait += tk1 - tk0; dg_bar += tk2 - tk1
+#define MP_KDIAG_C() tk0 = __builtin_readcyclecounter(); dg_mma += tk0 - tk2
+#else
+#define MP_KDIAG_A()
+#define MP_KDIAG_B()
+#define MP_KDIAG_C()
+#endif
 // SPLIT: see gemm_bf16_glds_kernel (three steps per k-tile, the DMA source planes rotate)
 template <int TRB, typename TC, int EPI, int SPLIT = 0, bool F16G = false>
 __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, int tiles_n, int ntiles) {
@@ -999,7 +1034,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   if (id >= ntiles) return;
   const int nk = g.K / GBK;                                 // K % 64 == 0, nk >= 2 (launcher)
   int m0 = (id / tiles_n) * BT, n0 = (id % tiles_n) * BT;
-  constexpr bool KASM = MP_KLOOP_ASM && (SPLIT == 0 || SPLIT == 1);      // the hand-scheduled k-step (bf16 MFMA; plain and three-product loops)
+  constexpr bool KASM8 = MP_KLOOP_ASM && MP_KLOOP_ASM8 && MP_KSTEP_YOUNG && SPLIT == 8 && TRB == 0;      // f16f8 loop, hand-scheduled (round 6)
+  constexpr bool KASM = MP_KLOOP_ASM && (SPLIT == 0 || SPLIT == 1 || KASM8);      // the hand-scheduled k-step (plain, three-product and f16f8 loops)
   constexpr bool YOUNG = KASM && MP_KSTEP_YOUNG;                         // its operand DMA comes from waves 4-7 only (8 pieces of a tile each)
   constexpr int NP = YOUNG ? 8 : 4;
   const int dma_first = YOUNG ? (wave >= 4 ? (wave - 4) * 8 : 0) : wave * 4;      // this wave's first piece of an operand tile
@@ -1024,7 +1060,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
   const long a_lo = PLANES ? reinterpret_cast<const char*>(g.A_lo) - A : 0, b_lo = PLANES ? reinterpret_cast<const char*>(g.B_lo) - B : 0;
   if constexpr (YOUNG) {
     if (wave >= 4) {
-      uneven_dma<NP>(smem, a_base(m0, 0) + a_lo, aoff, dma_first, NP);
+      uneven_dma<NP>(smem, a_base(m0, 0) + (SPLIT == 8 ? 0 : a_lo), aoff, dma_first, NP);      // SPLIT 1: the first step multiplies (A_lo, B_hi); 8: the fp16 planes
       uneven_dma<NP>(smem + OPB, b_base(n0, 0), boff, dma_first, NP);
     }
   } else {
@@ -1067,7 +1103,39 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if constexpr (SPLIT == 8) {
+    if constexpr (KASM8) {
+      // "f16f8", hand-scheduled: per k-tile one F block (fp16 tiles in stage 0; requests the k-tile's correction tiles into stage 1) and one E block
+      // (correction tiles in stage 1; requests the fp16 tiles of the next k-tile / tile into stage 0, the bias behind the tile's last step)
+      const char* pa = tile_a;                             // fp16 plane of A, k-tile kt
+      const char* pb = tile_b;
+      const unsigned coff = 4u * lane;
+      const KFragA fa1 = {{kfa[0].a[0] + (unsigned)STAGE, kfa[0].a[1] + (unsigned)STAGE}};
+      const KFragB fb1 = {{kfb[0].b[0] + (unsigned)STAGE, kfb[0].b[1] + (unsigned)STAGE, 0u, 0u}};
+      const int sca = F8_SCALE_A, scb = F8_SCALE_B;
+      for (int kt = 0; kt < nk; ++kt, pa += GBK * 2, pb += kstep_b) {
+        const bool last = kt + 1 == nk;
+        const int more_i = kflag_more(kt + 1, nk, has_next_i);
+#ifdef MP_GEMM_DIAG
+        unsigned long long tk0 = __builtin_readcyclecounter(), tk1, tk2;
+#endif
+        if (kt == 0 && landed) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) only
+        else __builtin_amdgcn_s_waitcnt(0x0070);                        // vmcnt(0) lgkmcnt(0)
+        MP_KDIAG_A();
+        __builtin_amdgcn_s_barrier();
+        MP_KDIAG_B();
+        kstep_asm_f(acc, kfa[0], kfb[0], KJob{dma_wave, dma_l + STAGE, pa + a_lo}, aoff, KJob{dma_wave, dma_l + STAGE + OPB, pb + b_lo}, boff);
+        MP_KDIAG_C();
+        if (last && more_i) persist_offsets_n<0, NP>(aoff, g.lda, m0n, g.M, opaque(lane), dma_first);      // (opaque: the rows are recomputed here, not kept - spilled - across the tile)
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        MP_KDIAG_A();
+        __builtin_amdgcn_s_barrier();
+        MP_KDIAG_B();
+        kstep_asm_e(acc, fa1, fb1, KJob{more_i & dma_wave, dma_l, last ? tile_an : pa + GBK * 2}, aoff, KJob{more_i & dma_wave, dma_l + OPB, last ? tile_bn : pb + kstep_b}, boff,
+                    KJob{kflag_last(kt + 1, nk, has_bias_i), img_l, reinterpret_cast<const char*>(g.bias + n0 + wc * 64)}, coff, sca, scb);
+        MP_KDIAG_C();
+      }
+      (void)stage;
+    } else if constexpr (SPLIT == 8) {
       // "f16f8": 2 nk steps over the two stages - even steps multiply the fp16 planes of k-tile v / 2 (fp16 MFMA), odd steps its 8-bit
       // correction planes (one 128-deep fp8 MFMA per 16 x 16 block); the plain kernel's pipeline with alternating source planes
       for (int v = 0; v < 2 * nk; ++v) {
@@ -1114,15 +1182,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
         const char* pb = tile_b;                           // B_hi of k-tile kt
         const KJob none = {0, 0u, nullptr};
         const unsigned coff = 4u * lane;
-#ifdef MP_GEMM_DIAG
-#define MP_KDIAG_A() tk1 = __builtin_readcyclecounter()
-#define MP_KDIAG_B() tk2 = __builtin_readcyclecounter(); dg_wait += tk1 - tk0; dg_bar += tk2 - tk1
-#define MP_KDIAG_C() tk0 = __builtin_readcyclecounter(); dg_mma += tk0 - tk2
-#else
-#define MP_KDIAG_A()
-#define MP_KDIAG_B()
-#define MP_KDIAG_C()
-#endif
         constexpr bool PIPE = MP_KLOOP_PIPE && YOUNG && TRB == 0;
         if constexpr (PIPE) {
           // k-tiles 0 .. nk-2 in one block (pipeline across the steps, barriers inside), then the last k-tile block by block: its step 0 needs no
@@ -1184,7 +1243,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(GemmB16Args g, i
           MP_KDIAG_C();
           // step 2: (A1 = A_hi, B1 = B_lo); requests B_hi of the next k-tile / tile -> B0, and the bias behind the tile's last step.  It waits with
           // vmcnt(4): B_lo has landed, the four A_lo requests issued behind it may still be in flight
-          if (more_i) __builtin_amdgcn_s_waitcnt(0x0074);
+          if (more_i) __builtin_amdgcn_s_waitcnt(YOUNG ? 0x0078 : 0x0074);      // (younger-wave DMA: the A_lo job behind B_lo is 8 pieces)
           else __builtin_amdgcn_s_waitcnt(0x0070);
           MP_KDIAG_A();
           __builtin_amdgcn_s_barrier();

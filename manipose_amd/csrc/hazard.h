@@ -26,13 +26,19 @@ inline HzAccess hz_w(const void* p, double bytes) { return HzAccess{p, (size_t)b
 
 class HazardTracker {
  public:
-  static constexpr int MAXS = 8;
-  struct Clock { uint64_t c[MAXS] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+  static constexpr int MAXS = 16;
+  struct Clock { uint64_t c[MAXS] = {}; };
 
   int stream_id(const void* stream) {                 // small integers in order of first appearance
     for (size_t i = 0; i < streams_.size(); ++i)
       if (streams_[i] == stream) return (int)i;
-    if ((int)streams_.size() == MAXS) return MAXS - 1;
+    if ((int)streams_.size() == MAXS) {
+      // more distinct streams than clocks: two streams would share an id and `r.stream == s` would hide their conflicts - that is a
+      // failed check, not a clean one
+      ++n_violations_;
+      if (msgs_.size() < 64) msgs_.push_back("hazard tracker: more than 16 distinct streams seen; streams share an id from here on and the check is void");
+      return MAXS - 1;
+    }
     streams_.push_back(stream);
     return (int)streams_.size() - 1;
   }

@@ -25,7 +25,8 @@ class LiftingTrainer:
         """health_interval / on_saturation: a model with f16_backward carries some gradient operands as fp16 of S x value; stores that hit
         the +-65504 clamp (or met a non-finite value, written as 0) are counted on the device (mp_model_grad_health).  The trainer sums the
         two counters of every backward on the device (no synchronisation) and reads the sums every `health_interval` steps: a non-zero sum
-        raises RuntimeError ("raise": the steps since the last check trained on clamped operands) or warns ("warn")."""
+        raises RuntimeError ("raise": the steps since the last check trained on clamped operands - they HAVE been applied; health_interval=1
+        stops on the first) or warns ("warn").  With more than one rank the sums are all-reduced first, so every rank decides alike."""
         self.model = model
         self.lib = _lib.load()
         self.opt = FusedAdam(model, lr=lr, weight_decay=weight_decay)
@@ -131,6 +132,10 @@ class LiftingTrainer:
         eng.grad_health_async(self._health)
         self._health_sum += self._health[1:3]
         if self.step_no % self.health_interval == 0:
+            if self.world > 1:
+                # every rank must take the same decision BEFORE the gradient collective: a rank that raised alone would leave the others
+                # waiting in the all-reduce until the RCCL timeout
+                dist.all_reduce(self._health_sum, group=self.pg)
             clamped, bad = (int(v) for v in self._health_sum.tolist())
             self._health_sum.zero_()
             if clamped or bad:

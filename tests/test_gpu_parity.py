@@ -2168,6 +2168,73 @@ def test_bench_batch_of_158_windows_is_two_times_its_half(lib):
     gc.collect(); torch.cuda.empty_cache()
 
 
+def test_batch_beyond_the_2_gib_plane_boundary_vs_oracle_and_small_batch(lib):
+    """172 windows of T=243 at full width in the benchmarked precision: 710 532 tokens, so each 2-byte plane of the fused qkv activation (and of
+    its gradient) is 2.18 GB - past 2^31 bytes, which bench.py's default batch (158) stays 7 % under.  (a) Forward: parity windows placed in the
+    FIRST, MIDDLE and LAST row of the batch against the fp32 CPU oracle (north-star bound), and bit-identical to the same windows run as a
+    3-window batch (a window's result does not depend on its row).  (b) Backward: with upstream gradients on those three rows only, the
+    parameter gradients of the 172-window step equal those of the 3-window step up to the summation order of the token sums - a wrong
+    address past the boundary in any forward or backward kernel of the LAST row would show in either."""
+    import gc
+    from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
+    gc.collect(); torch.cuda.empty_cache()
+    B = 172
+    torch.manual_seed(42)
+    model = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=243, n_hyp=5, drop_path_rate=0.1)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("pos_embed"):
+                p.normal_(0.0, 0.02)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.precision = "bf16x3"
+    model.max_batch_hint = B
+    model = model.cuda().eval()
+    assert 2 * B * 243 * 17 * 1536 > 2 ** 31
+    Xp, _ = orc.synthetic_batch(3, 243, seed=21)
+    with torch.no_grad():
+        o_poses, o_scores = orc.rmcl_manifold_forward(Xp, state, orc.oracle_cfg(orc.FULL_CFG))
+    Xb, _ = orc.synthetic_batch(B, 243, seed=22)
+    rows = [0, B // 2, B - 1]
+    Xb[rows] = Xp
+    Xb, Xp = Xb.cuda(), Xp.cuda()
+    model._ensure_engine(B, Xb.device)
+    eng, flat = model._engine, model.flat_parameters()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    dp3 = torch.randn(3, 5, 243, 17, 3, device="cuda", generator=gen) * 1e-3
+    ds3 = torch.randn(3, 5, 243, 1, device="cuda", generator=gen) * 1e-3
+    dpB = torch.zeros(B, 5, 243, 17, 3, device="cuda")
+    dsB = torch.zeros(B, 5, 243, 1, device="cuda")
+    dpB[rows], dsB[rows] = dp3, ds3
+
+    def run(x, gp, gs):
+        poses, scores = eng.forward(flat, x, train=False)
+        poses, scores = poses.clone(), scores.clone()
+        grads = torch.zeros_like(flat)
+        eng.backward(flat, grads, gp, gs)
+        torch.cuda.synchronize()
+        return poses, scores, grads
+    from manipose_amd import _lib
+    pB, sB, gB = run(Xb, dpB, dsB)
+    _lib.check(lib.mp_set_option(b"gemm_persist_min_tiles", 1))      # the 3-window batch on the persistent GEMM kernels too (same epilogue code: same bits)
+    try:
+        p3, s3, g3 = run(Xp, dp3, ds3)
+    finally:
+        _lib.check(lib.mp_set_option(b"gemm_persist_min_tiles", 0))
+    assert torch.isfinite(pB).all() and torch.isfinite(gB).all()
+    mp = (pB[rows].cpu() - o_poses).norm(dim=-1).mean(dim=(1, 2, 3))
+    print(f"\n[B=172, planes past 2^31 bytes] MPJPE vs oracle at rows {rows}: {[f'{v:.2e}' for v in mp.tolist()]} m; workspace {eng.workspace_bytes / 2**30:.1f} GiB")
+    assert float(mp.max()) <= MPJPE_TOL_M and float((sB[rows].cpu() - o_scores).abs().max()) < 1e-3
+    assert torch.equal(pB[rows], p3) and torch.equal(sB[rows], s3), "a window's forward depends on its row past the 2 GiB boundary"
+    rel = float((gB - g3).abs().max() / g3.abs().max())
+    cos = _cos(gB, g3)
+    print(f"[B=172] gradients of the three live rows vs the 3-window step: max |dg| / max |g| = {rel:.2e}, cosine {cos:.8f}")
+    assert rel < 2e-3 and cos > 0.999999, (rel, cos)
+    del eng
+    model._engine = None
+    del model
+    gc.collect(); torch.cuda.empty_cache()
+
+
 def test_training_step_is_bitwise_reproducible_and_batch_invariant(lib):
     """The benchmarked precision at full width (T=243 K=5 C=512 depth 8) and a batch of 16 windows - persistent GEMMs, side streams,
     train-mode DropPath from the engine's counter-based stream: two identical steps must produce the same BITS (poses, scores, segment
@@ -2450,6 +2517,23 @@ def test_stream_hazard_check_of_the_three_stream_engine(lib):
                 with pytest.raises(RuntimeError, match="debug bit 0"):
                     m._engine.hazard_report()
         assert torch.equal(grads[True], grads[False])
+    # MuReadout (readout multiplier != 1): the heads' weight gradients land in a zeroed scratch (memset on the caller's stream) that the
+    # parameter kernels fill on the weight-gradient stream and a flush adds to the gradient buffer - declared to the tracker since round 6
+    from test_host_cpu import _mup_model
+    from manipose_amd.metrics import rmcl_training_loss as rloss
+    fx = load_fixture("mup_rmcl")
+    mm = _mup_model(fx)
+    mm.precision, mm.hazard_check = "bf16x3", True
+    mm = mm.cuda().train()
+    Xm, ym = dev(fx["X"]), dev(fx["y"])
+    for step in range(2):
+        mm.zero_grad(set_to_none=True)
+        pm, sm = mm(Xm)
+        rloss(pm, sm, ym)[0].backward()
+    torch.cuda.synchronize()
+    rep = mm._engine.hazard_report()
+    assert rep["violations"] == 0, "\n".join(rep["messages"][:8])
+    print("mup_rmcl bf16x3", {k: v for k, v in rep.items() if k != "messages"})
 
 
 def test_backward_after_an_in_place_parameter_update_is_refused(lib):

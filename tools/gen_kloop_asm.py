@@ -101,6 +101,8 @@ CONFIGS = {"X0": dict(a="always", b="none", c="none"), "X1": dict(a="cond", b="a
            # SIMD's first MFMA of the step, while the younger wave waits for the pipe anyway
            "Z0": dict(a="cond", b="none", c="none", pieces=8), "Z1": dict(a="cond", b="cond", c="none", pieces=8),
            "Z2": dict(a="none", b="cond", c="cond", pieces=8), "ZP": dict(a="cond", b="cond", c="cond", pieces=8)}
+# (emitted separately, "N" operands only) the f16f8 loop's steps
+F8_CONFIGS = {"ZF": dict(a="cond", b="cond", c="none", pieces=8), "ZE": dict(a="cond", b="cond", c="cond", pieces=8)}
 
 # Variants (MP_KSTEP_VARIANT selects one at compile time; the A/B of round 5 is in DESIGN.md section 5):
 #   dma    'spread'       one DMA instruction behind the third and the sixth MFMA of groups 0-3 (job b in groups 0-1, job a in 2-3)
@@ -113,13 +115,13 @@ VARIANTS = {
 }
 
 
-def step(trb, cfg, dma="spread", ahead=2, base=200, pad=False):
+def step(trb, cfg, dma="spread", ahead=2, base=200, pad=False, mfma="v_mfma_f32_16x16x32_bf16"):
     """the instruction list of one step; `pend` = request batches in flight, oldest first, as (group that needs them, count)"""
     global FA0, FB0
     FA0, FB0 = base, base + 24
     ins = []
     pend = []
-    jm = CONFIGS[cfg]
+    jm = CONFIGS.get(cfg) or F8_CONFIGS[cfg]
 
     def request(lines, n, needed_by):
         ins.extend(lines)
@@ -158,7 +160,7 @@ def step(trb, cfg, dma="spread", ahead=2, base=200, pad=False):
         for f in range(2):
             for j in range(4):
                 c = f"%[c{2 * p + f}{j}]"
-                mf.append(f"v_mfma_f32_16x16x32_bf16 {c}, {vr(fb(kidx % 2, j))}, {vr(fa(slot, f))}, {c}")
+                mf.append(f"{mfma} {c}, {vr(fb(kidx % 2, j))}, {vr(fa(slot, f))}, {c}")
         ins.append(mf[0])
         # requests issued behind the first MFMA of the group: the fragments of group g + ahead (B of the next k-step with its first A)
         t = g + ahead
@@ -179,6 +181,66 @@ def step(trb, cfg, dma="spread", ahead=2, base=200, pad=False):
         ins.extend(mf[6:8])
         if g + 1 < ng:
             wait_for(g + 1)
+    assert not pend, pend
+    return ins
+
+
+def step_f8(cfg, dma="head_after", ahead=2, base=200):
+    """The correction step of the "f16f8" operand form (gemm_bf16.hip, SPLIT = 8) as one block: 32 v_mfma_scale_f32_16x16x128_f8f6f4 of a wave's
+    128 x 64 sub-tile - one per 16 x 16 block, 128 reduction BYTES deep (the whole 64-index k-tile of the 2-byte correction planes), 8 passes each:
+    the same 1024 matrix-pipe cycles as the 64 bf16 / fp16 MFMAs of the other steps.  A fragment = the lane's 16-byte chunks g and g + 4 of its
+    row (two ds_read_b128 through the step's two A address operands: exactly the k-step 0 / 1 fragments of the 16-bit steps), 8 registers; ring of
+    three A fragments (one group of four MFMAs each), the four B fragments stay for the step: 24 + 32 = the same 56 fixed registers.  The E8M0 block
+    scales (2^-15 on the first source, 1 on the second; all lanes and blocks alike) come in two VGPR operands.  Requests: B0, A0 first - the first
+    MFMA waits for those four reads only - then B1..B3 and A1; A(g + ahead) behind the first MFMA of group g; counted waits throughout."""
+    ins, pend = [], []          # pend: request batches in flight, oldest first, as (tag, count)
+    jm = F8_CONFIGS[cfg]
+    npc = jm.get("pieces", 4)
+    A0, B0 = base, base + 24
+
+    def req(tag, lines):
+        ins.extend(lines)
+        pend.append((tag, len(lines)))
+
+    def wait(tag):              # the batch `tag` (and everything older: LDS returns in order) has landed; younger batches stay in flight
+        idx = [t for t, _ in pend].index(tag)
+        ins.append(f"s_waitcnt lgkmcnt({sum(n for _, n in pend[idx + 1:])})")
+        del pend[:idx + 1]
+
+    def ra(i):
+        r = A0 + (i % 3) * 8
+        return [f"ds_read_b128 {vr(r)}, %[aa0] offset:{i * 2048}", f"ds_read_b128 {vr(r + 4)}, %[aa1] offset:{i * 2048}"]
+
+    def rb(j):
+        r = B0 + j * 8
+        return [f"ds_read_b128 {vr(r)}, %[ba0] offset:{j * 2048}", f"ds_read_b128 {vr(r + 4)}, %[ba1] offset:{j * 2048}"]
+
+    jobs = dma_job("b", jm["b"], npc) + dma_job("a", jm["a"], npc)
+    if dma == "head_before":
+        ins.extend(jobs)
+    req("b0", rb(0)); req("a0", ra(0))
+    for j in (1, 2, 3):
+        req(f"b{j}", rb(j))
+    if ahead >= 2:
+        req("a1", ra(1))
+    if dma != "head_before":
+        ins.extend(jobs)
+    live = {"b0", "a0", "b1", "b2", "b3"} | ({"a1"} if ahead >= 2 else set())
+    for g in range(8):
+        if f"a{g}" in live:
+            wait(f"a{g}") if g else wait("a0")
+            live.discard(f"a{g}")
+        for j in range(4):
+            if f"b{j}" in live and any(t == f"b{j}" for t, _ in pend):
+                wait(f"b{j}")
+            live.discard(f"b{j}")
+            c = f"%[c{g}{j}]"
+            ins.append(f"v_mfma_scale_f32_16x16x128_f8f6f4 {c}, {vr(B0 + j * 8, 8)}, {vr(A0 + (g % 3) * 8, 8)}, {c}, %[sca], %[scb] op_sel_hi:[0,0,0]")
+            # (behind the group's SECOND MFMA: the ring slot's last reader - the previous group's last MFMA - is then two 8-pass MFMAs back)
+            if j == 1 and g + ahead < 8:
+                req(f"a{g + ahead}", ra(g + ahead)); live.add(f"a{g + ahead}")
+            if j == 2 and g == 4:
+                ins.extend(bias_dma(jm["c"]))
     assert not pend, pend
     return ins
 
@@ -297,6 +359,19 @@ def emit():
                 for i, l in enumerate(lines):
                     out.append(f'  "{l}\\n"' + (" \\" if i + 1 < len(lines) else ""))
                 out.append("")
+    # the two steps of a k-tile of the "f16f8" loop (SPLIT = 8; forward, "N" operands, DMA by waves 4-7): F = the fp16 planes (the plain step with the
+    # fp16 instruction; it always requests the k-tile's correction tiles), E = the correction planes (requests the next k-tile's / tile's fp16 tiles)
+    for v, opt in sorted(VARIANTS.items()):
+        lines = step(0, "ZF", mfma="v_mfma_f32_16x16x32_f16", **opt)
+        out.append(f"#define MP_KSTEP_ASM_ZF_TRB0_V{v} \\")
+        for i, l in enumerate(lines):
+            out.append(f'  "{l}\\n"' + (" \\" if i + 1 < len(lines) else ""))
+        out.append("")
+        lines = step_f8("ZE", **opt)
+        out.append(f"#define MP_KSTEP_ASM_ZE_TRB0_V{v} \\")
+        for i, l in enumerate(lines):
+            out.append(f'  "{l}\\n"' + (" \\" if i + 1 < len(lines) else ""))
+        out.append("")
     lines = pipe_loop_x3()
     out.append("#define MP_KPIPE_X3_ASM \\")
     for i, l in enumerate(lines):
@@ -307,7 +382,7 @@ def emit():
     for v, opt in sorted(VARIANTS.items()):
         b = opt.get("base", 200)
         clob = ", ".join(f'"v{r}"' for r in range(b, b + 56))
-        out.append(f'#define MP_KSTEP_CLOBBERS_V{v} "memory", "scc", {clob}')
+        out.append(f'#define MP_KSTEP_CLOBBERS_V{v} "memory", "scc", "m0", {clob}')      # m0: every block's DMA set-up writes it (a later compiler-made global_load_lds / readlane must re-initialise it)
     out.append("")
     return "\n".join(out)
 
