@@ -22,10 +22,13 @@ Prints ONE JSON line on rank 0 with
                   against the oracle's composition of the same procedure);  `small_batch`: the headline workload at the reference's batch sizes 3 and 25;
   `cpu_baseline`  oracle/manipose_ref.py timed on the host cores (rank 0, N=1 only), B=1 and the reference's default B=3; `cores_limited_by` says which
                   limit (cgroup quota / affinity mask / MANIPOSE_CPU_THREADS) set the thread count.
-Default precision: "bf16x3" (split operands, fp32 accumulate: every Linear and attention product as three bf16 matrix-core products of bf16
-hi / lo planes, bf16 backward) - the fastest precision whose drift stays inside the 1e-4 m bound; "bf16" (BASELINE config #3's wording) is
-faster but drifts ~3 mm.  `--f16f8 1 [--f16-backward]` runs the qkv / fc1 products as one fp16 + one block-scaled fp8 product instead
-(mp_model_config::f16f8, ABI v7; named in `config.split_forms`): <= 1 % faster, 1.3e-5 m instead of 0.9e-5 m, so it is an option, not the default.
+Default precision: "bf16x3" (split operands, fp32 accumulate; bf16 backward) - the fastest precision whose drift stays inside the 1e-4 m bound;
+"bf16" (BASELINE config #3's wording) is faster but drifts ~3-4.6 mm.  Operand form of the split precision (mp_model_config::f16f8, named in
+`config.split_forms`): since round 6 the default is `--f16f8 3` - all four Linear layers of a block of the rotations net as ONE fp16 + ONE block-scaled
+fp8 matrix-core product per 64 reduction indices (hand-scheduled k-steps; the attention products stay three bf16 products; bf16 backward): same-box
+A/B +3.4 % poses/s over the three-product form at 1.6e-5 m instead of 0.94e-5 m.  `--f16f8 0` = every product as three
+bf16 products (rounds 2-5; timed for a few steps in every default run as `other_precisions.bf16x3_three_bf16_products`); 1 / 2 = the older partial
+forms (qkv / fc1 [/ fc2 with --f16-backward]).
 """
 import argparse
 import json
@@ -222,8 +225,9 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("MANIPOSE_PRECISION", "bf16x3"), choices=["bf16", "bf16x3", "fp32"],
                     help="bf16x3 (default) = split bf16 hi/lo operands, 3 matrix-core products per product: inside the 1e-4 m parity bound; "
                          "bf16 = plain bf16 matrix cores (fp32 accumulate/residual/softmax), ~3 mm drift; fp32 = fp32 matrix cores")
-    ap.add_argument("--f16f8", type=int, default=0, choices=[0, 1, 2],
-                    help="bf16x3 only (mp_model_config::f16f8): 1 = qkv / fc1 as one fp16 + one block-scaled fp8 product, 2 = fc2 as well")
+    ap.add_argument("--f16f8", type=int, default=int(os.environ.get("MANIPOSE_F16F8", "3")), choices=[0, 1, 2, 3],
+                    help="bf16x3 only (mp_model_config::f16f8): 1 = qkv / fc1 as one fp16 + one block-scaled fp8 product, 2 = fc2 as well (needs --f16-backward), "
+                         "3 (default since round 6) = all four Linear layers of a block, bf16 backward; 0 = every product as three bf16 products (rounds 2-5)")
     ap.add_argument("--f16-backward", action="store_true", help="with --f16f8 >= 1: backward GEMMs of those layers on saturating scaled-fp16 operands")
     ap.add_argument("--single-queue", action="store_true",
                     help="every kernel on the caller's stream (mp_model_config::streams = 3): isolated kernel durations under rocprofv3")
@@ -268,7 +272,7 @@ def main():
     from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
     from manipose_amd.training import LiftingTrainer
 
-    def build_model(precision, batch, arch="rmcl", frames=None):
+    def build_model(precision, batch, arch="rmcl", frames=None, f16f8=None):
         from manipose_amd import ManifoldMixSTE
         torch.manual_seed(42)
         frames = frames or args.frames
@@ -280,7 +284,7 @@ def main():
                     p.normal_(0.0, 0.02)
         mdl.precision = precision
         if precision == "bf16x3":
-            mdl.f16f8, mdl.f16_backward = args.f16f8, args.f16_backward
+            mdl.f16f8, mdl.f16_backward = (args.f16f8 if f16f8 is None else f16f8), (args.f16_backward if f16f8 is None else False)
         mdl.side_stream = mdl.wgrad_stream = not args.single_queue
         mdl.max_batch_hint = batch
         return mdl
@@ -524,12 +528,13 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_extra:
-        for prec in ("bf16x3", "bf16", "fp32"):
-            if prec == args.precision:
-                continue
+        variants = [(p_, p_, None) for p_ in ("bf16x3", "bf16", "fp32") if p_ != args.precision]
+        if args.precision == "bf16x3" and args.f16f8 != 0:      # the timed operand form's predecessor: every product as three bf16 products (rounds 2-5)
+            variants.insert(0, ("bf16x3_three_bf16_products", "bf16x3", 0))
+        for label, prec, f8 in variants:
             try:
                 Bx = EXTRA_BATCH[prec]
-                mx = build_model(prec, Bx).cuda()
+                mx = build_model(prec, Bx, f16f8=f8).cuda()
                 Xx = X[:Bx] if Bx <= B else X.repeat((Bx + B - 1) // B, 1, 1, 1)[:Bx]
                 yx = y[:Bx] if Bx <= B else y.repeat((Bx + B - 1) // B, 1, 1, 1)[:Bx]
                 par = parity_of(mx, Xx)
@@ -542,15 +547,15 @@ def main():
                     tx.train_step(Xx, yx)
                 torch.cuda.synchronize()
                 dtx = (time.perf_counter() - t1) / nst
-                other[prec] = {"poses_per_s": Bx * T / dtx, "ms_per_step": 1e3 * dtx, "windows_per_gpu": Bx, "steps": nst, "warmup": 1,
+                other[label] = {"poses_per_s": Bx * T / dtx, "ms_per_step": 1e3 * dtx, "windows_per_gpu": Bx, "steps": nst, "warmup": 1,
                                "parity_mpjpe_m": par["mpjpe_m"] if par else None,
                                "within_bound": (par["mpjpe_m"] <= PARITY_BOUND_M) if par else None}
-                log(f"{prec}: {other[prec]['poses_per_s']:.0f} poses/s, parity {other[prec]['parity_mpjpe_m']}")
+                log(f"{label}: {other[label]['poses_per_s']:.0f} poses/s, parity {other[label]['parity_mpjpe_m']}")
                 mx._engine = None
                 del tx, mx
                 torch.cuda.empty_cache()
             except Exception as e:       # noqa: BLE001
-                other[prec] = {"error": f"{type(e).__name__}: {e}"}
+                other[label] = {"error": f"{type(e).__name__}: {e}"}
     # N=1: the other single-GPU BASELINE configurations and the reference's own batch sizes, a few steps each in the timed precision, with the same
     # parity measurement (CPU-child oracle on the same weights; parity windows embedded at the first / middle / last row of the batch)
     other_cfgs, small_batch = {}, {}
@@ -642,7 +647,10 @@ def main():
                "config": {"workload": f"H36M lifting T={T} J=17 K={args.hyp} ManiPose full (C=512, depth 8), train step "
                                       f"fwd+WTA loss+bwd+allreduce+Adam", "windows_per_gpu": B, "global_batch": world * B,
                           "seq_len": T, "parallelism": f"dp{world}", "precision": args.precision, "drop_path_rate": 0.1,
-                          **({"split_forms": (("qkv, fc1" + (", fc2" if args.f16f8 >= 2 else "") + ": f16f8 (fp16 hi plane x fp16 hi plane + ONE block-scaled e4m3 "
+                          **({"split_forms": (("qkv, proj, fc1, fc2: f16f8 (fp16 plane x fp16 plane + ONE block-scaled e4m3 product of 8-bit correction planes per 64 "
+                                               "reduction indices; hand-scheduled k-steps); attention: bf16x3 (three bf16 products of bf16 hi/lo planes), its output "
+                                               "written as f16f8 planes; bf16 backward (the fp16 planes rounded to bf16 where it reads them)") if args.f16f8 == 3 else
+                                              ("qkv, fc1" + (", fc2" if args.f16f8 >= 2 else "") + ": f16f8 (fp16 hi plane x fp16 hi plane + ONE block-scaled e4m3 "
                                                "product of 8-bit correction planes per 64 reduction indices); " + ("proj" if args.f16f8 >= 2 else "proj, fc2")
                                                + ", attention: bf16x3 (three bf16 products of bf16 hi/lo planes)"
                                                + ("; backward of the f16f8 layers on saturating fp16 operands with a per-backward device-side power-of-two "
@@ -684,8 +692,10 @@ def main():
                 kname = ("gemm_bf16_persist_kernel (forward + dgrad Linear GEMMs: persistent, direct-to-LDS 256x256x64 tiles, "
                          "v_mfma_f32_16x16x32_bf16; all instantiations" +
                          ("; the split-precision forward instantiations read two planes per operand and issue 3 bf16 products per k-tile"
-                          + (" (proj, fc2) or one fp16 + one double-depth fp8 product (qkv, fc1: v_mfma_f32_16x16x32_f16 + "
-                             "v_mfma_scale_f32_16x16x128_f8f6f4)" if args.f16f8 >= 1 else "")
+                          + ((" - or, f16f8 = 3, ALL forward launches issue one fp16 + one double-depth fp8 product (v_mfma_f32_16x16x32_f16 + "
+                              "v_mfma_scale_f32_16x16x128_f8f6f4)") if args.f16f8 == 3 else
+                             (" (proj, fc2) or one fp16 + one double-depth fp8 product (qkv, fc1: v_mfma_f32_16x16x32_f16 + "
+                              "v_mfma_scale_f32_16x16x128_f8f6f4)" if args.f16f8 >= 1 else ""))
                           + "; flops = 2 M N K, bytes = both planes)" if args.precision == "bf16x3" else ")"))
             else:
                 k = prof["gemm_fwd"]

@@ -59,9 +59,11 @@ def instantiate_model(cfg):
 
 def _engine_options(model, cfg):
     """model.f16f8 / model.f16_backward of the config (mp_model_config, ABI v7): the operand form of the qkv / fc1 (/ fc2) layers of a
-    bf16x3 model.  Defaults (0 / false): three bf16 products everywhere, bf16 backward."""
-    model.f16f8 = int(getattr(cfg.model, "f16f8", 0))
-    model.f16_backward = bool(getattr(cfg.model, "f16_backward", False))
+    bf16x3 model (ignored for the other precisions).  Config default since round 6: f16f8 = 3 (all four Linear layers of a block as one fp16 + one
+    block-scaled fp8 product; a model that does not qualify runs three bf16 products everywhere), bf16 backward."""
+    bf16x3 = str(getattr(cfg.model, "precision", "")) == "bf16x3"
+    model.f16f8 = int(getattr(cfg.model, "f16f8", 0)) if bf16x3 else 0
+    model.f16_backward = bool(getattr(cfg.model, "f16_backward", False)) if bf16x3 else False
 
 
 def synthetic_windows(n, T, device, seed):

@@ -211,7 +211,11 @@ typedef struct mp_model_config {
    * the library reads no environment variable).  All 0 = the defaults.
    *   f16f8         precision 2 only, rotations net of a width that is a multiple of 256: 0 (default) = every Linear product as three bf16
    *                 products of bf16 hi / lo planes; 1 = the qkv and fc1 Linear layers read "f16f8" operands (mp_linear_fwd_f16f8: one fp16
-   *                 product + one block-scaled fp8 correction product per 64 reduction indices); 2 = the fc2 layer as well (needs f16_backward)
+   *                 product + one block-scaled fp8 correction product per 64 reduction indices); 2 = the fc2 layer as well (needs f16_backward);
+   *                 3 (round 6; head dim 64, residual scale 1) = ALL FOUR Linear layers of a block: the attention kernels and the fc1 epilogue
+   *                 write their outputs as f16f8 planes too, no bf16 copy of those activations exists, and the bf16 backward rounds the fp16
+   *                 planes to bf16 where it reads them (weight-gradient GEMM fragments, the temporal attention backward's O); f16_backward
+   *                 must be 0; a model that does not qualify (other head dims / widths, muP residual scale) runs as f16f8 = 0
    *   f16_backward  with f16f8 >= 1: 1 = the backward GEMMs of those layers run on fp16 operands - gradients carried as fp16 of S x value,
    *                 S a power of two chosen per backward on the device from the residual gradient at the top of the backbone, stores saturate at
    *                 +-65504 and are counted (mp_model_grad_health);

@@ -76,7 +76,7 @@ class FusedLiftingMixin:
         self._seed = 42
         self._injected_masks: Optional[Dict[str, torch.Tensor]] = None
         self.precision = os.environ.get("MANIPOSE_PRECISION", "fp32")
-        # engine options of THIS model (mp_model_config, ABI v7; read when the engine is (re)built): f16f8 0 / 1 / 2 and f16_backward = the
+        # engine options of THIS model (mp_model_config, ABI v7; read when the engine is (re)built): f16f8 0 / 1 / 2 / 3 and f16_backward = the
         # operand form of the qkv / fc1 (/ fc2) layers of a bf16x3 model (default: three bf16 products everywhere, bf16 backward);
         # side_stream / wgrad_stream = the engine's two extra HIP streams (off: everything on the caller's stream, same bits)
         self.f16f8 = 0

@@ -196,6 +196,9 @@ __device__ __forceinline__ void store4g(bf16* p, const f32x4& v, float s, float 
 // set by the engine for the backward launches issued next on this thread: device address of the scale (null = bf16 outputs); see store4g
 static thread_local const float* g_grad_f16 = nullptr;
 void attn_grad_f16_override(const float* gout) { g_grad_f16 = gout; }
+// set by the engine likewise: the temporal backward launches issued next read `out` as an fp16 plane (f16f8 = 3) instead of bf16
+static thread_local int g_out_f16 = 0;
+void attn_out_f16_override(int on) { g_out_f16 = on; }
 
 // =============================================================================================
 // forward: O = softmax(scale Q K^T) V ; lse = log sum exp of the scaled scores
@@ -309,7 +312,7 @@ template <int D, int NTC, bool F16G>
 __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                                const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                bf16* __restrict__ dqkv, int T, int J, int C, int H, float scale,
-                                                               int debug, const float* __restrict__ gout_p) {
+                                                               int debug, const float* __restrict__ gout_p, int out_is_f16) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int ROWB = ACfg<D>::ROWB, KS = ACfg<D>::KS, DB = ACfg<D>::DB, NW = 16, UNR = NTC ? NTC / 2 : 1;
   const float gout = F16G ? *gout_p : 0.f;      // this backward's gradient scale (engine: grad_scale_kernel); F16G false: bf16 outputs
@@ -345,7 +348,9 @@ __global__ __launch_bounds__(1024) void attn_tmfma_bwd_kernel(const bf16* __rest
     float dl = 0.f;
 #pragma unroll
     for (int i = 0; i < DQ; ++i) {
-      const float4 a4 = bf16x4_to_float4(a[i]), o4 = bf16x4_to_float4(o[i]);
+      // (out_is_f16: O exists as the fp16 plane of an f16f8 pair only - mp_model_config::f16f8 = 3 - and is rounded to bf16 here, so that delta is
+      // the sum a bf16 copy of O would have given)
+      const float4 a4 = bf16x4_to_float4(a[i]), o4 = bf16x4_to_float4(out_is_f16 ? f16x4_to_bf16x4(o[i]) : o[i]);
       dl += (a4.x * o4.x + a4.y * o4.y) + (a4.z * o4.z + a4.w * o4.w);
     }
     if (t >= T) dl = 0.f;
@@ -814,6 +819,17 @@ __device__ __forceinline__ void store4_x2(bf16* ph, bf16* pl, const f32x4& v, fl
   *reinterpret_cast<uint2*>(ph) = h;
   *reinterpret_cast<uint2*>(pl) = l;
 }
+// F8O (mp_model_config::f16f8 = 3): the attention output leaves as the "f16f8" planes the proj GEMM reads (common.h: ph = the fp16 plane, pl = the
+// 8-bit correction plane - the same 2 bytes per element and the same 8 bytes per four channels as a bf16 hi / lo pair)
+template <bool F8O>
+__device__ __forceinline__ void store4_o(bf16* ph, bf16* pl, const f32x4& v, float s) {
+  if constexpr (F8O) {
+    uint2 h, c;
+    pack4_f16f8(make_float4(v[0] * s, v[1] * s, v[2] * s, v[3] * s), h, c);
+    *reinterpret_cast<uint2*>(ph) = h;
+    *reinterpret_cast<uint2*>(pl) = c;
+  } else store4_x2(ph, pl, v, s);
+}
 __device__ __forceinline__ int img_off(int img, int img_bytes) { return img * img_bytes; }
 #define MP_MFMA3(acc, a_hi, a_lo, b_hi, b_lo)                                   \
   do {                                                                          \
@@ -827,7 +843,7 @@ __device__ __forceinline__ int img_off(int img, int img_bytes) { return img * im
 // PREFETCHED INTO REGISTERS while unit u is computed (the loads are issued right after the images of u were written to LDS), so the
 // HBM / L2 latency of the staging - as long as the compute of a unit when it is not overlapped - is hidden behind the MFMAs of the
 // previous unit.  (The bf16 kernel above overlaps staging and compute by running two 64 KiB workgroups per CU instead.)
-template <int D, bool FULL>      // FULL: all NTILE key tiles are in the window (T > 240): compile-time tile count, no per-tile branches
+template <int D, bool FULL, bool F8O = false>      // FULL: all NTILE key tiles are in the window (T > 240): compile-time tile count, no per-tile branches
 __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __restrict__ qkv_hi, const bf16* __restrict__ qkv_lo,
                                                                  bf16* __restrict__ out_hi, bf16* __restrict__ out_lo,
                                                                  float* __restrict__ lse, int nunits, int T, int J, int C, int H, float scale, int debug) {
@@ -985,7 +1001,7 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3_kernel(const bf16* __re
         const float inv = 1.0f / sum;
         const long oo = ((long)(b * T + tq) * J + j) * C + h * D;
 #pragma unroll
-        for (int db = 0; db < DB; ++db) store4_x2(out_hi + oo + 16 * db + 4 * g, out_lo + oo + 16 * db + 4 * g, o[db], inv);
+        for (int db = 0; db < DB; ++db) store4_o<F8O>(out_hi + oo + 16 * db + 4 * g, out_lo + oo + 16 * db + 4 * g, o[db], inv);
         if (g == 0) lse[(long)unit * T + tq] = (mx + __log2f(sum)) * 0.6931471805599453f;
       }
     }
@@ -1019,7 +1035,7 @@ __device__ __forceinline__ void tm_dma_region(char* __restrict__ region, const b
 
 // FULL: the window fills all NTILE key tiles (T > 240: the benchmark's 243 frames) - the tile count is a compile-time constant, so the unrolled
 // tile loops carry no wave-uniform branches and each phase is one basic block for the instruction scheduler
-template <bool FULL>
+template <bool FULL, bool F8O = false>
 __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3p_kernel(const bf16* __restrict__ qkv_hi, const bf16* __restrict__ qkv_lo,
                                                                   bf16* __restrict__ out_hi, bf16* __restrict__ out_lo,
                                                                   float* __restrict__ lse, int nunits, int T, int J, int C, int H, float scale) {
@@ -1160,8 +1176,11 @@ __global__ __launch_bounds__(512) void attn_tmfma_fwd_x3p_kernel(const bf16* __r
       uint2 hv[DB], lv[DB];
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        split_bf16x2(o[sidx][db][0] * inv, o[sidx][db][1] * inv, hv[db].x, lv[db].x);
-        split_bf16x2(o[sidx][db][2] * inv, o[sidx][db][3] * inv, hv[db].y, lv[db].y);
+        if constexpr (F8O) pack4_f16f8(make_float4(o[sidx][db][0] * inv, o[sidx][db][1] * inv, o[sidx][db][2] * inv, o[sidx][db][3] * inv), hv[db], lv[db]);
+        else {
+          split_bf16x2(o[sidx][db][0] * inv, o[sidx][db][1] * inv, hv[db].x, lv[db].x);
+          split_bf16x2(o[sidx][db][2] * inv, o[sidx][db][3] * inv, hv[db].y, lv[db].y);
+        }
       }
 #pragma unroll
       for (int plane = 0; plane < 2; ++plane) {
@@ -1200,7 +1219,7 @@ void attn_two_phase(int on) { g_attn_two_phase = on; }
 
 // spatial: workgroup per frame, wave per head; the frame's hi and lo qkv blocks (2 x N x 6C bytes, contiguous in HBM) are both staged.
 // Persistent with register prefetch of the next frame's blocks like the temporal kernel (105 KiB of LDS at C = 512: one workgroup per CU).
-template <int D>
+template <int D, bool F8O = false>
 __global__ __launch_bounds__(512) void attn_smfma_fwd_x3_kernel(const bf16* __restrict__ qkv_hi, const bf16* __restrict__ qkv_lo,
                                                                  bf16* __restrict__ out_hi, bf16* __restrict__ out_lo, int nframes, int N, int C,
                                                                  int H, float scale) {
@@ -1282,7 +1301,7 @@ __global__ __launch_bounds__(512) void attn_smfma_fwd_x3_kernel(const bf16* __re
         MP_MFMA3(o, vTh[db], vTl[db], bph, bpl);
         if (tq < N) {
           const long oo = ((long)f * N + tq) * C + h * D + 16 * db + 4 * g;
-          store4_x2(out_hi + oo, out_lo + oo, o, 1.0f);
+          store4_o<F8O>(out_hi + oo, out_lo + oo, o, 1.0f);
         }
       }
     }
@@ -1331,10 +1350,11 @@ bool attn_x3_needs_scratch(int temporal, int T, int J, int C, int H) {
 }
 
 int attn_spatial_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* scratch, int B, int T, int J, int C, int H,
-                        hipStream_t st) {
+                        hipStream_t st, int out_f16f8) {
   MP_CHECK(C % H == 0 && C % 4 == 0, MP_ERR_ARG, "attn_spatial_fwd_x3: C=%d H=%d", C, H);
   const int D = C / H;
   const long M = (long)B * T * J;
+  MP_CHECK(!out_f16f8 || (D == 64 && !attn_x3_needs_scratch(0, T, J, C, H)), MP_ERR_ARG, "attn_spatial_fwd_x3: f16f8 output needs head dim 64 and the MFMA kernel (J=%d C=%d H=%d)", J, C, H);
   if (attn_x3_needs_scratch(0, T, J, C, H)) {
     MP_CHECK(scratch != nullptr, MP_ERR_ARG, "attn_spatial_fwd_x3: J=%d D=%d H=%d needs the fp32 scratch", J, D, H);
     int rc = join_planes(qkv_hi, qkv_lo, scratch, 3 * M * C, st);
@@ -1356,6 +1376,14 @@ int attn_spatial_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf
       MP_HIP(hipFuncSetAttribute((const void*)attn_smfma_fwd_x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
+    if (out_f16f8) {
+      static bool attr8_set = false;
+      if (!attr8_set) {
+        MP_HIP(hipFuncSetAttribute((const void*)attn_smfma_fwd_x3_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr8_set = true;
+      }
+      hipLaunchKernelGGL((attn_smfma_fwd_x3_kernel<64, true>), dim3(grid), dim3(H * 64), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, nframes, J, C, H, scale);
+    } else
     hipLaunchKernelGGL(attn_smfma_fwd_x3_kernel<64>, dim3(grid), dim3(H * 64), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, nframes, J, C, H, scale);
   } else {
     static bool attr_set = false;
@@ -1375,7 +1403,7 @@ int attn_spatial_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf
 #else
 #define ATTN_X3P_FULL_GUARD
 #endif
-template <int D>
+template <int D, bool F8O = false>
 static int launch_tmfma_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* lse, int units, int T, int J, int C,
                                int H, float scale, hipStream_t st) {
   const int ntile = (T + 15) >> 4;
@@ -1385,8 +1413,8 @@ static int launch_tmfma_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out
   const size_t lds = 4 * (size_t)rows * ACfg<D>::ROWB;
   static bool attr_set = false;
   if (!attr_set) {
-    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * ACfg<D>::ROWB)));
-    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * ACfg<D>::ROWB)));
+    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3_kernel<D, false, F8O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * ACfg<D>::ROWB)));
+    MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3_kernel<D, true, F8O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * ACfg<D>::ROWB)));
     attr_set = true;
   }
   const int per_cu = (int)max((size_t)1, min((size_t)4, (size_t)(160 * 1024) / lds));
@@ -1397,18 +1425,19 @@ static int launch_tmfma_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out
   constexpr int dbg = 0;
 #endif
   if (ntile == NTILE ATTN_X3P_FULL_GUARD)
-    hipLaunchKernelGGL((attn_tmfma_fwd_x3_kernel<D, true>), dim3(grid), dim3(64 * waves), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, dbg);
+    hipLaunchKernelGGL((attn_tmfma_fwd_x3_kernel<D, true, F8O>), dim3(grid), dim3(64 * waves), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, dbg);
   else
-    hipLaunchKernelGGL((attn_tmfma_fwd_x3_kernel<D, false>), dim3(grid), dim3(64 * waves), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, dbg);
+    hipLaunchKernelGGL((attn_tmfma_fwd_x3_kernel<D, false, F8O>), dim3(grid), dim3(64 * waves), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, dbg);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }
 
 int attn_temporal_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* lse, float* scratch, int B, int T, int J,
-                         int C, int H, hipStream_t st) {
+                         int C, int H, hipStream_t st, int out_f16f8) {
   MP_CHECK(C % H == 0 && C % 4 == 0, MP_ERR_ARG, "attn_temporal_fwd_x3: C=%d H=%d", C, H);
   const int D = C / H;
   const long M = (long)B * T * J;
+  MP_CHECK(!out_f16f8 || (D == 64 && !attn_x3_needs_scratch(1, T, J, C, H)), MP_ERR_ARG, "attn_temporal_fwd_x3: f16f8 output needs head dim 64 and the MFMA kernel (T=%d C=%d H=%d)", T, C, H);
   if (attn_x3_needs_scratch(1, T, J, C, H)) {
     MP_CHECK(scratch != nullptr, MP_ERR_ARG, "attn_temporal_fwd_x3: T=%d D=%d needs the fp32 scratch", T, D);
     int rc = join_planes(qkv_hi, qkv_lo, scratch, 3 * M * C, st);
@@ -1426,16 +1455,23 @@ int attn_temporal_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, b
     if (!attr_set) {
       MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * 128 + 8 * 16 * 144)));
       MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * 128 + 8 * 16 * 144)));
+      MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * 128 + 8 * 16 * 144)));
+      MP_HIP(hipFuncSetAttribute((const void*)attn_tmfma_fwd_x3p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * TP * 128 + 8 * 16 * 144)));
       attr_set = true;
     }
     const int grid = min(units, num_cus());
-    if (((T + 15) >> 4) == NTILE ATTN_X3P_FULL_GUARD)
+    const bool full = ((T + 15) >> 4) == NTILE ATTN_X3P_FULL_GUARD;
+    if (out_f16f8) {
+      if (full) hipLaunchKernelGGL((attn_tmfma_fwd_x3p_kernel<true, true>), dim3(grid), dim3(512), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale);
+      else hipLaunchKernelGGL((attn_tmfma_fwd_x3p_kernel<false, true>), dim3(grid), dim3(512), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale);
+    } else if (full)
       hipLaunchKernelGGL(attn_tmfma_fwd_x3p_kernel<true>, dim3(grid), dim3(512), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale);
     else
       hipLaunchKernelGGL(attn_tmfma_fwd_x3p_kernel<false>, dim3(grid), dim3(512), lds, st, qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale);
     MP_LAUNCH_CHECK();
     return MP_OK;
   }
+  if (D == 64 && out_f16f8) return launch_tmfma_fwd_x3<64, true>(qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, st);
   if (D == 64) return launch_tmfma_fwd_x3<64>(qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, st);
   return launch_tmfma_fwd_x3<16>(qkv_hi, qkv_lo, out_hi, out_lo, lse, units, T, J, C, H, scale, st);
 }
@@ -1487,9 +1523,9 @@ static int launch_tmfma_bwd(const bf16* qkv, const bf16* out, const bf16* dout, 
     attr_set = true;
   }
   if (g_grad_f16 != nullptr)
-    hipLaunchKernelGGL((attn_tmfma_bwd_kernel<D, NTC, true>), dim3(units), dim3(64 * waves), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg, g_grad_f16);
+    hipLaunchKernelGGL((attn_tmfma_bwd_kernel<D, NTC, true>), dim3(units), dim3(64 * waves), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg, g_grad_f16, g_out_f16);
   else
-    hipLaunchKernelGGL((attn_tmfma_bwd_kernel<D, NTC, false>), dim3(units), dim3(64 * waves), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg, g_grad_f16);
+    hipLaunchKernelGGL((attn_tmfma_bwd_kernel<D, NTC, false>), dim3(units), dim3(64 * waves), lds, st, qkv, out, dout, lse, dqkv, T, J, C, H, scale, dbg, g_grad_f16, g_out_f16);
   MP_LAUNCH_CHECK();
   return MP_OK;
 }

@@ -140,6 +140,22 @@ __device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float
 }
 // four consecutive elements v (columns c .. c + 3, c % 4 == 0) of a row: hi16 = their place in the fp16 plane, corr8 = their 8 bytes in the
 // correction plane (byte offset 2 (row K + c))
+// the same in registers, activation form: h16 = the four fp16 values, c8 = their 8 correction bytes
+__device__ __forceinline__ void pack4_f16f8(float4 v, uint2& h16, uint2& c8) {
+  typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+  asm("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));      // split the ROUNDED values (see split_bf16x2: no fusing of a producer's multiply into the subtraction)
+  const h4_t h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  h16 = __builtin_bit_cast(uint2, h);
+  const float4 hf = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+  c8 = make_uint2(pack_e4m3x4((v.x - hf.x) * 2048.f, (v.y - hf.y) * 2048.f, (v.z - hf.z) * 2048.f, (v.w - hf.w) * 2048.f), pack_e4m3x4(hf.x, hf.y, hf.z, hf.w));
+}
+// four fp16 values (the fp16 plane of an f16f8 activation) -> four bf16 values, round to nearest even: what a bf16 backward kernel makes of an
+// operand that exists as an fp16 plane only (mp_model_config::f16f8 = 3: no bf16 copy of a1 / ao / a2 / f is written)
+__device__ __forceinline__ uint2 f16x4_to_bf16x4(uint2 h) {
+  typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+  const h4_t x = __builtin_bit_cast(h4_t, h);
+  return make_uint2(pack_bf16x2((float)x[0], (float)x[1]), pack_bf16x2((float)x[2], (float)x[3]));
+}
 __device__ __forceinline__ void st4_f16f8(f16f8* hi16, char* corr8, float4 v, bool weight) {
   typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
   const h4_t h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};

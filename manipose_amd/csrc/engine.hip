@@ -53,6 +53,9 @@ struct Module {
                           // fc2 dgrad, the fp16 planes of a1 / a2 as the weight-gradient operands, the f16f8 shadow's fp16 plane as the dgrads' weights): a1, a2 need no bf16 copy
   bool f8m = false;       // f8g and the fc2 layer too: f (the GELU output) is written as f16f8 planes by the fc1 epilogue and read so by the fc2 forward GEMM; its
                           // backward runs on fp16 operands (the gradient copy of the LayerNorm backward behind the block as scaled fp16)
+  bool f8a = false;       // f8 (without f8g) on ALL FOUR Linear layers (mp_model_config::f16f8 = 3, round 6): the attention kernels and the fc1 epilogue write f16f8
+                          // planes too (ao, f), NO bf16 copy of a1 / ao / a2 / f exists - the bf16 backward's weight-gradient GEMMs round the fp16 planes to
+                          // bf16 per fragment (wgrad_bf16 x_f16) and the temporal attention backward reads O from its fp16 plane
   float qk_scale, rs, readout;   // attention softmax scale (0 = head_dim^-0.5), residual scale, MuReadout input multiplier (1 unless muP)
   float *hw_eff, *hdw;    // readout != 1: the heads' weights times readout (forward / dx) and the scratch their gradient lands in
   int emb_w, emb_b, spos, tpos, sn_w, sn_b, tn_w, tn_b;
@@ -222,8 +225,8 @@ static void carve_module(Module& md, Bump& bp, long M, int T, int Bmax, int prec
     w.z = act(M * 2 * C);      w.f = act(M * 2 * C);       w.x_out = bp.take(M * C); w.stp = bp.take(M * 2);
     w.a1l = a1l; w.qkvl = qkvl; w.aol = aol; w.a2l = a2l; w.fl = fl;
     // f8g: nobody reads a bf16 a1 / a2 (the backward runs on the fp16 planes): the fp16 planes take their place
-    w.a1h = md.f8 ? (md.f8g ? w.a1 : bp.take((M * C + 1) / 2)) : nullptr;
-    w.a2h = md.f8 ? (md.f8g ? w.a2 : bp.take((M * C + 1) / 2)) : nullptr;
+    w.a1h = md.f8 ? ((md.f8g || md.f8a) ? w.a1 : bp.take((M * C + 1) / 2)) : nullptr;      // (f8a: no bf16 copy either)
+    w.a2h = md.f8 ? ((md.f8g || md.f8a) ? w.a2 : bp.take((M * C + 1) / 2)) : nullptr;
   }
   md.x_final = bp.take(M * C);
   md.hw_eff = md.readout != 1.0f ? bp.take((long)md.K * md.O * C) : nullptr;
@@ -466,14 +469,14 @@ static int linear_dgrad(mp_model* m, hipStream_t st, const float* fp, const void
   return MP_OK;
 }
 static int linear_wgrad(mp_model* m, hipStream_t st, const void* dY, int dy_f32, const void* X, float* dW, float* db, long M, int N,
-                        int K, bool f16 = false) {
+                        int K, bool f16 = false, bool x_f16 = false) {
   HZ(st, "linear_wgrad", HR(dY, (m->cfg.precision == 0 || dy_f32 ? 4.0 : 2.0) * M * N), HR(X, (m->cfg.precision == 0 ? 4.0 : 2.0) * M * K), HW(dW, 4.0 * N * K), HW(db, 4.0 * N),
      HW(m->slab, 4.0 * m->slab_floats));
   if (m->cfg.precision == 0)
     RUN(PC_GEMM_WGRAD, 2.0 * M * N * K, wgrad_f32((const float*)dY, N, (const float*)X, K, (int)M, N, K, dW, db, m->slab, m->slab_floats, st));
   else
     RUN(PC_GEMM_WGRAD, 2.0 * M * N * K, wgrad_bf16(dY, dy_f32, N, (const bf16*)X, K, (int)M, N, K, dW, db, m->slab, m->slab_floats, st, f16 ? 1 : 0,
-                                                   f16 ? m->gsc + 1 : nullptr));
+                                                   f16 ? m->gsc + 1 : nullptr, x_f16 ? 1 : 0));
   return MP_OK;
 }
 
@@ -538,7 +541,7 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     LnFwdArgs a = {};
     a.x = md.ws[0].x_in; a.M = (int)M; a.C = C;
     a.g2 = P(m, fp, md.bp[0].n1w); a.b2 = P(m, fp, md.bp[0].n1b); a.eps2 = 1e-6f; a.y2 = md.ws[0].a1; a.y2_lo = md.ws[0].a1l; a.stats2 = md.ws[0].st1;
-    if (md.f8) { a.y2 = md.ws[0].a1h; a.y2_b16 = (m->infer || md.f8g) ? nullptr : md.ws[0].a1; }
+    if (md.f8) { a.y2 = md.ws[0].a1h; a.y2_b16 = (m->infer || md.f8g || md.f8a) ? nullptr : md.ws[0].a1; }
     hz_ln_fwd(m, st, a, half);
     RUN(PC_LN, 0, ln_fwd(a, half, st));
   }
@@ -557,8 +560,8 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
          HW(spatial ? nullptr : w.lse, 4.0 * B * N * H * T), HW(xattn, xattn ? 16.0 * M * C : 0.0));
     }
     if (x3) {
-      if (spatial) RUN(PC_ATTN, 12.0 * B * T * N * N * C, attn_spatial_fwd_x3((const bf16*)w.qkv, (const bf16*)w.qkvl, (bf16*)w.ao, (bf16*)w.aol, xattn, B, T, N, C, H, st));
-      else RUN(PC_ATTN, 12.0 * B * N * (double)T * T * C, attn_temporal_fwd_x3((const bf16*)w.qkv, (const bf16*)w.qkvl, (bf16*)w.ao, (bf16*)w.aol, w.lse, xattn, B, T, N, C, H, st));
+      if (spatial) RUN(PC_ATTN, 12.0 * B * T * N * N * C, attn_spatial_fwd_x3((const bf16*)w.qkv, (const bf16*)w.qkvl, (bf16*)w.ao, (bf16*)w.aol, xattn, B, T, N, C, H, st, md.f8a));
+      else RUN(PC_ATTN, 12.0 * B * N * (double)T * T * C, attn_temporal_fwd_x3((const bf16*)w.qkv, (const bf16*)w.qkvl, (bf16*)w.ao, (bf16*)w.aol, w.lse, xattn, B, T, N, C, H, st, md.f8a));
     } else if (spatial) RUN(PC_ATTN, 4.0 * B * T * N * N * C, attn_spatial_fwd(w.qkv, w.ao, half, B, T, N, C, H, st));
     else RUN(PC_ATTN, 4.0 * B * N * (double)T * T * C, attn_temporal_fwd(w.qkv, w.ao, w.lse, half, B, T, N, C, H, st));
     // block input: materialised (blocks 0 and 1: embedding / positional table involved), or - bf16 mode - recomputed in the
@@ -569,29 +572,29 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
       m->cur_kind = (md.is_rot ? 0 : 12) + 0 * 4 + LK_PROJ;
       rc = linear_fwd(m, st, fp, w.ao, q.pw, q.pb, w.x_mid, M, C, C, EPI_BIAS_RESID, nullptr, md.ws[l - 1].x_out,
                       branch_mask(m, md, l, 0, B, m->train), mode, T, N, md.ws[l - 1].stp, P(m, fp, pspatial ? md.sn_w : md.tn_w),
-                      P(m, fp, pspatial ? md.sn_b : md.tn_b), w.aol);
+                      P(m, fp, pspatial ? md.sn_b : md.tn_b), w.aol, nullptr, md.f8a);
     } else {
       m->cur_kind = (md.is_rot ? 0 : 12) + 0 * 4 + LK_PROJ;
       rc = linear_fwd(m, st, fp, w.ao, q.pw, q.pb, w.x_mid, M, C, C, EPI_BIAS_RESID, nullptr, w.x_in,
-                      branch_mask(m, md, l, 0, B, m->train), mode, T, N, nullptr, nullptr, nullptr, w.aol);
+                      branch_mask(m, md, l, 0, B, m->train), mode, T, N, nullptr, nullptr, nullptr, w.aol, nullptr, md.f8a);
     }
     if (rc) return rc;
     {
       LnFwdArgs a = {};
       a.x = w.x_mid; a.M = (int)M; a.C = C;
       a.g2 = P(m, fp, q.n2w); a.b2 = P(m, fp, q.n2b); a.eps2 = 1e-6f; a.y2 = w.a2; a.y2_lo = w.a2l; a.stats2 = w.st2;
-      if (md.f8) { a.y2 = w.a2h; a.y2_b16 = (m->infer || md.f8g) ? nullptr : w.a2; }
+      if (md.f8) { a.y2 = w.a2h; a.y2_b16 = (m->infer || md.f8g || md.f8a) ? nullptr : w.a2; }
       hz_ln_fwd(m, st, a, half);
     RUN(PC_LN, 0, ln_fwd(a, half, st));
     }
     // (inference, precision >= 1: gelu' - read by the fc2 dgrad only - is not written)
     m->cur_kind = (md.is_rot ? 0 : 12) + 0 * 4 + LK_FC1;
     rc = linear_fwd(m, st, fp, md.f8 ? w.a2h : w.a2, q.f1w, q.f1b, w.f, M, 2 * C, C, EPI_BIAS_GELU, (m->infer && m->cfg.precision >= 1) ? nullptr : w.z, nullptr, nullptr, 0, T, N, nullptr, nullptr, nullptr, w.a2l, w.fl,
-                    md.f8, md.f8m);
+                    md.f8, md.f8m || md.f8a);
     if (rc) return rc;
     m->cur_kind = (md.is_rot ? 0 : 12) + 0 * 4 + LK_FC2;
     rc = linear_fwd(m, st, fp, w.f, q.f2w, q.f2b, w.x_out, M, C, 2 * C, EPI_BIAS_RESID, nullptr, w.x_mid,
-                    branch_mask(m, md, l, 1, B, m->train), mode, T, N, nullptr, nullptr, nullptr, w.fl, nullptr, md.f8m);
+                    branch_mask(m, md, l, 1, B, m->train), mode, T, N, nullptr, nullptr, nullptr, w.fl, nullptr, md.f8m || md.f8a);
     if (rc) return rc;
     // shared post-norm (mix_ste.py:143,154,166,170), Temporal_pos_embed after the first spatial block (:149),
     // fused with the next block's norm1
@@ -604,7 +607,7 @@ static int backbone_fwd_impl(mp_model* m, Module& md, const float* fp, int B, hi
     if (l + 1 < L) {
       a.g2 = P(m, fp, md.bp[l + 1].n1w); a.b2 = P(m, fp, md.bp[l + 1].n1b); a.eps2 = 1e-6f;
       a.y2 = md.ws[l + 1].a1; a.y2_lo = md.ws[l + 1].a1l; a.stats2 = md.ws[l + 1].st1;
-      if (md.f8) { a.y2 = md.ws[l + 1].a1h; a.y2_b16 = (m->infer || md.f8g) ? nullptr : md.ws[l + 1].a1; }
+      if (md.f8) { a.y2 = md.ws[l + 1].a1h; a.y2_b16 = (m->infer || md.f8g || md.f8a) ? nullptr : md.ws[l + 1].a1; }
     }
     hz_ln_fwd(m, st, a, half);
     RUN(PC_LN, 0, ln_fwd(a, half, st));
@@ -676,7 +679,7 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
     }
     E_READY(0);                                                    // gb is ready
     m->cur_kind = (md.is_rot ? 0 : 12) + 2 * 4 + LK_FC2;
-    int rc = linear_wgrad(m, sw, gb, 0, w.f, G(m, fg, q.f2w), G(m, fg, q.f2b), M, C, 2 * C, md.f8m);      // f8m: gb and f are fp16
+    int rc = linear_wgrad(m, sw, gb, 0, w.f, G(m, fg, q.f2w), G(m, fg, q.f2b), M, C, 2 * C, md.f8m, md.f8a);      // f8m: gb and f are fp16; f8a: f alone is (rounded to bf16 per fragment)
     if (rc) return rc;
     W_DONE(0);
     if (have_prev) WAIT_W(par ^ 1, 1);                             // previous block's fc1 wgrad still reads tmp2C
@@ -687,7 +690,7 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
     // (c) fc1
     E_READY(1);                                                    // dz (tmp2C) is ready
     m->cur_kind = (md.is_rot ? 0 : 12) + 2 * 4 + LK_FC1;
-    rc = linear_wgrad(m, sw, m->tmp2C, 0, md.f8g ? w.a2h : w.a2, G(m, fg, q.f1w), G(m, fg, q.f1b), M, 2 * C, C, md.f8g);
+    rc = linear_wgrad(m, sw, m->tmp2C, 0, (md.f8g || md.f8a) ? w.a2h : w.a2, G(m, fg, q.f1w), G(m, fg, q.f1b), M, 2 * C, C, md.f8g, md.f8a);
     if (rc) return rc;
     W_DONE(1);
     m->cur_kind = (md.is_rot ? 0 : 12) + 1 * 4 + LK_FC1;
@@ -711,7 +714,7 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
     }
     E_READY(2);                                                    // gb (second half of the block) is ready
     m->cur_kind = (md.is_rot ? 0 : 12) + 2 * 4 + LK_PROJ;
-    rc = linear_wgrad(m, sw, gb, 0, w.ao, G(m, fg, q.pw), G(m, fg, q.pb), M, C, C);
+    rc = linear_wgrad(m, sw, gb, 0, w.ao, G(m, fg, q.pw), G(m, fg, q.pb), M, C, C, false, md.f8a);
     if (rc) return rc;
     W_DONE(2);
     m->cur_kind = (md.is_rot ? 0 : 12) + 1 * 4 + LK_PROJ;
@@ -725,12 +728,18 @@ static int backbone_bwd_impl(mp_model* m, Module& md, const float* fp, float* fg
          HW(spatial ? nullptr : m->delta, 4.0 * B * N * H * T), HW(m->tmp3C, eb * M * 3 * C));
       AttnGradF16Scope f16_out(md.f8g ? m->gsc : nullptr);      // f8g: dqkv leaves as scaled fp16 (its two consumers below run on fp16 operands)
       if (spatial) RUN(PC_ATTN, 10.0 * B * T * N * N * C, attn_spatial_bwd(w.qkv, m->tmpC, m->tmp3C, half, B, T, N, C, H, st));
-      else RUN(PC_ATTN, 10.0 * B * N * (double)T * T * C, attn_temporal_bwd(w.qkv, w.ao, m->tmpC, w.lse, m->delta, m->tmp3C, half, B, T, N, C, H, st));
+      else {
+        attn_out_f16_override(md.f8a ? 1 : 0);      // f8a: O exists as an fp16 plane
+        ProfScope ps__(m, st, PC_ATTN, 10.0 * B * N * (double)T * T * C);
+        const int rc__ = attn_temporal_bwd(w.qkv, w.ao, m->tmpC, w.lse, m->delta, m->tmp3C, half, B, T, N, C, H, st);
+        attn_out_f16_override(0);
+        if (rc__) return rc__;
+      }
     }
     // (g) qkv
     E_READY(3);                                                    // dqkv (tmp3C) is ready
     m->cur_kind = (md.is_rot ? 0 : 12) + 2 * 4 + LK_QKV;
-    rc = linear_wgrad(m, sw, m->tmp3C, 0, md.f8g ? w.a1h : w.a1, G(m, fg, q.qkvw), G(m, fg, q.qkvb), M, 3 * C, C, md.f8g);
+    rc = linear_wgrad(m, sw, m->tmp3C, 0, (md.f8g || md.f8a) ? w.a1h : w.a1, G(m, fg, q.qkvw), G(m, fg, q.qkvb), M, 3 * C, C, md.f8g, md.f8a);
     if (rc) return rc;
     W_DONE(3);
     m->cur_kind = (md.is_rot ? 0 : 12) + 1 * 4 + LK_QKV;
@@ -851,12 +860,13 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   MP_CHECK(cfg->arch != 0 || (cfg->n_hyp >= 1 && cfg->n_hyp <= 8), MP_ERR_ARG, "mp_model_create: n_hyp in 1..8");
   MP_CHECK(cfg->rot_rep_dim == 0 || cfg->rot_rep_dim == 4 || cfg->rot_rep_dim == 6, MP_ERR_ARG,
            "mp_model_create: rot_rep_dim %d (4 or 6; 0 = 6)", cfg->rot_rep_dim);
-  MP_CHECK(cfg->f16f8 >= 0 && cfg->f16f8 <= 2 && (cfg->f16_backward == 0 || cfg->f16_backward == 1) && cfg->streams >= 0 && cfg->streams <= 3, MP_ERR_ARG,
-           "mp_model_create: f16f8 %d (0..2), f16_backward %d (0/1), streams %d (bit set 0..3)", cfg->f16f8, cfg->f16_backward, cfg->streams);
+  MP_CHECK(cfg->f16f8 >= 0 && cfg->f16f8 <= 3 && (cfg->f16_backward == 0 || cfg->f16_backward == 1) && cfg->streams >= 0 && cfg->streams <= 3, MP_ERR_ARG,
+           "mp_model_create: f16f8 %d (0..3), f16_backward %d (0/1), streams %d (bit set 0..3)", cfg->f16f8, cfg->f16_backward, cfg->streams);
+  MP_CHECK(cfg->f16f8 != 3 || cfg->f16_backward == 0, MP_ERR_ARG, "mp_model_create: f16f8 = 3 (all four Linear layers) keeps the bf16 backward: f16_backward must be 0");
   MP_CHECK(cfg->debug >= 0 && cfg->debug <= 1, MP_ERR_ARG, "mp_model_create: debug %d (bit 0 = stream-hazard check)", cfg->debug);
   MP_CHECK(cfg->f16f8 == 0 || cfg->precision == 2, MP_ERR_ARG, "mp_model_create: f16f8 operands belong to precision 2 (bf16x3)");
   MP_CHECK(cfg->f16_backward == 0 || cfg->f16f8 >= 1, MP_ERR_ARG, "mp_model_create: f16_backward needs f16f8 >= 1");
-  MP_CHECK(cfg->f16f8 < 2 || cfg->f16_backward == 1, MP_ERR_ARG, "mp_model_create: f16f8 = 2 (the fc2 layer) needs f16_backward");
+  MP_CHECK(cfg->f16f8 != 2 || cfg->f16_backward == 1, MP_ERR_ARG, "mp_model_create: f16f8 = 2 (the fc2 layer) needs f16_backward");
   mp_model* m = new mp_model();
   m->cfg = *cfg;
   if (cfg->rot_rep_dim == 0) m->cfg.rot_rep_dim = 6;
@@ -888,7 +898,12 @@ int mp_model_create(const mp_model_config* cfg, mp_model** out) {
   m->rot.f8m = false;
   m->rot.f8g = m->rot.f8 && cfg->f16_backward != 0 && attn_tmfma_supported(cfg->num_frame, m->rot.C / m->rot.H) &&
                attn_smfma_supported(m->rot.N, m->rot.C / m->rot.H, m->rot.H);
-  m->rot.f8m = m->rot.f8g && (m->rot.rs == 0.f || m->rot.rs == 1.0f) && cfg->f16f8 >= 2;      // (a residual scale other than 1 - muP - keeps the tiled bf16x3 fc2)
+  m->rot.f8m = m->rot.f8g && (m->rot.rs == 0.f || m->rot.rs == 1.0f) && cfg->f16f8 == 2;      // (a residual scale other than 1 - muP - keeps the tiled bf16x3 fc2)
+  // f16f8 = 3: all four layers, bf16 backward.  Needs the MFMA attention kernels with head dim 64 (their f16f8 output form) and the persistent residual
+  // epilogue (residual scale 1); a model that does not qualify runs plain bf16x3 (three bf16 products everywhere) - so 3 is a safe default of callers
+  m->rot.f8a = m->rot.f8 && cfg->f16f8 == 3 && (m->rot.rs == 0.f || m->rot.rs == 1.0f) && m->rot.C / m->rot.H == 64 && m->rot.C % m->rot.H == 0 &&
+               !attn_x3_needs_scratch(0, cfg->num_frame, m->rot.N, m->rot.C, m->rot.H) && !attn_x3_needs_scratch(1, cfg->num_frame, m->rot.N, m->rot.C, m->rot.H);
+  if (cfg->f16f8 == 3 && !m->rot.f8a) m->rot.f8 = false;
   Bump dry;
   carve_all(m, dry);
   m->arena_bytes = dry.off;

@@ -311,12 +311,22 @@ __device__ __forceinline__ float lds16_to_float(unsigned short b) {
   if constexpr (F16) return (float)__builtin_bit_cast(_Float16, b);
   else return __uint_as_float((unsigned)b << 16);
 }
-template <int TRA, int TRB, int BT, int ABL = 0, int F16 = 0, typename Mid = NoMid>
+// eight fp16 values of a B fragment -> bf16 (round to nearest even), in registers: the weight-gradient GEMM of a layer whose input exists as an
+// fp16 plane only (mp_model_config::f16f8 = 3; BCVT below).  12 VALU instructions per fragment, 8 fragments per 64 MFMAs.
+__device__ __forceinline__ bf16x8_t frag_f16_to_bf16(const bf16x8_t& f) {
+  const uint4 u = __builtin_bit_cast(uint4, f);
+  const uint2 lo = f16x4_to_bf16x4(make_uint2(u.x, u.y)), hi = f16x4_to_bf16x4(make_uint2(u.z, u.w));
+  return __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+template <int TRA, int TRB, int BT, int ABL = 0, int F16 = 0, typename Mid = NoMid, int BCVT = 0>
 __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const char* __restrict__ Bs, f32x4 (&acc)[BT / 32][4], int wr, int wc,
                                           int lane, Mid mid = Mid()) {
   constexpr int MI = BT / 32;
   constexpr int HS = MI / 2, NSTEP = (GBK / 32) * HS;
   bf16x8_t b_cur[4], b_nxt[4], a_cur[2], a_nxt[2];
+  // BCVT: b_cur keeps the RAW fp16 fragments at the start of a k-step; each is converted right in front of its first MFMA (below), so that the
+  // k-step's first MFMA waits for 12 conversion instructions, not 48 (the conversions of all four fragments as one block in front of the k-tile's
+  // first MFMA - where every wave of the workgroup stands at the same time, behind the barrier - cost the weight-gradient kernels 7 %)
 #pragma unroll
   for (int j = 0; j < 4; ++j) b_cur[j] = read_frag2<TRB, BT>(Bs, wc * 64 + j * 16, 0, lane);
   a_cur[0] = read_frag2<TRA, BT>(As, wr * (BT / 2), 0, lane);
@@ -331,6 +341,7 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
     // hints) hipcc issues most reads directly in front of an s_waitcnt lgkmcnt(0) and their first use - a dozen exposed LDS round trips per
     // k-tile and wave; and with the reads ahead of the group it still waits with lgkmcnt(0), i.e. for the reads it has just issued.
     __builtin_amdgcn_sched_barrier(0);
+    if (BCVT && ip == 0) { b_cur[0] = frag_f16_to_bf16(b_cur[0]); __builtin_amdgcn_sched_barrier(0); }
     acc[2 * ip][0] = mfma16<F16>(b_cur[0], a_cur[0], acc[2 * ip][0]);   // C^T tile
     __builtin_amdgcn_sched_barrier(0);
     if (step + 1 < NSTEP) {
@@ -347,7 +358,11 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 1; j < 4; ++j) acc[2 * ip][j] = mfma16<F16>(b_cur[j], a_cur[0], acc[2 * ip][j]);
+    for (int j = 1; j < 4; ++j) {
+      if (BCVT && ip == 0) { b_cur[j] = frag_f16_to_bf16(b_cur[j]); __builtin_amdgcn_sched_barrier(0); }      // (pinned: hipcc would gather the conversions in front of the group)
+      acc[2 * ip][j] = mfma16<F16>(b_cur[j], a_cur[0], acc[2 * ip][j]);
+      if (BCVT && ip == 0) __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[2 * ip + 1][j] = mfma16<F16>(b_cur[j], a_cur[1], acc[2 * ip + 1][j]);
     __builtin_amdgcn_sched_barrier(0);
@@ -357,7 +372,7 @@ __device__ __forceinline__ void mma_stage(const char* __restrict__ As, const cha
       a_cur[1] = a_nxt[1];
       if ((step + 1) % HS == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b_cur[j] = b_nxt[j];
+        for (int j = 0; j < 4; ++j) b_cur[j] = b_nxt[j];      // (BCVT: raw; converted in front of their first MFMAs)
       }
     }
   }
@@ -793,7 +808,7 @@ __global__ __launch_bounds__(BT * 2) void gemm_bf16_glds_kernel(GemmB16Args g) {
         for (int ks = 0; ks < GBK / 32; ++ks)
           accb[f] = mfma16<SPLIT == 16>(ones.v, read_frag2<1, BT>(As, (2 * wave + f) * 16, ks, lane), accb[f]);
     }
-    mma_stage<TRA, TRB, BT, 0, (SPLIT == 16)>(As, Bs, acc, wr, wc, lane);
+    mma_stage<TRA, TRB, BT, 0, (SPLIT == 16), NoMid, (SPLIT == 32)>(As, Bs, acc, wr, wc, lane);      // SPLIT 32: the B operand (X) is an fp16 plane, converted per fragment
   }
   }
 
@@ -1661,7 +1676,7 @@ static void wgrad_split_b16(int Mtok, int Nout, int Kin, int bt, int& splits, in
 
 // dW[N',K'] += dY[Mtok,N']^T X[Mtok,K'] (X bf16; dY bf16 or fp32) ; db += colsum(dY)
 int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
-               float* slab, long slab_floats, hipStream_t st, int f16, const float* oscale) {
+               float* slab, long slab_floats, hipStream_t st, int f16, const float* oscale, int x_f16) {
   MP_CHECK(Mtok > 0 && Nout % 8 == 0 && Kin % 8 == 0, MP_ERR_ARG, "wgrad_bf16: bad dims %d %d %d", Mtok, Nout, Kin);
   GemmB16Args g = {};
   g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx;
@@ -1684,8 +1699,10 @@ int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, i
 #endif
   g.k_per_split = kper;
   MP_CHECK(!f16 || !dy_f32, MP_ERR_ARG, "wgrad_bf16: fp16 operands with an fp32 dY");
+  MP_CHECK(!x_f16 || (!f16 && !dy_f32), MP_ERR_ARG, "wgrad_bf16: an fp16 X next to a bf16 dY is converted per fragment (x_f16): not with fp16 operands / an fp32 dY");
   int rc = dy_f32 ? launch_b16<float, 1, bf16, 1, float, EPI_SLAB>(g, splits, st)
-                  : (f16 ? launch_glds<1, 1, float, EPI_SLAB, 16>(g, splits, st) : launch_glds<1, 1, float, EPI_SLAB>(g, splits, st));
+                  : (f16 ? launch_glds<1, 1, float, EPI_SLAB, 16>(g, splits, st)
+                         : (x_f16 ? launch_glds<1, 1, float, EPI_SLAB, 32>(g, splits, st) : launch_glds<1, 1, float, EPI_SLAB>(g, splits, st)));
   if (rc) return rc;
   const long nW4 = (long)Nout * Kin / 4, nB4 = db != nullptr ? Nout / 4 : 0;        // Nout, Kin are multiples of 8
   hipLaunchKernelGGL(reduce_slabs_b16_kernel, dim3(cdiv(nW4, (long)RS_OUT) + cdiv(nB4, (long)RS_OUT)), dim3(256), 0, st, slab, dW, nW4, g.bias_slab, db, nB4, splits, splits * bparts,

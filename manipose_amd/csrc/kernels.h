@@ -71,7 +71,7 @@ int gemm_f16f8(GemmB16Args g, int c_f32, int epi, hipStream_t st);
 int cast_to_f16f8(const float* src, void* hi16, void* cat8, long n, int weight, hipStream_t st);     // n % 64 == 0; see common.h "f16f8"
 int cast_to_bf16x2(const float* src, bf16* hi, bf16* lo, long n, hipStream_t st);
 int wgrad_bf16(const void* dY, int dy_f32, long lddy, const bf16* X, long ldx, int Mtok, int Nout, int Kin, float* dW, float* db,
-               float* slab, long slab_floats, hipStream_t st, int f16 = 0, const float* oscale = nullptr);      // f16: dY and X are fp16, dW += *oscale x dY^T X (device address)
+               float* slab, long slab_floats, hipStream_t st, int f16 = 0, const float* oscale = nullptr, int x_f16 = 0);      // f16: dY and X are fp16, dW += *oscale x dY^T X (device address); x_f16: X alone is fp16 (the fp16 plane of an f16f8 activation), rounded to bf16 per fragment
 int cast_to_bf16(const float* src, bf16* dst, long n, hipStream_t st);
 void gemm_bf16_force_small_tile(bool on);          // test hooks (mp_set_option)
 void gemm_bf16_persist_min_tiles(int n);
@@ -132,6 +132,7 @@ int droppath_masks(float* masks, const MaskDesc* descs, int ndesc, unsigned long
 
 // ---------------------------------------------------------------- attention.hip
 void attn_grad_f16_override(const float* gout);   // attention_mfma.hip: the MFMA backward launches issued next on this thread write dQ / dK / dV as fp16(*gout x value) (device address; null = bf16)
+void attn_out_f16_override(int on);                // attention_mfma.hip: the temporal MFMA backward launches issued next on this thread read `out` as an fp16 plane (f16f8 = 3)
 void attn_scale_override(float s);   // softmax scale of the attention launches issued next on this thread (0 = head_dim ** -0.5)
 // qkv: [M][3C] (q | k | v, head-major inside each), out: [M][C]; token layout m = (b*T + t)*J + j
 int attn_spatial_fwd(const void* qkv, void* out, int is_bf16, int B, int T, int J, int C, int H, hipStream_t st);
@@ -142,10 +143,11 @@ int attn_temporal_bwd(const void* qkv, const void* out, const void* dout, const 
 // split-precision forward (planar hi/lo qkv and output, common.h).  scratch (4 M C floats) is only used for shapes the MFMA kernels
 // do not cover (the planes are joined to fp32, the fp32 kernels run, the result is split again); may be null otherwise.
 bool attn_x3_needs_scratch(int temporal, int T, int J, int C, int H);
+// out_f16f8: the output leaves as "f16f8" planes (out_hi = fp16 plane, out_lo = 8-bit correction plane; head dim 64, MFMA kernels only)
 int attn_spatial_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* scratch, int B, int T, int J, int C, int H,
-                        hipStream_t st);
+                        hipStream_t st, int out_f16f8 = 0);
 int attn_temporal_fwd_x3(const bf16* qkv_hi, const bf16* qkv_lo, bf16* out_hi, bf16* out_lo, float* lse, float* scratch, int B, int T, int J,
-                         int C, int H, hipStream_t st);
+                         int C, int H, hipStream_t st, int out_f16f8 = 0);
 void attn_two_phase(int on);        // 0 = one-strip-at-a-time split-precision temporal forward for every shape (mp_set_option)
 int join_planes(const bf16* hi, const bf16* lo, float* out, long n, hipStream_t st);
 int split_planes(const float* in, bf16* hi, bf16* lo, long n, hipStream_t st);

@@ -1540,7 +1540,7 @@ def test_f16f8_inputs_of_the_model_and_the_inference_flag(lib):
     (op.square().sum() + osc.square().sum()).backward()
     ref = {k: v.grad for k, v in req.items()}
     outs, models = {}, {}
-    for form in ((0, False), (1, False), (1, True), (2, True)):
+    for form in ((0, False), (1, False), (1, True), (2, True), (3, False)):
         model = models[form] = _f16f8_model(state, kw, *form)       # all four stay alive: the forms are per-model state
         poses, scores = model(X.cuda())
         err = (poses.cpu() - want).norm(dim=-1).mean().item()
@@ -1565,12 +1565,13 @@ def test_f16f8_inputs_of_the_model_and_the_inference_flag(lib):
             assert (health["scale"] > 0) == form[1]        # a scale exists exactly for the fp16-backward models
     assert torch.equal(outs[(1, False)], outs[(1, True)])                          # the backward's form does not touch the forward
     assert not torch.equal(outs[(0, False)], outs[(1, False)]) and not torch.equal(outs[(1, True)], outs[(2, True)])
+    assert not torch.equal(outs[(3, False)], outs[(1, False)]) and not torch.equal(outs[(3, False)], outs[(2, True)])      # proj reads f16f8 operands too
     p_again, _ = models[(0, False)](X.cuda())                                      # ... and the first model still computes what it computed
     assert torch.equal(p_again.detach(), outs[(0, False)])
     base = dict(arch="rmcl_manifold", num_frame=T, num_joints=17, num_bones=16, embed_dim_rot=C, depth_rot=3, num_heads_rot=H, embed_dim_seg=32,
                 depth_seg=1, num_heads_seg=4, n_hyp=K, drop_path_rate=0.0, max_batch=0)
     for bad in (dict(precision="bf16", f16f8=1), dict(precision="bf16x3", f16f8=0, f16_backward=True), dict(precision="bf16x3", f16f8=2, f16_backward=False),
-                dict(precision="bf16x3", f16f8=3)):
+                dict(precision="bf16x3", f16f8=3, f16_backward=True), dict(precision="bf16x3", f16f8=4)):
         with pytest.raises(RuntimeError):
             LiftEngine(**base, **bad)
 
@@ -1801,16 +1802,19 @@ def test_bf16x3_model_meets_the_parity_bound_on_the_reference_fixtures(lib, name
     assert worst[1] > 0.9995, worst            # measured 0.99998 - 0.99999 (bf16 backward on the hi planes)
 
 
-def test_bf16x3_full_size_model_meets_the_parity_bound(lib):
+@pytest.mark.parametrize("f16f8", [0, 3])
+def test_bf16x3_full_size_model_meets_the_parity_bound(lib, f16f8):
     """BASELINE config #3 shape (T=243 K=5 C=512 depth 8) at B=1 and B=3 in the split precision against the fp32 CPU oracle:
-    MPJPE <= 1e-4 m (the north-star bound), loss, gradient alignment, manifold property."""
+    MPJPE <= 1e-4 m (the north-star bound), loss, gradient alignment, manifold property.  f16f8 = 3 (round 6): all four Linear layers of
+    every block of the rotations net as one fp16 + one block-scaled fp8 product, the attention kernels and the GELU epilogue writing f16f8
+    planes, the bf16 backward rounding the fp16 planes where it reads them - the same bounds."""
     from manipose_amd import RMCLManifoldMixSTE, h36m_skeleton
     from manipose_amd.metrics import mpjpe_error, rmcl_training_loss
     cfg = orc.FULL_CFG
     st_ = orc.make_state(cfg, seed=3)
     model = RMCLManifoldMixSTE(h36m_skeleton(), drop_path_rate=0.0)
     model.load_state_dict(st_, strict=True)
-    model.precision = "bf16x3"
+    model.precision, model.f16f8 = "bf16x3", f16f8
     model.max_batch_hint = 3
     model = model.cuda().eval()
     X, y = orc.synthetic_batch(3, 243, seed=42)
@@ -1823,7 +1827,7 @@ def test_bf16x3_full_size_model_meets_the_parity_bound(lib):
     req = {k: v.clone().requires_grad_(True) for k, v in st_.items()}
     o_poses, o_scores = orc.rmcl_manifold_forward(X, req, orc.oracle_cfg(cfg))
     mp = mpjpe_error(poses, o_poses.detach().cuda(), "average").item()
-    print(f"\n[bf16x3 drift] full size T=243 K=5: MPJPE vs fp32 oracle = {mp * 1e3:.5f} mm (B=1), {mp3 * 1e3:.5f} mm (B=3)")
+    print(f"\n[bf16x3 drift] full size T=243 K=5 f16f8={f16f8}: MPJPE vs fp32 oracle = {mp * 1e3:.5f} mm (B=1), {mp3 * 1e3:.5f} mm (B=3)")
     assert mp <= MPJPE_TOL_M and mp3 <= MPJPE_TOL_M
     close(scores, o_scores.detach(), rtol=1e-3, atol=1e-5)
     total, _ = rmcl_training_loss(poses, scores, y.cuda())

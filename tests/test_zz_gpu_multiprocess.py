@@ -53,7 +53,7 @@ def test_bench_two_rank_path_rehearsal_on_one_gpu(lib):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     assert "cpu_baseline" not in d and d["roofline"]["launches"] >= 0
     assert d["dtype"] == "bf16x3" and d["parity"]["within_bound"] and d["parity"]["mpjpe_m"] <= 1e-4, d.get("parity")
-    assert "all: bf16x3" in d["config"]["split_forms"]                      # the default is the plain three-product split (no f16f8, bf16 backward)
+    assert "qkv, proj, fc1, fc2: f16f8" in d["config"]["split_forms"] and "bf16 backward" in d["config"]["split_forms"]      # the default operand form since round 6 (--f16f8 3)
     rf = d["roofline"]
     assert rf["bound"] == ("mfma" if rf["intensity_flop_per_byte"] is None or rf["intensity_flop_per_byte"] >= rf["ridge_flop_per_byte"] else "hbm")
     assert 0 < rf["frac"] <= rf["frac_attainable"] <= 1.0 and isinstance(rf["per_instantiation"], dict)
