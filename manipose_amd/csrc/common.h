@@ -140,14 +140,31 @@ __device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float
 }
 // four consecutive elements v (columns c .. c + 3, c % 4 == 0) of a row: hi16 = their place in the fp16 plane, corr8 = their 8 bytes in the
 // correction plane (byte offset 2 (row K + c))
-// the same in registers, activation form: h16 = the four fp16 values, c8 = their 8 correction bytes
+// the same in registers, activation form: h16 = the four fp16 values, c8 = their 8 correction bytes.  20 VALU instructions on the common path
+// (round 6; 30 before): the pairs go through v_cvt_pk_f16_f32, the 2^11 on the lo parts is the scale operand of v_cvt_scalef32_pk_fp8_f32 (it divides by
+// 2^floor(log2 s): tools/probes/cvt_scale.hip), and the +-448 clamps - both fp8 conversions return NaN (0x7f) beyond that, neither saturates - are only
+// taken by lanes that hold a value above 448 (|2^11 lo| <= |v|, so nothing can overflow below it).  Same bytes as the clamped form for every input.
 __device__ __forceinline__ void pack4_f16f8(float4 v, uint2& h16, uint2& c8) {
-  typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  typedef short s2_t __attribute__((ext_vector_type(2)));
   asm("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));      // split the ROUNDED values (see split_bf16x2: no fusing of a producer's multiply into the subtraction)
-  const h4_t h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-  h16 = __builtin_bit_cast(uint2, h);
-  const float4 hf = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-  c8 = make_uint2(pack_e4m3x4((v.x - hf.x) * 2048.f, (v.y - hf.y) * 2048.f, (v.z - hf.z) * 2048.f, (v.w - hf.w) * 2048.f), pack_e4m3x4(hf.x, hf.y, hf.z, hf.w));
+  const f2_t a = {v.x, v.y}, b = {v.z, v.w};
+  const h2_t ha = __builtin_convertvector(a, h2_t), hb = __builtin_convertvector(b, h2_t);
+  h16 = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+  const float4 hf = make_float4((float)ha[0], (float)ha[1], (float)hb[0], (float)hb[1]);
+  const float4 lo = make_float4(v.x - hf.x, v.y - hf.y, v.z - hf.z, v.w - hf.w);
+  const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+  if (__builtin_expect(!(m <= 448.f), 0)) {      // (also NaN / inf inputs: the clamped conversions below)
+    c8 = make_uint2(pack_e4m3x4(lo.x * 2048.f, lo.y * 2048.f, lo.z * 2048.f, lo.w * 2048.f), pack_e4m3x4(hf.x, hf.y, hf.z, hf.w));
+  } else {
+    s2_t r = {0, 0};
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, lo.x, lo.y, 0x1p-11f, false);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, lo.z, lo.w, 0x1p-11f, true);
+    int q = __builtin_amdgcn_cvt_pk_fp8_f32(hf.x, hf.y, 0, false);
+    q = __builtin_amdgcn_cvt_pk_fp8_f32(hf.z, hf.w, q, true);
+    c8 = make_uint2(__builtin_bit_cast(unsigned, r), (unsigned)q);
+  }
 }
 // four fp16 values (the fp16 plane of an f16f8 activation) -> four bf16 values, round to nearest even: what a bf16 backward kernel makes of an
 // operand that exists as an fp16 plane only (mp_model_config::f16f8 = 3: no bf16 copy of a1 / ao / a2 / f is written)
@@ -157,6 +174,13 @@ __device__ __forceinline__ uint2 f16x4_to_bf16x4(uint2 h) {
   return make_uint2(pack_bf16x2((float)x[0], (float)x[1]), pack_bf16x2((float)x[2], (float)x[3]));
 }
 __device__ __forceinline__ void st4_f16f8(f16f8* hi16, char* corr8, float4 v, bool weight) {
+  if (!weight) {      // (a compile-time constant at every call site) activation form: the register form above
+    uint2 h, c;
+    pack4_f16f8(v, h, c);
+    *reinterpret_cast<uint2*>(hi16) = h;
+    *reinterpret_cast<uint2*>(corr8) = c;
+    return;
+  }
   typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
   const h4_t h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
   *reinterpret_cast<uint2*>(hi16) = __builtin_bit_cast(uint2, h);
