@@ -1393,7 +1393,9 @@ int mp_model_peek_copy(const mp_model* m, int which, float* dst, int64_t numel, 
 int mp_prof_enable(mp_model* m, int on) {
   MP_CHECK(m, MP_ERR_ARG, "mp_prof_enable: null model");
   if (on && m->ev.empty()) {
-    m->ev.resize(16384);
+    // two events per profiled launch, ~480 launches per training step: room for ~130 steps between two collects (16384 events - 17 steps - silently
+    // truncated the per-class sums of a 30-step timed region until round 6: averages per launch were right, sums per step were not)
+    m->ev.resize(131072);
     for (auto& e : m->ev) MP_HIP(hipEventCreate(&e));
   }
   m->prof = on != 0;

@@ -2122,6 +2122,19 @@ def test_split_precision_linear_kernels_are_reproducible_at_scale(lib, ntok, C):
                     assert bad == 0, f"{name} (N={N}, K={K}, persist_mode={mode}): {bad} elements differ between two identical launches"
             finally:
                 _lib.check(lib.mp_set_option(b"gemm_persist_mode", 1))
+        # the same Linear on "f16f8" operands (the hand-scheduled fp16 + block-scaled fp8 k-steps of round 6; persistent kernel only)
+        if N % 256 == 0 and K % 64 == 0 and epi in (0, 1, 2):
+            x16, W16 = torch.empty(M, K, device="cuda", dtype=torch.float16), torch.empty(N, K, device="cuda", dtype=torch.float16)
+            x8, W8 = torch.empty(M, 2 * K, device="cuda", dtype=torch.uint8), torch.empty(N, 2 * K, device="cuda", dtype=torch.uint8)
+            _lib.check(lib.mp_split_f16f8(x.data_ptr(), x16.data_ptr(), x8.data_ptr(), x.numel(), 0, st()))
+            _lib.check(lib.mp_split_f16f8(W.data_ptr(), W16.data_ptr(), W8.data_ptr(), W.numel(), 1, st()))
+            outs = []
+            for _ in range(3):
+                y = torch.zeros(M, N, device="cuda")
+                _lib.check(lib.mp_linear_fwd_f16f8(x16.data_ptr(), x8.data_ptr(), W16.data_ptr(), W8.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, st()))
+                outs.append(y.view(torch.int32))
+            bad = sum(int((outs[0] != o).sum().item()) for o in outs[1:])
+            assert bad == 0, f"{name} f16f8 (N={N}, K={K}): {bad} elements differ between identical launches"
 
 
 def test_bench_batch_of_158_windows_is_two_times_its_half(lib):
@@ -2135,7 +2148,7 @@ def test_bench_batch_of_158_windows_is_two_times_its_half(lib):
     H, B = 79, 158
     torch.manual_seed(42)
     model = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=243, n_hyp=5, drop_path_rate=0.1)
-    model.precision = "bf16x3"
+    model.precision, model.f16f8 = "bf16x3", 3          # the benchmark's operand form since round 6
     model.max_batch_hint = B
     model = model.cuda().eval()
     X, _ = orc.synthetic_batch(H, 243, seed=11)
@@ -2190,7 +2203,7 @@ def test_batch_beyond_the_2_gib_plane_boundary_vs_oracle_and_small_batch(lib):
             if n.endswith("pos_embed"):
                 p.normal_(0.0, 0.02)
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    model.precision = "bf16x3"
+    model.precision, model.f16f8 = "bf16x3", 3          # the benchmark's operand form since round 6
     model.max_batch_hint = B
     model = model.cuda().eval()
     assert 2 * B * 243 * 17 * 1536 > 2 ** 31
@@ -2239,11 +2252,15 @@ def test_batch_beyond_the_2_gib_plane_boundary_vs_oracle_and_small_batch(lib):
     gc.collect(); torch.cuda.empty_cache()
 
 
-def test_training_step_is_bitwise_reproducible_and_batch_invariant(lib):
+@pytest.mark.parametrize("f16f8", [3, 0])
+def test_training_step_is_bitwise_reproducible_and_batch_invariant(lib, f16f8):
     """The benchmarked precision at full width (T=243 K=5 C=512 depth 8) and a batch of 16 windows - persistent GEMMs, side streams,
     train-mode DropPath from the engine's counter-based stream: two identical steps must produce the same BITS (poses, scores, segment
     lengths, every gradient: the backward is deterministic by construction - fixed-order slab / partial reductions, no atomics), the
-    forward of a window must not depend on the batch it sits in, and the kernel-family / stream choices may move a pose by rounding only."""
+    forward of a window must not depend on the batch it sits in, and the kernel-family / stream choices may move a pose by rounding only.
+    f16f8 = 3: the benchmark's operand form since round 6 (all four Linear layers as one fp16 + one fp8 product); 0: three bf16 products.
+    The persistent path's GRADIENTS are held against an independent path too (round-5 advisory): the same training step on the tiled GEMM
+    kernels, one queue."""
     from manipose_amd import RMCLManifoldMixSTE, _lib, h36m_skeleton
     B = 16
     torch.manual_seed(42)
@@ -2252,7 +2269,7 @@ def test_training_step_is_bitwise_reproducible_and_batch_invariant(lib):
         for n, p in model.named_parameters():
             if n.endswith("pos_embed"):
                 p.normal_(0.0, 0.02)
-    model.precision = "bf16x3"
+    model.precision, model.f16f8 = "bf16x3", f16f8
     model.max_batch_hint = B
     model = model.cuda().train()
     X, y = orc.synthetic_batch(B, 243, seed=7)
@@ -2285,15 +2302,26 @@ def test_training_step_is_bitwise_reproducible_and_batch_invariant(lib):
         # (mp_model_config::streams, per model since ABI v7) while the process-wide hook selects the tiled GEMM kernels
         single = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=243, n_hyp=5, drop_path_rate=0.1)
         single.load_state_dict(model.state_dict(), strict=True)
-        single.precision, single.side_stream, single.wgrad_stream, single.max_batch_hint = "bf16x3", False, False, B
+        single.precision, single.f16f8, single.side_stream, single.wgrad_stream, single.max_batch_hint = "bf16x3", f16f8, False, False, B
         single = single.cuda().eval()
         _lib.check(lib.mp_set_option(b"gemm_persist_mode", 0))
         try:
             plain, _ = single(X)
             plain = plain.clone()
+            # the training step of `step()` above on this engine: tiled bf16 / bf16x3 GEMM kernels (the f16f8 forward GEMMs exist in the persistent
+            # form only), every kernel on one queue - an independent path to the same gradients
+            seng, sflat = single._engine, single.flat_parameters()
+            seng.forward(sflat, X, train=True, seed=5, step=9)
+            g_tiled = torch.zeros_like(sflat)
+            seng.backward(sflat, g_tiled, dp, ds)
+            torch.cuda.synchronize()
         finally:
             _lib.check(lib.mp_set_option(b"gemm_persist_mode", 1))
         assert single._engine.cfg.streams == 3 and eng.cfg.streams == 0
+    rel_g = float((a[3] - g_tiled).abs().max() / g_tiled.abs().max())
+    cos_g = _cos(a[3], g_tiled)
+    print(f"\n[f16f8={f16f8}] gradients, persistent kernels + three queues vs tiled kernels on one queue: max |dg| / max |g| = {rel_g:.2e}, cosine {cos_g:.8f}")
+    assert rel_g < 2e-3 and cos_g > 0.99999, (rel_g, cos_g)
     # B = 16 runs the persistent GEMMs in the rotations net, B = 2 the tiled ones: same products, different epilogue code -> rounding-level
     # differences only (a wrong row would be ~1 m off)
     d_alone = (full[5:7] - alone).norm(dim=-1)
