@@ -764,6 +764,9 @@ def main():
                         e.update({"tflops": tf, "frac": tf / peak_tf})
                     tab[name[4:]] = e
                 out["roofline"]["per_instantiation"] = tab
+                out["roofline"]["per_instantiation_note"] = ("HIP-event times inside the timed three-queue steps: the *.wgrad rows run on the weight-gradient queue, which "
+                                                             "time-slices with the main queue - their ms_per_launch is queue time, not kernel duration (one-queue profile: "
+                                                             "profiles/*_single_queue_kernel_stats.csv; isolated: tools/wgrad_bench.py)")
             # kernel classes: `isolated_ms_per_step` / `share` from the one-queue pass (a kernel's own duration; they sum to that pass's step
             # time); `event_ms_three_queues` = HIP-event time inside the timed steps, where the engine's three queues time-slice (a class's
             # events then cover the other queues' kernels too: these sum to MORE than the step and rank the classes wrongly)
