@@ -16,7 +16,8 @@ seeds = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 def run(precision, X, y, seed=0):
     torch.manual_seed(seed)
     model = RMCLManifoldMixSTE(h36m_skeleton(), num_frame=243, n_hyp=5, drop_path_rate=0.1)
-    model.precision = precision
+    model.precision = precision.split("/")[0]
+    model.f16f8 = 3 if precision.endswith("/f16f8") else 0      # "bf16x3/f16f8": the benchmark's operand form since round 6
     model = model.cuda().train()
     tr = LiftingTrainer(model, lr=lr, weight_decay=1e-6, seed=seed)
     hist = []
@@ -56,9 +57,17 @@ del teacher
 torch.cuda.empty_cache()
 hists = {}
 for sd in range(seeds):
-    for p in ("fp32", "bf16x3", "bf16"):
+    for p in ("fp32", "bf16x3/f16f8", "bf16x3", "bf16"):
         hists[(p, sd)] = run(p, X, y, seed=sd)
 for p, hist in hists.items():
     assert all(torch.isfinite(torch.tensor(hist))), f"{p}: non-finite loss"
     assert hist[-1] < 0.6 * hist[0], (p, hist[0], hist[-1])
+# the split precision against fp32, same seed (round-5 advisory: not only "the loss falls"): the first step's loss is the forward at equal weights
+# (1e-3: DropPath streams are the same, the forward differs by ~1e-5 m); the end state of a winner-take-all trajectory is chaotic in the heads that win
+# ("ten-step trajectories"), so the final total is held to a band, not to digits
+for (p, sd), hist in hists.items():
+    if p.startswith("bf16x3"):
+        ref = hists[("fp32", sd)]
+        assert abs(hist[0] - ref[0]) <= 1e-3 * abs(ref[0]), (p, sd, hist[0], ref[0])
+        assert abs(hist[-1] - ref[-1]) <= 0.25 * abs(ref[-1]), (p, sd, hist[-1], ref[-1])
 print("ok:", {p: (round(h[0], 4), round(h[-1], 4)) for p, h in hists.items()})
