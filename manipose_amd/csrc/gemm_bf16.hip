@@ -562,6 +562,11 @@ __device__ __forceinline__ int kflag_last(int a, int b, int x) { int r; asm vola
 #ifndef MP_KLOOP_ASM8
 #define MP_KLOOP_ASM8 1
 #endif
+// schedule variant of the f16f8 steps (tools/gen_kloop_asm.py, F8_VARIANTS: 0 = DMA in front of the first fragment requests, requests one group ahead;
+// 1 = the same with requests two groups ahead; 2 = DMA behind the first requests, two groups ahead - the three-product loop's best)
+#ifndef MP_KSTEP_VARIANT_F8
+#define MP_KSTEP_VARIANT_F8 0
+#endif
 enum { KC_X0 = 0, KC_X1 = 1, KC_X2 = 2, KC_P = 3 };
 #define MP_KSTEP_SEL2(c, t, v) MP_KSTEP_ASM_##c##_TRB##t##_V##v
 #define MP_KSTEP_SEL(c, t, v) MP_KSTEP_SEL2(c, t, v)
@@ -620,12 +625,12 @@ __device__ __forceinline__ void kstep_asm_f(f32x4 (&acc)[8][4], const KFragA& fa
                                             const KJob& jb, const unsigned (&boff)[KNP]) {
   const KJob jc = {0, 0u, nullptr};
   const unsigned coff = 0;
-  MP_KSTEP_EMIT(ZF, 0, MP_KSTEP_VARIANT);
+  asm volatile(MP_KSTEP_SEL(ZF, 0, MP_KSTEP_VARIANT_F8) : MP_KSTEP_ACC_OPERANDS : MP_KSTEP_OPS_0 : MP_KSTEP_CLOB(2));
 }
 #define MP_KSTEP_OPS_E [aa0] "v"(fa.a[0]), [aa1] "v"(fa.a[1]), [ba0] "v"(fb.b[0]), [ba1] "v"(fb.b[1]), [sca] "v"(sca), [scb] "v"(scb), MP_KSTEP_JOBS
 __device__ __forceinline__ void kstep_asm_e(f32x4 (&acc)[8][4], const KFragA& fa, const KFragB& fb, const KJob& ja, const unsigned (&aoff)[KNP],
                                             const KJob& jb, const unsigned (&boff)[KNP], const KJob& jc, unsigned coff, int sca, int scb) {
-  asm volatile(MP_KSTEP_SEL(ZE, 0, MP_KSTEP_VARIANT) : MP_KSTEP_ACC_OPERANDS : MP_KSTEP_OPS_E : MP_KSTEP_CLOB(MP_KSTEP_VARIANT));
+  asm volatile(MP_KSTEP_SEL(ZE, 0, MP_KSTEP_VARIANT_F8) : MP_KSTEP_ACC_OPERANDS : MP_KSTEP_OPS_E : MP_KSTEP_CLOB(2));
 }
 // k-tiles 0 .. n-1 (n = nk - 1 >= 1) of a split-precision forward tile, behind the tile's first barrier (A_lo[0], B_hi[0] landed in A0, B0; A1, B1 free).
 // pa / pb: the hi planes' addresses of the tile's k-tile 0.  aoff / boff come back advanced by n k-tiles (128 bytes each) in the waves that issue DMA.

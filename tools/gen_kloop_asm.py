@@ -101,6 +101,8 @@ CONFIGS = {"X0": dict(a="always", b="none", c="none"), "X1": dict(a="cond", b="a
            # SIMD's first MFMA of the step, while the younger wave waits for the pipe anyway
            "Z0": dict(a="cond", b="none", c="none", pieces=8), "Z1": dict(a="cond", b="cond", c="none", pieces=8),
            "Z2": dict(a="none", b="cond", c="cond", pieces=8), "ZP": dict(a="cond", b="cond", c="cond", pieces=8)}
+# schedule variants of the f16f8 steps (MP_KSTEP_VARIANT_F8): measured on the block of four GEMMs at B = 79, same box (profiles/r06_probes/f16f8_step_variants.log)
+F8_VARIANTS = {0: dict(dma="head_before", ahead=1), 1: dict(dma="head_before", ahead=2), 2: dict(dma="head_after", ahead=2)}
 # (emitted separately, "N" operands only) the f16f8 loop's steps
 F8_CONFIGS = {"ZF": dict(a="cond", b="cond", c="none", pieces=8), "ZE": dict(a="cond", b="cond", c="cond", pieces=8)}
 
@@ -361,7 +363,7 @@ def emit():
                 out.append("")
     # the two steps of a k-tile of the "f16f8" loop (SPLIT = 8; forward, "N" operands, DMA by waves 4-7): F = the fp16 planes (the plain step with the
     # fp16 instruction; it always requests the k-tile's correction tiles), E = the correction planes (requests the next k-tile's / tile's fp16 tiles)
-    for v, opt in sorted(VARIANTS.items()):
+    for v, opt in sorted(F8_VARIANTS.items()):
         lines = step(0, "ZF", mfma="v_mfma_f32_16x16x32_f16", **opt)
         out.append(f"#define MP_KSTEP_ASM_ZF_TRB0_V{v} \\")
         for i, l in enumerate(lines):
