@@ -10,6 +10,10 @@
 //     4  as shipped: LDS image, dwordx4 loads / stores of 4 rows x 256 B per instruction
 //     5  no LDS, natural columns: dwordx4 loads / stores of 16 rows x 64 B per instruction
 //   (6 / 7: contiguous 16 KiB blocks; 8: form 1 with dwordx4 stores of 8 rows x 128 B; 9: form 4 with the residual requested two passes ahead)
+//   10 (round 6, review item 4): PAIRED COLUMN TILES of an N = 512 output + the LayerNorm behind it fused - a workgroup runs both 256-wide tiles of a row
+//      panel back to back (form 4 each, per-row sum / sum of squares collected in LDS), then normalises the 256 x 512 panel: re-reads the fp32 rows it has
+//      just written (256 KiB of them one tile old: L2 / Infinity Cache, not HBM - if the caches hold them) and writes the planar bf16 pair.  Compared with
+//      form 4 alone (+ the stand-alone LayerNorm kernel's known time) it says what the fused normalisation costs inside a tile's idle phase.
 // hipcc --offload-arch=gfx950 -O3 tools/probes/epi_shapes.hip -o /tmp/epi_shapes && /tmp/epi_shapes [steps per tile] [start stagger] [one in F workgroups stores] [wave mode]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -216,6 +220,104 @@ __global__ __launch_bounds__(512) void epi_kernel(unsigned short* __restrict__ h
   }
 }
 
+
+// form 10: see the header.  One workgroup per row panel (both column tiles), 256 panels in flight.
+__global__ __launch_bounds__(512) void pair_ln_kernel(unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, float* __restrict__ c32,
+                                                      const float* __restrict__ resid, const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                      int npanels, int steps, int fuse) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int N = 512;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, gq = lane >> 4;
+  float* const img = reinterpret_cast<float*>(smem + wave * 4096);
+  float* const rsum = reinterpret_cast<float*>(smem + 8 * 4096);      // [256][2]: sum, sum of squares of the panel's rows
+  const int per_xcd = gridDim.x >> 3;
+  union { unsigned u[4]; bf16x8_t v; } fa, fb;
+  for (int q = 0; q < 4; ++q) { fa.u[q] = 0x3F803C00u + lane * 0x00010001u + q; fb.u[q] = 0x3E803D00u + lane * 0x00030001u + 7 * q; }
+  for (int p = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3); p < npanels; p += gridDim.x) {
+    const int m0 = p * 256;
+    if (fuse) { rsum[tid] = 0.f; __syncthreads(); }
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n0 = tn * 256;
+      f32x4 acc[8][4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < steps; ++s) {
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb.v, fa.v, acc[i][j], 0, 0, 0);
+        fa.u[0] ^= 0x00010001u; fb.u[1] ^= 0x00010001u;
+      }
+      const int row0 = m0 + wr * 128, col = n0 + wc * 64 + 4 * l15;
+      const float4 b4 = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float4 in[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) in[it] = *reinterpret_cast<const float4*>(resid + (long)(row0 + i * 16 + it * 4 + gq) * N + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(img + l15 * 64 + (((4 * j + gq) ^ l15) << 2)) = acc[i][j];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int lr = it * 4 + gq;
+          float4 v = *reinterpret_cast<const float4*>(img + lr * 64 + ((l15 ^ lr) << 2));
+          v.x += b4.x + in[it].x; v.y += b4.y + in[it].y; v.z += b4.z + in[it].z; v.w += b4.w + in[it].w;
+          *reinterpret_cast<float4*>(c32 + (long)(row0 + i * 16 + lr) * N + col) = v;
+          if (fuse) {      // the row's 64 columns of this wave: 16 lanes, reduced by shuffles, one LDS atomic pair per row and wave
+            float s1 = (v.x + v.y) + (v.z + v.w), s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) { s1 += __shfl_xor(s1, d, 64); s2 += __shfl_xor(s2, d, 64); }
+            if (l15 == 0) { atomicAdd(rsum + 2 * (wr * 128 + i * 16 + lr), s1); atomicAdd(rsum + 2 * (wr * 128 + i * 16 + lr) + 1, s2); }
+          }
+        }
+      }
+    }
+    if (fuse) {
+      __syncthreads();      // (also: this workgroup's stores of the panel are visible to it - same CU, through the L2)
+      // normalise the 256 x 512 panel: wave w takes rows 32 w .. 32 w + 31, a lane 8 consecutive columns
+      const float4 g0 = *reinterpret_cast<const float4*>(gamma + 8 * lane), g1 = *reinterpret_cast<const float4*>(gamma + 8 * lane + 4);
+#pragma unroll 4
+      for (int r = 0; r < 32; ++r) {
+        const int row = wave * 32 + r;
+        const float mean = rsum[2 * row] * (1.0f / N), var = rsum[2 * row + 1] * (1.0f / N) - mean * mean, rstd = rsqrtf(var + 1e-6f);
+        const float* src = c32 + (long)(m0 + row) * N + 8 * lane;
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+        uint4 h, l;
+        split2((a.x - mean) * rstd * g0.x, (a.y - mean) * rstd * g0.y, h.x, l.x); split2((a.z - mean) * rstd * g0.z, (a.w - mean) * rstd * g0.w, h.y, l.y);
+        split2((b.x - mean) * rstd * g1.x, (b.y - mean) * rstd * g1.y, h.z, l.z); split2((b.z - mean) * rstd * g1.z, (b.w - mean) * rstd * g1.w, h.w, l.w);
+        *reinterpret_cast<uint4*>(hi + (long)(m0 + row) * N + 8 * lane) = h;
+        *reinterpret_cast<uint4*>(lo + (long)(m0 + row) * N + 8 * lane) = l;
+      }
+      __syncthreads();
+    }
+  }
+}
+// the stand-alone pass the fusion would replace: one wave per row, reads the fp32 row, writes the planar pair (the product's ln_fwd_kernel does two rows per wave)
+__global__ __launch_bounds__(256) void ln_pass_kernel(unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, const float* __restrict__ c32, const float* __restrict__ gamma, int M) {
+  constexpr int N = 512;
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* src = c32 + (long)row * N + 8 * lane;
+  const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+  float s1 = (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w), s2 = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { s1 += __shfl_xor(s1, d, 64); s2 += __shfl_xor(s2, d, 64); }
+  const float mean = s1 * (1.0f / N), rstd = rsqrtf(s2 * (1.0f / N) - mean * mean + 1e-6f);
+  const float4 g0 = *reinterpret_cast<const float4*>(gamma + 8 * lane), g1 = *reinterpret_cast<const float4*>(gamma + 8 * lane + 4);
+  uint4 h, l;
+  split2((a.x - mean) * rstd * g0.x, (a.y - mean) * rstd * g0.y, h.x, l.x); split2((a.z - mean) * rstd * g0.z, (a.w - mean) * rstd * g0.w, h.y, l.y);
+  split2((b.x - mean) * rstd * g1.x, (b.y - mean) * rstd * g1.y, h.z, l.z); split2((b.z - mean) * rstd * g1.z, (b.w - mean) * rstd * g1.w, h.w, l.w);
+  *reinterpret_cast<uint4*>(hi + (long)row * N + 8 * lane) = h;
+  *reinterpret_cast<uint4*>(lo + (long)row * N + 8 * lane) = l;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 template <int V>
@@ -271,6 +373,30 @@ int main(int argc, char** argv) {
     printf("  LDS image, residual rows requested two passes ahead: %.3f ms (+%.2f us / tile)\n", t9, (t9 - t0) * 1e3 / rounds);
     printf("fp32 + residual, N = 512 (%.1f tiles per workgroup): none %.3f ms | LDS image 4 rows x 256 B %.3f ms (+%.2f us / tile) | natural 16 rows x 64 B %.3f ms (+%.2f)\n",
            rounds, t0, t4, (t4 - t0) * 1e3 / rounds, t5, (t5 - t0) * 1e3 / rounds);
+    // form 10: paired column tiles, with and without the fused normalisation, and the stand-alone pass it would replace
+    float* gamma;
+    CK(hipMalloc(&gamma, 512 * 4)); CK(hipMemset(gamma, 0, 512 * 4));
+    hipFuncSetAttribute((const void*)pair_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float tp[2] = {1e30f, 1e30f}, tl = 1e30f;
+    for (int fuse = 0; fuse < 2; ++fuse)
+      for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(pair_ln_kernel, dim3(256), dim3(512), 8 * 4096 + 2048, 0, hi, lo, c32, resid, bias, gamma, M / 256, steps, fuse);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < tp[fuse]) tp[fuse] = ms;
+      }
+    for (int rep = 0; rep < 4; ++rep) {
+      hipEventRecord(e0, 0);
+      hipLaunchKernelGGL(ln_pass_kernel, dim3(M / 4), dim3(256), 0, 0, hi, lo, c32, gamma, M);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1);
+      float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+      if (rep > 0 && ms < tl) tl = ms;
+    }
+    printf("paired column tiles (one workgroup runs both tiles of a row panel), N = 512, M = %d: plain %.3f ms | + fused LayerNorm of the panel (re-read fp32, write planar) %.3f ms (+%.3f ms, +%.2f us / panel) | "
+           "stand-alone LayerNorm pass over the same rows %.3f ms (%.2f TB/s of 8 B / element)\n", M, tp[0], tp[1], tp[1] - tp[0], (tp[1] - tp[0]) * 1e3 / (M / 256 / 256.0), tl, (double)M * 512 * 8 / tl / 1e9);
   }
   return 0;
 }
