@@ -52,7 +52,8 @@ int mp_fk_decode_bwd(const float* rot6d, int rot_stride, int rot_dim, const floa
  * metrics/regularizations.py:160-174 assembled like make_loss/compute_and_acc_loss
  * (hpe/main_h36m_lifting.py:101-209).  terms (device, 4 floats) = wloss, score_reg, vloss, sreg (already
  * weighted; total = their sum).  argmin (device int32 (B,T)) / d_poses / d_scores may be NULL.
- * scratch: >= 4*ceil(B*T/256) floats. */
+ * scratch: >= 4*ceil(B*T/256) floats; with >= 4*ceil(B*T/48) the kernel runs on more, shorter-lived workgroups (same results up to the order of the
+ * final sum). */
 typedef struct mp_loss_config {
   float rmcl_score_reg; /* beta, conf/config.yaml:36 (0.1) */
   float vel_loss;       /* conf/config.yaml:33 (2.0) */

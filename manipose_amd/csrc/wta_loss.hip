@@ -7,7 +7,7 @@
 // vloss = vel_w * mean_{b,k,t,j,c} (d_t p - d_t y)^2 (losses.py:96-97); the other two terms do not change.
 // assembled as main_h36m_lifting.py:101-209 does (the reference evaluates the WTA part twice per step and
 // syncs the host 5 times; here it is one kernel + a 1-block finalize and no host sync).
-// One thread per frame (b,t).  K = 1 with scores == nullptr is the single-hypothesis loss of ManifoldMixSTE.
+// A lane per joint, three frames per wave (see wta_loss_kernel).  K = 1 with scores == nullptr is the single-hypothesis loss of ManifoldMixSTE.
 #include "common.h"
 #include "kernels.h"
 
@@ -28,53 +28,77 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// Wave mapping (round 6; the north star's "wavefront shuffles for the K-way argmin"): a LANE PER JOINT, three consecutive frames per wave (51 of 64
+// lanes, like the decoder kernel), so that a wave's loads are the whole 204-byte rows of its frames - consecutive frames of a window are consecutive rows:
+// 612 contiguous bytes per hypothesis - instead of one thread walking a row 12 bytes at a time (the thread-per-frame form of rounds 1-5 reached 6 % of the
+// HBM rate on 150 workgroups).  Per hypothesis the 17 per-joint distances of a frame are summed by a shuffle tree inside the frame's lane group; the
+// group's first lane takes the minimum over K and the winner goes back to the 17 lanes by a shuffle.  The K scoring terms of a frame are taken by the
+// group's first K lanes.  A workgroup owns `fpb` consecutive frames (a quarter per wave, three at a time) and writes ONE partial row: the sums keep a fixed
+// order (lane tree, wave order, workgroup order), two runs give the same bits.
+__device__ __forceinline__ float group17_sum(float v, int j) {      // sum over the 17 lanes of a frame's group (valid in the group's lane 0)
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) {
+    const float o = __shfl_down(v, d, 64);
+    if (j < d && j + d < LJ) v += o;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(256) void wta_loss_kernel(const float* __restrict__ poses, const float* __restrict__ scores,
                                                         const float* __restrict__ y, JointW jw, int squared, LossScales sc,
                                                         float* __restrict__ partial, int* __restrict__ argmin,
                                                         float* __restrict__ dposes, float* __restrict__ dscores, int B, int K,
-                                                        int T) {
+                                                        int T, int fpb) {
   __shared__ float red[4];
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = f < B * T;
-  const int b = valid ? f / T : 0, t = valid ? f % T : 0;
-  const float* yr = y + ((long)b * T + t) * LJ * 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / LJ, j = lane - slot * LJ;              // lanes 51-63: slot 3, idle
+  const bool lane_on = slot < 3;
+  const int per_wave = fpb >> 2;                                 // frames per wave (fpb % 4 == 0)
+  const int f_begin = blockIdx.x * fpb + wave * per_wave, f_end = min(min(f_begin + per_wave, (blockIdx.x + 1) * fpb), B * T);
+  const float wj = lane_on ? jw.w[j] : 0.f;
   float lw = 0.f, lb = 0.f, lv = 0.f, ls = 0.f;
-  if (valid) {
-    // ---- pass 1: per-hypothesis weighted MPJPE and the winner ----
+  for (int f0 = f_begin; f0 < f_end; f0 += 3) {                  // (wave-uniform trip count: the shuffles below see every lane)
+    const int f = f0 + slot;
+    const bool valid = lane_on && f < f_end;
+    const int fc = valid ? f : f_begin;                          // idle lanes read a valid frame and contribute nothing
+    const int b = fc / T, t = fc - b * T;
+    const float* yr = y + (long)fc * LJ * 3 + 3 * j * (lane_on ? 1 : 0);
+    const float y0 = yr[0], y1 = yr[1], y2 = yr[2];
+    // ---- pass 1: per-hypothesis weighted distance of this joint, summed over the frame's lane group; the winner ----
     float best = INFINITY;
     int kb = 0;
     for (int k = 0; k < K; ++k) {
-      const float* pr = poses + (((long)b * K + k) * T + t) * LJ * 3;
-      float e = 0.f;
-      for (int j = 0; j < LJ; ++j) {
-        const float dx = pr[3 * j] - yr[3 * j], dy = pr[3 * j + 1] - yr[3 * j + 1], dz = pr[3 * j + 2] - yr[3 * j + 2];
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        e += jw.w[j] * (squared ? d2 : sqrtf(d2));
-      }
+      const float* pr = poses + (((long)b * K + k) * T + t) * LJ * 3 + 3 * (lane_on ? j : 0);
+      const float dx = pr[0] - y0, dy = pr[1] - y1, dz = pr[2] - y2;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      float e = group17_sum(wj * (squared ? d2 : sqrtf(d2)), j);
       e /= squared ? (float)(LJ * 3) : (float)LJ;
-      if (e < best) { best = e; kb = k; }
+      if (e < best) { best = e; kb = k; }                        // (meaningful in the group's lane 0)
     }
-    lw = best * sc.wta;
-    if (argmin != nullptr) argmin[f] = kb;
-    // ---- scoring BCE (torch clamps log at -100; backward divides by max(s(1-s), 1e-12)) ----
-    if (scores != nullptr) {
+    const int src = min(slot, 2) * LJ;                           // the group's first lane
+    kb = __shfl(kb, src, 64);
+    best = __shfl(best, src, 64);
+    if (valid && j == 0) {
+      lw += best * sc.wta;
+      if (argmin != nullptr) argmin[f] = kb;
+    }
+    // ---- scoring BCE (torch clamps log at -100; backward divides by max(s(1-s), 1e-12)): hypothesis k on the group's lane k ----
+    if (scores != nullptr && valid && j < K) {
+      const float s = scores[((long)b * K + j) * T + t];
+      const float gt = (j == kb) ? 1.0f : 0.0f;
+      const float l1 = fmaxf(logf(s), -100.0f), l0 = fmaxf(logf(1.0f - s), -100.0f);
+      lb -= (gt * l1 + (1.0f - gt) * l0) * sc.bce;
+      if (dscores != nullptr) dscores[((long)b * K + j) * T + t] = sc.bce * (s - gt) / fmaxf(s * (1.0f - s), 1e-12f);
+    }
+    // ---- pass 2: velocity / smoothness terms and the pose gradient of this joint, all hypotheses ----
+    if (valid) {
+      const bool has_prev = t > 0, has_next = t < T - 1;
+      const float yn0 = has_next ? yr[LJ * 3] : 0.f, yn1 = has_next ? yr[LJ * 3 + 1] : 0.f, yn2 = has_next ? yr[LJ * 3 + 2] : 0.f;
+      const float yp0 = has_prev ? yr[-LJ * 3] : 0.f, yp1 = has_prev ? yr[-LJ * 3 + 1] : 0.f, yp2 = has_prev ? yr[-LJ * 3 + 2] : 0.f;
       for (int k = 0; k < K; ++k) {
-        const float s = scores[((long)b * K + k) * T + t];
-        const float gt = (k == kb) ? 1.0f : 0.0f;
-        const float l1 = fmaxf(logf(s), -100.0f), l0 = fmaxf(logf(1.0f - s), -100.0f);
-        lb -= (gt * l1 + (1.0f - gt) * l0) * sc.bce;
-        if (dscores != nullptr) dscores[((long)b * K + k) * T + t] = sc.bce * (s - gt) / fmaxf(s * (1.0f - s), 1e-12f);
-      }
-    }
-    // ---- pass 2: velocity / smoothness terms and all pose gradients ----
-    const bool has_prev = t > 0, has_next = t < T - 1;
-    for (int k = 0; k < K; ++k) {
-      const long fo = (((long)b * K + k) * T + t) * LJ * 3;
-      const float* pr = poses + fo;
-      for (int j = 0; j < LJ; ++j) {
-        const float wj = jw.w[j];
-        const float p0 = pr[3 * j], p1 = pr[3 * j + 1], p2 = pr[3 * j + 2];
-        const float y0 = yr[3 * j], y1 = yr[3 * j + 1], y2 = yr[3 * j + 2];
+        const long fo = (((long)b * K + k) * T + t) * LJ * 3 + 3 * j;
+        const float* pr = poses + fo;
+        const float p0 = pr[0], p1 = pr[1], p2 = pr[2];
         float g0 = 0.f, g1 = 0.f, g2 = 0.f;
         if (k == kb) {
           const float dx = p0 - y0, dy = p1 - y1, dz = p2 - y2;
@@ -88,9 +112,8 @@ __global__ __launch_bounds__(256) void wta_loss_kernel(const float* __restrict__
           }
         }
         if (has_next) {
-          const float s0 = pr[LJ * 3 + 3 * j] - p0, s1 = pr[LJ * 3 + 3 * j + 1] - p1, s2 = pr[LJ * 3 + 3 * j + 2] - p2;
-          const float u0 = s0 - (yr[LJ * 3 + 3 * j] - y0), u1 = s1 - (yr[LJ * 3 + 3 * j + 1] - y1),
-                      u2 = s2 - (yr[LJ * 3 + 3 * j + 2] - y2);
+          const float s0 = pr[LJ * 3] - p0, s1 = pr[LJ * 3 + 1] - p1, s2 = pr[LJ * 3 + 2] - p2;
+          const float u0 = s0 - (yn0 - y0), u1 = s1 - (yn1 - y1), u2 = s2 - (yn2 - y2);
           const float n2 = u0 * u0 + u1 * u1 + u2 * u2, n = sqrtf(n2);
           lv += (squared ? n2 : n) * sc.vel;
           ls += wj * (s0 * s0 + s1 * s1 + s2 * s2) * sc.smooth;
@@ -102,9 +125,8 @@ __global__ __launch_bounds__(256) void wta_loss_kernel(const float* __restrict__
           g0 -= c2 * s0; g1 -= c2 * s1; g2 -= c2 * s2;
         }
         if (has_prev) {
-          const float s0 = p0 - pr[-LJ * 3 + 3 * j], s1 = p1 - pr[-LJ * 3 + 3 * j + 1], s2 = p2 - pr[-LJ * 3 + 3 * j + 2];
-          const float u0 = s0 - (y0 - yr[-LJ * 3 + 3 * j]), u1 = s1 - (y1 - yr[-LJ * 3 + 3 * j + 1]),
-                      u2 = s2 - (y2 - yr[-LJ * 3 + 3 * j + 2]);
+          const float s0 = p0 - pr[-LJ * 3], s1 = p1 - pr[-LJ * 3 + 1], s2 = p2 - pr[-LJ * 3 + 2];
+          const float u0 = s0 - (y0 - yp0), u1 = s1 - (y1 - yp1), u2 = s2 - (y2 - yp2);
           const float n = sqrtf(u0 * u0 + u1 * u1 + u2 * u2);
           if (squared || n > 0.f) {
             const float c = squared ? 2.0f * sc.vel : sc.vel / n;
@@ -113,9 +135,7 @@ __global__ __launch_bounds__(256) void wta_loss_kernel(const float* __restrict__
           const float c2 = 2.0f * sc.smooth * wj;
           g0 += c2 * s0; g1 += c2 * s1; g2 += c2 * s2;
         }
-        if (dposes != nullptr) {
-          dposes[fo + 3 * j] = g0; dposes[fo + 3 * j + 1] = g1; dposes[fo + 3 * j + 2] = g2;
-        }
+        if (dposes != nullptr) { dposes[fo] = g0; dposes[fo + 1] = g1; dposes[fo + 2] = g2; }
       }
     }
   }
@@ -145,7 +165,10 @@ static int loss_impl(const float* poses, const float* scores, const float* y, co
                      float* dposes, float* dscores, int B, int K, int T, float* scratch, long scratch_floats, int skip_bce,
                      hipStream_t st) {
   MP_CHECK(B > 0 && K >= 1 && K <= 8 && T >= 2, MP_ERR_ARG, "wta_loss: B=%d K=%d T=%d unsupported (T >= 2, K <= 8)", B, K, T);
-  const int grid = cdiv(B * T, 256);
+  // frames per workgroup: 48 (four waves x 12 frames: short-lived workgroups, 800 of them at the benchmark's 38 394 frames) when the caller's scratch holds
+  // that many partial rows, else the 256 of the ABI's minimum scratch size (4 * ceil(B T / 256) floats)
+  const int fpb = scratch_floats >= 4L * cdiv(B * T, 48) ? 48 : 256;
+  const int grid = cdiv(B * T, fpb);
   MP_CHECK(scratch_floats >= 4L * grid, MP_ERR_ARG, "wta_loss: scratch too small");
   LossScales sc;
   sc.wta = 1.0f / ((float)B * T);
@@ -156,7 +179,7 @@ static int loss_impl(const float* poses, const float* scores, const float* y, co
   JointW jw;
   for (int j = 0; j < LJ; ++j) jw.w[j] = cfg.use_joint_weights == 1 ? H36M_W[j] : (cfg.use_joint_weights == 2 ? cfg.joint_weights[j] : 1.0f);
   hipLaunchKernelGGL(wta_loss_kernel, dim3(grid), dim3(256), 0, st, poses, scores, y, jw, cfg.squared, sc, scratch, argmin,
-                     dposes, dscores, B, K, T);
+                     dposes, dscores, B, K, T, fpb);
   MP_LAUNCH_CHECK();
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, grid, terms, 4, skip_bce);
   MP_LAUNCH_CHECK();

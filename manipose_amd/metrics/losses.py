@@ -40,7 +40,7 @@ def _loss_config(beta, vel_w, smooth_w, use_w, squared):
 
 
 def _scratch(B: int, T: int, device) -> torch.Tensor:
-    return torch.empty(4 * ((B * T + 255) // 256) + 8, dtype=torch.float32, device=device)
+    return torch.empty(4 * ((B * T + 47) // 48) + 8, dtype=torch.float32, device=device)      # >= 4 ceil(B T / 48): the loss kernel's short-lived workgroups
 
 
 class _FusedLoss(torch.autograd.Function):

@@ -68,7 +68,7 @@ class LiftingTrainer:
                 d_poses=torch.empty(B, K, T, 17, 3, device=device),
                 d_scores=torch.empty(B, K, T, 1, device=device) if self.rmcl else None,
                 terms=torch.zeros(4, device=device),
-                scratch=torch.empty(4 * ((B * T + 255) // 256) + 8, device=device),
+                scratch=torch.empty(4 * ((B * T + 47) // 48) + 8, device=device),      # (>= 4 ceil(B T / 48): the loss kernel's short-lived workgroups)
                 rigid=torch.empty(B, device=device))}
         return self._bufs[key]
 

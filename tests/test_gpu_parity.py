@@ -180,6 +180,38 @@ def test_wta_loss_terms_and_gradients_vs_reference_fixture(lib):
     close(scores.grad, fx["g_scores"], rtol=1e-4, atol=1e-8)
 
 
+def test_wta_loss_kernel_forms_by_scratch_size_and_ragged_frame_counts(lib):
+    """mp_wta_loss through the C ABI on the fixture and on frame counts that do not fill the last wave / workgroup (a lane per joint, three frames per
+    wave, shuffle sums over a frame's 17 lanes, winner broadcast by a shuffle): with the ABI's minimum scratch (256 frames per workgroup) and with
+    >= 4 ceil(B T / 48) floats (48 frames per workgroup) - the same argmin, the same gradients bit for bit (they do not depend on the partial sums),
+    terms equal to the oracle's."""
+    import ctypes as C
+    from manipose_amd import _lib
+    g = torch.Generator().manual_seed(9)
+    for B, K, T in ((1, 1, 2), (2, 5, 7), (3, 3, 50), (5, 5, 243), (2, 8, 100)):
+        poses = 0.3 * torch.randn(B, K, T, 17, 3, generator=g)
+        y = 0.3 * torch.randn(B, T, 17, 3, generator=g)
+        scores = torch.softmax(torch.randn(B, K, T, 1, generator=g), 1).contiguous()
+        o_tot, o_terms = orc.rmcl_training_loss(poses, scores, y)
+        cfg = _lib.LossConfig(rmcl_score_reg=0.1, vel_loss=2.0, smooth_reg=0.5, w_loss=1, sq_loss=0)
+        dposes, dscores, dy = poses.cuda(), scores.cuda(), y.cuda()
+        outs = []
+        for fpb in (256, 48):
+            terms = torch.zeros(4, device="cuda")
+            dp, dsc = torch.full((B, K, T, 17, 3), float("nan"), device="cuda"), torch.full((B, K, T, 1), float("nan"), device="cuda")
+            am = torch.full((B, T), -1, device="cuda", dtype=torch.int32)
+            sc = torch.empty(4 * ((B * T + fpb - 1) // fpb), device="cuda")
+            _lib.check(lib.mp_wta_loss(_lib.ptr(dposes), _lib.ptr(dscores), _lib.ptr(dy), C.byref(cfg), _lib.ptr(terms), _lib.ptr(am),
+                                       _lib.ptr(dp), _lib.ptr(dsc), B, K, T, _lib.ptr(sc), sc.numel(), st()), "mp_wta_loss")
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(terms.cpu().numpy(), [o_terms[k].item() for k in ("wloss", "score_reg", "vloss", "sreg")], rtol=2e-5, atol=1e-8)
+            assert torch.isfinite(dp).all() and torch.isfinite(dsc).all() and int(am.min()) >= 0 and int(am.max()) < K
+            outs.append((am.clone(), dp.clone(), dsc.clone()))
+        assert all(torch.equal(u, v) for u, v in zip(outs[0], outs[1])), (B, K, T)
+        want = ((poses - y[:, None]).norm(dim=-1) * torch.tensor(orc.STANDARD_H36M_WEIGHTS)).mean(-1).argmin(1)
+        assert torch.equal(outs[0][0].cpu().long(), want), (B, K, T)
+
+
 def test_reference_named_loss_functions(lib):
     from manipose_amd import metrics as M
     fx = load_fixture("loss")
