@@ -26,7 +26,7 @@ Default precision: "bf16x3" (split operands, fp32 accumulate; bf16 backward) - t
 "bf16" (BASELINE config #3's wording) is faster but drifts ~3-4.6 mm.  Operand form of the split precision (mp_model_config::f16f8, named in
 `config.split_forms`): since round 6 the default is `--f16f8 3` - all four Linear layers of a block of the rotations net as ONE fp16 + ONE block-scaled
 fp8 matrix-core product per 64 reduction indices (hand-scheduled k-steps; the attention products stay three bf16 products; bf16 backward): same-box
-A/B +3.4 % poses/s over the three-product form at 1.6e-5 m instead of 0.94e-5 m.  `--f16f8 0` = every product as three
+A/B +3.4 % poses/s (+4.3 % on the final round-6 tree) over the three-product form at 1.6e-5 m instead of 0.94e-5 m.  `--f16f8 0` = every product as three
 bf16 products (rounds 2-5; timed for a few steps in every default run as `other_precisions.bf16x3_three_bf16_products`); 1 / 2 = the older partial
 forms (qkv / fc1 [/ fc2 with --f16-backward]).
 """
